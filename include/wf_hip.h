@@ -1,0 +1,115 @@
+/*
+ * libwf_hip.so -- C-ABI of the MI355X-native WorldForge guided-denoising hot path.
+ *
+ * The reference (Westlake-AGI-Lab/WorldForge) is pure Python and has no FFI of its own; the drop-in
+ * boundary is therefore the set of tensor operations its sampler executes eagerly through PyTorch
+ * (SURVEY.md section 8b).  Every entry point below names the reference statement(s) it replaces
+ * (paths relative to /root/reference/wan_for_worldforge):
+ *   PIPE  = utils/pipeline_wan_i2v_clean.py
+ *   SCHED = utils/scheduling_unipc_multistep_clean.py
+ *   DIT   = wan/modules/model.py (+ attention.py)  -- in-tree statement of diffusers' WanTransformer3DModel
+ *   VAE   = wan/modules/vae.py                     -- in-tree statement of diffusers' AutoencoderKLWan
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all tensor pointers are DEVICE pointers owned by the caller
+ *     (the Python host allocates them with the PyTorch-ROCm caching allocator);
+ *   - contiguous row-major tensors unless a stride argument is given;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on that stream;
+ *   - return value: 0 = WF_OK, negative = WF_E*; text via wf_last_error(); nothing ever falls back
+ *     silently to another implementation (contrast SCHED:1284-1295, 1419-1421);
+ *   - no hidden host synchronisation and no allocation inside any call; reductions use a fixed tree
+ *     order (no floating-point atomics) so repeated runs are bit-identical;
+ *   - `rb*` flags: "this intermediate is a bfloat16 torch tensor in the reference", i.e. its value is
+ *     rounded to bf16 (round-to-nearest-even) exactly where eager PyTorch would round it.
+ */
+#ifndef WF_HIP_H_
+#define WF_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WF_OK 0
+#define WF_EINVAL (-1)   /* bad argument (shape / dtype / alignment) */
+#define WF_EHIP (-2)     /* a HIP runtime call or kernel launch failed */
+#define WF_ENOTSUP (-3)  /* configuration not built */
+
+#define WF_F32 0
+#define WF_BF16 1
+
+/* ---- library ------------------------------------------------------------------------------- */
+int wf_version(void);
+const char* wf_last_error(void);
+/* Number of compute units / name of device `dev` (host query, used by bench/roofline). */
+int wf_device_info(int dev, int* n_cu, int* clock_khz, char* name, int name_len);
+
+/* ---- scheduler / injection element-wise set (HBM-bound; latent tensors are [B,16,T,h,w]) -- */
+
+/* PIPE:611  noise_pred = cond + g * (cond - uncond).  Element dtype `dt` for all three. */
+int wf_cfg_combine(const void* cond, const void* uncond, void* out, int dt, float g, size_t n, void* stream);
+
+/* SCHED:952-958  x0 = sample - sigma * v.   dt_v / dt_s: dtypes of v and sample; out has the torch-promoted dtype
+ * (bf16 only if both are bf16). */
+int wf_x0_from_v(const void* sample, int dt_s, const void* v, int dt_v, void* out, float sigma, size_t n,
+                 void* stream);
+
+/* SCHED:1083-1098 (predict_x0, bh2)  x_t = c1*x - c2*m0 - c3 * 0.5 * (m1 - m0)/rk   (order 2; m1 == NULL -> order 1)
+ *   c1 = sigma_t/sigma_s0, c2 = alpha_t*expm1(-h), c3 = alpha_t*B_h, rk = (lambda_s1-lambda_s0)/h computed by the host in
+ *   fp32 exactly as SCHED:1016-1069 does.  out has x's dtype (SCHED:1098). */
+int wf_unipc_update(const void* x, int dt_x, const void* m0, int dt_m0, const void* m1, int dt_m1, void* out, float c1,
+                    float c2, float c3, float rk, size_t n, void* stream);
+
+/* SCHED:1584  noisy = (1 - sigma) * x0 + sigma * noise.  `one_minus_sigma` and `sigma` are supplied by the host already
+ * rounded to x0's dtype (SCHED:1552).  out dtype = promote(x0, noise). */
+int wf_add_noise(const void* x0, int dt_x0, const void* noise, int dt_n, void* out, float one_minus_sigma, float sigma,
+                 size_t n, void* stream);
+
+/* SCHED:1281 (dir 0: z / istd[c] + mean[c] -> f32 out)  and  SCHED:1385, PIPE:351 (dir 1: (z - mean[c]) * istd[c]).
+ * z is [B,C,inner]; mean/istd are HOST arrays of C floats (<= 64). in dtype dt_in, out dtype dt_out. */
+int wf_latent_affine(const void* z, int dt_in, void* out, int dt_out, const float* mean, const float* istd, int dir, int B,
+                     int C, size_t inner, void* stream);
+
+/* SCHED:1375-1380  fused = (2*ref - 1) * mask + dec * (1 - mask);  ref, dec, out: [B,3,inner] f32, mask: [B,1,inner] f32. */
+int wf_blend_pixels(const float* ref, const float* mask, const float* dec, float* out, int B, int C, size_t inner,
+                    void* stream);
+
+/* PIPE:744 (diffusers VideoProcessor.postprocess_video)  out = clamp(x/2 + 0.5, 0, 1), [C,F,H,W] -> [F,H,W,C]. */
+int wf_postprocess_video(const float* x, float* out, int C, int F, int H, int W, void* stream);
+
+/* dtype conversion / bf16 rounding of latent-shaped tensors (PIPE:590 .to(bf16), PIPE:708). */
+int wf_cast(const void* in, int dt_in, void* out, int dt_out, size_t n, void* stream);
+
+/* SCHED:1410-1412  enc[:, c] = pred[:, c] for the listed channels (host array, n_idx <= C). Tensors [B,C,inner]. */
+int wf_channel_swap(void* enc, int dt_enc, const void* pred, int dt_pred, const int* idx, int n_idx, int B, int C,
+                    size_t inner, void* stream);
+
+/* ---- resize (SCHED:1316-1324 bilinear align_corners=False for the reference video; SCHED:1355-1362 nearest for the mask).
+ * The temporal branches SCHED:1326-1334 / 1364-1371 call F.interpolate with a 3-element size on a 4-D tensor and raise
+ * ValueError in the reference, so a frame-count mismatch is an error here too (raised by the Python host). */
+int wf_resize_bilinear2d(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, void* stream);
+int wf_resize_nearest2d(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, void* stream);
+
+/* ---- DSG (PIPE:664-681) ---------------------------------------------------------------------- */
+/* Workspace floats needed by wf_dsg (partials + 8 result floats). */
+size_t wf_dsg_workspace_floats(void);
+/* One call = reduce (dot, |g|^2, |w|^2 in a fixed tree) -> coefficients on device -> apply:
+ *   better = g + omega*sin(theta) * (g - (|g|/(|w|+1e-8))*cos(theta) * w).   g = "good" (post-injection), w = "worse".
+ * ws: wf_dsg_workspace_floats() floats; ws[0..7] afterwards = {dot, ng2, nw2, cos, sin, ratio, 0, 0} for inspection. */
+int wf_dsg(const void* g, const void* w, void* out, int dt, float omega, size_t n, float* ws, void* stream);
+
+/* ---- FLF metric (SCHED:497-607) ------------------------------------------------------------------ */
+/* Temporal-difference motion (SCHED:391-392, 478-479): out[c,t,:] = x[c,t+1,:] - x[c,t,:];  x [C,T,hw] -> out [C,T-1,hw] f32. */
+int wf_temporal_diff(const void* x, int dt, float* out, int C, int T, size_t hw, void* stream);
+size_t wf_flow_metrics_workspace_floats(int n_channels);
+/* For each of n_channels: ref flow [Tm, Cr, hw], chan flow [Tm, Cc, hw] (Cr, Cc in {1,2}; 1 is replicated to 2 as SCHED:531-539),
+ * similarity = 1 - (.45*clamp(mEPE/10) + .45*clamp(Fl/.5) + .1*clamp(mAE/30))  -> sim[n_channels] (device floats). */
+int wf_flow_metrics(const float* ref_flow, const float* chan_flow, float* sim, int n_channels, int Tm, int Cr, int Cc,
+                    size_t hw, float* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WF_HIP_H_ */

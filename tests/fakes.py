@@ -1,0 +1,111 @@
+"""Deterministic stand-ins for the DiT and the VAE, used to pin the *sampler state machine* (scheduler, IRR, FLF, DSG).
+
+They are built only from element-wise IEEE multiplies/adds and index operations in a fixed order, so the same inputs
+give bit-identical outputs on CPU and on a GPU -- which lets the golden trajectories recorded from the reference
+pipeline (tools/make_goldens.py) be compared tightly with both the CPU oracle and the HIP-backed product sampler.
+They follow the diffusers call protocol the reference uses (PIPE:593-600, SCHED:1272-1285, 1384).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+
+VAE_MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508, 0.4134, -0.0715, 0.5517, -0.3632,
+            -0.1922, -0.9497, 0.2503, -0.2921]
+VAE_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743, 3.2687, 2.1526, 2.8652, 1.5579, 1.6382,
+           1.1253, 2.8251, 1.9160]
+
+
+def _coef(n, m, seed, scale):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(n, m, generator=g) * 2 - 1) * scale
+
+
+class FakeDiT:
+    """v[c] = a_c(t) * x[c] + b_c * x[16 + c] + g_c * x[(c + 5) % 16] + bias_c(ctx)   -> transformer dtype."""
+
+    def __init__(self, dtype=torch.bfloat16):
+        self.dtype = dtype
+        self.config = SimpleNamespace(patch_size=(1, 2, 2))
+        self.coef = _coef(16, 3, 1234, 0.8)
+        self.calls = 0
+
+    def __call__(self, hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_image=None,
+                 attention_kwargs=None, return_dict=False):
+        self.calls += 1
+        x = hidden_states.float()
+        ts = (timestep.reshape(-1)[0].float() / 1000.0).item()
+        ctx = encoder_hidden_states.float()[0, 0, :4].cpu().tolist()
+        outs = []
+        for c in range(16):
+            a, b, g = [float(v) for v in self.coef[c]]
+            bias = ctx[c % 4] * 0.25
+            o = x[:, c] * (a * (0.5 + ts)) + x[:, 16 + c] * b
+            o = o + x[:, (c + 5) % 16] * g
+            o = o + bias
+            outs.append(o)
+        return (torch.stack(outs, dim=1).to(self.dtype),)
+
+
+class _Dist:
+    def __init__(self, mu):
+        self._mu = mu
+
+    def mode(self):
+        return self._mu
+
+
+class FakeVAE:
+    """decode: channel mix 16->3, nearest x8 spatial, latent frame t -> output frames (1 + 4(T-1)), clamp(-1,1);
+    encode: frames 0,4,8,.., pixels ::8, channel mix 3->16."""
+
+    def __init__(self):
+        self.dtype = torch.float32
+        self.config = SimpleNamespace(z_dim=16, latents_mean=VAE_MEAN, latents_std=VAE_STD)
+        self.temperal_downsample = [False, True, True]
+        self.wd = _coef(3, 16, 77, 0.3)
+        self.we = _coef(16, 3, 78, 1.2)
+        self.n_dec = 0
+        self.n_enc = 0
+
+    def decode(self, z, return_dict=False):
+        self.n_dec += 1
+        B, C, T, h, w = z.shape
+        chans = []
+        for o in range(3):
+            acc = z[:, 0] * float(self.wd[o, 0])
+            for k in range(1, 16):
+                acc = acc + z[:, k] * float(self.wd[o, k])
+            chans.append(acc)
+        x = torch.stack(chans, dim=1)  # [B,3,T,h,w]
+        idx = torch.tensor([0] + [1 + (f - 1) // 4 for f in range(1, 1 + 4 * (T - 1))], device=z.device)
+        x = x.index_select(2, idx)
+        x = x.repeat_interleave(8, dim=3).repeat_interleave(8, dim=4)
+        return (x.clamp(-1, 1),)
+
+    def encode(self, x):
+        self.n_enc += 1
+        s = x[:, :, ::4, ::8, ::8]
+        chans = []
+        for o in range(16):
+            acc = s[:, 0] * float(self.we[o, 0])
+            for k in range(1, 3):
+                acc = acc + s[:, k] * float(self.we[o, k])
+            chans.append(acc)
+        return SimpleNamespace(latent_dist=_Dist(torch.stack(chans, dim=1)))
+
+
+def synthetic_ref_and_mask(F, H, W, seed=5, soften=True):
+    """Reference video [1,3,F,H,W] in [0,1] and a growing-hole mask [1,1,F,H,W]."""
+    g = torch.Generator().manual_seed(seed)
+    ref = torch.rand(1, 3, F, H, W, generator=g)
+    xs = torch.arange(W).view(1, 1, 1, 1, W).float()
+    fr = torch.arange(F).view(1, 1, F, 1, 1).float() / max(F - 1, 1)
+    edge = W * (1 - 0.35 * fr)
+    mask = (xs < edge).float().expand(1, 1, F, H, W).contiguous()
+    if soften:
+        d = (edge - xs).clamp(min=0)
+        soft = torch.sin(torch.pi / 2 * (d / 4).clamp(0, 1))
+        mask = (mask * soft.expand_as(mask)).contiguous()
+    return ref, mask

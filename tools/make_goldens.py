@@ -1,0 +1,241 @@
+"""Record golden vectors from the UNMODIFIED reference (runs only in the build container, where /root/reference exists).
+
+  python tools/make_goldens.py            # writes tests/golden/*.npz
+
+The reference is imported through tools/refshim (a stub `diffusers` with base classes only); its DiT / VAE / encoders
+are replaced by the deterministic fakes of tests/fakes.py, so the recorded trajectories pin the *sampler state machine*
+(scheduler arithmetic, IRR re-noise, FLF gate, DSG, dtype casts, RNG draw order).  Fixtures are data only.
+"""
+from __future__ import annotations
+
+import ast
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/wan_for_worldforge"
+sys.path.insert(0, os.path.join(ROOT, "tools", "refshim"))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from tests.fakes import FakeDiT, FakeVAE, synthetic_ref_and_mask  # noqa: E402
+
+
+def t2n(t):
+    if t.dtype == torch.bfloat16:
+        return t.float().numpy()
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------------------
+def g_schedules():
+    from utils.scheduling_unipc_multistep_clean import UniPCMultistepScheduler
+
+    out = {}
+    for n in (4, 16, 50):
+        for shift in (3.0, 5.0):
+            s = UniPCMultistepScheduler(prediction_type="flow_prediction", use_flow_sigmas=True, flow_shift=shift)
+            s.set_timesteps(n)
+            k = f"n{n}_s{int(shift)}"
+            out[k + "_timesteps"] = s.timesteps.numpy()
+            out[k + "_sigmas"] = s.sigmas.numpy()
+            out[k + "_rsig"] = s.resample_sigmas.numpy()
+            out[k + "_rts"] = s.resample_timesteps.numpy()
+    np.savez_compressed(os.path.join(OUT, "g1_schedules.npz"), **out)
+    print("g1_schedules", len(out))
+
+
+# ------------------------------------------------------------------------------------------------------------
+class _ImgProc:
+    def __call__(self, images=None, return_tensors="pt"):
+        class _D(dict):
+            def to(self, device):
+                return self
+
+        return _D(pixel_values=torch.zeros(1, 3, 4, 4))
+
+
+class _ImgEnc:
+    def __init__(self, embeds):
+        self.embeds = embeds
+
+    def __call__(self, pixel_values=None, output_hidden_states=True):
+        return SimpleNamespace(hidden_states=[None, self.embeds, None])
+
+
+PIPE_CASES = {
+    # name: (steps, R, guide, round, flf, omega, omega_resample, cfg, F, H, W, guided, shift)
+    "irr_dsg_small": dict(steps=4, R=2, guide=3, rnd=3, flf=False, omega=4.0, omega_r=4.0, cfg=4.0, F=9, H=32, W=32,
+                          guided=True, shift=3.0),
+    "flf_full": dict(steps=14, R=2, guide=12, rnd=12, flf=True, omega=4.0, omega_r=2.0, cfg=4.0, F=9, H=32, W=48,
+                     guided=True, shift=3.0),
+    "guide_lt_round": dict(steps=10, R=2, guide=4, rnd=7, flf=True, omega=6.0, omega_r=1.5, cfg=5.0, F=5, H=32, W=32,
+                           guided=True, shift=5.0),
+    "plain": dict(steps=6, R=1, guide=0, rnd=0, flf=False, omega=1.8, omega_r=1.0, cfg=5.0, F=5, H=32, W=32,
+                  guided=False, shift=3.0),
+    "nocfg_R3": dict(steps=5, R=3, guide=3, rnd=4, flf=False, omega=4.0, omega_r=4.0, cfg=1.0, F=5, H=32, W=32,
+                     guided=True, shift=3.0),
+}
+
+
+def case_inputs(c, seed=42):
+    g = torch.Generator().manual_seed(1000 + seed)
+    image = torch.rand(3, c["H"], c["W"], generator=g)
+    ref, mask = synthetic_ref_and_mask(c["F"], c["H"], c["W"], seed=seed)
+    ref[:, :, 0] = image  # first frame of the warped sequence is the input image
+    pe = torch.randn(1, 16, 32, generator=g).to(torch.bfloat16)
+    ne = torch.randn(1, 16, 32, generator=g).to(torch.bfloat16)
+    ie = torch.randn(1, 8, 16, generator=g)
+    return image, ref, mask, pe, ne, ie
+
+
+def g_pipeline():
+    from utils.pipeline_wan_i2v_clean import WanImageToVideoPipeline
+    from utils.scheduling_unipc_multistep_clean import UniPCMultistepScheduler
+
+    for name, c in PIPE_CASES.items():
+        image, ref, mask, pe, ne, ie = case_inputs(c)
+        dit, vae = FakeDiT(), FakeVAE()
+        sch = UniPCMultistepScheduler(prediction_type="flow_prediction", use_flow_sigmas=True, flow_shift=c["shift"])
+        pipe = WanImageToVideoPipeline(tokenizer=None, text_encoder=None, image_encoder=_ImgEnc(ie),
+                                       image_processor=_ImgProc(), transformer=dit, vae=vae, scheduler=sch)
+        rec = {}
+        calls = []
+        orig_step = sch.step
+
+        def wrapped(*a, **k):
+            o = orig_step(*a, **k)
+            calls.append((t2n(o.prev_sample), t2n(o.pred_x0), str(o.prev_sample.dtype), str(o.pred_x0.dtype)))
+            return o
+
+        sch.step = wrapped
+        lat_steps = []
+
+        def cb(p, i, t, kw):
+            lat_steps.append((t2n(kw["latents"]), str(kw["latents"].dtype)))
+            return {}
+
+        gen = torch.manual_seed(42)
+        out = pipe(image=image, prompt=None, negative_prompt=None, height=c["H"], width=c["W"], num_frames=c["F"],
+                   num_inference_steps=c["steps"], guidance_scale=c["cfg"], generator=gen, prompt_embeds=pe,
+                   negative_prompt_embeds=ne, output_type="np", video_ref=ref, mask=mask, guided=c["guided"],
+                   resample_steps=c["R"], guide_steps=c["guide"], omega=c["omega"], omega_resample=c["omega_r"],
+                   resample_round=c["rnd"], use_pca_channel_selection=c["flf"], static=True, callback_on_step_end=cb)
+        frames = out.frames
+        rec["frames"] = np.asarray(frames, dtype=np.float32)
+        rec["n_calls"] = np.array([dit.calls, vae.n_enc, vae.n_dec])
+        for j, (p, x0, dp, dx) in enumerate(calls):
+            rec[f"call{j}_prev"] = p
+            rec[f"call{j}_x0"] = x0
+            rec[f"call{j}_dtypes"] = np.array([dp, dx])
+        for j, (l, d) in enumerate(lat_steps):
+            rec[f"lat{j}"] = l
+            rec[f"lat{j}_dtype"] = np.array([d])
+        rec["n_step_calls"] = np.array([len(calls)])
+        np.savez_compressed(os.path.join(OUT, f"g6_pipe_{name}.npz"), **rec)
+        print("g6", name, "dit/enc/dec calls", rec["n_calls"], "step calls", len(calls), "frames", rec["frames"].shape)
+
+
+# ------------------------------------------------------------------------------------------------------------
+def g_flf():
+    from utils.scheduling_unipc_multistep_clean import VideoMotionPCASelector
+
+    sel = VideoMotionPCASelector()
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    # flow metric on random 2-component and 1-component flows of several magnitudes
+    for k, (scale_r, scale_c, cr, cc) in enumerate([(1.0, 1.0, 2, 2), (6.0, 5.0, 2, 2), (0.2, 0.3, 1, 1), (4.0, 0.5, 2, 1),
+                                                    (12.0, 12.0, 1, 1)]):
+        r = torch.randn(1, 6, cr, 10, 12, generator=g) * scale_r
+        c = r * 0.7 + torch.randn(1, 6, cc, 10, 12, generator=g) * scale_c if cr == cc else torch.randn(
+            1, 6, cc, 10, 12, generator=g) * scale_c
+        out[f"fm{k}_ref"] = r.numpy()
+        out[f"fm{k}_chan"] = c.numpy()
+        out[f"fm{k}_sim"] = np.array([sel._compute_flow_metrics(r, c, None)])
+    # threshold logic with injected similarities
+    sims_sets = [torch.rand(16, generator=g).numpy().astype(np.float64) for _ in range(3)]
+    sims_sets.append(np.full(16, 0.5))
+    sims_sets.append(np.concatenate([np.full(8, 0.1), np.full(8, 0.9)]))
+    for si, sims in enumerate(sims_sets):
+        out[f"sel{si}_sims"] = sims
+        for step in (0, 1, 2, 3, 5, 6, 10, 11, 30):
+            sel2 = VideoMotionPCASelector()
+            sel2._compute_channel_correlations = lambda *a, _s=sims, **k: list(_s)
+            x = torch.zeros(1, 16, 3, 4, 4)
+            ch = sel2.select_motion_related_channels(x, x, None, current_step=step, use_optical_flow=False)
+            out[f"sel{si}_step{step}"] = np.array(ch, dtype=np.int64)
+    # end-to-end temporal-difference branch (what the reference executes without cv2)
+    pred = torch.randn(1, 16, 5, 6, 8, generator=g)
+    enc = pred * 0.8 + 0.3 * torch.randn(1, 16, 5, 6, 8, generator=g)
+    enc[:, 3] = torch.randn(5, 6, 8, generator=g) * 9
+    enc[:, 9] = torch.randn(5, 6, 8, generator=g) * 7
+    for step in (3, 8, 12):
+        ch = VideoMotionPCASelector().select_motion_related_channels(pred, enc, None, current_step=step,
+                                                                     use_optical_flow=True)
+        out[f"e2e_step{step}"] = np.array(ch, dtype=np.int64)
+    out["e2e_pred"] = pred.numpy()
+    out["e2e_enc"] = enc.numpy()
+    sims = VideoMotionPCASelector()._compute_channel_correlations(
+        pred, enc, None, True,
+        [(enc[:, c:c + 1, 1:] - enc[:, c:c + 1, :-1]).permute(0, 2, 1, 3, 4) for c in range(16)])
+    out["e2e_sims"] = np.array(sims)
+    np.savez_compressed(os.path.join(OUT, "g4_flf.npz"), **out)
+    print("g4_flf", len(out))
+
+
+# ------------------------------------------------------------------------------------------------------------
+def _extract_functions(path, names):
+    """Execute only the named top-level function definitions of a reference script (INFER runs its CLI at import)."""
+    src = open(path).read()
+    tree = ast.parse(src)
+    ns = {}
+    exec("import os, glob\nimport numpy as np\nfrom PIL import Image\nfrom scipy.ndimage import distance_transform_edt\n", ns)
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def g_harness():
+    ns = _extract_functions(os.path.join(REF, "infer_worldforge.py"), {"soften_mask", "read_frames_from_directory"})
+    soften = ns["soften_mask"]
+    out = {}
+    yy, xx = np.mgrid[0:48, 0:64]
+    disc = ((yy - 24) ** 2 + (xx - 30) ** 2 < 18 ** 2).astype(np.float64)
+    half = (xx < 37).astype(np.float64)
+    grey = half.copy()
+    grey[:, 30:37] = 0.4  # non-binary edge values as produced by PIL bicubic resize (any non-zero counts as True)
+    masks = np.stack([disc, half, np.ones_like(disc), np.zeros_like(disc), grey])
+    out["masks"] = masks
+    for decay in ("linear", "exponential", "sine", "cosine"):
+        for d in (5, 15):
+            out[f"soft_{decay}_{d}"] = soften(masks, d, decay)
+    # size rule INFER:218-222
+    rows = []
+    for (ih, iw) in [(720, 1280), (480, 832), (512, 960), (1080, 1920), (1000, 1000), (832, 480)]:
+        for max_area in (480 * 832, 720 * 1280):
+            ar = ih / iw
+            h = round(np.sqrt(max_area * ar)) // 16 * 16
+            w = round(np.sqrt(max_area / ar)) // 16 * 16
+            rows.append([ih, iw, max_area, h, w])
+    out["size_rule"] = np.array(rows)
+    np.savez_compressed(os.path.join(OUT, "g10_harness.npz"), **out)
+    print("g10_harness", len(out))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["sched", "pipe", "flf", "harness"]
+    if "sched" in which:
+        g_schedules()
+    if "pipe" in which:
+        g_pipeline()
+    if "flf" in which:
+        g_flf()
+    if "harness" in which:
+        g_harness()

@@ -1,0 +1,271 @@
+// Trajectory-injection reductions and resizes: DSG (PIPE:664-681), FLF flow metric (SCHED:497-607),
+// temporal-difference motion (SCHED:391-392), bilinear / nearest resize (SCHED:1316-1324, 1355-1362).
+// HBM-bound; reductions use a fixed two-level tree (per-thread -> wave shuffle -> LDS -> per-block partial -> one
+// finishing block), no floating-point atomics, so results are bit-identical run to run.
+// Compiled with -ffp-contract=off (every torch op rounds separately).
+#include "common.h"
+
+using namespace wf;
+
+#define RED_BLOCK 256
+#define RED_NBLK 256  // per-block partials of the first level
+
+// Block-level sum of K floats per thread -> thread 0 holds the totals.
+template <int K>
+__device__ __forceinline__ void block_sum(float (&v)[K], float* smem /* K * 4 floats */) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) smem[k * 4 + wid] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = (smem[k * 4 + 0] + smem[k * 4 + 1]) + (smem[k * 4 + 2] + smem[k * 4 + 3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DSG
+// ------------------------------------------------------------------------------------------------
+template <bool RB>
+__global__ void k_dsg_reduce(TView g, TView w, float* ws, size_t n) {
+  __shared__ float sm[12];
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float a = tload(g, i), b = tload(w, i);
+    acc[0] += rnd<RB>(a * b);
+    acc[1] += rnd<RB>(a * a);
+    acc[2] += rnd<RB>(b * b);
+  }
+  block_sum<3>(acc, sm);
+  if (threadIdx.x == 0) {
+    ws[8 + 3 * blockIdx.x + 0] = acc[0];
+    ws[8 + 3 * blockIdx.x + 1] = acc[1];
+    ws[8 + 3 * blockIdx.x + 2] = acc[2];
+  }
+}
+// PIPE:669-676 on three scalars.  One block; fixed-order tree over the RED_NBLK partials.
+template <bool RB>
+__global__ void k_dsg_coeff(float* ws, int nblk) {
+  __shared__ float sm[12];
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+    acc[0] += ws[8 + 3 * i + 0];
+    acc[1] += ws[8 + 3 * i + 1];
+    acc[2] += ws[8 + 3 * i + 2];
+  }
+  block_sum<3>(acc, sm);
+  if (threadIdx.x == 0) {
+    float dot = rnd<RB>(acc[0]), ng2 = rnd<RB>(acc[1]), nw2 = rnd<RB>(acc[2]);
+    float ng = rnd<RB>(sqrtf(ng2)), nw = rnd<RB>(sqrtf(nw2));
+    float den = rnd<RB>(rnd<RB>(ng * nw) + 1e-8f);
+    float c = rnd<RB>(dot / den);
+    float cl = fminf(fmaxf(c, -1.0f), 1.0f);
+    float ang = rnd<RB>(acosf(cl));
+    float s = rnd<RB>(sinf(ang));
+    float ratio = rnd<RB>(ng / rnd<RB>(nw + 1e-8f));
+    ws[0] = dot;
+    ws[1] = ng2;
+    ws[2] = nw2;
+    ws[3] = c;
+    ws[4] = s;
+    ws[5] = ratio;
+    ws[6] = 0.f;
+    ws[7] = 0.f;
+  }
+}
+// PIPE:681  good + omega*sin_theta * (good - (magnitude_ratio*cos_theta) * worse)
+template <bool RB>
+__global__ void k_dsg_apply(TView g, TView w, TView o, const float* ws, float omega, size_t n) {
+  const float A = rnd<RB>(omega * ws[4]);
+  const float Bc = rnd<RB>(ws[5] * ws[3]);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float a = tload(g, i), b = tload(w, i);
+    float t = rnd<RB>(Bc * b);
+    t = rnd<RB>(a - t);
+    t = rnd<RB>(A * t);
+    tstore(o, i, rnd<RB>(a + t));
+  }
+}
+extern "C" size_t wf_dsg_workspace_floats(void) { return 8 + 3 * RED_NBLK; }
+extern "C" int wf_dsg(const void* g, const void* w, void* out, int dt, float omega, size_t n, float* ws, void* stream) {
+  WF_CHECK_ARG(g && w && out && ws, "wf_dsg: null pointer");
+  WF_CHECK_ARG(dt == WF_F32 || dt == WF_BF16, "wf_dsg: bad dtype %d", dt);
+  WF_CHECK_ARG(n > 0, "wf_dsg: empty tensor");
+  TView gv{(void*)g, dt}, wv{(void*)w, dt}, ov{out, dt};
+  hipStream_t s = (hipStream_t)stream;
+  int nblk = grid_for(n, RED_BLOCK, RED_NBLK);
+  if (dt == WF_BF16) {
+    hipLaunchKernelGGL(k_dsg_reduce<true>, dim3(nblk), dim3(RED_BLOCK), 0, s, gv, wv, ws, n);
+    hipLaunchKernelGGL(k_dsg_coeff<true>, dim3(1), dim3(RED_BLOCK), 0, s, ws, nblk);
+    hipLaunchKernelGGL(k_dsg_apply<true>, dim3(grid_for(n, RED_BLOCK)), dim3(RED_BLOCK), 0, s, gv, wv, ov, ws, omega, n);
+  } else {
+    hipLaunchKernelGGL(k_dsg_reduce<false>, dim3(nblk), dim3(RED_BLOCK), 0, s, gv, wv, ws, n);
+    hipLaunchKernelGGL(k_dsg_coeff<false>, dim3(1), dim3(RED_BLOCK), 0, s, ws, nblk);
+    hipLaunchKernelGGL(k_dsg_apply<false>, dim3(grid_for(n, RED_BLOCK)), dim3(RED_BLOCK), 0, s, gv, wv, ov, ws, omega, n);
+  }
+  WF_LAUNCH_CHECK("wf_dsg");
+  return WF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SCHED:391-392 / 478-479: channel_motion = x[:, :, 1:] - x[:, :, :-1] (then permuted to [T-1, 1, h, w] per channel)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_tdiff(TView x, float* out, int C, int T, size_t hw, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    size_t p = i % hw;
+    size_t ct = i / hw;
+    int t = (int)(ct % (T - 1));
+    size_t c = ct / (T - 1);
+    size_t src = (c * T + t) * hw + p;
+    out[i] = tload(x, src + hw) - tload(x, src);
+  }
+}
+extern "C" int wf_temporal_diff(const void* x, int dt, float* out, int C, int T, size_t hw, void* stream) {
+  WF_CHECK_ARG(x && out, "wf_temporal_diff: null pointer");
+  WF_CHECK_ARG(T >= 2, "wf_temporal_diff: needs at least 2 frames, got %d", T);
+  size_t n = (size_t)C * (T - 1) * hw;
+  if (n == 0) return WF_OK;
+  TView xv{(void*)x, dt};
+  hipLaunchKernelGGL(k_tdiff, dim3(grid_for(n, RED_BLOCK)), dim3(RED_BLOCK), 0, (hipStream_t)stream, xv, out, C, T, hw, n);
+  WF_LAUNCH_CHECK("wf_temporal_diff");
+  return WF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SCHED:497-607 _compute_flow_metrics (mask=None path): per channel three means -> similarity
+// ------------------------------------------------------------------------------------------------
+#define FM_NBLK 32
+__global__ void k_flow_partial(const float* __restrict__ ref, const float* __restrict__ chan, float* ws, int Tm, int Cr,
+                               int Cc, size_t hw) {
+  __shared__ float sm[12];
+  const int ch = blockIdx.y;
+  const size_t npix = (size_t)Tm * hw;
+  const float* r = ref + (size_t)ch * Tm * Cr * hw;
+  const float* c = chan + (size_t)ch * Tm * Cc * hw;
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+    size_t t = i / hw, p = i % hw;
+    float r0 = r[(t * Cr + 0) * hw + p];
+    float r1 = (Cr >= 2) ? r[(t * Cr + 1) * hw + p] : r0;
+    float c0 = c[(t * Cc + 0) * hw + p];
+    float c1 = (Cc >= 2) ? c[(t * Cc + 1) * hw + p] : c0;
+    float d0 = r0 - c0, d1 = r1 - c1;
+    float epe = sqrtf((d0 * d0 + d1 * d1) + 1e-8f);
+    float dot = r0 * c0 + r1 * c1;
+    float rn = sqrtf((r0 * r0 + r1 * r1) + 1e-8f);
+    float cn = sqrtf((c0 * c0 + c1 * c1) + 1e-8f);
+    float ca = dot / (rn * cn + 1e-8f);
+    ca = fminf(fmaxf(ca, -1.0f), 1.0f);
+    float ae = acosf(ca) * 180.0f / 3.14159265358979323846f;
+    bool outl = (epe > 3.0f) && (epe > rn * 0.05f);
+    acc[0] += epe;
+    acc[1] += ae;
+    acc[2] += outl ? 1.0f : 0.0f;
+  }
+  block_sum<3>(acc, sm);
+  if (threadIdx.x == 0) {
+    float* o = ws + ((size_t)ch * FM_NBLK + blockIdx.x) * 3;
+    o[0] = acc[0];
+    o[1] = acc[1];
+    o[2] = acc[2];
+  }
+}
+__global__ void k_flow_final(const float* ws, float* sim, int Tm, size_t hw) {
+  const int ch = blockIdx.x;
+  // 64 threads, FM_NBLK (=32) partials: fixed-order wave tree
+  float a[3] = {0.f, 0.f, 0.f};
+  if (threadIdx.x < FM_NBLK) {
+    const float* p = ws + ((size_t)ch * FM_NBLK + threadIdx.x) * 3;
+    a[0] = p[0];
+    a[1] = p[1];
+    a[2] = p[2];
+  }
+  a[0] = wave_sum(a[0]);
+  a[1] = wave_sum(a[1]);
+  a[2] = wave_sum(a[2]);
+  if (threadIdx.x == 0) {
+    float N = (float)((size_t)Tm * hw);
+    float m_epe = a[0] / N, m_ae = a[1] / N, fl = a[2] / N;
+    float ne = fminf(fmaxf(m_epe / 10.0f, 0.f), 1.f);
+    float nf = fminf(fmaxf(fl / 0.5f, 0.f), 1.f);
+    float na = fminf(fmaxf(m_ae / 30.0f, 0.f), 1.f);
+    float werr = (0.45f * ne + 0.45f * nf) + 0.1f * na;
+    float s = 1.0f - werr;
+    sim[ch] = fminf(fmaxf(s, 0.f), 1.f);
+  }
+}
+extern "C" size_t wf_flow_metrics_workspace_floats(int n_channels) { return (size_t)n_channels * FM_NBLK * 3; }
+extern "C" int wf_flow_metrics(const float* ref_flow, const float* chan_flow, float* sim, int n_channels, int Tm, int Cr,
+                               int Cc, size_t hw, float* ws, void* stream) {
+  WF_CHECK_ARG(ref_flow && chan_flow && sim && ws, "wf_flow_metrics: null pointer");
+  WF_CHECK_ARG((Cr == 1 || Cr == 2) && (Cc == 1 || Cc == 2), "wf_flow_metrics: flow components must be 1 or 2");
+  WF_CHECK_ARG(n_channels > 0 && Tm > 0 && hw > 0, "wf_flow_metrics: empty input");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_flow_partial, dim3(FM_NBLK, n_channels), dim3(RED_BLOCK), 0, s, ref_flow, chan_flow, ws, Tm, Cr, Cc, hw);
+  hipLaunchKernelGGL(k_flow_final, dim3(n_channels), dim3(64), 0, s, ws, sim, Tm, hw);
+  WF_LAUNCH_CHECK("wf_flow_metrics");
+  return WF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Resize: PyTorch upsample_bilinear2d (align_corners=False) and legacy 'nearest'
+// ------------------------------------------------------------------------------------------------
+__global__ void k_bilinear(const float* __restrict__ in, float* __restrict__ out, int Hi, int Wi, int Ho, int Wo, float rh,
+                           float rw, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    int x = (int)(i % Wo);
+    int y = (int)((i / Wo) % Ho);
+    size_t nimg = i / ((size_t)Wo * Ho);
+    float sy = rh * ((float)y + 0.5f) - 0.5f;
+    sy = sy < 0.f ? 0.f : sy;
+    int y0 = (int)sy;
+    int yp = (y0 < Hi - 1) ? 1 : 0;
+    float ly1 = sy - (float)y0, ly0 = 1.0f - ly1;
+    float sx = rw * ((float)x + 0.5f) - 0.5f;
+    sx = sx < 0.f ? 0.f : sx;
+    int x0 = (int)sx;
+    int xp = (x0 < Wi - 1) ? 1 : 0;
+    float lx1 = sx - (float)x0, lx0 = 1.0f - lx1;
+    const float* p = in + nimg * (size_t)Hi * Wi;
+    float v00 = p[(size_t)y0 * Wi + x0], v01 = p[(size_t)y0 * Wi + x0 + xp];
+    float v10 = p[(size_t)(y0 + yp) * Wi + x0], v11 = p[(size_t)(y0 + yp) * Wi + x0 + xp];
+    out[i] = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+  }
+}
+__global__ void k_nearest(const float* __restrict__ in, float* __restrict__ out, int Hi, int Wi, int Ho, int Wo, float rh,
+                          float rw, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    int x = (int)(i % Wo);
+    int y = (int)((i / Wo) % Ho);
+    size_t nimg = i / ((size_t)Wo * Ho);
+    int ys = min((int)floorf((float)y * rh), Hi - 1);
+    int xs = min((int)floorf((float)x * rw), Wi - 1);
+    out[i] = in[nimg * (size_t)Hi * Wi + (size_t)ys * Wi + xs];
+  }
+}
+static int resize_common(const char* name, bool bil, const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo,
+                         void* stream) {
+  WF_CHECK_ARG(in && out, "%s: null pointer", name);
+  WF_CHECK_ARG(N >= 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "%s: bad sizes", name);
+  size_t n = (size_t)N * Ho * Wo;
+  if (n == 0) return WF_OK;
+  float rh = (float)Hi / (float)Ho, rw = (float)Wi / (float)Wo;
+  if (bil)
+    hipLaunchKernelGGL(k_bilinear, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, in, out, Hi, Wi, Ho, Wo,
+                       rh, rw, n);
+  else
+    hipLaunchKernelGGL(k_nearest, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, in, out, Hi, Wi, Ho, Wo,
+                       rh, rw, n);
+  WF_LAUNCH_CHECK(name);
+  return WF_OK;
+}
+extern "C" int wf_resize_bilinear2d(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, void* stream) {
+  return resize_common("wf_resize_bilinear2d", true, in, out, N, Hi, Wi, Ho, Wo, stream);
+}
+extern "C" int wf_resize_nearest2d(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, void* stream) {
+  return resize_common("wf_resize_nearest2d", false, in, out, N, Hi, Wi, Ho, Wo, stream);
+}
