@@ -58,9 +58,9 @@ __global__ void k_cfg(TView c, TView u, TView o, float g, size_t n) {
   }
 }
 extern "C" int wf_cfg_combine(const void* cond, const void* uncond, void* out, int dt, float g, size_t n, void* stream) {
+  if (n == 0) return WF_OK;
   WF_CHECK_ARG(cond && uncond && out, "wf_cfg_combine: null pointer");
   WF_CHECK_ARG(dt == WF_F32 || dt == WF_BF16, "wf_cfg_combine: bad dtype %d", dt);
-  if (n == 0) return WF_OK;
   TView c{(void*)cond, dt}, u{(void*)uncond, dt}, o{out, dt};
   dim3 g3(grid_for(n, EW_BLOCK));
   if (dt == WF_BF16)
@@ -86,8 +86,8 @@ __global__ void k_x0(TView s, TView v, TView o, float sigma, bool rb_v, bool rb_
 }
 extern "C" int wf_x0_from_v(const void* sample, int dt_s, const void* v, int dt_v, void* out, float sigma, size_t n,
                             void* stream) {
-  WF_CHECK_ARG(sample && v && out, "wf_x0_from_v: null pointer");
   if (n == 0) return WF_OK;
+  WF_CHECK_ARG(sample && v && out, "wf_x0_from_v: null pointer");
   int dt_o = (dt_s == WF_BF16 && dt_v == WF_BF16) ? WF_BF16 : WF_F32;
   TView s{(void*)sample, dt_s}, vv{(void*)v, dt_v}, o{out, dt_o};
   hipLaunchKernelGGL(k_x0, dim3(grid_for(n, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream, s, vv, o, sigma,
@@ -131,8 +131,8 @@ __global__ void k_unipc(TView x, TView m0, TView m1, TView o, float c1, float c2
 }
 extern "C" int wf_unipc_update(const void* x, int dt_x, const void* m0, int dt_m0, const void* m1, int dt_m1, void* out,
                                float c1, float c2, float c3, float rk, size_t n, void* stream) {
-  WF_CHECK_ARG(x && m0 && out, "wf_unipc_update: null pointer");
   if (n == 0) return WF_OK;
+  WF_CHECK_ARG(x && m0 && out, "wf_unipc_update: null pointer");
   UniPFlags f;
   f.order2 = (m1 != nullptr);
   f.ra = dt_x == WF_BF16;
@@ -164,8 +164,8 @@ __global__ void k_add_noise(TView x0, TView nz, TView o, float oms, float s, boo
 }
 extern "C" int wf_add_noise(const void* x0, int dt_x0, const void* noise, int dt_n, void* out, float one_minus_sigma,
                             float sigma, size_t n, void* stream) {
-  WF_CHECK_ARG(x0 && noise && out, "wf_add_noise: null pointer");
   if (n == 0) return WF_OK;
+  WF_CHECK_ARG(x0 && noise && out, "wf_add_noise: null pointer");
   bool bx = dt_x0 == WF_BF16, bn = dt_n == WF_BF16;
   int dt_o = (bx && bn) ? WF_BF16 : WF_F32;
   TView a{(void*)x0, dt_x0}, b{(void*)noise, dt_n}, o{out, dt_o};
@@ -280,9 +280,9 @@ __global__ void k_post(const float* __restrict__ x, float* __restrict__ out, int
   }
 }
 extern "C" int wf_postprocess_video(const float* x, float* out, int C, int F, int H, int W, void* stream) {
-  WF_CHECK_ARG(x && out, "wf_postprocess_video: null pointer");
   size_t fhw = (size_t)F * H * W, n = fhw * C;
   if (n == 0) return WF_OK;
+  WF_CHECK_ARG(x && out, "wf_postprocess_video: null pointer");
   hipLaunchKernelGGL(k_post, dim3(grid_for(n, EW_BLOCK, 4096)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, out, C, fhw, n);
   WF_LAUNCH_CHECK("wf_postprocess_video");
   return WF_OK;
@@ -293,8 +293,8 @@ __global__ void k_cast(TView a, TView o, size_t n) {
   EW_LOOP(i, n) tstore(o, i, tload(a, i));
 }
 extern "C" int wf_cast(const void* in, int dt_in, void* out, int dt_out, size_t n, void* stream) {
-  WF_CHECK_ARG(in && out, "wf_cast: null pointer");
   if (n == 0) return WF_OK;
+  WF_CHECK_ARG(in && out, "wf_cast: null pointer");
   TView a{(void*)in, dt_in}, o{out, dt_out};
   hipLaunchKernelGGL(k_cast, dim3(grid_for(n, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream, a, o, n);
   WF_LAUNCH_CHECK("wf_cast");

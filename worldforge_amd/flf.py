@@ -1,0 +1,76 @@
+"""FLF (flow-gated latent fusion) channel selector, HIP-backed.
+
+Mirror of `VideoMotionPCASelector.select_motion_related_channels` (SCHED:338-437) and its metric
+`_compute_flow_metrics` (SCHED:497-607).  The per-channel motion extraction + the three-way metric reduction run on the
+GPU for all 16 channels in two launches; the 16 similarities come back in ONE device->host copy (the reference does 32
+D2H copies and 16 `.item()` syncs per call), and the threshold logic (16 scalars) stays on the host as in the reference.
+
+flow_backend:
+  "tdiff"     -- temporal difference motion (SCHED:391-392 / 478-479): the branch the reference executes whenever
+                 `import cv2` fails (SCHED:159-161 -> except at :390), and the one pinned by golden vectors.
+  "farneback" -- OpenCV Farneback (SCHED:220-224).  OpenCV is a third-party dependency absent from /root/reference and
+                 from this image; a GPU Farneback is scheduled and raises NotImplementedError until it
+                 can be pinned -- never a silent fallback.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class VideoMotionPCASelector:
+    def __init__(self, flow_backend: str = "tdiff"):
+        if flow_backend not in ("tdiff", "farneback"):
+            raise ValueError(f"unknown flow_backend {flow_backend!r}")
+        self.flow_backend = flow_backend
+        self.last_similarities = None
+
+    def channel_similarities(self, pred_original_sample: torch.Tensor, video_latents: torch.Tensor) -> np.ndarray:
+        """SCHED:373-397 + 439-495 -> numpy float64 array of C similarities."""
+        if self.flow_backend != "tdiff":
+            raise NotImplementedError("flow_backend='farneback' is not built yet (needs a cv2-pinned GPU Farneback)")
+        if pred_original_sample.shape[0] != 1:
+            raise NotImplementedError("FLF: batch size 1 only (as the reference's squeeze(0) path)")
+        ref_m = ops.temporal_diff(video_latents[0])        # [C, T-1, h, w] fp32 (video_latents promoted to fp32 first)
+        ch_m = ops.temporal_diff(pred_original_sample[0])  # [C, T-1, h, w] fp32
+        sim = ops.flow_metrics(ref_m.unsqueeze(2), ch_m.unsqueeze(2))
+        self.last_similarities = sim.cpu().numpy().astype(np.float64)  # the single sync of the FLF gate
+        return self.last_similarities
+
+    @staticmethod
+    def select_from_similarities(channel_correlations, current_step: int) -> List[int]:
+        """SCHED:408-437."""
+        if current_step < 2:
+            return []
+        corr = np.array(channel_correlations)
+        corr_mean, corr_std = np.mean(corr), np.std(corr)
+        if current_step <= 10:
+            max_replace = 0 if current_step <= 5 else 1
+            channels = np.argsort(corr)[:max_replace].tolist()
+        else:
+            threshold = corr_mean - 0.625 * corr_std
+            below = [i for i, s in enumerate(corr) if s < threshold]
+            if len(below) < 2:
+                channels = np.argsort(corr)[:2].tolist()
+            elif len(below) > 6:
+                scored = sorted([(i, corr[i]) for i in below], key=lambda x: x[1])
+                channels = [i for i, _ in scored[:6]]
+            else:
+                channels = below
+        channels.sort()
+        return channels
+
+    def select_motion_related_channels(self, pred_original_sample: torch.Tensor, video_latents: torch.Tensor, mask=None,
+                                       keep_channels: int = 12, current_step: int = 0, total_steps: int = 50,
+                                       use_optical_flow: bool = True, static: bool = False, **kwargs) -> List[int]:
+        """SCHED:338-437."""
+        if current_step < 2:
+            return []
+        if pred_original_sample.dim() != 5 or video_latents.dim() != 5:
+            return list(range(min(2, pred_original_sample.shape[1])))
+        sims = self.channel_similarities(pred_original_sample, video_latents)
+        return self.select_from_similarities(sims, current_step)

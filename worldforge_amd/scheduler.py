@@ -1,0 +1,366 @@
+"""HIP-backed UniPC(bh2) flow-matching scheduler with the WorldForge injection / resample extensions.
+
+Host-side mirror of the reference's scheduler protocol -- same method names, argument meaning, attribute names and
+error behaviour as `UniPCMultistepScheduler` in /root/reference/wan_for_worldforge/utils/scheduling_unipc_multistep_clean.py
+(SCHED) -- so the guided sampler (pipeline.py) and the reference's own loop can drive it unchanged.  All tensor
+arithmetic runs in hand-written HIP kernels through the C-ABI (ops.py); the host keeps only what the reference also
+keeps on the host: sigma tables, step counters and a handful of fp32 scalars per step.
+
+Only the configuration the Wan2.1 checkpoints ship is implemented (flow_prediction, use_flow_sigmas, bh2, predict_x0,
+solver_order 2, lower_order_final); anything else raises NotImplementedError instead of silently diverging.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Any, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .flf import VideoMotionPCASelector
+
+
+@dataclass
+class CustomSchedulerOutput:
+    """SCHED:1522-1534."""
+    prev_sample: torch.Tensor
+    pred_x0: torch.Tensor
+
+    def __getitem__(self, idx):
+        if idx == 0:
+            return self.prev_sample
+        if idx == 1:
+            return self.pred_x0
+        raise IndexError(f"Invalid index {idx}")
+
+
+class UniPCMultistepScheduler:
+    order = 1
+
+    def __init__(self, num_train_timesteps: int = 1000, solver_order: int = 2, prediction_type: str = "flow_prediction",
+                 predict_x0: bool = True, solver_type: str = "bh2", lower_order_final: bool = True,
+                 disable_corrector: Optional[List[int]] = None, use_flow_sigmas: bool = True, flow_shift: float = 3.0,
+                 final_sigmas_type: str = "zero", flow_backend: str = "tdiff"):
+        if prediction_type != "flow_prediction" or not use_flow_sigmas or not predict_x0 or solver_type != "bh2":
+            raise NotImplementedError("only the Wan2.1 configuration (flow_prediction, flow sigmas, bh2, predict_x0) is built")
+        if solver_order != 2 or final_sigmas_type != "zero":
+            raise NotImplementedError("solver_order must be 2 and final_sigmas_type 'zero'")
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, solver_order=solver_order,
+                                      prediction_type=prediction_type, predict_x0=predict_x0, solver_type=solver_type,
+                                      lower_order_final=lower_order_final, use_flow_sigmas=use_flow_sigmas,
+                                      flow_shift=flow_shift, final_sigmas_type=final_sigmas_type)
+        self.predict_x0 = predict_x0
+        self.num_inference_steps = None
+        self.model_outputs = [None] * solver_order
+        self.timestep_list = [None] * solver_order
+        self.lower_order_nums = 0
+        self.disable_corrector = list(disable_corrector or [])
+        self.last_sample = None
+        self._step_index = None
+        self._begin_index = None
+        self.derivative_history = []
+        self.last_lower_order_nums = 0
+        self.this_order = None
+        self.last_this_order = None
+        self._pca_selector = None
+        self.flow_backend = flow_backend
+        self.resample_sigmas = None
+        self.resample_timesteps = None
+        self.is_resampling = False
+        self.original_step_index = None
+        self.sigmas = None
+        self.timesteps = None
+
+    @classmethod
+    def from_config(cls, config, **kw):
+        cfg = dict(config) if not isinstance(config, SimpleNamespace) else dict(vars(config))
+        keys = ("num_train_timesteps", "solver_order", "prediction_type", "predict_x0", "solver_type", "lower_order_final",
+                "disable_corrector", "use_flow_sigmas", "flow_shift", "final_sigmas_type")
+        args = {k: cfg[k] for k in keys if k in cfg}
+        args.update(kw)
+        return cls(**args)
+
+    # ---- bookkeeping (SCHED:758-767) ----------------------------------------------------------------
+    @property
+    def step_index(self):
+        return self._step_index
+
+    @property
+    def begin_index(self):
+        return self._begin_index
+
+    def set_begin_index(self, begin_index: int = 0):
+        self._begin_index = begin_index
+
+    # ---- SCHED:769-846 ---------------------------------------------------------------------------------
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        n_train, shift = self.config.num_train_timesteps, self.config.flow_shift
+        alphas = np.linspace(1, 1 / n_train, num_inference_steps + 1)
+        sigmas = 1.0 - alphas
+        sigmas = np.flip(shift * sigmas / (1 + (shift - 1) * sigmas))[:-1].copy()
+        timesteps = (sigmas * n_train).copy()
+        sigmas = np.concatenate([sigmas, [0]]).astype(np.float32)
+        self.sigmas = torch.from_numpy(sigmas)  # host table, like the reference (SCHED:838)
+        self.timesteps = torch.from_numpy(timesteps).to(dtype=torch.int64)  # host; values only feed the DiT's time embedding
+        self.num_inference_steps = len(timesteps)
+        self.model_outputs = [None] * self.config.solver_order
+        self.lower_order_nums = 0
+        self.last_sample = None
+        self._step_index = None
+        self._begin_index = None
+        self.clear_motion_cache()
+        self._compute_resample_sigmas_and_timesteps()
+
+    def clear_motion_cache(self):
+        self._pca_selector = None
+
+    def _compute_resample_sigmas_and_timesteps(self):
+        """SCHED:1594-1629 (flow branch)."""
+        if len(self.sigmas) < 2:
+            self.resample_sigmas = None
+            self.resample_timesteps = None
+            return
+        self.resample_sigmas = self.sigmas[:-1].clone()
+        self.resample_timesteps = torch.floor(self.resample_sigmas * self.config.num_train_timesteps).to(torch.int64)
+
+    def set_resample_mode(self, enabled: bool):
+        """SCHED:1631-1638."""
+        if enabled and not self.is_resampling:
+            self.original_step_index = self.step_index
+        self.is_resampling = enabled
+        if not enabled and self.original_step_index is not None:
+            self._step_index = self.original_step_index
+            self.original_step_index = None
+
+    def get_resample_timestep(self, step_index: int) -> torch.Tensor:
+        """SCHED:1640-1648."""
+        if self.resample_timesteps is not None and step_index < len(self.resample_timesteps):
+            return self.resample_timesteps[step_index]
+        return self.timesteps[min(step_index, len(self.timesteps) - 1)]
+
+    def index_for_timestep(self, timestep, schedule_timesteps=None):
+        """SCHED:1224-1237."""
+        if schedule_timesteps is None:
+            schedule_timesteps = self.timesteps
+        if isinstance(timestep, torch.Tensor):
+            timestep = timestep.detach().to("cpu")
+        cand = (schedule_timesteps == timestep).nonzero()
+        if len(cand) == 0:
+            return len(self.timesteps) - 1
+        if len(cand) > 1:
+            return cand[1].item()
+        return cand[0].item()
+
+    def _init_step_index(self, timestep):
+        if self.begin_index is None:
+            self._step_index = self.index_for_timestep(timestep)
+        else:
+            self._step_index = self._begin_index
+
+    def _sigma_to_alpha_sigma_t(self, sigma):
+        return 1 - sigma, sigma
+
+    def _current_sigma(self) -> torch.Tensor:
+        """SCHED:953-957."""
+        if self.is_resampling and self.resample_sigmas is not None:
+            return self.resample_sigmas[min(self.step_index, len(self.resample_sigmas) - 1)]
+        return self.sigmas[self.step_index]
+
+    # ---- SCHED:925-976 -----------------------------------------------------------------------------------
+    def convert_model_output(self, model_output: torch.Tensor, *args, sample: torch.Tensor = None, **kwargs) -> torch.Tensor:
+        if sample is None:
+            if len(args) > 1:
+                sample = args[1]
+            else:
+                raise ValueError("missing `sample` as required argument")
+        return ops.x0_from_v(sample, model_output, scalar_as(self._current_sigma(), model_output.dtype))
+
+    # ---- SCHED:978-1099 -----------------------------------------------------------------------------------
+    def _unip_coeffs(self, order: int):
+        """Scalar part of SCHED:1005-1069 in fp32 torch scalars, exactly as the reference computes it on the host."""
+        if self.is_resampling and self.resample_sigmas is not None:
+            n = len(self.resample_sigmas)
+            current_index = min(self.step_index, n - 1)
+            next_index = min(self.step_index + 1, n - 1)
+            sigma_t = self.sigmas[next_index]
+            sigma_s0 = self.resample_sigmas[current_index]
+        else:
+            sigma_t, sigma_s0 = self.sigmas[self.step_index + 1], self.sigmas[self.step_index]
+        alpha_t, sigma_t = self._sigma_to_alpha_sigma_t(sigma_t)
+        alpha_s0, sigma_s0 = self._sigma_to_alpha_sigma_t(sigma_s0)
+        lambda_t = torch.log(alpha_t) - torch.log(sigma_t)
+        lambda_s0 = torch.log(alpha_s0) - torch.log(sigma_s0)
+        h = lambda_t - lambda_s0
+        rk = None
+        if order == 2:
+            si = self.step_index - 1
+            if self.is_resampling and self.resample_sigmas is not None:
+                sig_si = self.resample_sigmas[min(max(si, 0), len(self.resample_sigmas) - 1)]
+            else:
+                sig_si = self.sigmas[si]
+            alpha_si, sigma_si = self._sigma_to_alpha_sigma_t(sig_si)
+            lambda_si = torch.log(alpha_si) - torch.log(sigma_si)
+            rk = (lambda_si - lambda_s0) / h
+        elif order != 1:
+            raise NotImplementedError("UniP order > 2")
+        hh = -h
+        h_phi_1 = torch.expm1(hh)
+        B_h = torch.expm1(hh)
+        return sigma_t / sigma_s0, alpha_t * h_phi_1, alpha_t * B_h, rk
+
+    def multistep_uni_p_bh_update(self, model_output: torch.Tensor, *args, sample: torch.Tensor = None, order: int = None,
+                                  **kwargs) -> torch.Tensor:
+        if sample is None:
+            if len(args) > 1:
+                sample = args[1]
+            else:
+                raise ValueError("missing `sample` as required argument")
+        if order is None:
+            if len(args) > 2:
+                order = args[2]
+            else:
+                raise ValueError("missing `order` as required argument")
+        c1, c2, c3, rk = self._unip_coeffs(order)
+        m0 = self.model_outputs[-1]
+        m1 = self.model_outputs[-2] if order == 2 else None
+        # `scalar_tensor * tensor` (scalar first): eager CPU PyTorch rounds the 0-dim fp32 scalar to the tensor's dtype
+        # before multiplying, whereas `tensor / scalar_tensor` keeps the fp32 value (see scalar_as).
+        res_dtype = torch.bfloat16 if (m1 is not None and all(
+            t.dtype == torch.bfloat16 for t in (sample, m0, m1))) else torch.float32
+        return ops.unipc_update(sample, m0, m1, scalar_as(c1, sample.dtype), scalar_as(c2, m0.dtype),
+                                scalar_as(c3, res_dtype), rk.item() if rk is not None else 1.0)
+
+    # ---- SCHED:1248-1421 ---------------------------------------------------------------------------------
+    def fuse_latents(self, pred_original_sample, video_latents, mask, vae=None, static=False, **kwargs):
+        """IRR injection: de-normalise -> VAE decode -> blend warped pixels -> VAE encode (mode) -> re-normalise -> FLF."""
+        if mask is None or video_latents is None or vae is None:
+            return pred_original_sample
+        x0 = pred_original_sample
+        mean, std = vae.config.latents_mean, vae.config.latents_std
+        decoded = vae.decode(ops.latent_denorm(x0, mean, std), return_dict=False)[0]
+        ref, m = align_reference(video_latents, mask, decoded.shape)
+        fused = ops.blend_pixels(ref, m, decoded)
+        enc = vae.encode(fused).latent_dist.mode()
+        enc = ops.latent_norm(enc, mean, std, const_dtype=x0.dtype)
+        if kwargs.get("use_pca_channel_selection") and not kwargs.get("resampling", False):
+            if self._pca_selector is None:
+                self._pca_selector = VideoMotionPCASelector(flow_backend=self.flow_backend)
+            channels = self._pca_selector.select_motion_related_channels(
+                pred_original_sample=x0, video_latents=ops.cast(enc, x0.dtype), mask=None, keep_channels=12,
+                current_step=kwargs.get("current_step", 0), total_steps=kwargs.get("total_steps", 50),
+                use_optical_flow=kwargs.get("use_optical_flow", True), static=static)
+            ops.channel_swap_(enc, x0, channels)
+        return ops.cast(enc, x0.dtype)
+
+    # ---- SCHED:1423-1536 ---------------------------------------------------------------------------------
+    def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, return_dict: bool = True,
+             mask: Optional[torch.Tensor] = None, guided: bool = False, video_latents: Optional[torch.Tensor] = None,
+             resampling: bool = False, vae: Optional[Any] = None, current_step: int = -1, resample_count: int = 2,
+             is_resample_round: bool = False, static: bool = False, **kwargs):
+        if self.num_inference_steps is None:
+            raise ValueError("Run 'set_timesteps' after creating scheduler")
+        if self.step_index is None:
+            self._init_step_index(timestep)
+        use_corrector = (self.step_index > 0 and self.step_index - 1 not in self.disable_corrector
+                         and self.last_sample is not None)
+        model_output_convert = self.convert_model_output(model_output, sample=sample)
+        if guided and video_latents is not None:
+            fuse_kwargs = kwargs.copy()
+            fuse_kwargs.update({"current_step": current_step,
+                                "total_steps": self.num_inference_steps if self.num_inference_steps else 50,
+                                "resampling": resampling, "static": static})
+            model_output_convert = self.fuse_latents(model_output_convert, video_latents, mask, vae=vae, **fuse_kwargs)
+        if not resampling:
+            for i in range(self.config.solver_order - 1):
+                self.model_outputs[i] = self.model_outputs[i + 1]
+                self.timestep_list[i] = self.timestep_list[i + 1]
+        self.model_outputs[-1] = model_output_convert
+        self.timestep_list[-1] = timestep
+        if self.config.lower_order_final:
+            this_order = min(self.config.solver_order, len(self.timesteps) - self.step_index)
+        else:
+            this_order = self.config.solver_order
+        self.last_this_order = self.this_order
+        self.this_order = min(this_order, self.lower_order_nums + 1)
+        assert self.this_order > 0
+        if not use_corrector:
+            self.last_sample = sample
+        if not is_resample_round:
+            self.last_sample = sample
+        if resample_count < 2:
+            self.last_sample = sample
+        if resampling:
+            self.derivative_history.append(model_output)
+        prev_sample = self.multistep_uni_p_bh_update(model_output=model_output, sample=sample, order=self.this_order)
+        self.last_lower_order_nums = self.lower_order_nums
+        if self.lower_order_nums < self.config.solver_order:
+            self.lower_order_nums += 1
+        self._step_index += 1
+        if not return_dict:
+            return (prev_sample,)
+        return CustomSchedulerOutput(prev_sample=prev_sample, pred_x0=model_output_convert)
+
+    def scale_model_input(self, sample: torch.Tensor, *args, **kwargs) -> torch.Tensor:
+        return sample
+
+    # ---- SCHED:1542-1585 ---------------------------------------------------------------------------------
+    def add_noise(self, original_samples: torch.Tensor, noise: torch.Tensor, timesteps, r: int = 0,
+                  use_resample_sigma: bool = False) -> torch.Tensor:
+        if use_resample_sigma and self.resample_sigmas is not None:
+            sigmas = self.resample_sigmas.to(dtype=original_samples.dtype)
+            schedule_timesteps = self.resample_timesteps
+        else:
+            sigmas = self.sigmas.to(dtype=original_samples.dtype)
+            schedule_timesteps = self.timesteps
+        timesteps = torch.as_tensor(timesteps).reshape(-1)
+        if timesteps.numel() != 1:
+            raise NotImplementedError("add_noise: one timestep per call (batch size 1 path)")
+        if self.begin_index is None:
+            k = self.index_for_timestep(timesteps[0], schedule_timesteps)
+        elif self.step_index is not None:
+            k = min(self.step_index, len(sigmas) - 1) if use_resample_sigma else self.step_index
+        else:
+            k = self.begin_index
+        s = sigmas[k]
+        return ops.add_noise(original_samples, noise, (1 - s).item(), s.item())
+
+    def __len__(self):
+        return self.config.num_train_timesteps
+
+
+def scalar_as(s: torch.Tensor, dtype: torch.dtype) -> float:
+    """Value of a 0-dim fp32 host tensor as eager CPU PyTorch uses it in `s * tensor[dtype]` (scalar operand FIRST): the
+    TensorIterator casts the scalar tensor to the common dtype before the multiply, so for a bf16 tensor the scalar is
+    rounded to bf16.  (With the scalar SECOND, or a Python float, PyTorch keeps fp32 -- PIPE:611, SCHED:1044.)  The
+    goldens are recorded from the reference's CPU eager path, which is the parity target (BASELINE.json north_star)."""
+    return s.to(dtype).float().item()
+
+
+def align_reference(ref: torch.Tensor, mask: torch.Tensor, target_shape):
+    """SCHED:1300-1374: bring the reference video / mask to the decoded video's shape (fp32).
+    Spatial size mismatches are resized on the GPU (bilinear for RGB, nearest for the mask); a frame-count mismatch raises
+    ValueError exactly like the reference's F.interpolate call on a 4-D tensor does (SCHED:1326-1334, 1364-1371)."""
+    B, C, Fr, H, W = target_shape
+    ref = ops.cast(ref, torch.float32) if ref.dtype == torch.bfloat16 else ref.to(torch.float32)
+    mask = mask.to(torch.float32)
+    if tuple(ref.shape) != tuple(target_shape):
+        if ref.shape[0] != B:
+            ref = ref.repeat(B, 1, 1, 1, 1)
+        if ref.shape[-2:] != (H, W):
+            ref = ops.resize_bilinear2d(ref, H, W)
+        if ref.shape[2] != Fr:
+            raise ValueError(f"Input and output must have the same number of frames: reference video has {ref.shape[2]}, "
+                             f"decoded video has {Fr}")
+    if tuple(mask.shape) != (B, 1, Fr, H, W):
+        if mask.shape[0] != B:
+            mask = mask.repeat(B, 1, 1, 1, 1)
+        if mask.shape[1] != 1:
+            mask = mask[:, 0:1].contiguous()
+        if mask.shape[-2:] != (H, W):
+            mask = ops.resize_nearest2d(mask, H, W)
+        if mask.shape[2] != Fr:
+            raise ValueError(f"Input and output must have the same number of frames: mask has {mask.shape[2]}, "
+                             f"decoded video has {Fr}")
+    return ref, mask
