@@ -109,6 +109,46 @@ size_t wf_flow_metrics_workspace_floats(int n_channels);
 int wf_flow_metrics(const float* ref_flow, const float* chan_flow, float* sim, int n_channels, int Tm, int Cr, int Cc,
                     size_t hw, float* ws, void* stream);
 
+/* ---- DiT (wan/modules/model.py; the in-tree statement of diffusers' WanTransformer3DModel) --------------------------- */
+#define WF_EPI_BF16 0       /* out bf16 = acc + bias */
+#define WF_EPI_BF16_GELU 1  /* out bf16 = gelu_tanh(acc + bias)            (model.py:272) */
+#define WF_EPI_F32 2        /* out f32  = acc + bias */
+#define WF_EPI_RESID 3      /* out f32 += (acc + bias) * gate[n] (gate NULL -> 1)   (model.py:306, 310, 313) */
+#define WF_EPI_F32_ACC 4    /* out f32 += acc + bias */
+/* nn.Linear on MFMA (model.py:123-126, 271-273, 332, 456-464; vae.py 1x1 convs): out[M,N] = epi(X[M,K] . W[N,K]^T + bias).
+ * X, W bf16 (row strides ldx, K); bias/gate f32; K % 8 == 0, N % 4 == 0, 16-byte aligned pointers. */
+int wf_gemm_bf16(const void* X, const void* W, const float* bias, void* out, const float* gate, int M, int N, int K, int ldx,
+                 int ldo, int epilogue, void* stream);
+
+/* flash_attention (attention.py:24-130) as used by model.py:149-154 (self) and :220-222 (cross): fused
+ * softmax(Q K^T * softmax_scale) V, no mask, head_dim 128.  Q [H][Lq][128], K [H][Lkp][128] (rows >= kv_len zero),
+ * Vt [H][Lkp/64][128][64] (wf_v_transpose), O [Lq][ldo] bf16 with head h at columns h*128.  accumulate != 0: O += result. */
+int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int ldo,
+                float softmax_scale, int accumulate, void* stream);
+
+/* WanLayerNorm (model.py:92-102; eps, no affine) fused with y = ln * (plus_one + mul[c]) + add[c]:
+ *   AdaLN modulate (model.py:303, 311, 346): mul = scale e[1]/e[4], add = shift e[0]/e[3], plus_one = 1;
+ *   affine LayerNorm (norm3 :262-264, img_emb :356-358): mul = weight, add = bias, plus_one = 0.
+ * x f32 [L,C]; out bf16 or f32 [L,C]. */
+int wf_ln_modulate(const float* x, const float* mul, const float* add, void* out, int out_dtype, int L, int C, float eps,
+                   int plus_one, void* stream);
+
+/* WanRMSNorm over all C channels (model.py:73-89, 142-143, 215-218) + optional 3-axis RoPE (model.py:43-70; cos/sin tables
+ * [L][64] f32, NULL -> none), written head-major: in bf16 [L, ld] -> out bf16 [C/128][Lout][128] (rows L..Lout untouched). */
+int wf_rmsnorm_heads(const void* in, int ld, const float* weight, const float* cos_tab, const float* sin_tab, void* out, int L,
+                     int Lout, int C, float eps, void* stream);
+
+/* V [L, ld] bf16 (head h at columns h*128) -> Vt [H][Lp/64][128][64] bf16, keys >= L zero-filled. */
+int wf_v_transpose(const void* V, int ld, void* Vt, int L, int Lp, int H, void* stream);
+
+/* model.py:534-537 patch embedding as a GEMM: x bf16 [Cin,T,Hh,Ww] -> tokens bf16 [T*(Hh/2)*(Ww/2), Cin*4] (k = c*4+ph*2+pw). */
+int wf_patchify(const void* x, void* tokens, int Cin, int T, int Hh, int Ww, void* stream);
+/* model.py:584-607: y f32 [L, 4*Cout] (k = (ph*2+pw)*Cout + c) -> out f32 [Cout,T,Hh,Ww]. */
+int wf_unpatchify(const float* y, float* out, int Cout, int T, int Hh, int Ww, void* stream);
+
+/* out = f(a (+ b)); mode 0 SiLU (model.py:463-464), 1 GELU-erf (model.py:357), 2 identity (e = modulation + e0, model.py:298). */
+int wf_act(const void* a, int dt_a, const void* b, int dt_b, void* out, int dt_out, int mode, size_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -239,3 +239,59 @@ if __name__ == "__main__":
         g_flf()
     if "harness" in which:
         g_harness()
+
+
+def _load_wan_module(name):
+    """Import /root/reference/.../wan/modules/<name>.py without running wan/__init__.py (which needs easydict etc.)."""
+    import importlib
+    import types
+
+    for pkg, path in (("wan", os.path.join(REF, "wan")), ("wan.modules", os.path.join(REF, "wan", "modules"))):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = [path]
+            sys.modules[pkg] = m
+    return importlib.import_module(f"wan.modules.{name}")
+
+
+# ------------------------------------------------------------------------------------------------------------
+def g_dit():
+    """G7: tiny WanModel (in-tree twin, fp32, SDPA fallback for flash_attention) with the oracle's synthetic weights."""
+    wattn = _load_wan_module("attention")
+    wmodel = _load_wan_module("model")
+    from oracle import dit as odit
+
+    wmodel.flash_attention = lambda q, k, v, k_lens=None, window_size=(-1, -1): wattn.attention(
+        q, k, v, k_lens=k_lens, window_size=window_size, fa_version=None)
+    # attention.py:133-179 casts to `dtype` (bf16) by default before SDPA; keep fp32 so the golden is a pure fp32 statement
+    orig_attention = wattn.attention
+    wattn_attention = lambda q, k, v, **kw: orig_attention(q, k, v, **{**kw, "dtype": torch.float32})
+    wmodel.flash_attention = lambda q, k, v, k_lens=None, window_size=(-1, -1): wattn_attention(
+        q, k, v, k_lens=k_lens, window_size=window_size, fa_version=None)
+    out = {}
+    for name, (dim, heads, ffn, layers, T, h, w) in {"tiny": (256, 2, 512, 2, 2, 8, 12), "odd": (384, 3, 640, 1, 3, 6, 10)}.items():
+        cfg = odit.DiTConfig(dim=dim, ffn_dim=ffn, num_heads=heads, num_layers=layers, text_dim=64, img_dim=1280)
+        W = odit.random_weights(cfg, seed=11)
+        m = wmodel.WanModel(model_type="i2v", in_dim=36, dim=dim, ffn_dim=ffn, freq_dim=256, text_dim=64, out_dim=16,
+                            num_heads=heads, num_layers=layers)
+        missing, unexpected = m.load_state_dict(W, strict=True), None
+        m.eval()
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(16, T, h, w, generator=g)
+        y = torch.randn(20, T, h, w, generator=g)
+        ctx = torch.randn(40, 64, generator=g)
+        clip = torch.randn(1, 257, 1280, generator=g)
+        t = torch.tensor([749])
+        with torch.no_grad():
+            o = m([x], t, [ctx], seq_len=T * (h // 2) * (w // 2), clip_fea=clip, y=[y])[0]
+        out[f"{name}_x"] = torch.cat([x, y]).numpy()
+        out[f"{name}_ctx"] = ctx.numpy()
+        out[f"{name}_clip"] = clip[0].numpy()
+        out[f"{name}_out"] = o.numpy()
+        out[f"{name}_cfg"] = np.array([dim, heads, ffn, layers, T, h, w])
+    np.savez_compressed(os.path.join(OUT, "g7_dit.npz"), **out)
+    print("g7_dit", {k: v.shape for k, v in out.items() if k.endswith("_out")})
+
+
+if __name__ == "__main__" and "dit" in sys.argv[1:]:
+    g_dit()

@@ -1,0 +1,244 @@
+// bf16 MFMA GEMM for the DiT / VAE linear layers:  out[M,N] = epilogue( X[M,K] . W[N,K]^T + bias[N] )
+//
+// Replaces every nn.Linear of wan/modules/model.py (q/k/v/o :123-126, ffn :271-273, embeddings :456-464, head :332) and
+// the 1x1 convolutions of wan/modules/vae.py (:199, :234-235).  MFMA-bound (2*M*N*K flop).
+//
+// Design (gfx950, 64-lane waves):
+//   * workgroup tile 128(tokens) x 128(features), BK = 64, 4 waves in a 2x2 grid, each wave 64x64 = 2x2 MFMA 32x32x16 tiles;
+//     the WEIGHT rows are the MFMA A operand and the TOKEN rows the B operand, so each lane ends up owning one token row
+//     and quads of consecutive output features (see mfma.h) -> 8/16-byte epilogue stores and vector bias / gate loads;
+//   * both operands are K-contiguous (nn.Linear stores W as [N,K]); tiles are staged global -> VGPR -> LDS with 16-byte
+//     accesses, next tile's global loads issued before the current tile's MFMAs and written to the other LDS buffer
+//     after them (one barrier per K tile);
+//   * LDS rows are 128 B; 16-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 7): conflict-free for the
+//     ds_read_b128 lane groups of the fragment reads and for the ds_write_b128 staging writes;
+//   * XCD-aware rasterisation: workgroups of one XCD (blockIdx % 8) walk 8x8 super-tiles so that the 32 CUs sharing an
+//     L2 re-use the same 8 token panels and 8 weight panels;
+//   * ragged M / N are handled by clamping load rows and predicating stores; K tail chunks are zero-filled (K % 8 == 0).
+#include "common.h"
+#include "mfma.h"
+
+using namespace wf;
+
+namespace {
+
+constexpr int BM = 128;  // token rows per workgroup tile
+constexpr int BN = 128;  // output features per workgroup tile
+constexpr int BK = 64;
+constexpr int NTHREADS = 256;
+constexpr int ROW_BYTES = BK * 2;             // 128
+constexpr int TILE_BYTES = BM * ROW_BYTES;    // 16 KiB per operand tile
+constexpr int CHUNKS_PER_THREAD = (BM * 8) / NTHREADS;  // 4 x 16-byte chunks per operand per thread
+
+struct GemmArgs {
+  const uint16_t* X;  // [M, ldx] bf16
+  const uint16_t* W;  // [N, K] bf16
+  const float* bias;  // [N] or null
+  void* out;          // bf16 / f32 [M, ldo]
+  const float* gate;  // [N] f32 (EPI_RESID) or null
+  int M, N, K, ldx, ldo;
+  int mt, nt;  // tile counts
+};
+
+enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32 = 2, EPI_RESID = 3, EPI_F32_ACC = 4 };
+
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+  // nn.GELU(approximate='tanh') (model.py:272): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  float e = __expf(2.0f * u);
+  float t = 1.0f - 2.0f / (e + 1.0f);
+  return 0.5f * x * (1.0f + t);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void k_gemm(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // ---- XCD-aware tile assignment --------------------------------------------------------------------------
+  const int smt = (a.mt + 7) >> 3, snt = (a.nt + 7) >> 3;
+  const int nsuper = smt * snt;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, j = b >> 3;
+  const int gid = (j >> 6) * 8 + xcd;
+  if (gid >= nsuper) return;
+  const int within = j & 63;
+  const int tm = (gid / snt) * 8 + (within >> 3);
+  const int tn = (gid % snt) * 8 + (within & 7);
+  if (tm >= a.mt || tn >= a.nt) return;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wn = wid >> 1, wm = wid & 1;  // wave's 64x64 sub-tile: features wn*64.., tokens wm*64..
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // LDS: [buf0: W tile | X tile][buf1: W tile | X tile]
+
+  // ---- staging geometry: chunk id = tid + 256*i -> (row = id >> 3, chunk = id & 7) ----------------------------------
+  const int kchunks = a.K >> 3;
+  u32x4 rW[CHUNKS_PER_THREAD], rX[CHUNKS_PER_THREAD];
+  const uint16_t* pW[CHUNKS_PER_THREAD];
+  const uint16_t* pX[CHUNKS_PER_THREAD];
+  int ldsoff[CHUNKS_PER_THREAD];
+  const int ck = tid & 7;
+#pragma unroll
+  for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
+    int row = (tid >> 3) + 32 * i;
+    int wr = min(n0 + row, a.N - 1);
+    int xr = min(m0 + row, a.M - 1);
+    pW[i] = a.W + (size_t)wr * a.K + ck * 8;
+    pX[i] = a.X + (size_t)xr * a.ldx + ck * 8;
+    ldsoff[i] = row * ROW_BYTES + swz(row, ck) * 16;
+  }
+  auto gload = [&](int kt) {
+    const bool ok = (kt * 8 + ck) < kchunks;
+#pragma unroll
+    for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
+      u32x4 z = {0u, 0u, 0u, 0u};
+      rW[i] = ok ? *reinterpret_cast<const u32x4*>(pW[i] + (size_t)kt * BK) : z;
+      rX[i] = ok ? *reinterpret_cast<const u32x4*>(pX[i] + (size_t)kt * BK) : z;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
+      *reinterpret_cast<u32x4*>(smem + buf * (2 * TILE_BYTES) + ldsoff[i]) = rW[i];
+      *reinterpret_cast<u32x4*>(smem + buf * (2 * TILE_BYTES) + TILE_BYTES + ldsoff[i]) = rX[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+
+  // fragment row offsets (constant over K)
+  int offW[2], offX[2], rswW[2], rswX[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int rw = wn * 64 + i * 32 + l31;
+    int rx = wm * 64 + i * 32 + l31;
+    offW[i] = rw * ROW_BYTES;
+    offX[i] = rx * ROW_BYTES;
+    rswW[i] = (rw >> 1) & 7;
+    rswX[i] = (rx >> 1) & 7;
+  }
+
+  const int nk = (a.K + BK - 1) / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const unsigned char* sWb = smem + buf * (2 * TILE_BYTES);
+    const unsigned char* sXb = sWb + TILE_BYTES;
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      const int c = 2 * s + hi;
+      bf16x8 fw[2], fx[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fw[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(sWb + offW[i] + ((c ^ rswW[i]) << 4)));
+        fx[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(sXb + offX[i] + ((c ^ rswX[i]) << 4)));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) acc[i][jn] = mfma32(fw[i], fx[jn], acc[i][jn]);
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns token row (m) and feature quads -----------------------------------------------------------
+#pragma unroll
+  for (int jn = 0; jn < 2; ++jn) {
+    const int m = m0 + wm * 64 + jn * 32 + l31;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 64 + i * 32 + 8 * g + 4 * hi;
+        if (n >= a.N) continue;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = acc[i][jn][4 * g + q];
+        if (a.bias) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += bb[q];
+        }
+        const size_t o = (size_t)m * a.ldo + n;
+        if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+          if constexpr (EPI == EPI_BF16_GELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
+          }
+          u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + o) = pk;
+        } else if constexpr (EPI == EPI_F32) {
+          f32x4 ov = {v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + o) = ov;
+        } else if constexpr (EPI == EPI_F32_ACC) {
+          float* po = reinterpret_cast<float*>(a.out) + o;
+          f32x4 old = *reinterpret_cast<const f32x4*>(po);
+          f32x4 ov = {old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
+          *reinterpret_cast<f32x4*>(po) = ov;
+        } else {  // EPI_RESID: x += (acc + bias) * gate   (model.py:306, 310, 313)
+          float* po = reinterpret_cast<float*>(a.out) + o;
+          f32x4 old = *reinterpret_cast<const f32x4*>(po);
+          f32x4 gg = {1.f, 1.f, 1.f, 1.f};
+          if (a.gate) gg = *reinterpret_cast<const f32x4*>(a.gate + n);
+          f32x4 ov = {old[0] + v[0] * gg[0], old[1] + v[1] * gg[1], old[2] + v[2] * gg[2], old[3] + v[3] * gg[3]};
+          *reinterpret_cast<f32x4*>(po) = ov;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int wf_gemm_bf16(const void* X, const void* W, const float* bias, void* out, const float* gate, int M, int N,
+                            int K, int ldx, int ldo, int epilogue, void* stream) {
+  WF_CHECK_ARG(X && W && out, "wf_gemm_bf16: null pointer");
+  WF_CHECK_ARG(M > 0 && N > 0 && K > 0, "wf_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
+  WF_CHECK_ARG(K % 8 == 0 && ldx % 8 == 0, "wf_gemm_bf16: K (%d) and ldx (%d) must be multiples of 8", K, ldx);
+  WF_CHECK_ARG(N % 4 == 0 && ldo % 4 == 0, "wf_gemm_bf16: N (%d) and ldo (%d) must be multiples of 4", N, ldo);
+  WF_CHECK_ARG((((uintptr_t)X | (uintptr_t)W | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)gate) & 15) == 0,
+               "wf_gemm_bf16: pointers must be 16-byte aligned");
+  GemmArgs a;
+  a.X = (const uint16_t*)X;
+  a.W = (const uint16_t*)W;
+  a.bias = bias;
+  a.out = out;
+  a.gate = gate;
+  a.M = M;
+  a.N = N;
+  a.K = K;
+  a.ldx = ldx;
+  a.ldo = ldo;
+  a.mt = ceil_div(M, BM);
+  a.nt = ceil_div(N, BN);
+  const int nsuper = ((a.mt + 7) / 8) * ((a.nt + 7) / 8);
+  const int grid = ((nsuper + 7) / 8) * 8 * 64;
+  const size_t lds = 4 * TILE_BYTES;
+  hipStream_t s = (hipStream_t)stream;
+  switch (epilogue) {
+    case EPI_BF16: hipLaunchKernelGGL(k_gemm<EPI_BF16>, dim3(grid), dim3(NTHREADS), lds, s, a); break;
+    case EPI_BF16_GELU: hipLaunchKernelGGL(k_gemm<EPI_BF16_GELU>, dim3(grid), dim3(NTHREADS), lds, s, a); break;
+    case EPI_F32: hipLaunchKernelGGL(k_gemm<EPI_F32>, dim3(grid), dim3(NTHREADS), lds, s, a); break;
+    case EPI_RESID: hipLaunchKernelGGL(k_gemm<EPI_RESID>, dim3(grid), dim3(NTHREADS), lds, s, a); break;
+    case EPI_F32_ACC: hipLaunchKernelGGL(k_gemm<EPI_F32_ACC>, dim3(grid), dim3(NTHREADS), lds, s, a); break;
+    default: WF_CHECK_ARG(false, "wf_gemm_bf16: unknown epilogue %d", epilogue);
+  }
+  WF_LAUNCH_CHECK("wf_gemm_bf16");
+  return WF_OK;
+}

@@ -1,0 +1,438 @@
+"""Wan2.1 image-to-video DiT (WanTransformer3DModel) on hand-written HIP kernels.
+
+Speaks the diffusers call protocol the reference sampler uses (PIPE:593-600):
+    transformer(hidden_states[B,36,T,h,w], timestep[B], encoder_hidden_states[B,512,4096],
+                encoder_hidden_states_image[B,257,1280], attention_kwargs=None, return_dict=False)[0] -> [B,16,T,h,w]
+The arithmetic follows the in-tree statement of the model, /root/reference/wan_for_worldforge/wan/modules/model.py
+(the executed class lives in diffusers, outside the reference tree); file:line citations are on the kernels
+(csrc/gemm.hip, attention.hip, dit_ops.hip) and below.  Every FLOP runs in libwf_hip.so; PyTorch only owns the buffers.
+
+Numerics: bf16 weights and bf16 GEMM / attention operands with fp32 accumulation, fp32 residual stream, fp32
+LayerNorm / modulation (model.py:296-313) -- the reference's bf16 autocast flow.
+
+Weights are keyed like the in-tree twin's state_dict ("blocks.3.self_attn.q.weight"); `diffusers_key_map` translates a
+diffusers checkpoint.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _ffi, ops
+from ._ffi import WF_BF16, WF_F32, call
+
+EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_RESID, EPI_F32_ACC = 0, 1, 2, 3, 4
+
+
+@dataclass
+class DiTConfig:
+    dim: int = 5120
+    ffn_dim: int = 13824
+    num_heads: int = 40
+    num_layers: int = 40
+    in_dim: int = 36
+    out_dim: int = 16
+    freq_dim: int = 256
+    text_dim: int = 4096
+    text_len: int = 512
+    img_dim: int = 1280
+    patch_size: Tuple[int, int, int] = (1, 2, 2)
+    eps: float = 1e-6
+
+    @staticmethod
+    def wan_i2v_14b() -> "DiTConfig":
+        """wan/configs/wan_i2v_14B.py:27-36."""
+        return DiTConfig()
+
+
+def _pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epi: int,
+         gate: Optional[torch.Tensor] = None):
+    """out[M,N] = epi(x[M,K] @ w[N,K]^T + bias)."""
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    assert out.shape[0] == M and out.shape[1] == N
+    call("wf_gemm_bf16", x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
+         gate.data_ptr() if gate is not None else None, M, N, K, x.stride(0), out.stride(0), epi, ops.stream())
+    return out
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, kv_len: int, scale: float,
+              accumulate: bool = False):
+    """q [H,Lq,128], k [H,Lkp,128], vt [H,Lkp/64,128,64] bf16 -> out [Lq, H*128] bf16."""
+    H, Lq, D = q.shape
+    Lkp = k.shape[1]
+    assert D == 128 and vt.shape == (H, Lkp // 64, 128, 64)
+    call("wf_attn_fwd", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Lq, Lkp, kv_len, out.stride(0),
+         float(scale), 1 if accumulate else 0, ops.stream())
+    return out
+
+
+def rope_tables(head_dim: int, f: int, h: int, w: int, theta: float = 10000.0):
+    """model.py:32-39 + 478-485 + 57-62: cos/sin [f*h*w, head_dim/2], computed in fp64 on the host, stored fp32."""
+    c = head_dim // 2
+    d_hw = c // 3
+    d_f = c - 2 * d_hw
+
+    def axis(n, npairs):
+        dim = 2 * npairs
+        inv = 1.0 / np.power(theta, np.arange(0, dim, 2, dtype=np.float64) / dim)
+        return np.outer(np.arange(n, dtype=np.float64), inv)
+
+    af, ah, aw = axis(f, d_f), axis(h, d_hw), axis(w, d_hw)
+    ang = np.concatenate([np.broadcast_to(af[:, None, None, :], (f, h, w, d_f)),
+                          np.broadcast_to(ah[None, :, None, :], (f, h, w, d_hw)),
+                          np.broadcast_to(aw[None, None, :, :], (f, h, w, d_hw))], axis=-1).reshape(f * h * w, c)
+    return torch.from_numpy(np.cos(ang).astype(np.float32)), torch.from_numpy(np.sin(ang).astype(np.float32))
+
+
+def sinusoidal_embedding_1d(dim: int, t: float) -> torch.Tensor:
+    """model.py:18-28 (fp64 on the host) -> [1, dim] fp32."""
+    half = dim // 2
+    pos = np.float64(t)
+    s = pos * np.power(10000.0, -np.arange(half, dtype=np.float64) / half)
+    return torch.from_numpy(np.concatenate([np.cos(s), np.sin(s)])[None].astype(np.float32))
+
+
+def diffusers_key_map(num_layers: int) -> Dict[str, str]:
+    """diffusers WanTransformer3DModel parameter name -> in-tree twin name (verify on first contact
+    with a real checkpoint's *.safetensors.index.json)."""
+    m = {
+        "patch_embedding": "patch_embedding",
+        "condition_embedder.time_embedder.linear_1": "time_embedding.0",
+        "condition_embedder.time_embedder.linear_2": "time_embedding.2",
+        "condition_embedder.time_proj": "time_projection.1",
+        "condition_embedder.text_embedder.linear_1": "text_embedding.0",
+        "condition_embedder.text_embedder.linear_2": "text_embedding.2",
+        "condition_embedder.image_embedder.norm1": "img_emb.proj.0",
+        "condition_embedder.image_embedder.ff.net.0.proj": "img_emb.proj.1",
+        "condition_embedder.image_embedder.ff.net.2": "img_emb.proj.3",
+        "condition_embedder.image_embedder.norm2": "img_emb.proj.4",
+        "proj_out": "head.head",
+    }
+    for i in range(num_layers):
+        b, t = f"blocks.{i}.", f"blocks.{i}."
+        for a, n in (("attn1", "self_attn"), ("attn2", "cross_attn")):
+            for s, d in (("to_q", "q"), ("to_k", "k"), ("to_v", "v"), ("to_out.0", "o"), ("norm_q", "norm_q"),
+                         ("norm_k", "norm_k")):
+                m[f"{b}{a}.{s}"] = f"{t}{n}.{d}"
+        m[f"{b}attn2.add_k_proj"] = f"{t}cross_attn.k_img"
+        m[f"{b}attn2.add_v_proj"] = f"{t}cross_attn.v_img"
+        m[f"{b}attn2.norm_added_k"] = f"{t}cross_attn.norm_k_img"
+        m[f"{b}norm2"] = f"{t}norm3"
+        m[f"{b}ffn.net.0.proj"] = f"{t}ffn.0"
+        m[f"{b}ffn.net.2"] = f"{t}ffn.2"
+    return m
+
+
+class WanTransformer3DModel:
+    dtype = torch.bfloat16
+
+    def __init__(self, cfg: DiTConfig, device="cuda:0"):
+        self.cfg = cfg
+        self.config = SimpleNamespace(patch_size=cfg.patch_size, in_channels=cfg.in_dim, out_channels=cfg.out_dim)
+        self.device = torch.device(device)
+        self.w: Dict[str, torch.Tensor] = {}
+        self._ws = {}
+        self._rope = {}
+        assert cfg.dim % cfg.num_heads == 0 and cfg.dim // cfg.num_heads == 128, "attention kernel is built for head_dim 128"
+
+    # ------------------------------------------------------------------------------------------------------------
+    # weights
+    # ------------------------------------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        """Twin-keyed state dict (any dtype / device) -> device tensors: matrices bf16, vectors fp32, q/k/v fused."""
+        cfg, dev = self.cfg, self.device
+        W = {}
+
+        def mat(k):
+            return sd[k].to(device=dev, dtype=torch.bfloat16).contiguous()
+
+        def vec(k):
+            # biases / norm weights / modulation: kept in fp32 on the device (the upcast of a bf16 checkpoint value is exact)
+            return sd[k].to(device=dev, dtype=torch.float32).contiguous()
+
+        W["patch.w"] = mat("patch_embedding.weight").reshape(cfg.dim, -1).contiguous()
+        W["patch.b"] = vec("patch_embedding.bias")
+        for n in ("text_embedding.0", "text_embedding.2", "time_embedding.0", "time_embedding.2", "time_projection.1",
+                  "img_emb.proj.1", "img_emb.proj.3", "head.head"):
+            W[n + ".w"] = mat(n + ".weight")
+            W[n + ".b"] = vec(n + ".bias")
+        for n in ("img_emb.proj.0", "img_emb.proj.4"):
+            W[n + ".w"] = vec(n + ".weight")
+            W[n + ".b"] = vec(n + ".bias")
+        W["head.modulation"] = vec("head.modulation").reshape(2, cfg.dim).contiguous()
+        for i in range(cfg.num_layers):
+            p = f"blocks.{i}."
+            W[p + "qkv.w"] = torch.cat([mat(p + f"self_attn.{n}.weight") for n in "qkv"], dim=0).contiguous()
+            W[p + "qkv.b"] = torch.cat([vec(p + f"self_attn.{n}.bias") for n in "qkv"], dim=0).contiguous()
+            W[p + "self_attn.o.w"] = mat(p + "self_attn.o.weight")
+            W[p + "self_attn.o.b"] = vec(p + "self_attn.o.bias")
+            W[p + "self_attn.norm_q"] = vec(p + "self_attn.norm_q.weight")
+            W[p + "self_attn.norm_k"] = vec(p + "self_attn.norm_k.weight")
+            for n in ("q", "o"):
+                W[p + f"cross_attn.{n}.w"] = mat(p + f"cross_attn.{n}.weight")
+                W[p + f"cross_attn.{n}.b"] = vec(p + f"cross_attn.{n}.bias")
+            W[p + "cross_attn.kv.w"] = torch.cat([mat(p + "cross_attn.k.weight"), mat(p + "cross_attn.v.weight")], 0).contiguous()
+            W[p + "cross_attn.kv.b"] = torch.cat([vec(p + "cross_attn.k.bias"), vec(p + "cross_attn.v.bias")], 0).contiguous()
+            W[p + "cross_attn.kv_img.w"] = torch.cat([mat(p + "cross_attn.k_img.weight"), mat(p + "cross_attn.v_img.weight")], 0).contiguous()
+            W[p + "cross_attn.kv_img.b"] = torch.cat([vec(p + "cross_attn.k_img.bias"), vec(p + "cross_attn.v_img.bias")], 0).contiguous()
+            for n in ("norm_q", "norm_k", "norm_k_img"):
+                W[p + "cross_attn." + n] = vec(p + f"cross_attn.{n}.weight")
+            W[p + "norm3.w"] = vec(p + "norm3.weight")
+            W[p + "norm3.b"] = vec(p + "norm3.bias")
+            for n in ("ffn.0", "ffn.2"):
+                W[p + n + ".w"] = mat(p + n + ".weight")
+                W[p + n + ".b"] = vec(p + n + ".bias")
+            W[p + "modulation"] = vec(p + "modulation").reshape(6, cfg.dim).contiguous()
+        self.w = W
+        return self
+
+    def load_diffusers_state_dict(self, sd: Dict[str, torch.Tensor]):
+        km = diffusers_key_map(self.cfg.num_layers)
+        out = {}
+        for k, v in sd.items():
+            if k == "scale_shift_table":
+                out["head.modulation"] = v
+                continue
+            if k.endswith(".scale_shift_table"):
+                out[k.replace(".scale_shift_table", ".modulation")] = v
+                continue
+            base, _, leaf = k.rpartition(".")
+            if base not in km:
+                raise KeyError(f"unmapped diffusers parameter {k}")
+            out[f"{km[base]}.{leaf}"] = v
+        return self.load_state_dict(out)
+
+    def init_random(self, seed: int = 0):
+        """Synthetic weights of the right shapes, generated directly on the device: there are no checkpoints
+        offline.  Scaled so activations stay O(1) through 40 layers."""
+        cfg, dev = self.cfg, self.device
+        g = torch.Generator(device=dev).manual_seed(seed)
+        W = {}
+
+        def mat(n, k, std=None):
+            std = std if std is not None else 1.0 / math.sqrt(k)
+            return (torch.randn(n, k, generator=g, device=dev, dtype=torch.float32) * std).to(torch.bfloat16)
+
+        def vec(n, std=0.02, base=0.0):
+            return (torch.randn(n, generator=g, device=dev, dtype=torch.float32) * std + base).to(torch.bfloat16).float()
+
+        d, f = cfg.dim, cfg.ffn_dim
+        kp = cfg.in_dim * 4
+        W["patch.w"], W["patch.b"] = mat(d, kp), vec(d)
+        for n, (o, i) in {"text_embedding.0": (d, cfg.text_dim), "text_embedding.2": (d, d), "time_embedding.0": (d, cfg.freq_dim),
+                          "time_embedding.2": (d, d), "time_projection.1": (6 * d, d), "img_emb.proj.1": (cfg.img_dim, cfg.img_dim),
+                          "img_emb.proj.3": (d, cfg.img_dim), "head.head": (4 * cfg.out_dim, d)}.items():
+            W[n + ".w"], W[n + ".b"] = mat(o, i), vec(o)
+        W["img_emb.proj.0.w"], W["img_emb.proj.0.b"] = vec(cfg.img_dim, 0.05, 1.0), vec(cfg.img_dim)
+        W["img_emb.proj.4.w"], W["img_emb.proj.4.b"] = vec(d, 0.05, 1.0), vec(d)
+        W["head.modulation"] = vec(2 * d, 1.0 / math.sqrt(d)).reshape(2, d).contiguous()
+        for i in range(cfg.num_layers):
+            p = f"blocks.{i}."
+            W[p + "qkv.w"], W[p + "qkv.b"] = mat(3 * d, d), vec(3 * d)
+            W[p + "self_attn.o.w"], W[p + "self_attn.o.b"] = mat(d, d), vec(d)
+            W[p + "self_attn.norm_q"], W[p + "self_attn.norm_k"] = vec(d, 0.05, 1.0), vec(d, 0.05, 1.0)
+            for n in ("q", "o"):
+                W[p + f"cross_attn.{n}.w"], W[p + f"cross_attn.{n}.b"] = mat(d, d), vec(d)
+            W[p + "cross_attn.kv.w"], W[p + "cross_attn.kv.b"] = mat(2 * d, d), vec(2 * d)
+            W[p + "cross_attn.kv_img.w"], W[p + "cross_attn.kv_img.b"] = mat(2 * d, d), vec(2 * d)
+            for n in ("norm_q", "norm_k", "norm_k_img"):
+                W[p + "cross_attn." + n] = vec(d, 0.05, 1.0)
+            W[p + "norm3.w"], W[p + "norm3.b"] = vec(d, 0.05, 1.0), vec(d)
+            W[p + "ffn.0.w"], W[p + "ffn.0.b"] = mat(f, d), vec(f)
+            W[p + "ffn.2.w"], W[p + "ffn.2.b"] = mat(d, f), vec(d)
+            W[p + "modulation"] = vec(6 * d, 1.0 / math.sqrt(d)).reshape(6, d).contiguous()
+        self.w = W
+        return self
+
+    def param_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.w.values())
+
+    # ------------------------------------------------------------------------------------------------------------
+    # workspaces (allocated once per token count; everything stays resident in HBM)
+    # ------------------------------------------------------------------------------------------------------------
+    def _buf(self, name, shape, dtype, zero=False):
+        key = (name, tuple(shape), dtype)
+        t = self._ws.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self._ws[key] = t
+        return t
+
+    def _rope_tables(self, f, h, w):
+        key = (f, h, w)
+        if key not in self._rope:
+            c, s = rope_tables(128, f, h, w)
+            self._rope[key] = (c.to(self.device), s.to(self.device))
+        return self._rope[key]
+
+    # ------------------------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------------------------
+    def _embed_condition(self, t_value: float, text: torch.Tensor, img: torch.Tensor):
+        """model.py:546-563.  Returns e [1,dim] f32, e0 [6,dim] f32, ctx_text bf16 [512,dim], ctx_img bf16 [n_img,dim]."""
+        cfg, W, dev = self.cfg, self.w, self.device
+        bf, f32 = torch.bfloat16, torch.float32
+        sin = sinusoidal_embedding_1d(cfg.freq_dim, t_value).to(dev)
+        t0 = self._buf("t0", (1, cfg.dim), f32)
+        gemm(ops.cast(sin, bf), W["time_embedding.0.w"], W["time_embedding.0.b"], t0, EPI_F32)
+        t0a = self._act(t0, None, bf, 0)
+        e = self._buf("e", (1, cfg.dim), f32)
+        gemm(t0a, W["time_embedding.2.w"], W["time_embedding.2.b"], e, EPI_F32)
+        e0 = self._buf("e0", (1, 6 * cfg.dim), f32)
+        gemm(self._act(e, None, bf, 0), W["time_projection.1.w"], W["time_projection.1.b"], e0, EPI_F32)
+        # text: zero-pad to text_len rows (model.py:554-559), Linear -> GELU(tanh) -> Linear
+        n_txt = text.shape[0]
+        tx = self._buf("txt_in", (cfg.text_len, cfg.text_dim), bf, zero=True)
+        tx[:n_txt].copy_(text)
+        if n_txt < cfg.text_len:
+            tx[n_txt:].zero_()
+        th = self._buf("txt_h", (cfg.text_len, cfg.dim), bf)
+        gemm(tx, W["text_embedding.0.w"], W["text_embedding.0.b"], th, EPI_BF16_GELU)
+        ctx_t = self._buf("ctx_t", (cfg.text_len, cfg.dim), bf)
+        gemm(th, W["text_embedding.2.w"], W["text_embedding.2.b"], ctx_t, EPI_BF16)
+        # image: LayerNorm -> Linear -> GELU(erf) -> Linear -> LayerNorm (model.py:355-358)
+        n_img = img.shape[0]
+        i0 = self._buf("img_ln0", (n_img, cfg.img_dim), bf)
+        self._ln(ops.cast(img, f32), W["img_emb.proj.0.w"], W["img_emb.proj.0.b"], i0, 1e-5, plus_one=False)
+        i1 = self._buf("img_h", (n_img, cfg.img_dim), f32)
+        gemm(i0, W["img_emb.proj.1.w"], W["img_emb.proj.1.b"], i1, EPI_F32)
+        i2 = self._buf("img_o", (n_img, cfg.dim), f32)
+        gemm(self._act(i1, None, bf, 1), W["img_emb.proj.3.w"], W["img_emb.proj.3.b"], i2, EPI_F32)
+        ctx_i = self._buf("ctx_i", (n_img, cfg.dim), bf)
+        self._ln(i2, W["img_emb.proj.4.w"], W["img_emb.proj.4.b"], ctx_i, 1e-5, plus_one=False)
+        return e, e0.view(6, cfg.dim), ctx_t, ctx_i
+
+    def _act(self, a, b, out_dtype, mode):
+        out = torch.empty(a.shape, dtype=out_dtype, device=a.device)
+        dt = {torch.float32: WF_F32, torch.bfloat16: WF_BF16}
+        call("wf_act", a.data_ptr(), dt[a.dtype], b.data_ptr() if b is not None else None, dt[b.dtype] if b is not None else 0,
+             out.data_ptr(), dt[out_dtype], mode, a.numel(), ops.stream())
+        return out
+
+    def _ln(self, x, mul, add, out, eps, plus_one):
+        L, C = x.shape
+        assert x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
+        call("wf_ln_modulate", x.data_ptr(), mul.data_ptr() if mul is not None else None,
+             add.data_ptr() if add is not None else None, out.data_ptr(), WF_BF16 if out.dtype == torch.bfloat16 else WF_F32,
+             L, C, float(eps), 1 if plus_one else 0, ops.stream())
+        return out
+
+    def _heads(self, src, col0, weight, cos, sin, out, L):
+        """RMSNorm(+RoPE) of columns [col0, col0+dim) of src [L, ld] -> out [H, Lout, 128]."""
+        C = self.cfg.dim
+        view = src[:, col0:col0 + C]
+        call("wf_rmsnorm_heads", view.data_ptr(), src.stride(0), weight.data_ptr(), cos.data_ptr() if cos is not None else None,
+             sin.data_ptr() if sin is not None else None, out.data_ptr(), L, out.shape[1], C, float(self.cfg.eps), ops.stream())
+
+    def _vt(self, src, col0, out, L):
+        view = src[:, col0:col0 + self.cfg.dim]
+        call("wf_v_transpose", view.data_ptr(), src.stride(0), out.data_ptr(), L, out.shape[1] * 64, self.cfg.num_heads,
+             ops.stream())
+
+    def forward_tokens(self, x_in: torch.Tensor, t_value: float, text: torch.Tensor, img: torch.Tensor) -> torch.Tensor:
+        """x_in [in_dim, T, h, w] bf16; text [<=512, text_dim]; img [n_img, img_dim] -> velocity [out_dim, T, h, w] f32."""
+        cfg, W, dev = self.cfg, self.w, self.device
+        bf, f32 = torch.bfloat16, torch.float32
+        Cin, T, Hh, Ww = x_in.shape
+        assert Cin == cfg.in_dim
+        f, h2, w2 = T, Hh // 2, Ww // 2
+        L = f * h2 * w2
+        Lp = _pad64(L)
+        d, H = cfg.dim, cfg.num_heads
+        scale = 1.0 / math.sqrt(128.0)
+        cos, sin = self._rope_tables(f, h2, w2)
+        e, e0, ctx_t, ctx_i = self._embed_condition(t_value, text, img)
+        n_img = ctx_i.shape[0]
+
+        # patch embedding (model.py:534-537) as a GEMM -> fp32 residual stream
+        tok = self._buf("tok", (L, Cin * 4), bf)
+        call("wf_patchify", x_in.data_ptr(), tok.data_ptr(), Cin, T, Hh, Ww, ops.stream())
+        x = self._buf("x", (L, d), f32)
+        gemm(tok, W["patch.w"], W["patch.b"], x, EPI_F32)
+
+        hbuf = self._buf("h", (L, d), bf)
+        qkv = self._buf("qkv", (L, 3 * d), bf)
+        qh = self._buf("qh", (H, L, 128), bf)
+        kh = self._buf("kh", (H, Lp, 128), bf, zero=True)
+        vt = self._buf("vt", (H, Lp // 64, 128, 64), bf)
+        ao = self._buf("ao", (L, d), bf)
+        qc = self._buf("qc", (L, d), bf)
+        ffh = self._buf("ffh", (L, cfg.ffn_dim), bf)
+        Lt, Li = cfg.text_len, _pad64(n_img)
+        kvt = self._buf("kvt", (cfg.text_len, 2 * d), bf)
+        kvi = self._buf("kvi", (n_img, 2 * d), bf)
+        kth = self._buf("kth", (H, Lt, 128), bf, zero=True)
+        vtt = self._buf("vtt", (H, Lt // 64, 128, 64), bf)
+        kih = self._buf("kih", (H, Li, 128), bf, zero=True)
+        vti = self._buf("vti", (H, Li // 64, 128, 64), bf)
+        emod = self._buf("emod", (6, d), f32)
+
+        for i in range(cfg.num_layers):
+            p = f"blocks.{i}."
+            # e = modulation + e0 (model.py:298)
+            call("wf_act", W[p + "modulation"].data_ptr(), WF_F32, e0.data_ptr(), WF_F32, emod.data_ptr(), WF_F32, 2,
+                 emod.numel(), ops.stream())
+            # ---- self-attention (model.py:302-306) ----
+            self._ln(x, emod[1], emod[0], hbuf, cfg.eps, plus_one=True)
+            gemm(hbuf, W[p + "qkv.w"], W[p + "qkv.b"], qkv, EPI_BF16)
+            self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L)
+            self._heads(qkv, d, W[p + "self_attn.norm_k"], cos, sin, kh, L)
+            self._vt(qkv, 2 * d, vt, L)
+            attention(qh, kh, vt, ao, L, scale)
+            gemm(ao, W[p + "self_attn.o.w"], W[p + "self_attn.o.b"], x, EPI_RESID, gate=emod[2])
+            # ---- cross-attention (model.py:310, 202-229) ----
+            self._ln(x, W[p + "norm3.w"], W[p + "norm3.b"], hbuf, cfg.eps, plus_one=False)
+            gemm(hbuf, W[p + "cross_attn.q.w"], W[p + "cross_attn.q.b"], qc, EPI_BF16)
+            self._heads(qc, 0, W[p + "cross_attn.norm_q"], None, None, qh, L)
+            gemm(ctx_t, W[p + "cross_attn.kv.w"], W[p + "cross_attn.kv.b"], kvt, EPI_BF16)
+            self._heads(kvt, 0, W[p + "cross_attn.norm_k"], None, None, kth, Lt)
+            self._vt(kvt, d, vtt, Lt)
+            gemm(ctx_i, W[p + "cross_attn.kv_img.w"], W[p + "cross_attn.kv_img.b"], kvi, EPI_BF16)
+            self._heads(kvi, 0, W[p + "cross_attn.norm_k_img"], None, None, kih, n_img)
+            self._vt(kvi, d, vti, n_img)
+            attention(qh, kih, vti, ao, n_img, scale)
+            attention(qh, kth, vtt, ao, Lt, scale, accumulate=True)
+            gemm(ao, W[p + "cross_attn.o.w"], W[p + "cross_attn.o.b"], x, EPI_RESID, gate=None)
+            # ---- FFN (model.py:311-313) ----
+            self._ln(x, emod[4], emod[3], hbuf, cfg.eps, plus_one=True)
+            gemm(hbuf, W[p + "ffn.0.w"], W[p + "ffn.0.b"], ffh, EPI_BF16_GELU)
+            gemm(ffh, W[p + "ffn.2.w"], W[p + "ffn.2.b"], x, EPI_RESID, gate=emod[5])
+
+        # ---- head (model.py:337-347) + unpatchify (:584-607) ----
+        hm = self._buf("hm", (2, d), f32)
+        # head modulation (model.py:345): hm[r] = modulation[r] + e
+        for r in range(2):
+            call("wf_act", W["head.modulation"][r].data_ptr(), WF_F32, e.data_ptr(), WF_F32, hm[r].data_ptr(), WF_F32, 2, d,
+                 ops.stream())
+        self._ln(x, hm[1], hm[0], hbuf, cfg.eps, plus_one=True)
+        y = self._buf("y", (L, 4 * cfg.out_dim), f32)
+        gemm(hbuf, W["head.head.w"], W["head.head.b"], y, EPI_F32)
+        out = torch.empty((cfg.out_dim, T, Hh, Ww), dtype=f32, device=dev)
+        call("wf_unpatchify", y.data_ptr(), out.data_ptr(), cfg.out_dim, T, Hh, Ww, ops.stream())
+        return out
+
+    def __call__(self, hidden_states: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor,
+                 encoder_hidden_states_image: Optional[torch.Tensor] = None, attention_kwargs=None, return_dict: bool = False):
+        if hidden_states.shape[0] != 1:
+            raise NotImplementedError("batch size 1 (the reference path); run CFG branches as separate calls")
+        t_value = float(torch.as_tensor(timestep).reshape(-1)[0].item())
+        x = hidden_states[0]
+        if x.dtype != torch.bfloat16:
+            x = ops.cast(x.contiguous(), torch.bfloat16)
+        v = self.forward_tokens(x.contiguous(), t_value, encoder_hidden_states[0].to(torch.bfloat16).contiguous(),
+                                encoder_hidden_states_image[0].to(torch.bfloat16).contiguous())
+        out = ops.cast(v, self.dtype).unsqueeze(0)
+        if return_dict:
+            return SimpleNamespace(sample=out)
+        return (out,)
