@@ -116,9 +116,9 @@ int wf_flow_metrics(const float* ref_flow, const float* chan_flow, float* sim, i
 #define WF_EPI_RESID 3      /* out f32 += (acc + bias) * gate[n] (gate NULL -> 1)   (model.py:306, 310, 313) */
 #define WF_EPI_F32_ACC 4    /* out f32 += acc + bias */
 /* nn.Linear on MFMA (model.py:123-126, 271-273, 332, 456-464; vae.py 1x1 convs): out[M,N] = epi(X[M,K] . W[N,K]^T + bias).
- * X, W bf16 (row strides ldx, K); bias/gate f32; K % 8 == 0, N % 4 == 0, 16-byte aligned pointers. */
+ * X, W bf16 (row strides ldx, ldw); bias/gate f32; K % 8 == 0, N % 4 == 0, 16-byte aligned pointers. */
 int wf_gemm_bf16(const void* X, const void* W, const float* bias, void* out, const float* gate, int M, int N, int K, int ldx,
-                 int ldo, int epilogue, void* stream);
+                 int ldw, int ldo, int epilogue, void* stream);
 
 /* flash_attention (attention.py:24-130) as used by model.py:149-154 (self) and :220-222 (cross): fused
  * softmax(Q K^T * softmax_scale) V, no mask, head_dim 128.  Q [H][Lq][128], K [H][Lkp][128] (rows >= kv_len zero),
@@ -148,6 +148,30 @@ int wf_unpatchify(const float* y, float* out, int Cout, int T, int Hh, int Ww, v
 
 /* out = f(a (+ b)); mode 0 SiLU (model.py:463-464), 1 GELU-erf (model.py:357), 2 identity (e = modulation + e0, model.py:298). */
 int wf_act(const void* a, int dt_a, const void* b, int dt_b, void* out, int dt_out, int mode, size_t n, void* stream);
+
+/* ---- 3D causal VAE (wan/modules/vae.py; the in-tree statement of diffusers' AutoencoderKLWan), channels-last ----------- */
+/* CausalConv3d / Conv2d as implicit GEMM on MFMA (vae.py:17-36, 76-96, 186-220).  in bf16 [Ti,Hi,Wi,Cin] (Cin % 32 == 0),
+ * w bf16 [Cout][kt*kh*kw][Cin], bias f32; out (f32 and/or bf16) [To,Ho,Wo,Cout] (+ resid f32 of the same shape).
+ *   out[t,y,x] = sum_taps in[t*st+dt-pt, y*ss+dy-ps, x*ss+dx-ps] . w[tap]   (zero outside the input)
+ * up2: read the input through a nearest-exact 2x spatial upsample (vae.py:78);  tsplit: 'upsample3d' frame interleave
+ * (vae.py:134-137): output frame t, channel half h -> frame 1 + 2t + h of a [1+2*To, Ho, Wo, Cout/2] tensor. */
+int wf_conv3d_cl(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_bf16, int Ti,
+                 int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st, int ss, int pt, int ps,
+                 int up2, int tsplit, void* stream);
+/* Direct convolution for the thin layers (3->96, 16->384, 96->3, 384->32, 1x1x1 quant convs; vae.py:288, 316, 392, 421, 505-506).
+ * in f32 or bf16 channels-last, w f32 [taps][Cin][Cout]; clamp > 0 clamps the output (autoencoder_kl_wan.py:1222). */
+int wf_conv3d_small(const void* in, int in_dtype, const float* w, const float* bias, float* out_f32, void* out_bf16, int Ti, int Hi,
+                    int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st, int ss, int pt, int ps,
+                    float clamp, void* stream);
+/* RMS_norm over channels (vae.py:39-54) [+ SiLU]: x f32 [npix, C] -> bf16 and/or f32. */
+int wf_rms_silu_cl(const float* x, const float* gamma, void* out_bf16, float* out_f32, size_t npix, int C, int silu, void* stream);
+/* Row softmax of the mid-block attention scores (vae.py:252-256): P[m, :N] = softmax(S[m, :N] * scale), P[m, N:ldp] = 0. */
+int wf_softmax_rows(const float* S, int lds, void* P, int ldp, int M, int N, float scale, void* stream);
+/* bf16 in [R, ld_in] (first C columns) -> out [C, ld_out], columns R..ld_out zero. */
+int wf_transpose_bf16(const void* in, int ld_in, void* out, int ld_out, int R, int C, void* stream);
+/* [C, N] f32 -> [N, C] (f32 and/or bf16);  [N, C] f32 -> [C, N] f32 with optional clamp.  N = T*H*W. */
+int wf_ncthw_to_cl(const float* in, float* out_f32, void* out_bf16, int C, size_t N, void* stream);
+int wf_cl_to_ncthw(const float* in, float* out, int C, size_t N, float clamp, void* stream);
 
 #ifdef __cplusplus
 }

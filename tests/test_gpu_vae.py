@@ -1,0 +1,149 @@
+"""GPU: the HIP VAE (implicit-GEMM MFMA convolutions, whole-sequence causal processing) against goldens recorded from
+the reference's chunked / cached WanVAE_ and against the CPU oracle.
+
+Tolerance (stated): bf16 MFMA operands with fp32 accumulation and an fp32 residual stream vs the fp32 reference:
+  relative L2 error <= 1.5e-2 on latents and pixels, max abs pixel error <= 6e-2 (pixels in [-1,1]); per-kernel checks
+  are tighter."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import vae as ovae
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF, F32 = torch.bfloat16, torch.float32
+CASES = ["f9_32x32", "f5_48x40", "f1_32x32", "f17_16x24"]
+
+
+@pytest.fixture(scope="module")
+def model():
+    from worldforge_amd.vae import AutoencoderKLWan
+    return AutoencoderKLWan(DEV).load_state_dict(ovae.random_weights(seed=5))
+
+
+def _rel(a, b):
+    return (a - b).norm().item() / (b.norm().item() + 1e-12)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_encode_decode_vs_twin_goldens(name, model, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g8_vae.npz"))
+    x, z = torch.from_numpy(g[f"{name}_x"]), torch.from_numpy(g[f"{name}_z"])
+    mu = model.encode(x.to(DEV)).latent_dist.mode().cpu()
+    dec = model.decode(z.to(DEV), return_dict=False)[0].cpu()
+    mu_ref, dec_ref = torch.from_numpy(g[f"{name}_mu"]), torch.from_numpy(g[f"{name}_dec"])
+    assert mu.shape == mu_ref.shape and dec.shape == dec_ref.shape
+    e_mu, e_dec = _rel(mu, mu_ref), _rel(dec, dec_ref)
+    print(f"[{name}] rel L2: mu {e_mu:.3e} dec {e_dec:.3e}; max abs: mu {(mu - mu_ref).abs().max():.3e} "
+          f"dec {(dec - dec_ref).abs().max():.3e}")
+    assert e_mu <= 1.5e-2 and e_dec <= 1.5e-2
+    assert (dec - dec_ref).abs().max().item() <= 6e-2
+    assert dec.abs().max().item() <= 1.0
+
+
+def _conv_ref(x_cl, w, b, k, st, ss, pt, ps, up2=False):
+    """x_cl [T,H,W,C] -> torch conv3d reference with the kernel's padding convention -> [T',H',W',Cout]."""
+    x = x_cl.permute(3, 0, 1, 2).unsqueeze(0).float()
+    if up2:
+        x = F.interpolate(x, scale_factor=(1.0, 2.0, 2.0), mode="nearest-exact")
+    pad_after_h = max(0, k[1] - 1 - ps) if ss == 1 else 1
+    x = F.pad(x, (ps, pad_after_h, ps, pad_after_h, pt, 0))
+    y = F.conv3d(x, w, b, stride=(st, ss, ss))
+    return y[0].permute(1, 2, 3, 0)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(T=3, H=10, W=12, cin=96, cout=96, k=(3, 3, 3), st=1, ss=1, pt=2, ps=1),
+    dict(T=2, H=9, W=7, cin=192, cout=384, k=(3, 3, 3), st=1, ss=1, pt=2, ps=1),
+    dict(T=2, H=8, W=10, cin=96, cout=96, k=(1, 3, 3), st=1, ss=2, pt=0, ps=0),       # downsample conv (pad (0,1,0,1))
+    dict(T=2, H=6, W=5, cin=192, cout=96, k=(1, 3, 3), st=1, ss=1, pt=0, ps=1, up2=True),  # upsample2x + conv
+    dict(T=5, H=4, W=6, cin=384, cout=384, k=(3, 1, 1), st=2, ss=1, pt=0, ps=0),     # downsample3d time_conv
+    dict(T=40, H=16, W=16, cin=96, cout=192, k=(3, 3, 3), st=1, ss=1, pt=2, ps=1),  # several pixel tiles, ragged M
+])
+def test_conv3d_cl_vs_torch(cfg):
+    from worldforge_amd import _ffi, ops
+    g = torch.Generator().manual_seed(3)
+    T, H, W, cin, cout, k = cfg["T"], cfg["H"], cfg["W"], cfg["cin"], cfg["cout"], cfg["k"]
+    st, ss, pt, ps, up2 = cfg["st"], cfg["ss"], cfg["pt"], cfg["ps"], cfg.get("up2", False)
+    x = torch.randn(T, H, W, cin, generator=g).to(BF)
+    w = (torch.randn(cout, cin, *k, generator=g) / math.sqrt(cin * math.prod(k))).to(BF)
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = _conv_ref(x, w.float(), b, k, st, ss, pt, ps, up2)
+    To, Ho, Wo, _ = ref.shape
+    resid = torch.randn(To, Ho, Wo, cout, generator=g)
+    wk = w.permute(0, 2, 3, 4, 1).reshape(cout, -1, cin).contiguous().to(DEV)
+    xd, bd, rd = x.to(DEV), b.to(DEV), resid.to(DEV)
+    of = torch.full((To, Ho, Wo, cout), float("nan"), dtype=F32, device=DEV)
+    ob = torch.empty((To, Ho, Wo, cout), dtype=BF, device=DEV)
+    _ffi.call("wf_conv3d_cl", xd.data_ptr(), wk.data_ptr(), bd.data_ptr(), rd.data_ptr(), of.data_ptr(), ob.data_ptr(), T, H, W, cin,
+              To, Ho, Wo, cout, k[0], k[1], k[2], st, ss, pt, ps, 1 if up2 else 0, 0, ops.stream())
+    want = ref + resid
+    err = (of.cpu() - want).abs().max().item()
+    assert err <= 2e-3 * max(1.0, want.abs().max().item()), err
+    assert (ob.float().cpu() - want).abs().max().item() <= 1e-2 * want.abs().max().item()
+
+
+def test_conv3d_tsplit_matches_upsample3d_interleave():
+    from worldforge_amd import _ffi, ops
+    g = torch.Generator().manual_seed(4)
+    T, H, W, C = 3, 4, 5, 96
+    x = torch.randn(T, H, W, C, generator=g).to(BF)
+    w = (torch.randn(2 * C, C, 3, 1, 1, generator=g) / math.sqrt(3 * C)).to(BF)
+    b = torch.randn(2 * C, generator=g) * 0.1
+    y = _conv_ref(x, w.float(), b, (3, 1, 1), 1, 1, 2, 0)            # [T, H, W, 2C]
+    want = torch.stack((y[..., :C], y[..., C:]), dim=1).reshape(2 * T, H, W, C)
+    out = torch.zeros((1 + 2 * T, H, W, C), dtype=BF, device=DEV)
+    wk = w.permute(0, 2, 3, 4, 1).reshape(2 * C, -1, C).contiguous().to(DEV)
+    xd, bd = x.to(DEV), b.to(DEV)
+    _ffi.call("wf_conv3d_cl", xd.data_ptr(), wk.data_ptr(), bd.data_ptr(), None, None, out.data_ptr(), T, H, W, C, T, H, W, 2 * C,
+              3, 1, 1, 1, 1, 2, 0, 0, 1, ops.stream())
+    assert out[0].abs().max().item() == 0
+    assert (out[1:].float().cpu() - want).abs().max().item() <= 1e-2 * want.abs().max().item()
+
+
+def test_rms_silu_softmax_transpose_permute():
+    from worldforge_amd import _ffi, ops
+    g = torch.Generator().manual_seed(6)
+    for C in (96, 192, 384):
+        x = torch.randn(50, C, generator=g) * 2
+        gam = 1 + 0.1 * torch.randn(C, generator=g)
+        xd, gd = x.to(DEV), gam.to(DEV)
+        ob = torch.empty((50, C), dtype=BF, device=DEV)
+        of = torch.empty((50, C), dtype=F32, device=DEV)
+        for silu in (0, 1):
+            _ffi.call("wf_rms_silu_cl", xd.data_ptr(), gd.data_ptr(), ob.data_ptr(), of.data_ptr(), 50, C, silu, ops.stream())
+            ref = F.normalize(x, dim=1) * C ** 0.5 * gam
+            ref = F.silu(ref) if silu else ref
+            assert (of.cpu() - ref).abs().max().item() <= 1e-5 * max(1, ref.abs().max().item())
+            assert (ob.float().cpu() - ref).abs().max().item() <= 8e-3 * ref.abs().max().item()
+    S = torch.randn(37, 200, generator=g) * 3
+    Sd = S.to(DEV)
+    P = torch.full((37, 208), float("nan"), dtype=BF, device=DEV)
+    _ffi.call("wf_softmax_rows", Sd.data_ptr(), 200, P.data_ptr(), 208, 37, 200, 0.5, ops.stream())
+    ref = torch.softmax(S * 0.5, dim=-1)
+    assert (P[:, :200].float().cpu() - ref).abs().max().item() <= 4e-3 and P[:, 200:].abs().max().item() == 0
+    A = torch.randn(70, 100, generator=g).to(BF)
+    Ad = A.to(DEV)
+    At = torch.full((40, 72), float("nan"), dtype=BF, device=DEV)
+    _ffi.call("wf_transpose_bf16", Ad[:, 30:].data_ptr(), 100, At.data_ptr(), 72, 70, 40, ops.stream())
+    assert torch.equal(At[:, :70].cpu(), A[:, 30:70].t()) and At[:, 70:].abs().max().item() == 0
+    v = torch.randn(3, 2 * 4 * 5, generator=g)
+    vd = v.to(DEV)
+    cl = torch.empty((40, 3), dtype=F32, device=DEV)
+    _ffi.call("wf_ncthw_to_cl", vd.data_ptr(), cl.data_ptr(), None, 3, 40, ops.stream())
+    assert torch.equal(cl.cpu(), v.t())
+    back = torch.empty((3, 40), dtype=F32, device=DEV)
+    _ffi.call("wf_cl_to_ncthw", cl.data_ptr(), back.data_ptr(), 3, 40, 1.0, ops.stream())
+    assert torch.equal(back.cpu(), v.clamp(-1, 1))
+
+
+def test_vae_protocol_and_errors(model):
+    assert model.config.z_dim == 16 and len(model.config.latents_mean) == 16 and model.dtype == torch.float32
+    assert model.temperal_downsample == [False, True, True]
+    with pytest.raises(ValueError):
+        model.encode(torch.zeros(1, 3, 4, 16, 16, device=DEV))

@@ -295,3 +295,38 @@ def g_dit():
 
 if __name__ == "__main__" and "dit" in sys.argv[1:]:
     g_dit()
+
+
+# ------------------------------------------------------------------------------------------------------------
+def g_vae():
+    """G8: the in-tree WanVAE_ (real config: dim 96, z 16, 127 M parameters, chunked + feat_cache) with the oracle's
+    synthetic weights; small videos so the fixture stays small.  Also pins the state_dict names / shapes."""
+    wvae = _load_wan_module("vae")
+    from oracle import vae as ovae
+
+    m = wvae.WanVAE_(dim=96, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[],
+                     temperal_downsample=[False, True, True], dropout=0.0)
+    W = ovae.random_weights(seed=5)
+    sd = m.state_dict()
+    assert set(sd) == set(W), (set(sd) ^ set(W))
+    assert all(tuple(sd[k].shape) == tuple(W[k].shape) for k in sd)
+    m.load_state_dict(W, strict=True)
+    m.eval()
+    out = {}
+    g = torch.Generator().manual_seed(9)
+    cases = {"f9_32x32": (9, 32, 32), "f5_48x40": (5, 48, 40), "f1_32x32": (1, 32, 32), "f17_16x24": (17, 16, 24)}
+    with torch.no_grad():
+        for name, (Fr, H, Wd) in cases.items():
+            x = torch.rand(1, 3, Fr, H, Wd, generator=g) * 2 - 1
+            mu = m.encode(x, [0.0, 1.0])
+            T = (Fr - 1) // 4 + 1
+            z = torch.randn(1, 16, T, H // 8, Wd // 8, generator=g)
+            dec = m.decode(z, [0.0, 1.0]).clamp(-1, 1)
+            out[f"{name}_x"], out[f"{name}_mu"] = x.numpy(), mu.numpy()
+            out[f"{name}_z"], out[f"{name}_dec"] = z.numpy(), dec.numpy()
+            print("g8", name, tuple(mu.shape), tuple(dec.shape), float(mu.abs().max()), float(dec.abs().mean()))
+    np.savez_compressed(os.path.join(OUT, "g8_vae.npz"), **out)
+
+
+if __name__ == "__main__" and "vae" in sys.argv[1:]:
+    g_vae()

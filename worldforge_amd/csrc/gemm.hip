@@ -36,7 +36,7 @@ struct GemmArgs {
   const float* bias;  // [N] or null
   void* out;          // bf16 / f32 [M, ldo]
   const float* gate;  // [N] f32 (EPI_RESID) or null
-  int M, N, K, ldx, ldo;
+  int M, N, K, ldx, ldw, ldo;
   int mt, nt;  // tile counts
 };
 
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_gemm(GemmArgs a) {
     int row = (tid >> 3) + 32 * i;
     int wr = min(n0 + row, a.N - 1);
     int xr = min(m0 + row, a.M - 1);
-    pW[i] = a.W + (size_t)wr * a.K + ck * 8;
+    pW[i] = a.W + (size_t)wr * a.ldw + ck * 8;
     pX[i] = a.X + (size_t)xr * a.ldx + ck * 8;
     ldsoff[i] = row * ROW_BYTES + swz(row, ck) * 16;
   }
@@ -207,10 +207,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_gemm(GemmArgs a) {
 }  // namespace
 
 extern "C" int wf_gemm_bf16(const void* X, const void* W, const float* bias, void* out, const float* gate, int M, int N,
-                            int K, int ldx, int ldo, int epilogue, void* stream) {
+                            int K, int ldx, int ldw, int ldo, int epilogue, void* stream) {
   WF_CHECK_ARG(X && W && out, "wf_gemm_bf16: null pointer");
   WF_CHECK_ARG(M > 0 && N > 0 && K > 0, "wf_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
-  WF_CHECK_ARG(K % 8 == 0 && ldx % 8 == 0, "wf_gemm_bf16: K (%d) and ldx (%d) must be multiples of 8", K, ldx);
+  WF_CHECK_ARG(K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldw >= K && ldx >= K,
+               "wf_gemm_bf16: K (%d), ldx (%d), ldw (%d) must be multiples of 8 with ld >= K", K, ldx, ldw);
   WF_CHECK_ARG(N % 4 == 0 && ldo % 4 == 0, "wf_gemm_bf16: N (%d) and ldo (%d) must be multiples of 4", N, ldo);
   WF_CHECK_ARG((((uintptr_t)X | (uintptr_t)W | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)gate) & 15) == 0,
                "wf_gemm_bf16: pointers must be 16-byte aligned");
@@ -224,6 +225,7 @@ extern "C" int wf_gemm_bf16(const void* X, const void* W, const float* bias, voi
   a.N = N;
   a.K = K;
   a.ldx = ldx;
+  a.ldw = ldw;
   a.ldo = ldo;
   a.mt = ceil_div(M, BM);
   a.nt = ceil_div(N, BN);

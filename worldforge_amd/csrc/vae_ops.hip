@@ -1,0 +1,167 @@
+// HBM-bound companions of the VAE convolutions (wan/modules/vae.py), channels-last activations:
+//   wf_rms_silu_cl   : RMS_norm (vae.py:39-54: F.normalize over channels * sqrt(C) * gamma) + optional SiLU (:195,197)
+//   wf_softmax_rows  : softmax of the single-head mid-block attention scores (vae.py:252-256)
+//   wf_transpose_bf16: V -> V^T for the P.V GEMM of that attention
+//   wf_ncthw_to_cl / wf_cl_to_ncthw : layout change at the VAE boundary ([C,T,H,W] <-> [T,H,W,C])
+#include "common.h"
+#include "mfma.h"
+
+using namespace wf;
+
+namespace {
+
+// one wave per pixel: C f32 channels (C % 4 == 0, C <= 1024)
+__global__ __launch_bounds__(256) void k_rms_silu(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                  uint16_t* __restrict__ out_bf16, float* __restrict__ out_f32, int C,
+                                                  float scale, int silu, size_t npix) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  const int nvec = C >> 2;
+  for (size_t p = wave; p < npix; p += nwaves) {
+    const float4* xr = reinterpret_cast<const float4*>(x + p * C);
+    float4 v[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int id = lane + 64 * i;
+      if (id < nvec) {
+        v[i] = xr[id];
+        ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+      }
+    }
+    ss = wave_sum(ss);
+    const float inv = scale / fmaxf(sqrtf(ss), 1e-12f);  // F.normalize eps = 1e-12
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int id = lane + 64 * i;
+      if (id < nvec) {
+        const float4 g = reinterpret_cast<const float4*>(gamma)[id];
+        float y[4] = {v[i].x * inv * g.x, v[i].y * inv * g.y, v[i].z * inv * g.z, v[i].w * inv * g.w};
+        if (silu) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) y[k] = y[k] / (1.0f + __expf(-y[k]));
+        }
+        if (out_bf16) {
+          u32x2 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+          reinterpret_cast<u32x2*>(out_bf16 + p * C)[id] = pk;
+        }
+        if (out_f32) reinterpret_cast<float4*>(out_f32 + p * C)[id] = make_float4(y[0], y[1], y[2], y[3]);
+      }
+    }
+  }
+}
+
+// softmax over each row of S [M, N] f32 (row stride lds) * scale -> P bf16 [M, ldp], columns N..ldp zero-filled
+__global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ S, int lds, uint16_t* __restrict__ P, int ldp,
+                                                      int N, float scale) {
+  __shared__ float sm[8];
+  const size_t row = blockIdx.x;
+  const float* s = S + row * lds;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < N; i += 256) mx = fmaxf(mx, s[i]);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) sum += __expf((s[i] - mx) * scale);
+  sum = wave_sum(sum);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[4 + (threadIdx.x >> 6)] = sum;
+  __syncthreads();
+  sum = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+  const float inv = 1.0f / sum;
+  uint16_t* p = P + row * ldp;
+  for (int i = threadIdx.x; i < ldp; i += 256) p[i] = i < N ? f32_to_bf16(__expf((s[i] - mx) * scale) * inv) : (uint16_t)0;
+}
+
+// in [R, ld_in] (first C columns) bf16 -> out [C, ld_out] bf16, columns R..ld_out zero-filled.  32x32 tiles through LDS.
+__global__ void k_transpose(const uint16_t* __restrict__ in, int ld_in, uint16_t* __restrict__ out, int ld_out, int R, int C) {
+  __shared__ uint16_t tile[32][34];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    int r = r0 + k, c = c0 + tx;
+    tile[k][tx] = (r < R && c < C) ? in[(size_t)r * ld_in + c] : (uint16_t)0;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    int c = c0 + k, r = r0 + tx;
+    if (c < C && r < ld_out) out[(size_t)c * ld_out + r] = tile[tx][k];
+  }
+}
+
+// [C, N] -> [N, C] (N = T*H*W), in f32 -> out f32 or bf16
+__global__ void k_to_cl(const float* __restrict__ in, float* __restrict__ of, uint16_t* __restrict__ ob, int C, size_t N) {
+  const size_t n = N * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t p = i / C;
+    const float v = in[(size_t)c * N + p];
+    if (of) of[i] = v;
+    if (ob) ob[i] = f32_to_bf16(v);
+  }
+}
+// [N, C] f32 -> [C, N] f32, optional clamp
+__global__ void k_from_cl(const float* __restrict__ in, float* __restrict__ out, int C, size_t N, float clampv) {
+  const size_t n = N * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = i % N;
+    const int c = (int)(i / N);
+    float v = in[p * C + c];
+    if (clampv > 0.f) v = fminf(fmaxf(v, -clampv), clampv);
+    out[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int wf_rms_silu_cl(const float* x, const float* gamma, void* out_bf16, float* out_f32, size_t npix, int C, int silu,
+                              void* stream) {
+  WF_CHECK_ARG(x && gamma && (out_bf16 || out_f32), "wf_rms_silu_cl: null pointer");
+  WF_CHECK_ARG(C % 4 == 0 && C > 0 && C <= 1024, "wf_rms_silu_cl: C=%d must be a multiple of 4 and <= 1024", C);
+  if (npix == 0) return WF_OK;
+  size_t blocks = (npix + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_rms_silu, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, (uint16_t*)out_bf16,
+                     out_f32, C, sqrtf((float)C), silu, npix);
+  WF_LAUNCH_CHECK("wf_rms_silu_cl");
+  return WF_OK;
+}
+
+extern "C" int wf_softmax_rows(const float* S, int lds, void* P, int ldp, int M, int N, float scale, void* stream) {
+  WF_CHECK_ARG(S && P, "wf_softmax_rows: null pointer");
+  WF_CHECK_ARG(N > 0 && ldp >= N && lds >= N, "wf_softmax_rows: bad sizes");
+  if (M == 0) return WF_OK;
+  hipLaunchKernelGGL(k_softmax_rows, dim3(M), dim3(256), 0, (hipStream_t)stream, S, lds, (uint16_t*)P, ldp, N, scale);
+  WF_LAUNCH_CHECK("wf_softmax_rows");
+  return WF_OK;
+}
+
+extern "C" int wf_transpose_bf16(const void* in, int ld_in, void* out, int ld_out, int R, int C, void* stream) {
+  WF_CHECK_ARG(in && out, "wf_transpose_bf16: null pointer");
+  WF_CHECK_ARG(ld_out >= R && ld_in >= C, "wf_transpose_bf16: bad leading dimensions");
+  if (R == 0 || C == 0) return WF_OK;
+  hipLaunchKernelGGL(k_transpose, dim3((C + 31) / 32, (ld_out + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)in, ld_in, (uint16_t*)out, ld_out, R, C);
+  WF_LAUNCH_CHECK("wf_transpose_bf16");
+  return WF_OK;
+}
+
+extern "C" int wf_ncthw_to_cl(const float* in, float* out_f32, void* out_bf16, int C, size_t N, void* stream) {
+  WF_CHECK_ARG(in && (out_f32 || out_bf16), "wf_ncthw_to_cl: null pointer");
+  if (N == 0) return WF_OK;
+  hipLaunchKernelGGL(k_to_cl, dim3(grid_for(N * C, 256, 8192)), dim3(256), 0, (hipStream_t)stream, in, out_f32,
+                     (uint16_t*)out_bf16, C, N);
+  WF_LAUNCH_CHECK("wf_ncthw_to_cl");
+  return WF_OK;
+}
+
+extern "C" int wf_cl_to_ncthw(const float* in, float* out, int C, size_t N, float clamp, void* stream) {
+  WF_CHECK_ARG(in && out, "wf_cl_to_ncthw: null pointer");
+  if (N == 0) return WF_OK;
+  hipLaunchKernelGGL(k_from_cl, dim3(grid_for(N * C, 256, 8192)), dim3(256), 0, (hipStream_t)stream, in, out, C, N, clamp);
+  WF_LAUNCH_CHECK("wf_cl_to_ncthw");
+  return WF_OK;
+}

@@ -62,7 +62,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     assert w.shape[1] == K and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
     assert out.shape[0] == M and out.shape[1] == N
     call("wf_gemm_bf16", x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
-         gate.data_ptr() if gate is not None else None, M, N, K, x.stride(0), out.stride(0), epi, ops.stream())
+         gate.data_ptr() if gate is not None else None, M, N, K, x.stride(0), w.stride(0), out.stride(0), epi, ops.stream())
     return out
 
 

@@ -1,0 +1,376 @@
+"""Wan2.1 3D causal VAE (AutoencoderKLWan) on hand-written HIP kernels.
+
+Speaks the diffusers protocol the reference uses (SCHED:1272-1285, 1384; PIPE:162-163, 348, 743):
+    vae.encode(x[B,3,F,H,W]).latent_dist.mode() -> [B,16,T,h,w]      vae.decode(z[B,16,T,h,w], return_dict=False)[0]
+    vae.config.{z_dim, latents_mean, latents_std}, vae.dtype, vae.temperal_downsample
+The arithmetic follows /root/reference/wan_for_worldforge/wan/modules/vae.py (in-tree statement of the diffusers class).
+
+MI355X-first design: instead of the reference's 21 sequential per-latent-frame decoder passes with a Python-side
+feature cache, the WHOLE frame sequence stays resident in HBM (channels-last [T,H,W,C]; 81x480x832x96 fp32 = 12.4 GB,
+trivial against 288 GB) and every layer is ONE launch over all frames with causal zero padding in time -- arithmetically
+the same function (oracle/vae.py proves it against the chunked twin).  Convolutions with MFMA-sized channel counts run as
+implicit GEMM (csrc/conv.hip); RMS-norm + SiLU is a fused one-pass kernel producing the bf16 conv operand; the nearest
+2x upsample and the stride-2 / zero-pad of Resample are folded into the convolution's gather; the mid-block attention is
+two MFMA GEMMs around a row softmax.  fp32 residual stream, bf16 MFMA operands, fp32 accumulation.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from ._ffi import WF_BF16, WF_F32, call
+from .dit import EPI_BF16, EPI_F32, EPI_F32_ACC, gemm
+
+DIM, Z_DIM = 96, 16
+DIM_MULT = [1, 2, 4, 4]
+NUM_RES = 2
+T_DOWN = [False, True, True]
+LATENTS_MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508, 0.4134, -0.0715, 0.5517, -0.3632,
+                -0.1922, -0.9497, 0.2503, -0.2921]  # vae.py:629-632
+LATENTS_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743, 3.2687, 2.1526, 2.8652, 1.5579, 1.6382,
+               1.1253, 2.8251, 1.9160]  # vae.py:633-636
+
+BF, F32 = torch.bfloat16, torch.float32
+
+
+def encoder_plan() -> List[Tuple]:
+    """vae.py:283-316."""
+    dims = [DIM * u for u in [1] + DIM_MULT]
+    plan = [("conv_in", "encoder.conv1", 3, dims[0])]
+    idx = 0
+    for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+        for _ in range(NUM_RES):
+            plan.append(("res", f"encoder.downsamples.{idx}", cin, cout))
+            idx += 1
+            cin = cout
+        if i != len(DIM_MULT) - 1:
+            plan.append(("down3d" if T_DOWN[i] else "down2d", f"encoder.downsamples.{idx}", cout, cout))
+            idx += 1
+    c = dims[-1]
+    plan += [("res", "encoder.middle.0", c, c), ("attn", "encoder.middle.1", c, c), ("res", "encoder.middle.2", c, c),
+             ("head", "encoder.head", c, 2 * Z_DIM)]
+    return plan
+
+
+def decoder_plan() -> List[Tuple]:
+    """vae.py:387-421."""
+    dims = [DIM * u for u in [DIM_MULT[-1]] + DIM_MULT[::-1]]
+    t_up = T_DOWN[::-1]
+    plan = [("conv_in", "decoder.conv1", Z_DIM, dims[0]), ("res", "decoder.middle.0", dims[0], dims[0]),
+            ("attn", "decoder.middle.1", dims[0], dims[0]), ("res", "decoder.middle.2", dims[0], dims[0])]
+    idx = 0
+    for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+        if i in (1, 2, 3):
+            cin = cin // 2
+        for _ in range(NUM_RES + 1):
+            plan.append(("res", f"decoder.upsamples.{idx}", cin, cout))
+            idx += 1
+            cin = cout
+        if i != len(DIM_MULT) - 1:
+            plan.append(("up3d" if t_up[i] else "up2d", f"decoder.upsamples.{idx}", cout, cout // 2))
+            idx += 1
+    plan.append(("head", "decoder.head", dims[-1], 3))
+    return plan
+
+
+class _LatentDist:
+    def __init__(self, mean):
+        self._mean = mean
+
+    def mode(self):
+        return self._mean
+
+
+class AutoencoderKLWan:
+    dtype = torch.float32
+
+    def __init__(self, device="cuda:0"):
+        self.device = torch.device(device)
+        self.config = SimpleNamespace(z_dim=Z_DIM, latents_mean=LATENTS_MEAN, latents_std=LATENTS_STD)
+        self.temperal_downsample = list(T_DOWN)
+        self.w: Dict[str, torch.Tensor] = {}
+        self.flops_last = 0
+
+    # ------------------------------------------------------------------------------------------------------------
+    # weights (keys as in WanVAE_.state_dict())
+    # ------------------------------------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        dev = self.device
+        W: Dict[str, torch.Tensor] = {}
+
+        def mfma_conv(p):  # [Cout,Cin,kt,kh,kw] -> bf16 [Cout, taps, Cin]
+            w = sd[p + ".weight"]
+            if w.dim() == 4:
+                w = w.unsqueeze(2)
+            co, ci = w.shape[:2]
+            W[p + ".w"] = w.permute(0, 2, 3, 4, 1).reshape(co, -1, ci).to(device=dev, dtype=BF).contiguous()
+            W[p + ".b"] = sd[p + ".bias"].to(device=dev, dtype=F32).contiguous()
+
+        def small_conv(p):  # -> f32 [taps, Cin, Cout]
+            w = sd[p + ".weight"]
+            co, ci = w.shape[:2]
+            W[p + ".w"] = w.permute(2, 3, 4, 1, 0).reshape(-1, ci, co).to(device=dev, dtype=F32).contiguous()
+            W[p + ".b"] = sd[p + ".bias"].to(device=dev, dtype=F32).contiguous()
+
+        def lin(p):  # 1x1(x1) conv as GEMM weight bf16 [Cout, Cin]
+            w = sd[p + ".weight"]
+            W[p + ".w"] = w.reshape(w.shape[0], w.shape[1]).to(device=dev, dtype=BF).contiguous()
+            W[p + ".b"] = sd[p + ".bias"].to(device=dev, dtype=F32).contiguous()
+
+        def gamma(p):
+            W[p] = sd[p].reshape(-1).to(device=dev, dtype=F32).contiguous()
+
+        for plan in (encoder_plan(), decoder_plan()):
+            for kind, p, cin, cout in plan:
+                if kind == "conv_in":
+                    small_conv(p)
+                elif kind == "res":
+                    gamma(p + ".residual.0.gamma")
+                    mfma_conv(p + ".residual.2")
+                    gamma(p + ".residual.3.gamma")
+                    mfma_conv(p + ".residual.6")
+                    if cin != cout:
+                        lin(p + ".shortcut")
+                elif kind == "attn":
+                    gamma(p + ".norm.gamma")
+                    lin(p + ".to_qkv")
+                    lin(p + ".proj")
+                elif kind in ("down2d", "down3d", "up2d", "up3d"):
+                    mfma_conv(p + ".resample.1")
+                    if kind.endswith("3d"):
+                        mfma_conv(p + ".time_conv")
+                elif kind == "head":
+                    gamma(p + ".0.gamma")
+                    small_conv(p + ".2")
+        small_conv("conv1")
+        small_conv("conv2")
+        self.w = W
+        return self
+
+    def init_random(self, seed: int = 0):
+        """Synthetic weights of the real shapes, generated on the host in twin layout (127 M parameters)."""
+        g = torch.Generator().manual_seed(seed)
+        sd = {}
+
+        def conv(p, cin, cout, k):
+            sd[p + ".weight"] = torch.randn((cout, cin) + k, generator=g) / math.sqrt(cin * math.prod(k))
+            sd[p + ".bias"] = 0.02 * torch.randn(cout, generator=g)
+
+        for plan in (encoder_plan(), decoder_plan()):
+            for kind, p, cin, cout in plan:
+                if kind == "conv_in":
+                    conv(p, cin, cout, (3, 3, 3))
+                elif kind == "res":
+                    sd[p + ".residual.0.gamma"] = 1 + 0.05 * torch.randn(cin, generator=g)
+                    conv(p + ".residual.2", cin, cout, (3, 3, 3))
+                    sd[p + ".residual.3.gamma"] = 1 + 0.05 * torch.randn(cout, generator=g)
+                    conv(p + ".residual.6", cout, cout, (3, 3, 3))
+                    if cin != cout:
+                        conv(p + ".shortcut", cin, cout, (1, 1, 1))
+                elif kind == "attn":
+                    sd[p + ".norm.gamma"] = 1 + 0.05 * torch.randn(cin, generator=g)
+                    conv(p + ".to_qkv", cin, 3 * cin, (1, 1))
+                    conv(p + ".proj", cin, cin, (1, 1))
+                elif kind in ("down2d", "down3d"):
+                    conv(p + ".resample.1", cin, cin, (3, 3))
+                    if kind == "down3d":
+                        conv(p + ".time_conv", cin, cin, (3, 1, 1))
+                elif kind in ("up2d", "up3d"):
+                    conv(p + ".resample.1", cin, cin // 2, (3, 3))
+                    if kind == "up3d":
+                        conv(p + ".time_conv", cin, cin * 2, (3, 1, 1))
+                elif kind == "head":
+                    sd[p + ".0.gamma"] = 1 + 0.05 * torch.randn(cin, generator=g)
+                    conv(p + ".2", cin, cout, (3, 3, 3))
+        conv("conv1", 2 * Z_DIM, 2 * Z_DIM, (1, 1, 1))
+        conv("conv2", Z_DIM, Z_DIM, (1, 1, 1))
+        return self.load_state_dict(sd)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # kernels wrappers; activations are channels-last [T, H, W, C]
+    # ------------------------------------------------------------------------------------------------------------
+    def _conv(self, x, p, To, Ho, Wo, Cout, k, st=1, ss=1, pt=0, ps=0, up2=False, tsplit=False, resid=None, out_f32=True,
+              out_bf16=False, out_shape=None, out_bf_tensor=None):
+        Ti, Hi, Wi, Cin = x.shape
+        assert x.dtype == BF and x.is_contiguous()
+        shape = out_shape or (To, Ho, Wo, Cout)
+        of = torch.empty(shape, dtype=F32, device=x.device) if out_f32 else None
+        ob = out_bf_tensor if out_bf_tensor is not None else (torch.empty(shape, dtype=BF, device=x.device) if out_bf16 else None)
+        W = self.w
+        call("wf_conv3d_cl", x.data_ptr(), W[p + ".w"].data_ptr(), W[p + ".b"].data_ptr(),
+             resid.data_ptr() if resid is not None else None, of.data_ptr() if of is not None else None,
+             ob.data_ptr() if ob is not None else None, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, k[0], k[1], k[2], st, ss, pt, ps,
+             1 if up2 else 0, 1 if tsplit else 0, ops.stream())
+        self.flops_last += 2 * To * Ho * Wo * Cout * k[0] * k[1] * k[2] * Cin
+        return of, ob
+
+    def _small_conv(self, x, p, To, Ho, Wo, Cout, k, pt=0, ps=0, clamp=0.0):
+        Ti, Hi, Wi, Cin = x.shape
+        out = torch.empty((To, Ho, Wo, Cout), dtype=F32, device=x.device)
+        W = self.w
+        call("wf_conv3d_small", x.data_ptr(), WF_BF16 if x.dtype == BF else WF_F32, W[p + ".w"].data_ptr(), W[p + ".b"].data_ptr(),
+             out.data_ptr(), None, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, k[0], k[1], k[2], 1, 1, pt, ps, float(clamp), ops.stream())
+        self.flops_last += 2 * To * Ho * Wo * Cout * k[0] * k[1] * k[2] * Cin
+        return out
+
+    def _rms(self, x, gamma, silu=True):
+        C = x.shape[-1]
+        out = torch.empty(x.shape, dtype=BF, device=x.device)
+        call("wf_rms_silu_cl", x.data_ptr(), gamma.data_ptr(), out.data_ptr(), None, x.numel() // C, C, 1 if silu else 0,
+             ops.stream())
+        return out
+
+    def _res(self, x, p, cin, cout):
+        """vae.py:186-220."""
+        T, H, Wd, _ = x.shape
+        W = self.w
+        a = self._rms(x, W[p + ".residual.0.gamma"])
+        y, _ = self._conv(a, p + ".residual.2", T, H, Wd, cout, (3, 3, 3), pt=2, ps=1)
+        del a
+        a2 = self._rms(y, W[p + ".residual.3.gamma"])
+        del y
+        if cin != cout:
+            xb = ops.cast(x, BF)
+            h = torch.empty((T, H, Wd, cout), dtype=F32, device=x.device)
+            gemm(xb.view(-1, cin), W[p + ".shortcut.w"], W[p + ".shortcut.b"], h.view(-1, cout), EPI_F32)
+            self.flops_last += 2 * T * H * Wd * cin * cout
+            del xb
+        else:
+            h = x
+        out, _ = self._conv(a2, p + ".residual.6", T, H, Wd, cout, (3, 3, 3), pt=2, ps=1, resid=h)
+        return out
+
+    def _attn(self, x, p):
+        """vae.py:223-262: per-frame single-head attention over the H*W positions (C = 384)."""
+        T, H, Wd, C = x.shape
+        hw = H * Wd
+        hwp = (hw + 7) // 8 * 8  # K / N padding for the MFMA GEMMs; padded score columns are never read by the softmax
+        W = self.w
+        a = self._rms(x, W[p + ".norm.gamma"], silu=False)
+        qkv = torch.empty((T * hw + 8, 3 * C), dtype=BF, device=x.device)  # +8 rows: the padded K rows stay in-bounds
+        qkv[T * hw:].zero_()
+        gemm(a.view(-1, C), W[p + ".to_qkv.w"], W[p + ".to_qkv.b"], qkv[:T * hw], EPI_BF16)
+        del a
+        S = torch.empty((hw, hwp), dtype=F32, device=x.device)
+        P = torch.empty((hw, hwp), dtype=BF, device=x.device)
+        Vt = torch.empty((C, hwp), dtype=BF, device=x.device)
+        O = torch.empty((T * hw, C), dtype=BF, device=x.device)
+        scale = 1.0 / math.sqrt(C)
+        for t in range(T):
+            blk = qkv[t * hw:t * hw + hwp]
+            gemm(blk[:hw, 0:C], blk[:, C:2 * C], None, S, EPI_F32)
+            call("wf_softmax_rows", S.data_ptr(), hwp, P.data_ptr(), hwp, hw, hw, float(scale), ops.stream())
+            call("wf_transpose_bf16", blk[:, 2 * C:].data_ptr(), 3 * C, Vt.data_ptr(), hwp, hw, C, ops.stream())
+            gemm(P, Vt, None, O[t * hw:(t + 1) * hw], EPI_BF16)
+        gemm(O, W[p + ".proj.w"], W[p + ".proj.b"], x.view(-1, C), EPI_F32_ACC)  # x + proj(attn)  (vae.py:262)
+        self.flops_last += T * (4 * hw * hw * C) + 2 * T * hw * C * 4 * C
+        return x
+
+    def _down(self, x, p, C, temporal):
+        """vae.py:87-96, 139-159."""
+        T, H, Wd, _ = x.shape
+        Ho, Wo = H // 2, Wd // 2
+        xb = ops.cast(x, BF)
+        if not temporal or T == 1:
+            y, _ = self._conv(xb, p + ".resample.1", T, Ho, Wo, C, (1, 3, 3), ss=2, ps=0)
+            return y
+        y, yb = self._conv(xb, p + ".resample.1", T, Ho, Wo, C, (1, 3, 3), ss=2, ps=0, out_f32=True, out_bf16=True)
+        del xb
+        To = (T - 1) // 2
+        out = torch.empty((1 + To, Ho, Wo, C), dtype=F32, device=x.device)
+        out[0].copy_(y[0])  # frame 0 by-passes time_conv (vae.py:146-148)
+        W = self.w
+        call("wf_conv3d_cl", yb.data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
+             out[1:].data_ptr(), None, T, Ho, Wo, C, To, Ho, Wo, C, 3, 1, 1, 2, 1, 0, 0, 0, 0, ops.stream())
+        self.flops_last += 2 * To * Ho * Wo * C * 3 * C
+        return out
+
+    def _up(self, x, p, C, temporal):
+        """vae.py:76-86, 101-141."""
+        T, H, Wd, _ = x.shape
+        xb = ops.cast(x, BF)
+        if temporal and T > 1:
+            T2 = 1 + 2 * (T - 1)
+            yb = torch.empty((T2, H, Wd, C), dtype=BF, device=x.device)
+            yb[0].copy_(xb[0])  # first latent frame by-passes time_conv ('Rep', vae.py:106-108)
+            W = self.w
+            call("wf_conv3d_cl", xb[1:].data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
+                 None, yb.data_ptr(), T - 1, H, Wd, C, T - 1, H, Wd, 2 * C, 3, 1, 1, 1, 1, 2, 0, 0, 1, ops.stream())
+            self.flops_last += 2 * (T - 1) * H * Wd * 2 * C * 3 * C
+            xb = yb
+        Tn = xb.shape[0]
+        out, _ = self._conv(xb, p + ".resample.1", Tn, 2 * H, 2 * Wd, C // 2, (1, 3, 3), ps=1, up2=True)
+        return out
+
+    def _run(self, x, plan, clamp=0.0):
+        W = self.w
+        for kind, p, cin, cout in plan:
+            T, H, Wd, _ = x.shape
+            if kind == "conv_in":
+                x = self._small_conv(x, p, T, H, Wd, cout, (3, 3, 3), pt=2, ps=1)
+            elif kind == "res":
+                x = self._res(x, p, cin, cout)
+            elif kind == "attn":
+                x = self._attn(x, p)
+            elif kind in ("down2d", "down3d"):
+                x = self._down(x, p, cin, kind == "down3d")
+            elif kind in ("up2d", "up3d"):
+                x = self._up(x, p, cin, kind == "up3d")
+            elif kind == "head":
+                a = self._rms(x, W[p + ".0.gamma"])
+                x = self._small_conv(a, p + ".2", T, H, Wd, cout, (3, 3, 3), pt=2, ps=1, clamp=clamp)
+        return x
+
+    # ------------------------------------------------------------------------------------------------------------
+    # diffusers protocol
+    # ------------------------------------------------------------------------------------------------------------
+    def _encode_one(self, video: torch.Tensor) -> torch.Tensor:
+        """[3,F,H,W] f32 -> posterior mean [16,T,h,w] f32  (vae.py:516-542 without the scale; mode() = mean half)."""
+        C, Fr, H, Wd = video.shape
+        if (Fr - 1) % 4 != 0:
+            raise ValueError(f"number of frames must be 1 + 4k, got {Fr}")
+        if H % 8 or Wd % 8:
+            raise ValueError("height and width must be multiples of 8")
+        self.flops_last = 0
+        x = torch.empty((Fr, H, Wd, 3), dtype=F32, device=self.device)
+        call("wf_ncthw_to_cl", video.data_ptr(), x.data_ptr(), None, 3, Fr * H * Wd, ops.stream())
+        y = self._run(x, encoder_plan())
+        T, h, w, _ = y.shape
+        q = self._small_conv(y, "conv1", T, h, w, 2 * Z_DIM, (1, 1, 1))
+        out = torch.empty((2 * Z_DIM, T, h, w), dtype=F32, device=self.device)
+        call("wf_cl_to_ncthw", q.data_ptr(), out.data_ptr(), 2 * Z_DIM, T * h * w, 0.0, ops.stream())
+        return out[:Z_DIM]
+
+    def _decode_one(self, z: torch.Tensor) -> torch.Tensor:
+        """[16,T,h,w] f32 -> [3, 4T-3, 8h, 8w] f32 clamped to [-1,1] (vae.py:544-568, autoencoder_kl_wan.py:1222)."""
+        C, T, h, w = z.shape
+        self.flops_last = 0
+        x = torch.empty((T, h, w, Z_DIM), dtype=F32, device=self.device)
+        call("wf_ncthw_to_cl", z.data_ptr(), x.data_ptr(), None, Z_DIM, T * h * w, ops.stream())
+        x = self._small_conv(x, "conv2", T, h, w, Z_DIM, (1, 1, 1))
+        y = self._run(x, decoder_plan(), clamp=1.0)
+        Fo, Ho, Wo, _ = y.shape
+        out = torch.empty((3, Fo, Ho, Wo), dtype=F32, device=self.device)
+        call("wf_cl_to_ncthw", y.data_ptr(), out.data_ptr(), 3, Fo * Ho * Wo, 0.0, ops.stream())
+        return out
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        x = x.to(device=self.device, dtype=F32).contiguous()
+        mean = torch.stack([self._encode_one(v) for v in x])
+        post = _LatentDist(mean)
+        if not return_dict:
+            return (post,)
+        return SimpleNamespace(latent_dist=post)
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, return_dict: bool = True):
+        z = z.to(device=self.device, dtype=F32).contiguous()
+        out = torch.stack([self._decode_one(v) for v in z])
+        if not return_dict:
+            return (out,)
+        return SimpleNamespace(sample=out)
