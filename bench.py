@@ -1,0 +1,233 @@
+"""bench.py -- denoising steps/s of the IRR/FLF/DSG guided sampler (Wan2.1-I2V-14B, 81 frames x 480x832) on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W   ->  ONE JSON line on rank 0.
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; the DiT token sequence is sharded over ranks
+(K/V all-gather over RCCL, see worldforge_amd/parallel.py) -- "strong" scaling: the job (one video) is fixed.
+
+Workload (BASELINE.json configs[1]): synthetic 81 x 480 x 832 video -> latents [1,16,21,60,104], L = 32 760 tokens,
+random-init Wan2.1-I2V-14B DiT (40 layers, d = 5120, 40 heads, FFN 13824; bf16) and random-init real-config VAE (fp32 I/O),
+CFG 4 (two DiT forwards per evaluation), 50-step schedule, guide_steps = resample_round = 15, resample_steps = 2, omega = 4,
+FLF on.  A "step" is one outer iteration of PIPE:563.  The timed window holds K consecutive steps of that schedule entered at
+step 15 - W - n_g so that n_g = max(1, round(0.3 K)) of them are guided steps (4 DiT forwards + 2 VAE decodes + 2 VAE encodes
++ FLF + DSG) and the rest are plain steps (2 DiT forwards) -- the 15:35 mix of the 50-step job.  Nothing is skipped or cached
+inside the timed region; inputs are resident in HBM before it starts.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS_BF16 = 2500.0  # dense, MI355X_MICROARCH.md
+
+
+def synthetic_inputs(F, H, W, device, seed=42):
+    """SURVEY 8d synthetic inputs."""
+    g = torch.Generator().manual_seed(seed)
+    image = torch.rand(3, H, W, generator=g)
+    ref = torch.rand(1, 3, F, H, W, generator=g)
+    ref[:, :, 0] = image
+    xs = torch.arange(W).view(1, 1, 1, 1, W).float()
+    fr = torch.arange(F).view(1, 1, F, 1, 1).float() / max(F - 1, 1)
+    edge = W * (1 - 0.35 * fr)
+    d = (edge - xs).clamp(min=0)
+    mask = (torch.sin(math.pi / 2 * (d / 15).clamp(0, 1)) * (xs < edge)).expand(1, 1, F, H, W).contiguous()
+    text = torch.randn(1, 512, 4096, generator=g) * 0.1
+    text[:, 200:] = 0
+    neg = torch.randn(1, 512, 4096, generator=g) * 0.1
+    neg[:, 120:] = 0
+    img_emb = torch.randn(1, 257, 1280, generator=g)
+    bf = torch.bfloat16
+    return image, ref.to(device), mask.to(device), text.to(bf).to(device), neg.to(bf).to(device), img_emb.to(bf).to(device)
+
+
+def cpu_baseline(budget_s=25.0):
+    """Oracle (CPU port of the reference arithmetic, fp32) timed on this host: one full-width DiT block and one VAE
+    decode+encode on a bounded sample; converted to steps/s of the timed step mix by the algorithmic FLOP counts."""
+    from oracle import dit as odit
+    from oracle import vae as ovae
+
+    torch.manual_seed(0)
+    cores = torch.get_num_threads()
+    cfg = odit.DiTConfig(num_layers=1)
+    Ls = 1024
+    W = odit.random_weights(cfg, seed=1)
+    f, h, w = 1, 32, 32
+    tok = torch.randn(Ls, cfg.dim)
+    e0 = torch.randn(6, cfg.dim) * 0.1
+    ctx = torch.randn(769, cfg.dim)
+    ang = odit.rope_tables(128, f, h, w)
+    with torch.no_grad():
+        odit.block(tok[:64], e0, ctx, W, 0, cfg, ang[:64])  # warm-up
+        t0 = time.time()
+        odit.block(tok, e0, ctx, W, 0, cfg, ang)
+        t_blk = time.time() - t0
+    d, ff = cfg.dim, cfg.ffn_dim
+    flop_blk = Ls * (12 * d * d + 4 * d * ff) + 4 * 769 * d * d + 4 * Ls * Ls * d + 4 * Ls * 769 * d
+    dit_rate = flop_blk / t_blk
+    del W
+    Wv = ovae.random_weights(seed=2)
+    Fs, Hs, Ws = 5, 64, 64
+    with torch.no_grad():
+        t0 = time.time()
+        z = ovae.encode_mode(Wv, torch.rand(1, 3, Fs, Hs, Ws) * 2 - 1)
+        ovae.decode(Wv, z)
+        t_vae = time.time() - t0
+    flop_vae = (5.19e6 + 8.70e6) * Fs * Hs * Ws
+    vae_rate = flop_vae / t_vae
+    return dict(cores=cores, dit_flops_per_s=dit_rate, vae_flops_per_s=vae_rate, t_block_s=t_blk, t_vae_s=t_vae,
+                sample=f"oracle fp32: 1 DiT block (d=5120, 40 heads, FFN 13824) at L={Ls} tokens in {t_blk:.2f}s + VAE "
+                       f"encode+decode of {Fs}x{Hs}x{Ws} in {t_vae:.2f}s; extrapolated by algorithmic FLOPs to the timed step mix")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=81)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=832)
+    ap.add_argument("--layers", type=int, default=40, help="DiT depth (40 = Wan2.1-14B; smaller only for debugging -> flagged)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device(f"cuda:{local_rank}")
+
+    from worldforge_amd import dit as wdit
+    from worldforge_amd import parallel
+    from worldforge_amd.pipeline import WanImageToVideoPipeline
+    from worldforge_amd.scheduler import UniPCMultistepScheduler
+    from worldforge_amd.vae import AutoencoderKLWan
+
+    comm = parallel.init(world, rank, local_rank) if world > 1 else None
+
+    cfg = wdit.DiTConfig.wan_i2v_14b()
+    cfg.num_layers = a.layers
+    t0 = time.time()
+    model = wdit.WanTransformer3DModel(cfg, device, comm=comm).init_random(seed=0)
+    vae = AutoencoderKLWan(device).init_random(seed=1)
+    sch = UniPCMultistepScheduler(flow_shift=3.0)
+    pipe = WanImageToVideoPipeline(model, vae, sch, device=device)
+    image, ref, mask, text, neg, img_emb = synthetic_inputs(a.frames, a.height, a.width, device)
+    torch.cuda.synchronize()
+    t_setup = time.time() - t0
+
+    K, Wm = a.steps, a.warmup
+    n_g = max(1, round(0.3 * K)) if K > 1 else 1
+    n_g = min(n_g, K)
+    guide = 15
+    start = max(0, guide - Wm - n_g)
+    marks = {}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if comm is not None:
+            comm.barrier()
+        torch.cuda.synchronize()
+
+    def hook(i, phase):
+        idx = i - start
+        if phase == "begin" and idx == Wm:
+            barrier()
+            marks["t0"] = time.perf_counter()
+            wdit.PROFILE_ATTN = []
+        if phase == "begin":
+            torch.cuda.synchronize()
+            marks[("b", i)] = time.perf_counter()
+        if phase == "end":
+            torch.cuda.synchronize()
+            marks[("e", i)] = time.perf_counter()
+        if phase == "end" and idx == Wm + K - 1:
+            barrier()
+            marks["t1"] = time.perf_counter()
+
+    gen = torch.manual_seed(42)
+    pipe(image=image, height=a.height, width=a.width, num_frames=a.frames, num_inference_steps=50, guidance_scale=4.0,
+         generator=gen, prompt_embeds=text, negative_prompt_embeds=neg, image_embeds=img_emb, output_type="latent",
+         video_ref=ref, mask=mask, guided=True, resample_steps=2, guide_steps=guide, omega=4.0, omega_resample=4.0,
+         resample_round=guide, use_pca_channel_selection=True, static=True, start_step=start, max_steps=Wm + K, step_hook=hook)
+    elapsed = marks["t1"] - marks["t0"]
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if comm is not None:
+        comm.all_reduce_max(el)
+    elapsed = el.item()
+
+    # per-kernel roofline figure: self-attention launches inside the timed region (HIP events on the launch stream)
+    prof = wdit.PROFILE_ATTN or []
+    wdit.PROFILE_ATTN = None
+    torch.cuda.synchronize()
+    attn_ms = [s.elapsed_time(e) for s, e in prof]
+    T = (a.frames - 1) // 4 + 1
+    L = T * (a.height // 16) * (a.width // 16)
+    Lq = model.local_tokens(L)
+    attn_flop = 4.0 * Lq * L * 128 * cfg.num_heads
+    guided_ms = [1e3 * (marks[("e", i)] - marks[("b", i)]) for i in range(start + Wm, start + Wm + K) if i < guide]
+    plain_ms = [1e3 * (marks[("e", i)] - marks[("b", i)]) for i in range(start + Wm, start + Wm + K) if i >= guide]
+
+    if rank == 0:
+        out = {
+            "metric": "denoising steps/sec (81f x 480p, Wan2.1-14B)",
+            "value": K / elapsed,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": Wm,
+            "ms_per_step": 1e3 * elapsed / K,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": f"Wan2.1-I2V-14B-480P, {a.frames}f {a.height}x{a.width}, 50-step schedule, full IRR+FLF+DSG, CFG 4; "
+                            f"timed steps {start + Wm}..{start + Wm + K - 1} = {len(guided_ms)} guided + {len(plain_ms)} plain",
+                "tokens": L, "dit_layers": cfg.num_layers, "dit_params_bytes": model.param_bytes(),
+                "parallelism": "single" if world == 1 else f"sp{world} (token-sharded DiT, K/V all-gather over RCCL)",
+                "flow_backend": "tdiff",
+            },
+            "guided_step_ms": sum(guided_ms) / len(guided_ms) if guided_ms else None,
+            "plain_step_ms": sum(plain_ms) / len(plain_ms) if plain_ms else None,
+            "setup_s": t_setup,
+        }
+        if guided_ms and plain_ms:
+            g, p = out["guided_step_ms"], out["plain_step_ms"]
+            out["job50_steps_per_s"] = 50.0 / ((15 * g + 35 * p) / 1e3)
+        if attn_ms:
+            avg = sum(attn_ms) / len(attn_ms)
+            ach = attn_flop / (avg * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "k_attn (DiT self-attention, model.py:149-154)", "bound": "mfma", "achieved": ach,
+                               "peak": MFMA_PEAK_TFLOPS_BF16, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS_BF16,
+                               "traffic": None, "launches": len(attn_ms), "avg_launch_ms": avg,
+                               "flop_per_launch": attn_flop}
+        if a.layers != 40:
+            out["invalid_reason"] = f"debug run with {a.layers} DiT layers (the named model has 40)"
+        if not a.no_cpu_baseline and world == 1:
+            cb = cpu_baseline()
+            ng, npl = len(guided_ms), len(plain_ms)
+            dit_flop = 40 * (8 * L * 5120 ** 2 + 4 * L * 5120 ** 2 + 4 * 769 * 5120 ** 2 + 4 * L * 5120 * 13824 + 4 * L * L * 5120 + 4 * L * 769 * 5120)
+            vae_flop = (5.19e6 + 8.70e6) * a.frames * a.height * a.width
+            t_cpu = (ng * 4 + npl * 2) * dit_flop / cb["dit_flops_per_s"] + ng * 2 * vae_flop / cb["vae_flops_per_s"]
+            out["cpu_baseline"] = {"value": K / t_cpu, "unit": "steps/s", "cores": cb["cores"], "kind": "port", "sample": cb["sample"]}
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -122,8 +122,10 @@ int wf_gemm_bf16(const void* X, const void* W, const float* bias, void* out, con
 
 /* flash_attention (attention.py:24-130) as used by model.py:149-154 (self) and :220-222 (cross): fused
  * softmax(Q K^T * softmax_scale) V, no mask, head_dim 128.  Q [H][Lq][128], K [H][Lkp][128] (rows >= kv_len zero),
- * Vt [H][Lkp/64][128][64] (wf_v_transpose), O [Lq][ldo] bf16 with head h at columns h*128.  accumulate != 0: O += result. */
-int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int ldo,
+ * Vt [H][Lkp/64][128][64] (wf_v_transpose), O [Lq][ldo] bf16 with head h at columns h*128.  accumulate != 0: O += result.
+ * seg_len: Lkp for one contiguous K/V; with sequence parallelism K/V are the all-gathered per-rank shards [P][H][seg_len][128]
+ * (seg_len % 64 == 0, Lkp = P*seg_len) and key index = seg*seg_len + row. */
+int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len, int ldo,
                 float softmax_scale, int accumulate, void* stream);
 
 /* WanLayerNorm (model.py:92-102; eps, no affine) fused with y = ln * (plus_one + mul[c]) + add[c]:

@@ -10,6 +10,11 @@ import os
 import re
 from typing import Dict, List, Tuple
 
+# Import torch BEFORE dlopen()ing libwf_hip.so: PyTorch-ROCm ships its own libamdhip64.so.7 / libhsa-runtime64 (rocm 7.0)
+# under torch/lib, and /opt/rocm carries 7.2 with the same SONAME.  Whichever is loaded first serves both; if ours pulled in
+# /opt/rocm's copy first, torch would run on a runtime / HSA pair it was not built with ("no ROCm-capable device").
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "wf_hip.h")

@@ -45,6 +45,7 @@ struct AttnArgs {
   const uint16_t* Vt;
   uint16_t* O;
   int H, Lq, Lkp, kv_len, ldo;
+  int seg_len;  // keys per K/V segment (= Lkp, or the per-rank shard length when K/V were all-gathered: [P][H][seg_len][128])
   int n_qblk;
   float scale_log2;  // softmax_scale * log2(e)
   int accumulate;    // O += result (second cross-attention, model.py:227)
@@ -79,8 +80,9 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
   }
 
   // ---- staging: K tile 1024 chunks, V tile 1024 chunks, 512 threads -> 2 + 2 per thread -------------------------------
-  const uint16_t* Kh = a.K + (size_t)head * a.Lkp * D;
-  const uint16_t* Vh = a.Vt + (size_t)head * a.Lkp * D;
+  // K/V may be a concatenation of P per-rank segments [P][H][seg_len][128] (sequence-parallel all-gather); seg_len % 64 == 0,
+  // so a 64-key tile never straddles two segments.  Single GPU: seg_len == Lkp, one segment.
+  const int tiles_per_seg = a.seg_len / KB;
   u32x4 rK[2], rV[2];
   int koff[2], voff[2], ksrc[2], vsrc[2];
 #pragma unroll
@@ -94,8 +96,10 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
     voff[i] = vr * 128 + ((vc ^ ((vr >> 1) & 7)) << 4);
   }
   auto gload = [&](int t) {
-    const uint16_t* kp = Kh + (size_t)t * KB * D;
-    const uint16_t* vp = Vh + (size_t)t * KB * D;
+    const int seg = t / tiles_per_seg;
+    const size_t tile_off = ((size_t)(seg * a.H + head) * tiles_per_seg + (t - seg * tiles_per_seg)) * (KB * D);
+    const uint16_t* kp = a.K + tile_off;
+    const uint16_t* vp = a.Vt + tile_off;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       rK[i] = *reinterpret_cast<const u32x4*>(kp + ksrc[i]);
@@ -246,12 +250,14 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
 
 }  // namespace
 
-extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int ldo,
-                           float softmax_scale, int accumulate, void* stream) {
+extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len,
+                           int ldo, float softmax_scale, int accumulate, void* stream) {
   WF_CHECK_ARG(Q && K && Vt && O, "wf_attn_fwd: null pointer");
   WF_CHECK_ARG(H > 0 && Lq > 0 && kv_len > 0, "wf_attn_fwd: empty problem");
   WF_CHECK_ARG(Lkp % KB == 0 && kv_len <= Lkp, "wf_attn_fwd: Lkp (%d) must be a multiple of 64 and >= kv_len (%d)", Lkp,
                kv_len);
+  WF_CHECK_ARG(seg_len > 0 && seg_len % KB == 0 && Lkp % seg_len == 0, "wf_attn_fwd: seg_len (%d) must be a multiple of 64 dividing Lkp",
+               seg_len);
   WF_CHECK_ARG(ldo % 4 == 0 && ldo >= H * D, "wf_attn_fwd: bad ldo %d", ldo);
   WF_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O) & 15) == 0, "wf_attn_fwd: 16-byte alignment");
   AttnArgs a;
@@ -263,6 +269,7 @@ extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O
   a.Lq = Lq;
   a.Lkp = Lkp;
   a.kv_len = kv_len;
+  a.seg_len = seg_len;
   a.ldo = ldo;
   a.n_qblk = ceil_div(Lq, QB);
   a.scale_log2 = softmax_scale * 1.4426950408889634f;

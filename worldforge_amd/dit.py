@@ -66,14 +66,31 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     return out
 
 
+PROFILE_ATTN = None  # bench.py sets this to a list: (start, end) HIP events around every self-attention launch
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, kv_len: int, scale: float,
-              accumulate: bool = False):
-    """q [H,Lq,128], k [H,Lkp,128], vt [H,Lkp/64,128,64] bf16 -> out [Lq, H*128] bf16."""
+              accumulate: bool = False, profile: bool = False):
+    """q [H,Lq,128]; k [H,Lkp,128] and vt [H,Lkp/64,128,64], or their all-gathered per-rank shards k [P,H,S,128],
+    vt [P,H,S/64,128,64] (S = shard length, keys in shard-major order) -> out [Lq, H*128] bf16."""
     H, Lq, D = q.shape
-    Lkp = k.shape[1]
-    assert D == 128 and vt.shape == (H, Lkp // 64, 128, 64)
-    call("wf_attn_fwd", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Lq, Lkp, kv_len, out.stride(0),
+    if k.dim() == 4:
+        P, _, seg, _ = k.shape
+        assert vt.shape == (P, H, seg // 64, 128, 64)
+        Lkp = P * seg
+    else:
+        Lkp = seg = k.shape[1]
+        assert vt.shape == (H, Lkp // 64, 128, 64)
+    assert D == 128
+    prof = PROFILE_ATTN if profile else None
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    call("wf_attn_fwd", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Lq, Lkp, kv_len, seg, out.stride(0),
          float(scale), 1 if accumulate else 0, ops.stream())
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1))
     return out
 
 
@@ -137,8 +154,9 @@ def diffusers_key_map(num_layers: int) -> Dict[str, str]:
 class WanTransformer3DModel:
     dtype = torch.bfloat16
 
-    def __init__(self, cfg: DiTConfig, device="cuda:0"):
+    def __init__(self, cfg: DiTConfig, device="cuda:0", comm=None):
         self.cfg = cfg
+        self.comm = comm  # parallel.Comm for sequence parallelism (None = single GPU)
         self.config = SimpleNamespace(patch_size=cfg.patch_size, in_channels=cfg.in_dim, out_channels=cfg.out_dim)
         self.device = torch.device(device)
         self.w: Dict[str, torch.Tensor] = {}
@@ -255,6 +273,13 @@ class WanTransformer3DModel:
         self.w = W
         return self
 
+    def local_tokens(self, L: int) -> int:
+        """Query rows this rank processes (all of them on one GPU)."""
+        if self.comm is None:
+            return L
+        from .parallel import shard_plan
+        return shard_plan(L, self.comm.world).local_tokens(self.comm.rank)
+
     def param_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.w.values())
 
@@ -347,17 +372,27 @@ class WanTransformer3DModel:
         Cin, T, Hh, Ww = x_in.shape
         assert Cin == cfg.in_dim
         f, h2, w2 = T, Hh // 2, Ww // 2
-        L = f * h2 * w2
-        Lp = _pad64(L)
+        Lfull = f * h2 * w2
         d, H = cfg.dim, cfg.num_heads
         scale = 1.0 / math.sqrt(128.0)
         cos, sin = self._rope_tables(f, h2, w2)
         e, e0, ctx_t, ctx_i = self._embed_condition(t_value, text, img)
         n_img = ctx_i.shape[0]
+        comm = self.comm
+        tok = self._buf("tok", (Lfull, Cin * 4), bf)
+        call("wf_patchify", x_in.data_ptr(), tok.data_ptr(), Cin, T, Hh, Ww, ops.stream())
+        if comm is not None:
+            # sequence parallelism: this rank owns a contiguous token shard; K / V^T are exchanged per layer (parallel.py)
+            from .parallel import shard_plan
+            plan = shard_plan(Lfull, comm.world)
+            lo, hi = plan.bounds(comm.rank)
+            L, Lp = hi - lo, plan.shard_len
+            tok, cos, sin = tok[lo:hi], cos[lo:hi], sin[lo:hi]
+        else:
+            plan = None
+            L, Lp = Lfull, _pad64(Lfull)
 
         # patch embedding (model.py:534-537) as a GEMM -> fp32 residual stream
-        tok = self._buf("tok", (L, Cin * 4), bf)
-        call("wf_patchify", x_in.data_ptr(), tok.data_ptr(), Cin, T, Hh, Ww, ops.stream())
         x = self._buf("x", (L, d), f32)
         gemm(tok, W["patch.w"], W["patch.b"], x, EPI_F32)
 
@@ -366,6 +401,9 @@ class WanTransformer3DModel:
         qh = self._buf("qh", (H, L, 128), bf)
         kh = self._buf("kh", (H, Lp, 128), bf, zero=True)
         vt = self._buf("vt", (H, Lp // 64, 128, 64), bf)
+        if comm is not None:
+            kh_all = self._buf("kh_all", (comm.world, H, Lp, 128), bf)
+            vt_all = self._buf("vt_all", (comm.world, H, Lp // 64, 128, 64), bf)
         ao = self._buf("ao", (L, d), bf)
         qc = self._buf("qc", (L, d), bf)
         ffh = self._buf("ffh", (L, cfg.ffn_dim), bf)
@@ -385,11 +423,25 @@ class WanTransformer3DModel:
                  emod.numel(), ops.stream())
             # ---- self-attention (model.py:302-306) ----
             self._ln(x, emod[1], emod[0], hbuf, cfg.eps, plus_one=True)
-            gemm(hbuf, W[p + "qkv.w"], W[p + "qkv.b"], qkv, EPI_BF16)
-            self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L)
-            self._heads(qkv, d, W[p + "self_attn.norm_k"], cos, sin, kh, L)
-            self._vt(qkv, 2 * d, vt, L)
-            attention(qh, kh, vt, ao, L, scale)
+            if comm is None:
+                gemm(hbuf, W[p + "qkv.w"], W[p + "qkv.b"], qkv, EPI_BF16)
+                self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L)
+                self._heads(qkv, d, W[p + "self_attn.norm_k"], cos, sin, kh, L)
+                self._vt(qkv, 2 * d, vt, L)
+                attention(qh, kh, vt, ao, L, scale, profile=True)
+            else:
+                # K and V first, their all-gather runs on the communication stream under the Q projection
+                gemm(hbuf, W[p + "qkv.w"][d:], W[p + "qkv.b"][d:], qkv[:, d:], EPI_BF16)
+                self._heads(qkv, d, W[p + "self_attn.norm_k"], cos, sin, kh, L)
+                self._vt(qkv, 2 * d, vt, L)
+                ev_k = comm.all_gather_async(kh_all, kh)
+                ev_v = comm.all_gather_async(vt_all, vt)
+                gemm(hbuf, W[p + "qkv.w"][:d], W[p + "qkv.b"][:d], qkv[:, :d], EPI_BF16)
+                self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L)
+                for ev in (ev_k, ev_v):
+                    if ev is not None:
+                        torch.cuda.current_stream().wait_event(ev)
+                attention(qh, kh_all, vt_all, ao, Lfull, scale, profile=True)
             gemm(ao, W[p + "self_attn.o.w"], W[p + "self_attn.o.b"], x, EPI_RESID, gate=emod[2])
             # ---- cross-attention (model.py:310, 202-229) ----
             self._ln(x, W[p + "norm3.w"], W[p + "norm3.b"], hbuf, cfg.eps, plus_one=False)
@@ -418,6 +470,9 @@ class WanTransformer3DModel:
         self._ln(x, hm[1], hm[0], hbuf, cfg.eps, plus_one=True)
         y = self._buf("y", (L, 4 * cfg.out_dim), f32)
         gemm(hbuf, W["head.head.w"], W["head.head.b"], y, EPI_F32)
+        if comm is not None:
+            from .parallel import gather_rows
+            y = gather_rows(comm, y, plan).contiguous()
         out = torch.empty((cfg.out_dim, T, Hh, Ww), dtype=f32, device=dev)
         call("wf_unpatchify", y.data_ptr(), out.data_ptr(), cfg.out_dim, T, Hh, Ww, ops.stream())
         return out
