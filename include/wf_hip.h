@@ -171,9 +171,10 @@ int wf_rms_silu_cl(const float* x, const float* gamma, void* out_bf16, float* ou
 int wf_softmax_rows(const float* S, int lds, void* P, int ldp, int M, int N, float scale, void* stream);
 /* bf16 in [R, ld_in] (first C columns) -> out [C, ld_out], columns R..ld_out zero. */
 int wf_transpose_bf16(const void* in, int ld_in, void* out, int ld_out, int R, int C, void* stream);
-/* [C, N] f32 -> [N, C] (f32 and/or bf16);  [N, C] f32 -> [C, N] f32 with optional clamp.  N = T*H*W. */
-int wf_ncthw_to_cl(const float* in, float* out_f32, void* out_bf16, int C, size_t N, void* stream);
-int wf_cl_to_ncthw(const float* in, float* out, int C, size_t N, float clamp, void* stream);
+/* [C, N] f32 -> [N, Cpad] (f32 and/or bf16; channels C..Cpad zero, so thin inputs fill an MFMA K slice);
+ * [N, ld] f32 (first C channels) -> [C, N] f32 with optional clamp (autoencoder_kl_wan.py:1222).  N = T*H*W. */
+int wf_ncthw_to_cl(const float* in, float* out_f32, void* out_bf16, int C, int Cpad, size_t N, void* stream);
+int wf_cl_to_ncthw(const float* in, float* out, int C, int ld, size_t N, float clamp, void* stream);
 
 #ifdef __cplusplus
 }

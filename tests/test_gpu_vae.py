@@ -135,11 +135,17 @@ def test_rms_silu_softmax_transpose_permute():
     v = torch.randn(3, 2 * 4 * 5, generator=g)
     vd = v.to(DEV)
     cl = torch.empty((40, 3), dtype=F32, device=DEV)
-    _ffi.call("wf_ncthw_to_cl", vd.data_ptr(), cl.data_ptr(), None, 3, 40, ops.stream())
+    _ffi.call("wf_ncthw_to_cl", vd.data_ptr(), cl.data_ptr(), None, 3, 3, 40, ops.stream())
     assert torch.equal(cl.cpu(), v.t())
     back = torch.empty((3, 40), dtype=F32, device=DEV)
-    _ffi.call("wf_cl_to_ncthw", cl.data_ptr(), back.data_ptr(), 3, 40, 1.0, ops.stream())
+    _ffi.call("wf_cl_to_ncthw", cl.data_ptr(), back.data_ptr(), 3, 3, 40, 1.0, ops.stream())
     assert torch.equal(back.cpu(), v.clamp(-1, 1))
+    clp = torch.full((40, 8), float("nan"), dtype=BF, device=DEV)
+    _ffi.call("wf_ncthw_to_cl", vd.data_ptr(), None, clp.data_ptr(), 3, 8, 40, ops.stream())
+    assert torch.equal(clp[:, :3].cpu(), v.t().to(BF)) and clp[:, 3:].abs().max().item() == 0
+    back2 = torch.empty((2, 40), dtype=F32, device=DEV)
+    _ffi.call("wf_cl_to_ncthw", cl.data_ptr(), back2.data_ptr(), 2, 3, 40, 0.0, ops.stream())
+    assert torch.equal(back2.cpu(), v[:2])
 
 
 def test_vae_protocol_and_errors(model):

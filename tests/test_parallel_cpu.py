@@ -1,0 +1,76 @@
+"""CPU (gloo, world size 2): the sequence-parallel plan, the all-gather layout the attention kernel consumes and the
+velocity gather -- the N > 1 path of worldforge_amd/parallel.py."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from worldforge_amd.parallel import shard_plan
+
+
+def test_shard_plan():
+    p = shard_plan(32760, 8)
+    assert p.shard_len == 4096 and p.padded_total == 32768
+    assert [p.local_tokens(r) for r in range(8)] == [4096] * 7 + [4088]
+    assert p.bounds(7) == (28672, 32760)
+    p1 = shard_plan(32760, 1)
+    assert p1.shard_len == 32768 and p1.local_tokens(0) == 32760
+    p2 = shard_plan(4524, 4)
+    assert p2.shard_len % 64 == 0 and sum(p2.local_tokens(r) for r in range(4)) == 4524
+    for L, P in ((75600, 8), (4524, 2), (100, 3)):
+        pl = shard_plan(L, P)
+        assert sum(pl.local_tokens(r) for r in range(P)) == L and pl.shard_len * P >= L
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, L, H, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from worldforge_amd import parallel
+    comm = parallel.init(world, rank, 0, backend="gloo")
+    plan = parallel.shard_plan(L, world)
+    lo, hi = plan.bounds(rank)
+    g = torch.Generator().manual_seed(0)
+    k_full = torch.randn(H, L, 8, generator=g)          # stands in for [H, L, 128]
+    y_full = torch.randn(L, 4, generator=g)
+    # per-rank K shard in the kernel's layout [H, shard_len, D], zero pad rows
+    k_loc = torch.zeros(H, plan.shard_len, 8)
+    k_loc[:, :hi - lo] = k_full[:, lo:hi]
+    k_all = torch.empty(world, H, plan.shard_len, 8)
+    ev = comm.all_gather_async(k_all, k_loc)
+    assert ev is None  # CPU: synchronous
+    # segment addressing of the attention kernel: key index g -> (seg = g // shard_len, row = g % shard_len)
+    ok = True
+    for gi in (0, 1, plan.shard_len - 1, min(plan.shard_len, L - 1), L - 1):
+        seg, row = gi // plan.shard_len, gi % plan.shard_len
+        ok &= torch.equal(k_all[seg, :, row], k_full[:, gi])
+    ok &= float(k_all[world - 1, :, plan.local_tokens(world - 1):].abs().max()) == 0.0 if plan.local_tokens(world - 1) < plan.shard_len else True
+    y = parallel.gather_rows(comm, y_full[lo:hi].contiguous(), plan)
+    ok &= torch.equal(y, y_full)
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    comm.all_reduce_max(t)
+    ok &= t.item() == world - 1
+    b = torch.full((3,), float(rank))
+    comm.broadcast(b, src=0)
+    ok &= float(b.sum()) == 0.0
+    comm.barrier()
+    ret[rank] = bool(ok)
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gloo_world2_gather_layout():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), 200, 3, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)

@@ -92,24 +92,24 @@ __global__ void k_transpose(const uint16_t* __restrict__ in, int ld_in, uint16_t
   }
 }
 
-// [C, N] -> [N, C] (N = T*H*W), in f32 -> out f32 or bf16
-__global__ void k_to_cl(const float* __restrict__ in, float* __restrict__ of, uint16_t* __restrict__ ob, int C, size_t N) {
-  const size_t n = N * C;
+// [C, N] -> [N, Cpad] (N = T*H*W; channels C..Cpad zero), in f32 -> out f32 or bf16
+__global__ void k_to_cl(const float* __restrict__ in, float* __restrict__ of, uint16_t* __restrict__ ob, int C, int Cpad, size_t N) {
+  const size_t n = N * Cpad;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const size_t p = i / C;
-    const float v = in[(size_t)c * N + p];
+    const int c = (int)(i % Cpad);
+    const size_t p = i / Cpad;
+    const float v = c < C ? in[(size_t)c * N + p] : 0.f;
     if (of) of[i] = v;
     if (ob) ob[i] = f32_to_bf16(v);
   }
 }
-// [N, C] f32 -> [C, N] f32, optional clamp
-__global__ void k_from_cl(const float* __restrict__ in, float* __restrict__ out, int C, size_t N, float clampv) {
+// [N, ld] f32 (first C channels) -> [C, N] f32, optional clamp
+__global__ void k_from_cl(const float* __restrict__ in, float* __restrict__ out, int C, int ld, size_t N, float clampv) {
   const size_t n = N * C;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const size_t p = i % N;
     const int c = (int)(i / N);
-    float v = in[p * C + c];
+    float v = in[p * ld + c];
     if (clampv > 0.f) v = fminf(fmaxf(v, -clampv), clampv);
     out[i] = v;
   }
@@ -149,19 +149,21 @@ extern "C" int wf_transpose_bf16(const void* in, int ld_in, void* out, int ld_ou
   return WF_OK;
 }
 
-extern "C" int wf_ncthw_to_cl(const float* in, float* out_f32, void* out_bf16, int C, size_t N, void* stream) {
+extern "C" int wf_ncthw_to_cl(const float* in, float* out_f32, void* out_bf16, int C, int Cpad, size_t N, void* stream) {
   WF_CHECK_ARG(in && (out_f32 || out_bf16), "wf_ncthw_to_cl: null pointer");
+  WF_CHECK_ARG(Cpad >= C && C > 0, "wf_ncthw_to_cl: Cpad (%d) must be >= C (%d)", Cpad, C);
   if (N == 0) return WF_OK;
-  hipLaunchKernelGGL(k_to_cl, dim3(grid_for(N * C, 256, 8192)), dim3(256), 0, (hipStream_t)stream, in, out_f32,
-                     (uint16_t*)out_bf16, C, N);
+  hipLaunchKernelGGL(k_to_cl, dim3(grid_for(N * Cpad, 256, 8192)), dim3(256), 0, (hipStream_t)stream, in, out_f32,
+                     (uint16_t*)out_bf16, C, Cpad, N);
   WF_LAUNCH_CHECK("wf_ncthw_to_cl");
   return WF_OK;
 }
 
-extern "C" int wf_cl_to_ncthw(const float* in, float* out, int C, size_t N, float clamp, void* stream) {
+extern "C" int wf_cl_to_ncthw(const float* in, float* out, int C, int ld, size_t N, float clamp, void* stream) {
   WF_CHECK_ARG(in && out, "wf_cl_to_ncthw: null pointer");
+  WF_CHECK_ARG(ld >= C && C > 0, "wf_cl_to_ncthw: ld (%d) must be >= C (%d)", ld, C);
   if (N == 0) return WF_OK;
-  hipLaunchKernelGGL(k_from_cl, dim3(grid_for(N * C, 256, 8192)), dim3(256), 0, (hipStream_t)stream, in, out, C, N, clamp);
+  hipLaunchKernelGGL(k_from_cl, dim3(grid_for(N * C, 256, 8192)), dim3(256), 0, (hipStream_t)stream, in, out, C, ld, N, clamp);
   WF_LAUNCH_CHECK("wf_cl_to_ncthw");
   return WF_OK;
 }

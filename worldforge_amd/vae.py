@@ -110,11 +110,31 @@ class AutoencoderKLWan:
             W[p + ".w"] = w.permute(0, 2, 3, 4, 1).reshape(co, -1, ci).to(device=dev, dtype=BF).contiguous()
             W[p + ".b"] = sd[p + ".bias"].to(device=dev, dtype=F32).contiguous()
 
-        def small_conv(p):  # -> f32 [taps, Cin, Cout]
-            w = sd[p + ".weight"]
+        def mfma_conv_padded(p, cin_pad=None, cout_pad=None):
+            """Thin layers on the MFMA path: zero-pad Cin to a 32-channel K slice / Cout to a multiple of 4 (the kernel
+            computes a 96-wide tile anyway and only stores Cout columns)."""
+            w = sd[p + ".weight"].to(F32)
+            b = sd[p + ".bias"].to(F32)
             co, ci = w.shape[:2]
-            W[p + ".w"] = w.permute(2, 3, 4, 1, 0).reshape(-1, ci, co).to(device=dev, dtype=F32).contiguous()
-            W[p + ".b"] = sd[p + ".bias"].to(device=dev, dtype=F32).contiguous()
+            cip, cop = cin_pad or ci, cout_pad or co
+            wp = torch.zeros((cop, cip) + tuple(w.shape[2:]), dtype=F32)
+            wp[:co, :ci] = w
+            bp = torch.zeros(cop, dtype=F32)
+            bp[:co] = b
+            W[p + ".w"] = wp.permute(0, 2, 3, 4, 1).reshape(cop, -1, cip).to(device=dev, dtype=BF).contiguous()
+            W[p + ".b"] = bp.to(dev)
+
+        def small_conv(p, cout_pad=None):  # -> f32 [taps, Cin, Cout]
+            w = sd[p + ".weight"].to(F32)
+            b = sd[p + ".bias"].to(F32)
+            co, ci = w.shape[:2]
+            cop = cout_pad or co
+            wp = torch.zeros((cop, ci) + tuple(w.shape[2:]), dtype=F32)
+            wp[:co] = w
+            bp = torch.zeros(cop, dtype=F32)
+            bp[:co] = b
+            W[p + ".w"] = wp.permute(2, 3, 4, 1, 0).reshape(-1, ci, cop).to(dev).contiguous()
+            W[p + ".b"] = bp.to(dev)
 
         def lin(p):  # 1x1(x1) conv as GEMM weight bf16 [Cout, Cin]
             w = sd[p + ".weight"]
@@ -127,7 +147,7 @@ class AutoencoderKLWan:
         for plan in (encoder_plan(), decoder_plan()):
             for kind, p, cin, cout in plan:
                 if kind == "conv_in":
-                    small_conv(p)
+                    mfma_conv_padded(p, cin_pad=32)
                 elif kind == "res":
                     gamma(p + ".residual.0.gamma")
                     mfma_conv(p + ".residual.2")
@@ -145,9 +165,9 @@ class AutoencoderKLWan:
                         mfma_conv(p + ".time_conv")
                 elif kind == "head":
                     gamma(p + ".0.gamma")
-                    small_conv(p + ".2")
+                    mfma_conv_padded(p + ".2", cout_pad=(cout + 3) // 4 * 4)
         small_conv("conv1")
-        small_conv("conv2")
+        small_conv("conv2", cout_pad=32)  # decoder input, zero-padded to one 32-channel MFMA K slice
         self.w = W
         return self
 
@@ -208,12 +228,13 @@ class AutoencoderKLWan:
         self.flops_last += 2 * To * Ho * Wo * Cout * k[0] * k[1] * k[2] * Cin
         return of, ob
 
-    def _small_conv(self, x, p, To, Ho, Wo, Cout, k, pt=0, ps=0, clamp=0.0):
+    def _small_conv(self, x, p, To, Ho, Wo, Cout, k, pt=0, ps=0, clamp=0.0, out_dtype=F32):
         Ti, Hi, Wi, Cin = x.shape
-        out = torch.empty((To, Ho, Wo, Cout), dtype=F32, device=x.device)
+        out = torch.empty((To, Ho, Wo, Cout), dtype=out_dtype, device=x.device)
         W = self.w
         call("wf_conv3d_small", x.data_ptr(), WF_BF16 if x.dtype == BF else WF_F32, W[p + ".w"].data_ptr(), W[p + ".b"].data_ptr(),
-             out.data_ptr(), None, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, k[0], k[1], k[2], 1, 1, pt, ps, float(clamp), ops.stream())
+             out.data_ptr() if out_dtype == F32 else None, out.data_ptr() if out_dtype == BF else None, Ti, Hi, Wi, Cin, To, Ho,
+             Wo, Cout, k[0], k[1], k[2], 1, 1, pt, ps, float(clamp), ops.stream())
         self.flops_last += 2 * To * Ho * Wo * Cout * k[0] * k[1] * k[2] * Cin
         return out
 
@@ -306,12 +327,12 @@ class AutoencoderKLWan:
         out, _ = self._conv(xb, p + ".resample.1", Tn, 2 * H, 2 * Wd, C // 2, (1, 3, 3), ps=1, up2=True)
         return out
 
-    def _run(self, x, plan, clamp=0.0):
+    def _run(self, x, plan):
         W = self.w
         for kind, p, cin, cout in plan:
             T, H, Wd, _ = x.shape
-            if kind == "conv_in":
-                x = self._small_conv(x, p, T, H, Wd, cout, (3, 3, 3), pt=2, ps=1)
+            if kind == "conv_in":  # x arrives bf16, zero-padded to 32 channels
+                x, _ = self._conv(x, p, T, H, Wd, cout, (3, 3, 3), pt=2, ps=1)
             elif kind == "res":
                 x = self._res(x, p, cin, cout)
             elif kind == "attn":
@@ -322,7 +343,7 @@ class AutoencoderKLWan:
                 x = self._up(x, p, cin, kind == "up3d")
             elif kind == "head":
                 a = self._rms(x, W[p + ".0.gamma"])
-                x = self._small_conv(a, p + ".2", T, H, Wd, cout, (3, 3, 3), pt=2, ps=1, clamp=clamp)
+                x, _ = self._conv(a, p + ".2", T, H, Wd, (cout + 3) // 4 * 4, (3, 3, 3), pt=2, ps=1)
         return x
 
     # ------------------------------------------------------------------------------------------------------------
@@ -336,13 +357,13 @@ class AutoencoderKLWan:
         if H % 8 or Wd % 8:
             raise ValueError("height and width must be multiples of 8")
         self.flops_last = 0
-        x = torch.empty((Fr, H, Wd, 3), dtype=F32, device=self.device)
-        call("wf_ncthw_to_cl", video.data_ptr(), x.data_ptr(), None, 3, Fr * H * Wd, ops.stream())
+        x = torch.empty((Fr, H, Wd, 32), dtype=BF, device=self.device)  # 3 channels zero-padded to one MFMA K slice
+        call("wf_ncthw_to_cl", video.data_ptr(), None, x.data_ptr(), 3, 32, Fr * H * Wd, ops.stream())
         y = self._run(x, encoder_plan())
         T, h, w, _ = y.shape
         q = self._small_conv(y, "conv1", T, h, w, 2 * Z_DIM, (1, 1, 1))
         out = torch.empty((2 * Z_DIM, T, h, w), dtype=F32, device=self.device)
-        call("wf_cl_to_ncthw", q.data_ptr(), out.data_ptr(), 2 * Z_DIM, T * h * w, 0.0, ops.stream())
+        call("wf_cl_to_ncthw", q.data_ptr(), out.data_ptr(), 2 * Z_DIM, 2 * Z_DIM, T * h * w, 0.0, ops.stream())
         return out[:Z_DIM]
 
     def _decode_one(self, z: torch.Tensor) -> torch.Tensor:
@@ -350,12 +371,12 @@ class AutoencoderKLWan:
         C, T, h, w = z.shape
         self.flops_last = 0
         x = torch.empty((T, h, w, Z_DIM), dtype=F32, device=self.device)
-        call("wf_ncthw_to_cl", z.data_ptr(), x.data_ptr(), None, Z_DIM, T * h * w, ops.stream())
-        x = self._small_conv(x, "conv2", T, h, w, Z_DIM, (1, 1, 1))
-        y = self._run(x, decoder_plan(), clamp=1.0)
-        Fo, Ho, Wo, _ = y.shape
+        call("wf_ncthw_to_cl", z.data_ptr(), x.data_ptr(), None, Z_DIM, Z_DIM, T * h * w, ops.stream())
+        x = self._small_conv(x, "conv2", T, h, w, 32, (1, 1, 1), out_dtype=BF)  # 16 channels + 16 zero channels
+        y = self._run(x, decoder_plan())
+        Fo, Ho, Wo, Cy = y.shape
         out = torch.empty((3, Fo, Ho, Wo), dtype=F32, device=self.device)
-        call("wf_cl_to_ncthw", y.data_ptr(), out.data_ptr(), 3, Fo * Ho * Wo, 0.0, ops.stream())
+        call("wf_cl_to_ncthw", y.data_ptr(), out.data_ptr(), 3, Cy, Fo * Ho * Wo, 1.0, ops.stream())
         return out
 
     @torch.no_grad()
