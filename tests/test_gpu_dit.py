@@ -221,3 +221,23 @@ def test_dit_call_protocol_matches_diffusers_signature():
     assert out.shape == (1, 16, 2, 8, 8) and out.dtype == BF and torch.isfinite(out).all()
     with pytest.raises(NotImplementedError):
         m(hidden_states=torch.cat([x, x]), timestep=torch.tensor([1]), encoder_hidden_states=None)
+
+
+def test_sequence_parallel_path_world1_matches_single():
+    """The N > 1 code path (token shard plan, K / V^T all-gather over RCCL, segment-addressed attention, velocity
+    gather) exercised with a 1-rank RCCL group on the single test GPU: must equal the single-GPU path bit for bit."""
+    import os
+    from worldforge_amd import dit, parallel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    comm = parallel.init(1, 0, 0, backend="nccl")
+    cfg = dit.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    x = _rand((36, 3, 8, 10), 60).to(BF).to(DEV)
+    ctx, clip = _rand((30, 64), 61).to(BF).to(DEV), _rand((257, 1280), 62).to(BF).to(DEV)
+    m0 = dit.WanTransformer3DModel(cfg, DEV).init_random(5)
+    ref = m0.forward_tokens(x, 500.0, ctx, clip).clone()
+    m1 = dit.WanTransformer3DModel(cfg, DEV, comm=comm)
+    m1.w = m0.w
+    got = m1.forward_tokens(x, 500.0, ctx, clip)
+    assert torch.equal(got, ref)
+    torch.distributed.destroy_process_group()

@@ -18,9 +18,14 @@
 //     needs no cross-lane movement (cvt to bf16 only);
 //   * O^T[d][q] += mfma(A = V^T tile, B = P^T): the lane ends up with quads of consecutive head-dim values of its query
 //     row -> 8-byte stores;
-//   * K and V^T tiles are double-buffered in LDS (64 KiB), staged global -> VGPR -> LDS with the next tile's loads issued
-//     before the current tile's MFMAs; 16-byte chunk c of row r is stored at c ^ (r & 15) (K, 256-B rows) resp.
-//     c ^ ((r >> 1) & 7) (V^T, 128-B rows): conflict-free ds_read_b128 fragment reads;
+//   * K and V^T tiles live in a ring of three 32 KiB LDS buffers filled by LDS-DMA (global_load_lds, no staging VGPRs, no
+//     ds_write pass); the XOR swizzle of the LDS image -- 16-byte chunk c of row r at c ^ (r & 15) (K, 256-B rows) resp.
+//     c ^ ((r >> 1) & 7) (V^T, 128-B rows), conflict-free for the ds_read_b128 lane groups (SQ_LDS_BANK_CONFLICT = 0) -- is
+//     applied to the per-lane SOURCE address because the DMA destination is lane-linear;
+//   * MFMA operand fragments are read 4 ahead of the MFMA that consumes them and the read/MFMA interleave is pinned with
+//     sched_group_barrier (hipcc otherwise serialises read -> wait -> MFMA through one register quad);
+//   * ping-pong: the 8 waves form two groups (one wave of each per SIMD) that run [QK^T | softmax | P.V] one phase apart,
+//     phase-locked by raw s_barrier, so the VALU-only softmax of one wave coincides with an MFMA phase of the other;
 //   * online softmax in fp32 with exp2 and the 1/sqrt(d)*log2(e) scale folded into one FMA; O is rescaled only when some
 //     row maximum in the wave actually grew (exact, threshold 0);
 //   * XCD-aware grid: workgroup b runs on XCD b % 8; all query blocks of a head are given to one XCD so its 32 CUs share
@@ -79,40 +84,22 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
     for (int s = 0; s < 8; ++s) qf[s] = as_bf16x8(*reinterpret_cast<const u32x4*>(qp + 16 * s + 8 * hi));
   }
 
-  // ---- staging: K tile 1024 chunks, V tile 1024 chunks, 512 threads -> 2 + 2 per thread -------------------------------
-  // K/V may be a concatenation of P per-rank segments [P][H][seg_len][128] (sequence-parallel all-gather); seg_len % 64 == 0,
-  // so a 64-key tile never straddles two segments.  Single GPU: seg_len == Lkp, one segment.
-  const int tiles_per_seg = a.seg_len / KB;
-  u32x4 rK[2], rV[2];
-  int koff[2], voff[2], ksrc[2], vsrc[2];
+  // ---- staging: direct global -> LDS copies (no staging VGPRs).  A wave instruction moves 64 x 16 B = 1 KiB to LDS bytes
+  // [base, base + 1 KiB) in lane order; the XOR swizzle of the LDS image is applied to the per-lane SOURCE address.
+  //   K tile  (64 rows x 256 B): 16 pieces of 4 rows;  lane -> (row = 4*piece + lane/16, slot = lane%16) holds chunk slot ^ (row&15)
+  //   V^T tile (128 rows x 128 B): 16 pieces of 8 rows; lane -> (row = 8*piece + lane/8,  slot = lane%8)  holds chunk slot ^ ((row>>1)&7)
+  // 8 waves x 2 pieces each per tile and operand.
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  int ksrc[2], vsrc[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    int id = tid + NT * i;
-    int kr = id >> 4, kc = id & 15;  // K: 64 rows x 16 chunks
-    ksrc[i] = kr * D + kc * 8;
-    koff[i] = kr * 256 + ((kc ^ (kr & 15)) << 4);
-    int vr = id >> 3, vc = id & 7;  // V^T: 128 rows x 8 chunks
-    vsrc[i] = vr * KB + vc * 8;
-    voff[i] = vr * 128 + ((vc ^ ((vr >> 1) & 7)) << 4);
+    const int piece = wu * 2 + i;
+    const int kr = 4 * piece + (lane >> 4), ks = lane & 15;
+    ksrc[i] = kr * D + ((ks ^ (kr & 15)) << 3);
+    const int vr = 8 * piece + (lane >> 3), vs = lane & 7;
+    vsrc[i] = vr * KB + ((vs ^ ((vr >> 1) & 7)) << 3);
   }
-  auto gload = [&](int t) {
-    const int seg = t / tiles_per_seg;
-    const size_t tile_off = ((size_t)(seg * a.H + head) * tiles_per_seg + (t - seg * tiles_per_seg)) * (KB * D);
-    const uint16_t* kp = a.K + tile_off;
-    const uint16_t* vp = a.Vt + tile_off;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      rK[i] = *reinterpret_cast<const u32x4*>(kp + ksrc[i]);
-      rV[i] = *reinterpret_cast<const u32x4*>(vp + vsrc[i]);
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<u32x4*>(smem + buf * BUF_BYTES + koff[i]) = rK[i];
-      *reinterpret_cast<u32x4*>(smem + buf * BUF_BYTES + K_TILE_BYTES + voff[i]) = rV[i];
-    }
-  };
+  const int tiles_per_seg = a.seg_len / KB;
 
   // fragment read offsets
   int krow_off[2], krow_sw[2];
@@ -139,30 +126,61 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
   const float c = a.scale_log2;
 
   const int ntiles = (a.kv_len + KB - 1) / KB;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    const unsigned char* sKb = smem + buf * BUF_BYTES;
-    const unsigned char* sVb = sKb + K_TILE_BYTES;
-    if (t + 1 < ntiles) gload(t + 1);
+  constexpr int PF = 4;  // fragment prefetch depth (LDS reads in flight ahead of the MFMA that consumes them)
+  constexpr int NBUF = 3;
 
-    // ---- S^T = K Q^T : two 32-key blocks ------------------------------------------------------------------------------
-    f32x16 s[2];
+  // LDS: ring of NBUF tile buffers, each [K tile 16 KiB | V^T tile 16 KiB]; tile j lives in buffer j % NBUF.
+  const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_offset(smem));
+  auto stage = [&](int t) {
+    const int seg = t / tiles_per_seg;
+    const size_t tile_off = ((size_t)(seg * a.H + head) * tiles_per_seg + (t - seg * tiles_per_seg)) * (KB * D);
+    const uint32_t base = smem_base + (t % NBUF) * BUF_BYTES + wu * 2048;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int i = 0; i < 2; ++i) {
+      glds16(a.K + tile_off + ksrc[i], smem + (base - smem_base) + i * 1024);
+      glds16(a.Vt + tile_off + vsrc[i], smem + (base - smem_base) + K_TILE_BYTES + i * 1024);
+    }
+  };
+  auto kread = [&](const unsigned char* sKb, int i) {
+    const int kb = i & 1, st = i >> 1;  // alternate the two score accumulators: no back-to-back dependent MFMAs
+    return *reinterpret_cast<const u32x4*>(sKb + krow_off[kb] + (((2 * st + hi) ^ krow_sw[kb]) << 4));
+  };
+  auto vread = [&](const unsigned char* sVb, int i) {
+    const int db = i & 3, m4 = i >> 2;  // rotate over the four output accumulators
+    return *reinterpret_cast<const u32x4*>(sVb + vrow_off[db] + (((2 * m4 + hi) ^ vrow_sw[db]) << 4));
+  };
+  const bool ragged = (a.kv_len & (KB - 1)) != 0;
+
+  f32x16 s[2];
+  bf16x8 pf[4];
+
+  // ---- the three phases of one KV tile (one wave, 32 query rows) ----------------------------------------------------------
+  auto phase_qk = [&](int t) {  // S^T = K Q^T: 16 MFMAs, K fragments PF ahead
+    const unsigned char* sKb = smem + (t % NBUF) * BUF_BYTES;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+    u32x4 ring[PF];
 #pragma unroll
-      for (int st = 0; st < 8; ++st) {
-        const int ch = 2 * st + hi;
-        bf16x8 kf = as_bf16x8(*reinterpret_cast<const u32x4*>(sKb + krow_off[kb] + ((ch ^ krow_sw[kb]) << 4)));
-        s[kb] = mfma32(kf, qf[st], s[kb]);
-      }
+    for (int i = 0; i < PF; ++i) ring[i] = kread(sKb, i);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const bf16x8 kf = as_bf16x8(ring[i % PF]);
+      if (i + PF < 16) ring[i % PF] = kread(sKb, i + PF);
+      s[i & 1] = mfma32(kf, qf[i >> 1], s[i & 1]);
     }
-    // lane holds, for query column l31: register r of block kb  <->  key  t*64 + 32*kb + 16*(r>>3) + 8*hi + (r&7)
-    if (t == ntiles - 1 && (a.kv_len & (KB - 1))) {
+    __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+    for (int i = 0; i < 16 - PF; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
+  };
+  auto phase_softmax = [&](int t) {  // online softmax of the 64 scores per query row held by the lane pair (l, l^32)
+    if (ragged && t == ntiles - 1) {
+      // lane holds, for query column l31: register r of block kb  <->  key  t*64 + 32*kb + 16*(r>>3) + 8*hi + (r&7)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -171,13 +189,21 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
           if (key >= a.kv_len) s[kb][r] = -INFINITY;
         }
     }
-    // ---- online softmax ----------------------------------------------------------------------------------------------
-    float mloc = s[0][0];
+    // four independent max chains (the serial 32-deep chain was latency-bound), then a small tree
+    float mx[4] = {s[0][0], s[0][1], s[1][0], s[1][1]};
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kb][r]);
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    for (int r = 2; r < 16; r += 2) {
+      mx[0] = fmaxf(mx[0], s[0][r]);
+      mx[1] = fmaxf(mx[1], s[0][r + 1]);
+      mx[2] = fmaxf(mx[2], s[1][r]);
+      mx[3] = fmaxf(mx[3], s[1][r + 1]);
+    }
+    float mloc = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+    {
+      const unsigned mu = __float_as_uint(mloc);
+      auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);  // {x of lane&31, x of lane|32}: no LDS traffic
+      mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
     const float m_new = fmaxf(m_run, mloc);
     if (__any(m_new > m_run)) {
       const float alpha = __builtin_amdgcn_exp2f(c * (m_run - m_new));
@@ -189,15 +215,14 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
       m_run = m_new;
     }
     const float mc = c * m_run;
-    float lsum = 0.f;
-    bf16x8 pf[4];
+    float ls[4] = {0.f, 0.f, 0.f, 0.f};  // independent partial row sums
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       float p[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         p[r] = __builtin_amdgcn_exp2f(c * s[kb][r] - mc);
-        lsum += p[r];
+        ls[r & 3] += p[r];
       }
 #pragma unroll
       for (int m2 = 0; m2 < 2; ++m2) {
@@ -206,20 +231,72 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
         pf[kb * 2 + m2] = as_bf16x8(pk);
       }
     }
-    l_run += lsum;
-
-    // ---- O^T += V^T P^T : 4 head-dim blocks x 4 key steps ------------------------------------------------------------
+    l_run += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+  };
+  auto phase_pv = [&](int t) {  // O^T += V^T P^T: 16 MFMAs, V^T fragments PF ahead
+    const unsigned char* sVb = smem + (t % NBUF) * BUF_BYTES + K_TILE_BYTES;
+    u32x4 vring[PF];
 #pragma unroll
-    for (int db = 0; db < 4; ++db) {
+    for (int i = 0; i < PF; ++i) vring[i] = vread(sVb, i);
 #pragma unroll
-      for (int m4 = 0; m4 < 4; ++m4) {
-        const int ch = 2 * m4 + hi;
-        bf16x8 vf = as_bf16x8(*reinterpret_cast<const u32x4*>(sVb + vrow_off[db] + ((ch ^ vrow_sw[db]) << 4)));
-        o[db] = mfma32(vf, pf[m4], o[db]);
-      }
+    for (int i = 0; i < 16; ++i) {
+      const bf16x8 vf = as_bf16x8(vring[i % PF]);
+      if (i + PF < 16) vring[i % PF] = vread(sVb, i + PF);
+      o[i & 3] = mfma32(vf, pf[i >> 2], o[i & 3]);
     }
-    if (t + 1 < ntiles) lstore(buf ^ 1);
-    __syncthreads();
+    __builtin_amdgcn_sched_group_barrier(0x100, PF, 1);
+#pragma unroll
+    for (int i = 0; i < 16 - PF; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, PF, 1);
+  };
+  // workgroup barrier WITHOUT the implicit vmcnt(0) drain of __syncthreads(): LDS-DMA stays in flight across it;
+  // LDS reads of this wave are complete (their results were consumed by MFMAs), so only lgkmcnt needs draining
+  auto bar = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  auto drain_dma = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  // ---- ping-pong schedule -------------------------------------------------------------------------------------------------
+  // The 8 waves form two groups (waves 0-3 / 4-7: one wave of each group per SIMD).  Both run [QK^T | softmax | P.V] per tile,
+  // separated by workgroup barriers, but group B runs ONE PHASE behind group A.  On every SIMD the VALU-only softmax of one
+  // wave then always coincides with an MFMA phase of the other wave (A softmax || B QK^T,  A P.V || B softmax); only
+  // A's QK^T(t+1) and B's P.V(t) share the matrix pipe.  Barrier k is reached by every wave; all waves issue the LDS-DMA of
+  // tile t+1 right after barrier 3t and drain it before barrier 3t+2, whichever phase they are in (ring of 3 buffers:
+  // the buffer of tile t+1 was last read two tiles ago by either group).
+  const bool groupB = __builtin_amdgcn_readfirstlane(wid) >= 4;
+  stage(0);
+  drain_dma();
+  bar();
+  if (!groupB) {
+    for (int t = 0; t < ntiles; ++t) {
+      if (t + 1 < ntiles) stage(t + 1);
+      phase_qk(t);
+      bar();  // 3t+1
+      phase_softmax(t);
+      drain_dma();
+      bar();  // 3t+2
+      phase_pv(t);
+      bar();  // 3t+3
+    }
+    bar();  // matches group B's last phase
+  } else {
+    if (ntiles > 1) stage(1);
+    bar();  // barrier 1: group A did QK^T(0)
+    for (int t = 0; t < ntiles; ++t) {
+      phase_qk(t);
+      drain_dma();
+      bar();  // 3t+2
+      phase_softmax(t);
+      bar();  // 3t+3
+      if (t + 2 < ntiles) stage(t + 2);
+      phase_pv(t);
+      bar();  // 3t+4
+    }
   }
 
   // ---- finish: combine the two half-wave partial sums, normalise, store ------------------------------------------------
@@ -276,7 +353,7 @@ extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O
   a.accumulate = accumulate;
   const int hslots = (H + 7) / 8;
   const int grid = hslots * a.n_qblk * 8;
-  hipLaunchKernelGGL(k_attn, dim3(grid), dim3(NT), 2 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_attn, dim3(grid), dim3(NT), 3 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream, a);
   WF_LAUNCH_CHECK("wf_attn_fwd");
   return WF_OK;
 }

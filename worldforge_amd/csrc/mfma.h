@@ -32,12 +32,44 @@ __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) {
   return x.b;
 }
 
-// pack two f32 -> two bf16 (round-to-nearest-even) in one dword: lo in bits 0..15
+// pack two f32 -> two bf16 (round-to-nearest-even) in one dword, lo in bits 0..15: one v_cvt_pk_bf16_f32 on gfx950
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  uint32_t a = __float_as_uint(lo), b = __float_as_uint(hi);
-  a += 0x7fffu + ((a >> 16) & 1u);
-  b += 0x7fffu + ((b >> 16) & 1u);
-  return (a >> 16) | (b & 0xffff0000u);
+  f32x2_t v = {lo, hi};
+  union {
+    bf16x2_t b;
+    uint32_t u;
+  } x;
+  x.b = __builtin_convertvector(v, bf16x2_t);
+  return x.u;
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+// async global -> LDS copy, 16 bytes per lane; LDS destination = wave-uniform base + lane * 16 (so any swizzle goes on the
+// per-lane SOURCE address), completion tracked by vmcnt
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)gsrc, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+// The same LDS-DMA issued from inline asm, invisible to hipcc's s_waitcnt bookkeeping: with the builtin the compiler drains
+// vmcnt(0) in front of the next ds_read (it cannot prove the DMA's LDS destination does not alias it), which serialises the
+// copy with the MFMA phase it is supposed to hide under.  The caller owns the ordering: s_waitcnt vmcnt(N) + a workgroup barrier
+// before anyone reads the destination.  M0 (the LDS base of the DMA) is compiler-reserved: saved / restored in the statement.
+__device__ __forceinline__ void glds16_async(const void* gsrc, uint32_t lds_wave_base_byte) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_wave_base_byte)
+      : "memory");
+}
+__device__ __forceinline__ uint32_t lds_offset(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
 
 }  // namespace wf
