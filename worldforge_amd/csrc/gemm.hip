@@ -92,20 +92,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_gemm(GemmArgs a) {
     pX[i] = a.X + (size_t)xr * a.ldx + ck * 8;
     ldsoff[i] = row * ROW_BYTES + swz(row, ck) * 16;
   }
+  bool stage_ok = true;
   auto gload = [&](int kt) {
-    const bool ok = (kt * 8 + ck) < kchunks;
+    // K-tail chunks (only in the last K tile of a K % 64 != 0 problem) must read as zero.  The load always targets a valid
+    // (clamped) address and the zero-select is applied when the registers are written to LDS, AFTER the MFMAs of the current
+    // tile: neither exec-mask branches nor an early use of the load result sit between the load issue and those MFMAs.
+    const int kc = kt * 8 + ck;
+    stage_ok = kc < kchunks;
+    const size_t koff = (size_t)min(kc, kchunks - 1) * 8 - (size_t)ck * 8;
 #pragma unroll
     for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
-      u32x4 z = {0u, 0u, 0u, 0u};
-      rW[i] = ok ? *reinterpret_cast<const u32x4*>(pW[i] + (size_t)kt * BK) : z;
-      rX[i] = ok ? *reinterpret_cast<const u32x4*>(pX[i] + (size_t)kt * BK) : z;
+      rW[i] = *reinterpret_cast<const u32x4*>(pW[i] + koff);
+      rX[i] = *reinterpret_cast<const u32x4*>(pX[i] + koff);
     }
   };
   auto lstore = [&](int buf) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
-      *reinterpret_cast<u32x4*>(smem + buf * (2 * TILE_BYTES) + ldsoff[i]) = rW[i];
-      *reinterpret_cast<u32x4*>(smem + buf * (2 * TILE_BYTES) + TILE_BYTES + ldsoff[i]) = rX[i];
+      *reinterpret_cast<u32x4*>(smem + buf * (2 * TILE_BYTES) + ldsoff[i]) = stage_ok ? rW[i] : z;
+      *reinterpret_cast<u32x4*>(smem + buf * (2 * TILE_BYTES) + TILE_BYTES + ldsoff[i]) = stage_ok ? rX[i] : z;
     }
   };
 
