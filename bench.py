@@ -121,7 +121,7 @@ def main():
     cfg.num_layers = a.layers
     t0 = time.time()
     model = wdit.WanTransformer3DModel(cfg, device, comm=comm).init_random(seed=0)
-    vae = AutoencoderKLWan(device).init_random(seed=1)
+    vae = AutoencoderKLWan(device, comm=comm).init_random(seed=1)  # high-resolution stages row-sharded over the ranks
     sch = UniPCMultistepScheduler(flow_shift=3.0)
     pipe = WanImageToVideoPipeline(model, vae, sch, device=device)
     image, ref, mask, text, neg, img_emb = synthetic_inputs(a.frames, a.height, a.width, device)
@@ -198,7 +198,7 @@ def main():
                 "workload": f"Wan2.1-I2V-14B-480P, {a.frames}f {a.height}x{a.width}, 50-step schedule, full IRR+FLF+DSG, CFG 4; "
                             f"timed steps {start + Wm}..{start + Wm + K - 1} = {len(guided_ms)} guided + {len(plain_ms)} plain",
                 "tokens": L, "dit_layers": cfg.num_layers, "dit_params_bytes": model.param_bytes(),
-                "parallelism": "single" if world == 1 else f"sp{world} (token-sharded DiT, K/V all-gather over RCCL)",
+                "parallelism": "single" if world == 1 else f"sp{world} (token-sharded DiT with K/V all-gather + row-sharded VAE with halo all-gather, RCCL)",
                 "flow_backend": "tdiff",
             },
             "guided_step_ms": sum(guided_ms) / len(guided_ms) if guided_ms else None,

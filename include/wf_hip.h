@@ -154,12 +154,13 @@ int wf_act(const void* a, int dt_a, const void* b, int dt_b, void* out, int dt_o
 /* ---- 3D causal VAE (wan/modules/vae.py; the in-tree statement of diffusers' AutoencoderKLWan), channels-last ----------- */
 /* CausalConv3d / Conv2d as implicit GEMM on MFMA (vae.py:17-36, 76-96, 186-220).  in bf16 [Ti,Hi,Wi,Cin] (Cin % 32 == 0),
  * w bf16 [Cout][kt*kh*kw][Cin], bias f32; out (f32 and/or bf16) [To,Ho,Wo,Cout] (+ resid f32 of the same shape).
- *   out[t,y,x] = sum_taps in[t*st+dt-pt, y*ss+dy-ps, x*ss+dx-ps] . w[tap]   (zero outside the input)
+ *   out[t,y,x] = sum_taps in[t*st+dt-pt, y*ss+dy-ph, x*ss+dx-pw] . w[tap]   (zero outside the input; ph may be negative when
+ *   the input is a row slab that already carries its halo rows -- multi-GPU row sharding)
  * up2: read the input through a nearest-exact 2x spatial upsample (vae.py:78);  tsplit: 'upsample3d' frame interleave
  * (vae.py:134-137): output frame t, channel half h -> frame 1 + 2t + h of a [1+2*To, Ho, Wo, Cout/2] tensor. */
 int wf_conv3d_cl(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_bf16, int Ti,
-                 int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st, int ss, int pt, int ps,
-                 int up2, int tsplit, void* stream);
+                 int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st, int ss, int pt, int ph,
+                 int pw, int up2, int tsplit, void* stream);
 /* Direct convolution for the thin layers (3->96, 16->384, 96->3, 384->32, 1x1x1 quant convs; vae.py:288, 316, 392, 421, 505-506).
  * in f32 or bf16 channels-last, w f32 [taps][Cin][Cout]; clamp > 0 clamps the output (autoencoder_kl_wan.py:1222). */
 int wf_conv3d_small(const void* in, int in_dtype, const float* w, const float* bias, float* out_f32, void* out_bf16, int Ti, int Hi,

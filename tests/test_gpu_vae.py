@@ -81,7 +81,7 @@ def test_conv3d_cl_vs_torch(cfg):
     of = torch.full((To, Ho, Wo, cout), float("nan"), dtype=F32, device=DEV)
     ob = torch.empty((To, Ho, Wo, cout), dtype=BF, device=DEV)
     _ffi.call("wf_conv3d_cl", xd.data_ptr(), wk.data_ptr(), bd.data_ptr(), rd.data_ptr(), of.data_ptr(), ob.data_ptr(), T, H, W, cin,
-              To, Ho, Wo, cout, k[0], k[1], k[2], st, ss, pt, ps, 1 if up2 else 0, 0, ops.stream())
+              To, Ho, Wo, cout, k[0], k[1], k[2], st, ss, pt, ps, ps, 1 if up2 else 0, 0, ops.stream())
     want = ref + resid
     err = (of.cpu() - want).abs().max().item()
     assert err <= 2e-3 * max(1.0, want.abs().max().item()), err
@@ -101,7 +101,7 @@ def test_conv3d_tsplit_matches_upsample3d_interleave():
     wk = w.permute(0, 2, 3, 4, 1).reshape(2 * C, -1, C).contiguous().to(DEV)
     xd, bd = x.to(DEV), b.to(DEV)
     _ffi.call("wf_conv3d_cl", xd.data_ptr(), wk.data_ptr(), bd.data_ptr(), None, None, out.data_ptr(), T, H, W, C, T, H, W, 2 * C,
-              3, 1, 1, 1, 1, 2, 0, 0, 1, ops.stream())
+              3, 1, 1, 1, 1, 2, 0, 0, 0, 1, ops.stream())
     assert out[0].abs().max().item() == 0
     assert (out[1:].float().cpu() - want).abs().max().item() <= 1e-2 * want.abs().max().item()
 
@@ -153,3 +153,54 @@ def test_vae_protocol_and_errors(model):
     assert model.temperal_downsample == [False, True, True]
     with pytest.raises(ValueError):
         model.encode(torch.zeros(1, 3, 4, 16, 16, device=DEV))
+
+
+class _SimComm:
+    """Stand-in for parallel.Comm that runs P simulated ranks as threads of ONE process on one GPU: all_gather deposits each
+    rank's tensor in a shared slot and meets at a barrier.  Exercises the row-slab sharded VAE (halo exchange, slab
+    convolutions, row gather) without a multi-GPU node."""
+
+    def __init__(self, world, rank, shared):
+        self.world, self.rank, self.sh = world, rank, shared
+
+    def all_gather(self, out, inp):
+        sh = self.sh
+        sh["slots"][self.rank] = inp
+        sh["bar"].wait()
+        for r in range(self.world):
+            out[r].copy_(sh["slots"][r])
+        torch.cuda.current_stream().synchronize()
+        sh["bar"].wait()
+        return out
+
+
+@pytest.mark.parametrize("P,H", [(2, 64), (4, 64), (8, 64), (2, 24)])   # (2, 24): odd slab height at the decoder entry
+def test_row_sharded_vae_equals_unsharded(P, H, model):
+    import threading
+    from worldforge_amd.vae import AutoencoderKLWan
+    g = torch.Generator().manual_seed(21)
+    Fr, Wd = 9, 48
+    x = (torch.rand(1, 3, Fr, H, Wd, generator=g) * 2 - 1).to(DEV)
+    z = torch.randn(1, 16, 3, H // 8, Wd // 8, generator=g).to(DEV)
+    ref_mu = model.encode(x).latent_dist.mode()
+    ref_dec = model.decode(z, return_dict=False)[0]
+    shared = {"slots": [None] * P, "bar": threading.Barrier(P)}
+    res, errs = [None] * P, []
+
+    def worker(r):
+        try:
+            m = AutoencoderKLWan(DEV, comm=_SimComm(P, r, shared))
+            m.w = model.w
+            assert m.can_shard(H // 8)
+            res[r] = (m.encode(x).latent_dist.mode(), m.decode(z, return_dict=False)[0])
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            shared["bar"].abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(P)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for r in range(P):
+        assert torch.equal(res[r][0], ref_mu), (r, (res[r][0] - ref_mu).abs().max())
+        assert torch.equal(res[r][1], ref_dec), (r, (res[r][1] - ref_dec).abs().max())

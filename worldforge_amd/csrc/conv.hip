@@ -6,7 +6,7 @@
 // is what the chunked cache computes, one latent frame at a time, in the reference (derivation in DESIGN.md "VAE").
 // MFMA-bound: 2 * pixels * Cout * taps * Cin flop.
 //
-//   out[t,y,x,co] = bias[co] + sum_{dt,dy,dx,ci} in[t*st + dt - pt, y*ss + dy - ps, x*ss + dx - ps, ci] * w[co][dt][dy][dx][ci]
+//   out[t,y,x,co] = bias[co] + sum_{dt,dy,dx,ci} in[t*st + dt - pt, y*ss + dy - ph, x*ss + dx - pw, ci] * w[co][dt][dy][dx][ci]
 //   (+ residual[t,y,x,co]);  out-of-range input coordinates read as zero;  up2: the input is read through a nearest 2x
 //   spatial upsample (source pixel = coordinate >> 1).
 //
@@ -41,7 +41,7 @@ struct ConvArgs {
   int To, Ho, Wo, Cout;
   int kt, kh, kw;
   int st, ss;      // temporal / spatial stride
-  int pt, ps;      // temporal (front) / spatial (top-left) zero padding
+  int pt, ph, pw;  // temporal (front) / top / left zero padding (ph may be negative: input slab carries halo rows)
   int up2;         // read input through nearest 2x spatial upsample
   int tsplit;      // Resample 'upsample3d' (vae.py:134-137): channel half h of output frame t goes to frame 1 + 2*t + h
   int silu_out;    // unused (reserved)
@@ -97,8 +97,8 @@ __global__ __launch_bounds__(CNT, 2) void k_conv(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int ti = pt_[i] * a.st + dt - a.pt;
-      int yi = py_[i] * a.ss + dy - a.ps;
-      int xi = px_[i] * a.ss + dx - a.ps;
+      int yi = py_[i] * a.ss + dy - a.ph;
+      int xi = px_[i] * a.ss + dx - a.pw;
       bool ok = pvalid[i] && ti >= 0 && ti < a.Ti && yi >= 0 && yi < Hs && xi >= 0 && xi < Ws;
       if (a.up2) {
         yi >>= 1;
@@ -270,7 +270,7 @@ __global__ void k_conv_small(SmallConvArgs a) {
 
 extern "C" int wf_conv3d_cl(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_bf16,
                             int Ti, int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st,
-                            int ss, int pt, int ps, int up2, int tsplit, void* stream) {
+                            int ss, int pt, int ph, int pw, int up2, int tsplit, void* stream) {
   WF_CHECK_ARG(in && w && (out_f32 || out_bf16), "wf_conv3d_cl: null pointer");
   WF_CHECK_ARG(Cin % CBK == 0, "wf_conv3d_cl: Cin (%d) must be a multiple of 32 (use wf_conv3d_small otherwise)", Cin);
   WF_CHECK_ARG(Cout % 4 == 0, "wf_conv3d_cl: Cout (%d) must be a multiple of 4", Cout);
@@ -288,7 +288,7 @@ extern "C" int wf_conv3d_cl(const void* in, const void* w, const float* bias, co
   a.Ti = Ti; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin;
   a.To = To; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   a.kt = kt; a.kh = kh; a.kw = kw;
-  a.st = st; a.ss = ss; a.pt = pt; a.ps = ps;
+  a.st = st; a.ss = ss; a.pt = pt; a.ph = ph; a.pw = pw;
   a.up2 = up2; a.tsplit = tsplit; a.silu_out = 0;
   dim3 grid((unsigned)((M + CBM - 1) / CBM), (unsigned)((Cout + CBN - 1) / CBN));
   hipLaunchKernelGGL(k_conv, grid, dim3(CNT), 2 * CBUF, (hipStream_t)stream, a);

@@ -88,8 +88,9 @@ class _LatentDist:
 class AutoencoderKLWan:
     dtype = torch.float32
 
-    def __init__(self, device="cuda:0"):
+    def __init__(self, device="cuda:0", comm=None):
         self.device = torch.device(device)
+        self.comm = comm  # row-slab sharding of the high-resolution stages over the ranks of `comm` (parallel.Comm or a stand-in)
         self.config = SimpleNamespace(z_dim=Z_DIM, latents_mean=LATENTS_MEAN, latents_std=LATENTS_STD)
         self.temperal_downsample = list(T_DOWN)
         self.w: Dict[str, torch.Tensor] = {}
@@ -214,7 +215,8 @@ class AutoencoderKLWan:
     # kernels wrappers; activations are channels-last [T, H, W, C]
     # ------------------------------------------------------------------------------------------------------------
     def _conv(self, x, p, To, Ho, Wo, Cout, k, st=1, ss=1, pt=0, ps=0, up2=False, tsplit=False, resid=None, out_f32=True,
-              out_bf16=False, out_shape=None, out_bf_tensor=None):
+              out_bf16=False, out_shape=None, out_bf_tensor=None, ph=None):
+        """ps: symmetric spatial padding (top = left); ph overrides the top padding (row slabs with halo rows)."""
         Ti, Hi, Wi, Cin = x.shape
         assert x.dtype == BF and x.is_contiguous()
         shape = out_shape or (To, Ho, Wo, Cout)
@@ -223,8 +225,8 @@ class AutoencoderKLWan:
         W = self.w
         call("wf_conv3d_cl", x.data_ptr(), W[p + ".w"].data_ptr(), W[p + ".b"].data_ptr(),
              resid.data_ptr() if resid is not None else None, of.data_ptr() if of is not None else None,
-             ob.data_ptr() if ob is not None else None, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, k[0], k[1], k[2], st, ss, pt, ps,
-             1 if up2 else 0, 1 if tsplit else 0, ops.stream())
+             ob.data_ptr() if ob is not None else None, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, k[0], k[1], k[2], st, ss, pt,
+             ps if ph is None else ph, ps, 1 if up2 else 0, 1 if tsplit else 0, ops.stream())
         self.flops_last += 2 * To * Ho * Wo * Cout * k[0] * k[1] * k[2] * Cin
         return of, ob
 
@@ -306,7 +308,7 @@ class AutoencoderKLWan:
         out[0].copy_(y[0])  # frame 0 by-passes time_conv (vae.py:146-148)
         W = self.w
         call("wf_conv3d_cl", yb.data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
-             out[1:].data_ptr(), None, T, Ho, Wo, C, To, Ho, Wo, C, 3, 1, 1, 2, 1, 0, 0, 0, 0, ops.stream())
+             out[1:].data_ptr(), None, T, Ho, Wo, C, To, Ho, Wo, C, 3, 1, 1, 2, 1, 0, 0, 0, 0, 0, ops.stream())
         self.flops_last += 2 * To * Ho * Wo * C * 3 * C
         return out
 
@@ -320,7 +322,7 @@ class AutoencoderKLWan:
             yb[0].copy_(xb[0])  # first latent frame by-passes time_conv ('Rep', vae.py:106-108)
             W = self.w
             call("wf_conv3d_cl", xb[1:].data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
-                 None, yb.data_ptr(), T - 1, H, Wd, C, T - 1, H, Wd, 2 * C, 3, 1, 1, 1, 1, 2, 0, 0, 1, ops.stream())
+                 None, yb.data_ptr(), T - 1, H, Wd, C, T - 1, H, Wd, 2 * C, 3, 1, 1, 1, 1, 2, 0, 0, 0, 1, ops.stream())
             self.flops_last += 2 * (T - 1) * H * Wd * 2 * C * 3 * C
             xb = yb
         Tn = xb.shape[0]
@@ -347,6 +349,180 @@ class AutoencoderKLWan:
         return x
 
     # ------------------------------------------------------------------------------------------------------------
+    # multi-GPU: row-slab sharding of the high-resolution stages.  The low-resolution stage (60 x 104 at 480p:
+    # ~4 % of the FLOPs, and the only place with global spatial coupling -- the mid-block attention) is computed replicated;
+    # every other layer runs on H/P rows per rank.  A 3x3 convolution needs one halo row from each neighbour: the ranks
+    # all-gather their top / bottom rows of the convolution INPUT (bf16) and pick their neighbours' (zeros at the image edge).
+    # Only all-gather is used.  Results are bit-identical to the unsharded path (same per-pixel accumulation order).
+    # ------------------------------------------------------------------------------------------------------------
+    def _halo_pad(self, a):
+        """a [T,Hs,W,C] bf16 -> [T,Hs+2,W,C] with the neighbours' boundary rows (zeros at the image boundary)."""
+        comm = self.comm
+        T, Hs, Wd, C = a.shape
+        out = torch.empty((T, Hs + 2, Wd, C), dtype=a.dtype, device=a.device)
+        out[:, 1:Hs + 1].copy_(a)
+        mine = torch.stack([a[:, 0], a[:, Hs - 1]])  # [2,T,W,C]
+        allb = torch.empty((comm.world,) + tuple(mine.shape), dtype=a.dtype, device=a.device)
+        comm.all_gather(allb, mine.contiguous())
+        if comm.rank > 0:
+            out[:, 0].copy_(allb[comm.rank - 1, 1])
+        else:
+            out[:, 0].zero_()
+        if comm.rank < comm.world - 1:
+            out[:, Hs + 1].copy_(allb[comm.rank + 1, 0])
+        else:
+            out[:, Hs + 1].zero_()
+        return out
+
+    def _rows_from_full(self, x, r0, r1):
+        """Rows [r0, r1) of a replicated [T,H,W,C] tensor with zero rows outside the image -> contiguous slab."""
+        T, H, Wd, C = x.shape
+        out = torch.zeros((T, r1 - r0, Wd, C), dtype=x.dtype, device=x.device)
+        lo, hi = max(r0, 0), min(r1, H)
+        out[:, lo - r0:hi - r0].copy_(x[:, lo:hi])
+        return out
+
+    def _gather_rows(self, slab):
+        """[T,Hs,W,C] per rank -> full [T,P*Hs,W,C] on every rank."""
+        comm = self.comm
+        allr = torch.empty((comm.world,) + tuple(slab.shape), dtype=slab.dtype, device=slab.device)
+        comm.all_gather(allr, slab.contiguous())
+        return allr.permute(1, 0, 2, 3, 4).reshape(slab.shape[0], comm.world * slab.shape[1], slab.shape[2], slab.shape[3]).contiguous()
+
+    def _res_slab(self, x, p, cin, cout):
+        T, Hs, Wd, _ = x.shape
+        W = self.w
+        a = self._halo_pad(self._rms(x, W[p + ".residual.0.gamma"]))
+        y, _ = self._conv(a, p + ".residual.2", T, Hs, Wd, cout, (3, 3, 3), pt=2, ps=1, ph=0)
+        del a
+        a2 = self._halo_pad(self._rms(y, W[p + ".residual.3.gamma"]))
+        del y
+        if cin != cout:
+            xb = ops.cast(x, BF)
+            h = torch.empty((T, Hs, Wd, cout), dtype=F32, device=x.device)
+            gemm(xb.view(-1, cin), W[p + ".shortcut.w"], W[p + ".shortcut.b"], h.view(-1, cout), EPI_F32)
+            del xb
+        else:
+            h = x
+        out, _ = self._conv(a2, p + ".residual.6", T, Hs, Wd, cout, (3, 3, 3), pt=2, ps=1, ph=0, resid=h)
+        return out
+
+    def _time_up(self, xb, p, C):
+        """'upsample3d' temporal part on a bf16 tensor (pointwise in space): [T,..] -> [1+2(T-1),..]."""
+        T, H, Wd, _ = xb.shape
+        if T == 1:
+            return xb
+        yb = torch.empty((1 + 2 * (T - 1), H, Wd, C), dtype=BF, device=xb.device)
+        yb[0].copy_(xb[0])
+        W = self.w
+        call("wf_conv3d_cl", xb[1:].data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
+             None, yb.data_ptr(), T - 1, H, Wd, C, T - 1, H, Wd, 2 * C, 3, 1, 1, 1, 1, 2, 0, 0, 0, 1, ops.stream())
+        return yb
+
+    def _up_slab(self, xsrc_b, p, C, temporal, s0, y0, Ho, h_src):
+        """Nearest-2x upsample + 3x3 conv for output rows [y0, y0+Ho) (upsampled coordinates) from a bf16 source slab that
+        starts at source row s0 (may be -1: zero row) and covers (y0-1)>>1 .. (y0+Ho)>>1.  Output row j reads upsampled rows
+        y0 + j - 1 + dy, i.e. slab-local upsampled row j + dy - ph with ph = 1 + 2*s0 - y0."""
+        if temporal:
+            xsrc_b = self._time_up(xsrc_b, p, C)
+            # rows outside the image are the spatial conv's ZERO padding: the (pointwise) time_conv turned them into its bias
+            if s0 < 0:
+                xsrc_b[:, 0].zero_()
+            if s0 + xsrc_b.shape[1] > h_src:
+                xsrc_b[:, -1].zero_()
+        T, _, Wd, _ = xsrc_b.shape
+        out, _ = self._conv(xsrc_b, p + ".resample.1", T, Ho, 2 * Wd, C // 2, (1, 3, 3), ps=1, ph=1 + 2 * s0 - y0, up2=True)
+        return out
+
+    def _down_slab(self, x, p, C, temporal):
+        """fp32 slab [T,Hs,W,C] -> [T',Hs/2,W/2,C]  (ZeroPad2d((0,1,0,1)) + stride-2 conv: bottom halo row only)."""
+        T, Hs, Wd, _ = x.shape
+        xpad = self._halo_pad(ops.cast(x, BF))
+        Ho, Wo = Hs // 2, Wd // 2
+        if not temporal or T == 1:
+            y, _ = self._conv(xpad, p + ".resample.1", T, Ho, Wo, C, (1, 3, 3), ss=2, ps=0, ph=-1)
+            return y
+        y, yb = self._conv(xpad, p + ".resample.1", T, Ho, Wo, C, (1, 3, 3), ss=2, ps=0, ph=-1, out_f32=True, out_bf16=True)
+        To = (T - 1) // 2
+        out = torch.empty((1 + To, Ho, Wo, C), dtype=F32, device=x.device)
+        out[0].copy_(y[0])
+        W = self.w
+        call("wf_conv3d_cl", yb.data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
+             out[1:].data_ptr(), None, T, Ho, Wo, C, To, Ho, Wo, C, 3, 1, 1, 2, 1, 0, 0, 0, 0, 0, ops.stream())
+        return out
+
+    def can_shard(self, H_lat: int) -> bool:
+        """Row sharding needs every sharded stage to hold an integer (even, where a stride-2 conv follows) number of rows."""
+        if self.comm is None or self.comm.world == 1:
+            return False
+        P = self.comm.world
+        return (2 * H_lat) % P == 0 and (8 * H_lat) % (4 * P) == 0
+
+    def _decode_one_sharded(self, z: torch.Tensor) -> torch.Tensor:
+        comm = self.comm
+        P, rank = comm.world, comm.rank
+        C, T, h, w = z.shape
+        x = torch.empty((T, h, w, Z_DIM), dtype=F32, device=self.device)
+        call("wf_ncthw_to_cl", z.data_ptr(), x.data_ptr(), None, Z_DIM, Z_DIM, T * h * w, ops.stream())
+        x = self._small_conv(x, "conv2", T, h, w, 32, (1, 1, 1), out_dtype=BF)
+        plan = decoder_plan()
+        first_up = next(i for i, e in enumerate(plan) if e[0] in ("up2d", "up3d"))
+        x = self._run(x, plan[:first_up])                      # stage 0 replicated: [T,h,w,384] fp32
+        kind, p, cin, cout = plan[first_up]
+        Hs = 2 * h // P                                        # my rows at the next resolution
+        y0 = rank * Hs
+        s0, s1 = (y0 - 1) >> 1, ((y0 + Hs) >> 1) + 1               # source rows incl. halo (s0 = -1 -> zero row)
+        src = self._rows_from_full(ops.cast(x, BF), s0, s1)
+        x = self._up_slab(src, p, cin, kind == "up3d", s0, y0, Hs, h)
+        h_cur = 2 * h                                          # full image height at the current resolution
+        row0 = y0                                              # global first row of my slab at the current resolution
+        for kind, p, cin, cout in plan[first_up + 1:]:
+            if kind == "res":
+                x = self._res_slab(x, p, cin, cout)
+            elif kind in ("up2d", "up3d"):
+                Hcur = x.shape[1]
+                x = self._up_slab(self._halo_pad(ops.cast(x, BF)), p, cin, kind == "up3d", row0 - 1, 2 * row0, 2 * Hcur, h_cur)
+                row0 *= 2
+                h_cur *= 2
+            elif kind == "head":
+                Tn, Hn, Wn, _ = x.shape
+                a = self._halo_pad(self._rms(x, self.w[p + ".0.gamma"]))
+                x, _ = self._conv(a, p + ".2", Tn, Hn, Wn, (cout + 3) // 4 * 4, (3, 3, 3), pt=2, ps=1, ph=0)
+        y = self._gather_rows(x)
+        Fo, Ho, Wo, Cy = y.shape
+        out = torch.empty((3, Fo, Ho, Wo), dtype=F32, device=self.device)
+        call("wf_cl_to_ncthw", y.data_ptr(), out.data_ptr(), 3, Cy, Fo * Ho * Wo, 1.0, ops.stream())
+        return out
+
+    def _encode_one_sharded(self, video: torch.Tensor) -> torch.Tensor:
+        comm = self.comm
+        P, rank = comm.world, comm.rank
+        C, Fr, H, Wd = video.shape
+        xfull = torch.empty((Fr, H, Wd, 32), dtype=BF, device=self.device)
+        call("wf_ncthw_to_cl", video.data_ptr(), None, xfull.data_ptr(), 3, 32, Fr * H * Wd, ops.stream())
+        plan = encoder_plan()
+        Hs = H // P
+        y0 = rank * Hs
+        xpad = self._rows_from_full(xfull, y0 - 1, y0 + Hs + 1)
+        del xfull
+        kind, p, cin, cout = plan[0]
+        x, _ = self._conv(xpad, p, Fr, Hs, Wd, cout, (3, 3, 3), pt=2, ps=1, ph=0)
+        downs = [i for i, e in enumerate(plan) if e[0] in ("down2d", "down3d")]
+        last_down = downs[-1]
+        for kind, p, cin, cout in plan[1:last_down]:
+            if kind == "res":
+                x = self._res_slab(x, p, cin, cout)
+            else:
+                x = self._down_slab(x, p, cin, kind == "down3d")
+        x = self._gather_rows(x)                                # replicated from the last downsample on
+        y = self._run(x, plan[last_down:])
+        T, h, w, _ = y.shape
+        q = self._small_conv(y, "conv1", T, h, w, 2 * Z_DIM, (1, 1, 1))
+        out = torch.empty((2 * Z_DIM, T, h, w), dtype=F32, device=self.device)
+        call("wf_cl_to_ncthw", q.data_ptr(), out.data_ptr(), 2 * Z_DIM, 2 * Z_DIM, T * h * w, 0.0, ops.stream())
+        return out[:Z_DIM]
+
+    # ------------------------------------------------------------------------------------------------------------
     # diffusers protocol
     # ------------------------------------------------------------------------------------------------------------
     def _encode_one(self, video: torch.Tensor) -> torch.Tensor:
@@ -357,6 +533,8 @@ class AutoencoderKLWan:
         if H % 8 or Wd % 8:
             raise ValueError("height and width must be multiples of 8")
         self.flops_last = 0
+        if self.can_shard(H // 8):
+            return self._encode_one_sharded(video)
         x = torch.empty((Fr, H, Wd, 32), dtype=BF, device=self.device)  # 3 channels zero-padded to one MFMA K slice
         call("wf_ncthw_to_cl", video.data_ptr(), None, x.data_ptr(), 3, 32, Fr * H * Wd, ops.stream())
         y = self._run(x, encoder_plan())
@@ -370,6 +548,8 @@ class AutoencoderKLWan:
         """[16,T,h,w] f32 -> [3, 4T-3, 8h, 8w] f32 clamped to [-1,1] (vae.py:544-568, autoencoder_kl_wan.py:1222)."""
         C, T, h, w = z.shape
         self.flops_last = 0
+        if self.can_shard(h):
+            return self._decode_one_sharded(z)
         x = torch.empty((T, h, w, Z_DIM), dtype=F32, device=self.device)
         call("wf_ncthw_to_cl", z.data_ptr(), x.data_ptr(), None, Z_DIM, Z_DIM, T * h * w, ops.stream())
         x = self._small_conv(x, "conv2", T, h, w, 32, (1, 1, 1), out_dtype=BF)  # 16 channels + 16 zero channels
