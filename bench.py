@@ -27,6 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS_BF16 = 2500.0  # dense, MI355X_MICROARCH.md
+# HBM bytes per self-attention launch at the C2 shape, measured with rocprofv3 PMC passes (profiles/r1_attn_pmc.md):
+# FETCH_SIZE 1 474 606 KB x 2 (gfx950 reports half of wide coalesced reads) + WRITE_SIZE 327 608 KB.  Algorithmic minimum 1.34e9.
+ATTN_TRAFFIC_BYTES_C2 = int(1474606 * 1024 * 2 + 327608 * 1024)
 
 
 def synthetic_inputs(F, H, W, device, seed=42):
@@ -213,7 +216,9 @@ def main():
             ach = attn_flop / (avg * 1e-3) / 1e12
             out["roofline"] = {"kernel": "k_attn (DiT self-attention, model.py:149-154)", "bound": "mfma", "achieved": ach,
                                "peak": MFMA_PEAK_TFLOPS_BF16, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS_BF16,
-                               "traffic": None, "launches": len(attn_ms), "avg_launch_ms": avg,
+                               "traffic": ATTN_TRAFFIC_BYTES_C2 if (L == 32760 and world == 1 and cfg.num_heads == 40) else None,
+                               "traffic_source": "rocprofv3 PMC FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, profiles/r1_attn_pmc.md",
+                               "launches": len(attn_ms), "avg_launch_ms": avg,
                                "flop_per_launch": attn_flop}
         if a.layers != 40:
             out["invalid_reason"] = f"debug run with {a.layers} DiT layers (the named model has 40)"
