@@ -27,7 +27,9 @@ def _rel(got, want):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 384, 144), (1, 512, 256), (300, 132, 200), (1000, 64, 1280),
-                                   (2050, 1100, 520)])
+                                   (2050, 1100, 520),
+                                   # large shapes with K % 64 == 0 take the 256x256 ping-pong kernel (ragged M and N included)
+                                   (2048, 2048, 512), (4100, 1028, 640), (16384, 256, 64), (3000, 5120, 1280)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
 def test_gemm(M, N, K, epi):
     from worldforge_amd import dit

@@ -17,6 +17,7 @@
 //   * ragged M / N are handled by clamping load rows and predicating stores; K tail chunks are zero-filled (K % 8 == 0).
 #include "common.h"
 #include "mfma.h"
+#include <stdlib.h>
 
 using namespace wf;
 
@@ -210,6 +211,224 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_gemm(GemmArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Large-problem variant: 256 x 256 tile, 8 waves (2 token-halves x 4 feature-quarters, wave tile 128 tokens x 64 features =
+// 4 x 2 MFMA 32x32x16 tiles), BK = 64, LDS-DMA staging into a double buffer (128 KiB), two-group ping-pong schedule.
+//
+// Each K tile is processed in four phases per wave: R0 (LDS reads of k-steps 0,1 -> 12 fragment quads), M0 (16 MFMAs, registers
+// only), R1, M1.  Waves 0-3 (group A) and 4-7 (group B, one wave of each group per SIMD) run the same phase sequence ONE PHASE
+// APART, phase-locked by raw s_barrier, so that on every SIMD one wave's MFMA phase always coincides with the other wave's
+// LDS-read / DMA-issue phase: the matrix pipe never waits for LDS latency.  All waves issue the LDS-DMA of tile t+1 right after
+// barrier 4t (its buffer was last read two intervals earlier) and drain it (vmcnt(0)) before barrier 4t+4.
+// Requirements: K % 64 == 0 (no K tail in the DMA path); ragged M / N handled by clamped source rows + predicated stores.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int PM = 256, PN = 256, PK = 64, PT = 512;
+constexpr int P_TILE = PM * PK * 2;  // 32 KiB per operand tile
+constexpr int P_BUF = 2 * P_TILE;    // W tile | X tile
+
+template <int EPI>
+__global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // XCD-aware tile assignment (4 x 4 super-tiles of 256 x 256 tiles per XCD pass)
+  const int smt = (a.mt + 3) >> 2, snt = (a.nt + 3) >> 2;
+  const int nsuper = smt * snt;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, j = b >> 3;
+  const int gid = (j >> 4) * 8 + xcd;
+  if (gid >= nsuper) return;
+  const int within = j & 15;
+  const int tm = (gid / snt) * 4 + (within >> 2);
+  const int tn = (gid % snt) * 4 + (within & 3);
+  if (tm >= a.mt || tn >= a.nt) return;
+  const int m0 = tm * PM, n0 = tn * PN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wq = wid & 3;   // feature quarter (64 features)
+  const int wh = (wid >> 2) ^ 0;  // provisional; group = wid >> 2
+  const bool groupB = wid >= 4;
+  const int wmh = wid >> 2;  // token half is tied to the group: A -> tokens 0..127, B -> 128..255
+  (void)wh;
+
+  // ---- LDS-DMA geometry: an operand tile = 256 rows x 128 B = 32 pieces of 1 KiB (8 rows); wave w moves pieces 4w..4w+3 of W
+  // and of X.  lane -> (row = 8*piece + lane/8, slot = lane%8) receives source chunk slot ^ ((row >> 1) & 7).
+  const uint16_t* srcW[4];
+  const uint16_t* srcX[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wid * 4 + i;
+    const int row = 8 * piece + (lane >> 3), slot = lane & 7;
+    const int ch = slot ^ ((row >> 1) & 7);
+    srcW[i] = a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw + ch * 8;
+    srcX[i] = a.X + (size_t)min(m0 + row, a.M - 1) * a.ldx + ch * 8;
+  }
+  auto dma_piece = [&](int kt, int i) {  // i in 0..7: W pieces 0..3, X pieces 0..3
+    unsigned char* base = smem + (kt & 1) * P_BUF + wid * 4096;
+    if (i < 4)
+      glds16(srcW[i] + (size_t)kt * PK, base + i * 1024);
+    else
+      glds16(srcX[i - 4] + (size_t)kt * PK, base + P_TILE + (i - 4) * 1024);
+  };
+  auto dma = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_piece(kt, i);
+  };
+
+  // ---- fragment addressing ------------------------------------------------------------------------------------------------
+  int offW[2], swW[2], offX[4], swX[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = wq * 64 + i * 32 + l31;
+    offW[i] = r * 128;
+    swW[i] = (r >> 1) & 7;
+  }
+#pragma unroll
+  for (int jx = 0; jx < 4; ++jx) {
+    const int r = wmh * 128 + jx * 32 + l31;
+    offX[jx] = P_TILE + r * 128;
+    swX[jx] = (r >> 1) & 7;
+  }
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jx = 0; jx < 4; ++jx)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jx][r] = 0.f;
+
+  u32x4 fw[2][2], fx[2][4];
+  auto read_half = [&](int kt, int half) {
+    const unsigned char* base = smem + (kt & 1) * P_BUF;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = 2 * (2 * half + ks) + hi;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fw[ks][i] = *reinterpret_cast<const u32x4*>(base + offW[i] + ((c ^ swW[i]) << 4));
+#pragma unroll
+      for (int jx = 0; jx < 4; ++jx) fx[ks][jx] = *reinterpret_cast<const u32x4*>(base + offX[jx] + ((c ^ swX[jx]) << 4));
+    }
+  };
+  // 16 MFMAs on register operands; optionally the 8 LDS-DMA pieces of tile `dma_kt` are issued in the gaps (one behind every
+  // second MFMA: the MFMA pipe hides their issue cost, and the read phases stay pure LDS reads)
+  auto mma_half = [&](int dma_kt) {
+    __builtin_amdgcn_s_setprio(1);  // the MFMA phase outranks the co-resident wave's LDS phase at the issue arbiter
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+          acc[i][jx] = mfma32(as_bf16x8(fw[ks][i]), as_bf16x8(fx[ks][jx]), acc[i][jx]);
+          const int idx = ks * 8 + i * 4 + jx;
+          if (dma_kt >= 0 && (idx & 1)) dma_piece(dma_kt, idx >> 1);
+        }
+    if (dma_kt >= 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto bar = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  auto drain = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  const int nk = a.K / PK;
+  dma(0);
+  drain();
+  bar();
+  if (!groupB) {
+    for (int kt = 0; kt < nk; ++kt) {
+      read_half(kt, 0);
+      bar();  // 4kt+1
+      mma_half(kt + 1 < nk ? kt + 1 : -1);  // DMA of tile kt+1 rides in the MFMA gaps (its buffer is free since barrier 4kt)
+      bar();  // 4kt+2
+      read_half(kt, 1);
+      bar();  // 4kt+3
+      mma_half(-1);
+      drain();
+      bar();  // 4kt+4
+    }
+    bar();
+  } else {
+    if (nk > 1) dma(1);
+    bar();  // 1
+    for (int kt = 0; kt < nk; ++kt) {
+      read_half(kt, 0);
+      bar();  // 4kt+2
+      mma_half(-1);
+      bar();  // 4kt+3
+      read_half(kt, 1);
+      drain();
+      bar();  // 4kt+4
+      mma_half(kt + 2 < nk ? kt + 2 : -1);
+      bar();  // 4kt+5
+    }
+  }
+
+  // ---- epilogue: lane owns token row m and feature quads (as k_gemm) ------------------------------------------------------
+#pragma unroll
+  for (int jx = 0; jx < 4; ++jx) {
+    const int m = m0 + wmh * 128 + jx * 32 + l31;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wq * 64 + i * 32 + 8 * g + 4 * hi;
+        if (n >= a.N) continue;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = acc[i][jx][4 * g + q];
+        if (a.bias) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += bb[q];
+        }
+        const size_t o = (size_t)m * a.ldo + n;
+        if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+          if constexpr (EPI == EPI_BF16_GELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
+          }
+          u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + o) = pk;
+        } else if constexpr (EPI == EPI_F32) {
+          f32x4 ov = {v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + o) = ov;
+        } else if constexpr (EPI == EPI_F32_ACC) {
+          float* po = reinterpret_cast<float*>(a.out) + o;
+          f32x4 old = *reinterpret_cast<const f32x4*>(po);
+          f32x4 ov = {old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
+          *reinterpret_cast<f32x4*>(po) = ov;
+        } else {
+          float* po = reinterpret_cast<float*>(a.out) + o;
+          f32x4 old = *reinterpret_cast<const f32x4*>(po);
+          f32x4 gg = {1.f, 1.f, 1.f, 1.f};
+          if (a.gate) gg = *reinterpret_cast<const f32x4*>(a.gate + n);
+          f32x4 ov = {old[0] + v[0] * gg[0], old[1] + v[1] * gg[1], old[2] + v[2] * gg[2], old[3] + v[3] * gg[3]};
+          *reinterpret_cast<f32x4*>(po) = ov;
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+static void launch_pp(GemmArgs a, hipStream_t s) {
+  a.mt = ceil_div(a.M, PM);
+  a.nt = ceil_div(a.N, PN);
+  const int nsuper = ((a.mt + 3) / 4) * ((a.nt + 3) / 4);
+  const int grid = ((nsuper + 7) / 8) * 8 * 16;
+  hipLaunchKernelGGL(k_gemm_pp<EPI>, dim3(grid), dim3(PT), 2 * P_BUF, s, a);
+}
+
 }  // namespace
 
 extern "C" int wf_gemm_bf16(const void* X, const void* W, const float* bias, void* out, const float* gate, int M, int N,
@@ -239,6 +458,20 @@ extern "C" int wf_gemm_bf16(const void* X, const void* W, const float* bias, voi
   const int grid = ((nsuper + 7) / 8) * 8 * 64;
   const size_t lds = 4 * TILE_BYTES;
   hipStream_t s = (hipStream_t)stream;
+  // large problems with a whole number of 64-wide K tiles take the 256x256 ping-pong kernel
+  static const bool no_pp = getenv("WF_GEMM_NO_PP") != nullptr;
+  if (!no_pp && K % PK == 0 && M >= 1024 && N >= 256 && (long)M * N >= (1L << 22)) {
+    switch (epilogue) {
+      case EPI_BF16: launch_pp<EPI_BF16>(a, s); break;
+      case EPI_BF16_GELU: launch_pp<EPI_BF16_GELU>(a, s); break;
+      case EPI_F32: launch_pp<EPI_F32>(a, s); break;
+      case EPI_RESID: launch_pp<EPI_RESID>(a, s); break;
+      case EPI_F32_ACC: launch_pp<EPI_F32_ACC>(a, s); break;
+      default: WF_CHECK_ARG(false, "wf_gemm_bf16: unknown epilogue %d", epilogue);
+    }
+    WF_LAUNCH_CHECK("wf_gemm_bf16");
+    return WF_OK;
+  }
   switch (epilogue) {
     case EPI_BF16: hipLaunchKernelGGL(k_gemm<EPI_BF16>, dim3(grid), dim3(NTHREADS), lds, s, a); break;
     case EPI_BF16_GELU: hipLaunchKernelGGL(k_gemm<EPI_BF16_GELU>, dim3(grid), dim3(NTHREADS), lds, s, a); break;
