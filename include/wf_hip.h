@@ -157,10 +157,11 @@ int wf_act(const void* a, int dt_a, const void* b, int dt_b, void* out, int dt_o
  *   out[t,y,x] = sum_taps in[t*st+dt-pt, y*ss+dy-ph, x*ss+dx-pw] . w[tap]   (zero outside the input; ph may be negative when
  *   the input is a row slab that already carries its halo rows -- multi-GPU row sharding)
  * up2: read the input through a nearest-exact 2x spatial upsample (vae.py:78);  tsplit: 'upsample3d' frame interleave
- * (vae.py:134-137): output frame t, channel half h -> frame 1 + 2t + h of a [1+2*To, Ho, Wo, Cout/2] tensor. */
+ * (vae.py:134-137): output frame t, channel half h -> frame 1 + 2t + h of a [1+2*To, Ho, Wo, Cout/2] tensor.
+ * zero_page: >= 16 bytes of zeros in device memory (enables the DMA-gather ping-pong kernel for large stride-1 layers) or NULL. */
 int wf_conv3d_cl(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_bf16, int Ti,
                  int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st, int ss, int pt, int ph,
-                 int pw, int up2, int tsplit, void* stream);
+                 int pw, int up2, int tsplit, const void* zero_page, void* stream);
 /* Direct convolution for the thin layers (3->96, 16->384, 96->3, 384->32, 1x1x1 quant convs; vae.py:288, 316, 392, 421, 505-506).
  * in f32 or bf16 channels-last, w f32 [taps][Cin][Cout]; clamp > 0 clamps the output (autoencoder_kl_wan.py:1222). */
 int wf_conv3d_small(const void* in, int in_dtype, const float* w, const float* bias, float* out_f32, void* out_bf16, int Ti, int Hi,

@@ -64,6 +64,12 @@ def _conv_ref(x_cl, w, b, k, st, ss, pt, ps, up2=False):
     dict(T=2, H=6, W=5, cin=192, cout=96, k=(1, 3, 3), st=1, ss=1, pt=0, ps=1, up2=True),  # upsample2x + conv
     dict(T=5, H=4, W=6, cin=384, cout=384, k=(3, 1, 1), st=2, ss=1, pt=0, ps=0),     # downsample3d time_conv
     dict(T=40, H=16, W=16, cin=96, cout=192, k=(3, 3, 3), st=1, ss=1, pt=2, ps=1),  # several pixel tiles, ragged M
+    # >= 32768 pixels, stride 1: the 512-pixel DMA-gather ping-pong kernel (odd and even numbers of 32-channel K tiles, ragged M)
+    dict(T=9, H=61, W=64, cin=96, cout=96, k=(3, 3, 3), st=1, ss=1, pt=2, ps=1),
+    dict(T=5, H=80, W=90, cin=192, cout=192, k=(3, 3, 3), st=1, ss=1, pt=2, ps=1),
+    dict(T=3, H=100, W=120, cin=384, cout=96, k=(1, 3, 3), st=1, ss=1, pt=0, ps=1),
+    dict(T=33, H=32, W=32, cin=96, cout=384, k=(3, 1, 1), st=1, ss=1, pt=2, ps=0),
+    dict(T=4, H=96, W=96, cin=32, cout=96, k=(3, 3, 3), st=1, ss=1, pt=2, ps=1),
 ])
 def test_conv3d_cl_vs_torch(cfg):
     from worldforge_amd import _ffi, ops
@@ -78,10 +84,11 @@ def test_conv3d_cl_vs_torch(cfg):
     resid = torch.randn(To, Ho, Wo, cout, generator=g)
     wk = w.permute(0, 2, 3, 4, 1).reshape(cout, -1, cin).contiguous().to(DEV)
     xd, bd, rd = x.to(DEV), b.to(DEV), resid.to(DEV)
+    zp = torch.zeros(64, dtype=BF, device=DEV)
     of = torch.full((To, Ho, Wo, cout), float("nan"), dtype=F32, device=DEV)
     ob = torch.empty((To, Ho, Wo, cout), dtype=BF, device=DEV)
     _ffi.call("wf_conv3d_cl", xd.data_ptr(), wk.data_ptr(), bd.data_ptr(), rd.data_ptr(), of.data_ptr(), ob.data_ptr(), T, H, W, cin,
-              To, Ho, Wo, cout, k[0], k[1], k[2], st, ss, pt, ps, ps, 1 if up2 else 0, 0, ops.stream())
+              To, Ho, Wo, cout, k[0], k[1], k[2], st, ss, pt, ps, ps, 1 if up2 else 0, 0, zp.data_ptr(), ops.stream())
     want = ref + resid
     err = (of.cpu() - want).abs().max().item()
     assert err <= 2e-3 * max(1.0, want.abs().max().item()), err
@@ -101,7 +108,7 @@ def test_conv3d_tsplit_matches_upsample3d_interleave():
     wk = w.permute(0, 2, 3, 4, 1).reshape(2 * C, -1, C).contiguous().to(DEV)
     xd, bd = x.to(DEV), b.to(DEV)
     _ffi.call("wf_conv3d_cl", xd.data_ptr(), wk.data_ptr(), bd.data_ptr(), None, None, out.data_ptr(), T, H, W, C, T, H, W, 2 * C,
-              3, 1, 1, 1, 1, 2, 0, 0, 0, 1, ops.stream())
+              3, 1, 1, 1, 1, 2, 0, 0, 0, 1, None, ops.stream())
     assert out[0].abs().max().item() == 0
     assert (out[1:].float().cpu() - want).abs().max().item() <= 1e-2 * want.abs().max().item()
 

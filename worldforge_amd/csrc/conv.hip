@@ -17,6 +17,7 @@
 // global -> VGPR -> LDS staging with the next slice's gathers issued before the current slice's MFMAs.
 #include "common.h"
 #include "mfma.h"
+#include <stdlib.h>
 
 using namespace wf;
 
@@ -217,6 +218,288 @@ __global__ __launch_bounds__(CNT, 2) void k_conv(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Stride-1 variant for the FLOP-heavy 3x3x3 residual-block convolutions: 512 pixels x 96 output channels per workgroup,
+// 8 waves (wave = 64 pixels x 96 channels), LDS-DMA staging into a double buffer, two-group ping-pong schedule (see gemm.hip
+// k_gemm_pp): per 64-channel K super-tile each wave runs R0 | M0 | R1 | M1 (10 LDS fragment reads, 12 register-only MFMAs,
+// twice); waves 0-3 and 4-7 run one phase apart so that one wave's MFMA phase always covers the other's LDS phase.
+//   * a K super-tile is two independent 32-channel sub-tiles (tap, channel offset) stored side by side in 128-byte LDS rows
+//     (chunk c of row r at c ^ ((r >> 1) & 7));
+//   * the im2col gather is done by the DMA itself: every lane's source address is its pixel + tap offset, or a 16-byte zero
+//     page when the tap falls outside the input (separable validity bits per pixel, prepared once per workgroup);
+//   * all LDS-DMA pieces of super-tile t+1 are issued in the gaps of an MFMA phase of super-tile t.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int QM = 512, QN = 96, QT = 512;
+constexpr int QX_BYTES = QM * 128;  // 64 KiB
+constexpr int QW_BYTES = QN * 128;  // 12 KiB
+constexpr int QBUF = QX_BYTES + QW_BYTES;
+
+// select between two global pointers with two 32-bit v_cndmask (a ?: on pointers is lowered to exec-mask branches by hipcc
+// when one arm carries address arithmetic)
+__device__ __forceinline__ const void* sel_ptr(int ok, const void* p, const void* z) {
+  const uint64_t up = (uint64_t)p, uz = (uint64_t)z;
+  const uint32_t lo = ok ? (uint32_t)up : (uint32_t)uz;
+  const uint32_t hi = ok ? (uint32_t)(up >> 32) : (uint32_t)(uz >> 32);
+  return (const void*)(((uint64_t)hi << 32) | lo);
+}
+
+struct ConvPPArgs {
+  ConvArgs c;
+  const uint16_t* zeros;  // >= 16 bytes of zeros in device memory
+};
+
+__global__ __launch_bounds__(QT, 2) void k_conv_pp(ConvPPArgs pa) {
+  const ConvArgs& a = pa.c;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const long M = (long)a.To * a.Ho * a.Wo;
+  const long m0 = (long)blockIdx.x * QM;
+  const int n0 = blockIdx.y * QN;
+  const int taps = a.kt * a.kh * a.kw;
+  const int kc_per_tap = a.Cin / CBK;
+  const int nk = taps * kc_per_tap;       // 32-channel sub-tiles
+  const int nk2 = (nk + 1) >> 1;          // 64-channel super-tiles
+  const bool groupB = wid >= 4;
+
+  // ---- per-lane DMA geometry ----------------------------------------------------------------------------------------------
+  // X: wave w stages its own 64 pixel rows as 8 pieces (8 rows x 128 B).  lane -> (row = 64w + 8i + lane/8, slot = lane%8);
+  // source chunk ch = slot ^ ((row >> 1) & 7); sub-tile = ch >> 2; chunk within the sub-tile = ch & 3.
+  const int cin8 = a.Cin >> 3;
+  int pixchunk[8];   // pixel base offset in 16-byte chunks (pixel index * Cin / 8), valid pixels only
+  int vbits[8];      // separable validity: bit dt | bit (3+dy) | bit (6+dx) set when that tap offset stays inside the input
+  const int cc = (lane & 3) ^ ((lane >> 4) & 3);
+  const int sub_even = (lane & 7) >> 2;  // sub-tile handled by this lane for even pieces; odd pieces: the other one
+  {
+    // pixel coordinates of the lane's first row by one 32-bit division, the other 7 rows (8 pixels further each) incrementally
+    const int Mi = (int)M;
+    int m = (int)m0 + wid * 64 + (lane >> 3);
+    const int mc = m < Mi ? m : 0;
+    const int hw = a.Ho * a.Wo;
+    int t = mc / hw;
+    int rem = mc - t * hw;
+    int y = rem / a.Wo;
+    int x = rem - y * a.Wo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int bits = 0;
+      if (m < Mi) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          if (d < a.kt && (unsigned)(t + d - a.pt) < (unsigned)a.Ti) bits |= 1 << d;
+          if (d < a.kh && (unsigned)(y + d - a.ph) < (unsigned)a.Hi) bits |= 1 << (3 + d);
+          if (d < a.kw && (unsigned)(x + d - a.pw) < (unsigned)a.Wi) bits |= 1 << (6 + d);
+        }
+      }
+      vbits[i] = bits;
+      pixchunk[i] = ((t * a.Hi + y) * a.Wi + x) * cin8;
+      m += 8;
+      x += 8;
+      while (x >= a.Wo) {
+        x -= a.Wo;
+        if (++y == a.Ho) {
+          y = 0;
+          ++t;
+        }
+      }
+    }
+  }
+  // W: 12 pieces (96 rows x 128 B): waves 0-3 stage pieces 2w, 2w+1; waves 4-7 stage piece 8 + (w - 4)
+  const int nwp = wid < 4 ? 2 : 1;
+  const int wp0 = wid < 4 ? 2 * wid : 4 + wid;
+  int wchunk[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 8 * (wp0 + i) + (lane >> 3);
+    const int co = min(n0 + row, a.Cout - 1);
+    wchunk[i] = co * taps * (a.Cin >> 3);
+  }
+  // scalar description of the two 32-channel sub-tiles of super-tile kt2 (computed ONCE per tile, wave-uniform)
+  struct Sub {
+    int toff, sel, woff;
+    bool ok;
+  };
+  // sub-tile iterator (wave-uniform scalars): walks (tap, 32-channel chunk) pairs in order without integer divisions
+  int it_kidx, it_kc, it_dx, it_dy, it_dt;
+  auto it_seek = [&](int kidx) {
+    it_kidx = kidx;
+    const int kk = kidx < nk ? kidx : 0;
+    const int tap = kk / kc_per_tap;
+    it_kc = kk - tap * kc_per_tap;
+    it_dx = tap % a.kw;
+    it_dy = (tap / a.kw) % a.kh;
+    it_dt = tap / (a.kw * a.kh);
+  };
+  auto describe_next = [&](Sub (&d)[2]) {  // describes sub-tiles it_kidx, it_kidx + 1 and advances by two
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      d[s2].ok = it_kidx < nk;
+      const int cin0c = it_kc * (CBK >> 3);
+      d[s2].toff = (((it_dt - a.pt) * a.Hi + (it_dy - a.ph)) * a.Wi + (it_dx - a.pw)) * cin8 + cin0c;
+      d[s2].sel = (1 << it_dt) | (1 << (3 + it_dy)) | (1 << (6 + it_dx));
+      d[s2].woff = ((it_dt * a.kh + it_dy) * a.kw + it_dx) * cin8 + cin0c;
+      ++it_kidx;
+      if (++it_kc == kc_per_tap) {
+        it_kc = 0;
+        if (++it_dx == a.kw) {
+          it_dx = 0;
+          if (++it_dy == a.kh) {
+            it_dy = 0;
+            ++it_dt;
+          }
+        }
+      }
+    }
+  };
+  auto dma_piece = [&](int kt2, const Sub (&d)[2], int i) {  // i in 0..7: X pieces of this wave; 8, 9: its W pieces
+    unsigned char* xb = smem + (kt2 & 1) * QBUF + wid * 8192;
+    unsigned char* wb = smem + (kt2 & 1) * QBUF + QX_BYTES + wp0 * 1024;
+    if (i < 8) {
+      const int sb = (i & 1) ? (sub_even ^ 1) : sub_even;
+      const int to = sb ? d[1].toff : d[0].toff;
+      const int se = sb ? d[1].sel : d[0].sel;
+      const int ok = (int)(sb ? d[1].ok : d[0].ok) & (int)((vbits[i] & se) == se);
+      glds16(sel_ptr(ok, a.in + ((long)(pixchunk[i] + to + cc) << 3), pa.zeros), xb + i * 1024);
+    } else if (i - 8 < nwp) {
+      const int sb = ((wp0 + i - 8) & 1) ? (sub_even ^ 1) : sub_even;
+      const int ok = (int)(sb ? d[1].ok : d[0].ok);
+      glds16(sel_ptr(ok, a.w + ((long)(wchunk[i - 8] + (sb ? d[1].woff : d[0].woff) + cc) << 3), pa.zeros), wb + (i - 8) * 1024);
+    }
+  };
+  auto dma_tile = [&](int kt2) {  // all pieces at once (prologue); the iterator must stand at sub-tile 2*kt2
+    Sub d[2];
+    describe_next(d);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) dma_piece(kt2, d, i);
+  };
+
+  // ---- fragment addressing --------------------------------------------------------------------------------------------------
+  int fxoff[2], fxsw[2], fwoff[3], fwsw[3];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = wid * 64 + j * 32 + l31;
+    fxoff[j] = row * 128;
+    fxsw[j] = (row >> 1) & 7;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int row = i * 32 + l31;
+    fwoff[i] = QX_BYTES + row * 128;
+    fwsw[i] = (row >> 1) & 7;
+  }
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  u32x4 fw[2][3], fx[2][2];
+  auto read_half = [&](int kt2, int half) {
+    const unsigned char* base = smem + (kt2 & 1) * QBUF;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = 4 * half + 2 * ks + hi;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) fw[ks][i] = *reinterpret_cast<const u32x4*>(base + fwoff[i] + ((c ^ fwsw[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fx[ks][j] = *reinterpret_cast<const u32x4*>(base + fxoff[j] + ((c ^ fxsw[j]) << 4));
+    }
+  };
+  auto mma_half = [&](int dma_kt2) {
+    Sub d[2];
+    if (dma_kt2 >= 0) describe_next(d);  // tiles are described in increasing order by each wave
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = mfma32(as_bf16x8(fw[ks][i]), as_bf16x8(fx[ks][j]), acc[i][j]);
+          const int idx = ks * 6 + i * 2 + j;
+          if (dma_kt2 >= 0 && idx < 10) dma_piece(dma_kt2, d, idx);
+        }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto bar = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  auto drain = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  it_seek(0);
+  dma_tile(0);  // iterator now at tile 1
+  drain();
+  bar();
+  if (!groupB) {
+    for (int kt2 = 0; kt2 < nk2; ++kt2) {
+      read_half(kt2, 0);
+      bar();
+      mma_half(kt2 + 1 < nk2 ? kt2 + 1 : -1);
+      bar();
+      read_half(kt2, 1);
+      bar();
+      mma_half(-1);
+      drain();
+      bar();
+    }
+    bar();
+  } else {
+    if (nk2 > 1) dma_tile(1);  // iterator now at tile 2
+    bar();
+    for (int kt2 = 0; kt2 < nk2; ++kt2) {
+      read_half(kt2, 0);
+      bar();
+      mma_half(-1);
+      bar();
+      read_half(kt2, 1);
+      drain();
+      bar();
+      mma_half(kt2 + 2 < nk2 ? kt2 + 2 : -1);
+      bar();
+    }
+  }
+
+  // ---- epilogue (as k_conv) ---------------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const long m = m0 + wid * 64 + j * 32 + l31;
+    if (m >= M) continue;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = n0 + i * 32 + 8 * g + 4 * hi;
+        if (co >= a.Cout) continue;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q];
+        if (a.bias) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += bb[q];
+        }
+        const size_t o = (size_t)m * a.Cout + co;
+        if (a.resid) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(a.resid + o);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += rr[q];
+        }
+        if (a.out_f32) {
+          f32x4 ov = {v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(a.out_f32 + o) = ov;
+        }
+        if (a.out_bf16) {
+          u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(a.out_bf16 + o) = pk;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Direct (VALU) convolution for the few layers whose channel counts do not fill an MFMA tile: encoder conv1 (3 -> 96),
 // decoder conv1 (16 -> 384), decoder head (96 -> 3), encoder head (384 -> 32), quant convs (1x1x1).  vae.py:288, 392, 421, 316.
 // in: channels-last f32 or bf16; w: [taps][Cin][Cout] f32 (Cout fastest, so consecutive lanes read consecutive weights).
@@ -270,7 +553,7 @@ __global__ void k_conv_small(SmallConvArgs a) {
 
 extern "C" int wf_conv3d_cl(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_bf16,
                             int Ti, int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st,
-                            int ss, int pt, int ph, int pw, int up2, int tsplit, void* stream) {
+                            int ss, int pt, int ph, int pw, int up2, int tsplit, const void* zero_page, void* stream) {
   WF_CHECK_ARG(in && w && (out_f32 || out_bf16), "wf_conv3d_cl: null pointer");
   WF_CHECK_ARG(Cin % CBK == 0, "wf_conv3d_cl: Cin (%d) must be a multiple of 32 (use wf_conv3d_small otherwise)", Cin);
   WF_CHECK_ARG(Cout % 4 == 0, "wf_conv3d_cl: Cout (%d) must be a multiple of 4", Cout);
@@ -290,6 +573,20 @@ extern "C" int wf_conv3d_cl(const void* in, const void* w, const float* bias, co
   a.kt = kt; a.kh = kh; a.kw = kw;
   a.st = st; a.ss = ss; a.pt = pt; a.ph = ph; a.pw = pw;
   a.up2 = up2; a.tsplit = tsplit; a.silu_out = 0;
+  // stride-1, no upsample / frame interleave, big enough to fill the chip: the 512-pixel ping-pong kernel (needs a zero page
+  // for the out-of-range taps of its DMA gather and chunk-granular 32-bit offsets)
+  static const bool no_pp = getenv("WF_CONV_NO_PP") != nullptr;
+  const long in_chunks = (long)Ti * Hi * Wi * (Cin / 8);
+  if (!no_pp && zero_page && st == 1 && ss == 1 && !up2 && !tsplit && kt <= 3 && kh <= 3 && kw <= 3 && M >= 64 * QM &&
+      in_chunks < (1L << 31) - (1L << 24) && (long)Cout * kt * kh * kw * (Cin / 8) < (1L << 31)) {
+    ConvPPArgs pa;
+    pa.c = a;
+    pa.zeros = (const uint16_t*)zero_page;
+    dim3 grid((unsigned)((M + QM - 1) / QM), (unsigned)((Cout + QN - 1) / QN));
+    hipLaunchKernelGGL(k_conv_pp, grid, dim3(QT), 2 * QBUF, (hipStream_t)stream, pa);
+    WF_LAUNCH_CHECK("wf_conv3d_cl");
+    return WF_OK;
+  }
   dim3 grid((unsigned)((M + CBM - 1) / CBM), (unsigned)((Cout + CBN - 1) / CBN));
   hipLaunchKernelGGL(k_conv, grid, dim3(CNT), 2 * CBUF, (hipStream_t)stream, a);
   WF_LAUNCH_CHECK("wf_conv3d_cl");

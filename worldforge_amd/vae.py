@@ -226,9 +226,15 @@ class AutoencoderKLWan:
         call("wf_conv3d_cl", x.data_ptr(), W[p + ".w"].data_ptr(), W[p + ".b"].data_ptr(),
              resid.data_ptr() if resid is not None else None, of.data_ptr() if of is not None else None,
              ob.data_ptr() if ob is not None else None, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, k[0], k[1], k[2], st, ss, pt,
-             ps if ph is None else ph, ps, 1 if up2 else 0, 1 if tsplit else 0, ops.stream())
+             ps if ph is None else ph, ps, 1 if up2 else 0, 1 if tsplit else 0, self._zero_page().data_ptr(), ops.stream())
         self.flops_last += 2 * To * Ho * Wo * Cout * k[0] * k[1] * k[2] * Cin
         return of, ob
+
+    def _zero_page(self):
+        z = getattr(self, "_zeros", None)
+        if z is None:
+            z = self._zeros = torch.zeros(64, dtype=BF, device=self.device)
+        return z
 
     def _small_conv(self, x, p, To, Ho, Wo, Cout, k, pt=0, ps=0, clamp=0.0, out_dtype=F32):
         Ti, Hi, Wi, Cin = x.shape
@@ -308,7 +314,7 @@ class AutoencoderKLWan:
         out[0].copy_(y[0])  # frame 0 by-passes time_conv (vae.py:146-148)
         W = self.w
         call("wf_conv3d_cl", yb.data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
-             out[1:].data_ptr(), None, T, Ho, Wo, C, To, Ho, Wo, C, 3, 1, 1, 2, 1, 0, 0, 0, 0, 0, ops.stream())
+             out[1:].data_ptr(), None, T, Ho, Wo, C, To, Ho, Wo, C, 3, 1, 1, 2, 1, 0, 0, 0, 0, 0, None, ops.stream())
         self.flops_last += 2 * To * Ho * Wo * C * 3 * C
         return out
 
@@ -322,7 +328,7 @@ class AutoencoderKLWan:
             yb[0].copy_(xb[0])  # first latent frame by-passes time_conv ('Rep', vae.py:106-108)
             W = self.w
             call("wf_conv3d_cl", xb[1:].data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
-                 None, yb.data_ptr(), T - 1, H, Wd, C, T - 1, H, Wd, 2 * C, 3, 1, 1, 1, 1, 2, 0, 0, 0, 1, ops.stream())
+                 None, yb.data_ptr(), T - 1, H, Wd, C, T - 1, H, Wd, 2 * C, 3, 1, 1, 1, 1, 2, 0, 0, 0, 1, None, ops.stream())
             self.flops_last += 2 * (T - 1) * H * Wd * 2 * C * 3 * C
             xb = yb
         Tn = xb.shape[0]
@@ -416,7 +422,7 @@ class AutoencoderKLWan:
         yb[0].copy_(xb[0])
         W = self.w
         call("wf_conv3d_cl", xb[1:].data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
-             None, yb.data_ptr(), T - 1, H, Wd, C, T - 1, H, Wd, 2 * C, 3, 1, 1, 1, 1, 2, 0, 0, 0, 1, ops.stream())
+             None, yb.data_ptr(), T - 1, H, Wd, C, T - 1, H, Wd, 2 * C, 3, 1, 1, 1, 1, 2, 0, 0, 0, 1, None, ops.stream())
         return yb
 
     def _up_slab(self, xsrc_b, p, C, temporal, s0, y0, Ho, h_src):
@@ -448,7 +454,7 @@ class AutoencoderKLWan:
         out[0].copy_(y[0])
         W = self.w
         call("wf_conv3d_cl", yb.data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
-             out[1:].data_ptr(), None, T, Ho, Wo, C, To, Ho, Wo, C, 3, 1, 1, 2, 1, 0, 0, 0, 0, 0, ops.stream())
+             out[1:].data_ptr(), None, T, Ho, Wo, C, To, Ho, Wo, C, 3, 1, 1, 2, 1, 0, 0, 0, 0, 0, None, ops.stream())
         return out
 
     def can_shard(self, H_lat: int) -> bool:
