@@ -109,3 +109,26 @@ def synthetic_ref_and_mask(F, H, W, seed=5, soften=True):
         soft = torch.sin(torch.pi / 2 * (d / 4).clamp(0, 1))
         mask = (mask * soft.expand_as(mask)).contiguous()
     return ref, mask
+
+
+class SimComm:
+    """Stand-in for parallel.Comm that runs P simulated ranks as threads of ONE process on one GPU: all_gather deposits each
+    rank's tensor in a shared slot and meets at a barrier.  Exercises the row-slab sharded VAE (halo exchange, slab
+    convolutions, row gather) without a multi-GPU node."""
+
+    def __init__(self, world, rank, shared):
+        self.world, self.rank, self.sh = world, rank, shared
+
+    def all_gather(self, out, inp):
+        sh = self.sh
+        sh["slots"][self.rank] = inp
+        sh["bar"].wait()
+        for r in range(self.world):
+            out[r].copy_(sh["slots"][r])
+        torch.cuda.current_stream().synchronize()
+        sh["bar"].wait()
+        return out
+
+    def all_gather_async(self, out, inp):
+        self.all_gather(out, inp)
+        return None

@@ -162,23 +162,7 @@ def test_vae_protocol_and_errors(model):
         model.encode(torch.zeros(1, 3, 4, 16, 16, device=DEV))
 
 
-class _SimComm:
-    """Stand-in for parallel.Comm that runs P simulated ranks as threads of ONE process on one GPU: all_gather deposits each
-    rank's tensor in a shared slot and meets at a barrier.  Exercises the row-slab sharded VAE (halo exchange, slab
-    convolutions, row gather) without a multi-GPU node."""
-
-    def __init__(self, world, rank, shared):
-        self.world, self.rank, self.sh = world, rank, shared
-
-    def all_gather(self, out, inp):
-        sh = self.sh
-        sh["slots"][self.rank] = inp
-        sh["bar"].wait()
-        for r in range(self.world):
-            out[r].copy_(sh["slots"][r])
-        torch.cuda.current_stream().synchronize()
-        sh["bar"].wait()
-        return out
+from tests.fakes import SimComm as _SimComm  # noqa: E402
 
 
 @pytest.mark.parametrize("P,H", [(2, 64), (4, 64), (8, 64), (2, 24)])   # (2, 24): odd slab height at the decoder entry

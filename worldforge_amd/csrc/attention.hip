@@ -58,6 +58,9 @@ struct AttnArgs {
 
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
+// KIND only names the launch for profilers: 0 = long K/V (self-attention), 1 = short K/V (<= 1024 keys: the text / image
+// cross-attentions).  Same code; rocprofv3 then reports the two populations separately.
+template <int KIND>
 __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // LDS: [buf0: K tile | V^T tile][buf1: K tile | V^T tile]
@@ -353,7 +356,11 @@ extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O
   a.accumulate = accumulate;
   const int hslots = (H + 7) / 8;
   const int grid = hslots * a.n_qblk * 8;
-  hipLaunchKernelGGL(k_attn, dim3(grid), dim3(NT), 3 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream, a);
+  const size_t lds = 3 * (K_TILE_BYTES + V_TILE_BYTES);
+  if (Lkp > 1024)
+    hipLaunchKernelGGL(k_attn<0>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(k_attn<1>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, a);
   WF_LAUNCH_CHECK("wf_attn_fwd");
   return WF_OK;
 }

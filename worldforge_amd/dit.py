@@ -387,6 +387,9 @@ class WanTransformer3DModel:
             plan = shard_plan(Lfull, comm.world)
             lo, hi = plan.bounds(comm.rank)
             L, Lp = hi - lo, plan.shard_len
+            if L <= 0:
+                raise ValueError(f"sequence-parallel plan leaves rank {comm.rank} of {comm.world} without tokens "
+                                 f"({Lfull} tokens in shards of {Lp}); use fewer ranks for this size")
             tok, cos, sin = tok[lo:hi], cos[lo:hi], sin[lo:hi]
         else:
             plan = None
