@@ -242,4 +242,10 @@ def test_sequence_parallel_path_world1_matches_single():
     m1.w = m0.w
     got = m1.forward_tokens(x, 500.0, ctx, clip)
     assert torch.equal(got, ref)
+    # CFG pair in lock-step: the exchanges run on the communication stream under the other branch's layer (real streams / events)
+    ctx_b = _rand((17, 64), 63).to(BF).to(DEV)
+    ref_b = m0.forward_tokens(x, 500.0, ctx_b, clip).clone()
+    for _ in range(3):
+        a, b = m1.forward_tokens_pair(x, 500.0, ctx, ctx_b, clip)
+        assert torch.equal(a, ref) and torch.equal(b, ref_b)
     torch.distributed.destroy_process_group()

@@ -100,3 +100,30 @@ def test_guided_sampler_on_sharded_dit_and_vae_equals_single(P):
     assert torch.isfinite(want).all()
     for r, got in enumerate(_run_ranks(P, run)):
         assert torch.equal(got, want), (r, (got - want).abs().max())
+
+
+@pytest.mark.parametrize("P", [1, 2, 4])
+def test_cfg_pair_lockstep_equals_two_sequential_forwards(P):
+    """forward_tokens_pair advances the positive- and negative-prompt forwards one layer apart (so each K / V exchange hides under
+    the other branch's layer); each branch must still equal its own stand-alone forward bit for bit."""
+    from worldforge_amd import dit
+    cfg = dit.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=3, text_dim=64)
+    T, Hh, Ww = 5, 16, 24
+    x = _rand((36, T, Hh, Ww), 70).to(BF).to(DEV)
+    ca, cb = _rand((30, 64), 71).to(BF).to(DEV), _rand((12, 64), 72).to(BF).to(DEV)
+    clip = _rand((257, 1280), 73).to(BF).to(DEV)
+    m0 = dit.WanTransformer3DModel(cfg, DEV).init_random(5)
+    ref_a = m0.forward_tokens(x, 321.0, ca, clip).clone()
+    ref_b = m0.forward_tokens(x, 321.0, cb, clip).clone()
+    assert not torch.equal(ref_a, ref_b)
+
+    def rank_fn(comm):
+        m = dit.WanTransformer3DModel(cfg, DEV, comm=comm)
+        m.w = m0.w
+        a, b = m.forward_tokens_pair(x, 321.0, ca, cb, clip, interleave=True)
+        return a.clone(), b.clone()
+
+    results = [rank_fn(None)] if P == 1 else _run_ranks(P, rank_fn)
+    for r, (a, b) in enumerate(results):
+        assert torch.equal(a, ref_a), (r, (a - ref_a).abs().max())
+        assert torch.equal(b, ref_b), (r, (b - ref_b).abs().max())

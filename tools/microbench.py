@@ -37,6 +37,21 @@ def bench_attn(L, H=40):
     print(f"attn L={L} H={H}: {ms:.2f} ms  {flop / ms / 1e9:.1f} TFLOP/s  ({flop / ms / 1e9 / 2500 * 100:.1f}% of 2.5 PF)")
 
 
+def bench_attn_shard(L, P, H=40):
+    """Per-rank self-attention of the P-way sequence-parallel plan: Lq = one token shard, keys = all L tokens."""
+    from worldforge_amd.parallel import shard_plan
+    dev = "cuda:0"
+    plan = shard_plan(L, P)
+    Lq, Lp = plan.shard_len, plan.shard_len
+    q = torch.randn(H, Lq, 128, device=dev).to(torch.bfloat16)
+    k = torch.randn(P, H, Lp, 128, device=dev).to(torch.bfloat16)
+    vt = torch.randn(P, H, Lp // 64, 128, 64, device=dev).to(torch.bfloat16)
+    out = torch.empty(Lq, H * 128, device=dev, dtype=torch.bfloat16)
+    ms = timeit(lambda: dit.attention(q, k, vt, out, L, 1 / math.sqrt(128)))
+    flop = 4.0 * Lq * L * 128 * H
+    print(f"attn shard P={P} Lq={Lq} L={L}: {ms:.2f} ms  {flop / ms / 1e9:.1f} TFLOP/s  ({flop / ms / 1e9 / 2500 * 100:.1f}% of 2.5 PF)")
+
+
 def bench_gemm(M, N, K, epi=0):
     dev = "cuda:0"
     x = torch.randn(M, K, device=dev).to(torch.bfloat16)
@@ -56,6 +71,13 @@ if __name__ == "__main__":
     if a.what in ("attn", "all"):
         for L in (4524, a.L):
             bench_attn(L)
+    if a.what in ("shard",):
+        for P in (2, 4, 8):
+            bench_attn_shard(a.L, P)
+            M = (a.L + P - 1) // P
+            bench_gemm(M, 15360, 5120, 0)
+            bench_gemm(M, 13824, 5120, 1)
+            bench_gemm(M, 5120, 13824, 3)
     if a.what in ("gemm", "all"):
         L = a.L
         bench_gemm(L, 15360, 5120, 0)

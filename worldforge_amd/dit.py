@@ -304,37 +304,38 @@ class WanTransformer3DModel:
     # ------------------------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------------------------
-    def _embed_condition(self, t_value: float, text: torch.Tensor, img: torch.Tensor):
+    def _embed_condition(self, t_value: float, text: torch.Tensor, img: torch.Tensor, tag: str = ""):
         """model.py:546-563.  Returns e [1,dim] f32, e0 [6,dim] f32, ctx_text bf16 [512,dim], ctx_img bf16 [n_img,dim]."""
         cfg, W, dev = self.cfg, self.w, self.device
         bf, f32 = torch.bfloat16, torch.float32
+        _buf = lambda name, shape, dtype, zero=False: self._buf(name + tag, shape, dtype, zero)  # noqa: E731
         sin = sinusoidal_embedding_1d(cfg.freq_dim, t_value).to(dev)
-        t0 = self._buf("t0", (1, cfg.dim), f32)
+        t0 = _buf("t0", (1, cfg.dim), f32)
         gemm(ops.cast(sin, bf), W["time_embedding.0.w"], W["time_embedding.0.b"], t0, EPI_F32)
         t0a = self._act(t0, None, bf, 0)
-        e = self._buf("e", (1, cfg.dim), f32)
+        e = _buf("e", (1, cfg.dim), f32)
         gemm(t0a, W["time_embedding.2.w"], W["time_embedding.2.b"], e, EPI_F32)
-        e0 = self._buf("e0", (1, 6 * cfg.dim), f32)
+        e0 = _buf("e0", (1, 6 * cfg.dim), f32)
         gemm(self._act(e, None, bf, 0), W["time_projection.1.w"], W["time_projection.1.b"], e0, EPI_F32)
         # text: zero-pad to text_len rows (model.py:554-559), Linear -> GELU(tanh) -> Linear
         n_txt = text.shape[0]
-        tx = self._buf("txt_in", (cfg.text_len, cfg.text_dim), bf, zero=True)
+        tx = _buf("txt_in", (cfg.text_len, cfg.text_dim), bf, zero=True)
         tx[:n_txt].copy_(text)
         if n_txt < cfg.text_len:
             tx[n_txt:].zero_()
-        th = self._buf("txt_h", (cfg.text_len, cfg.dim), bf)
+        th = _buf("txt_h", (cfg.text_len, cfg.dim), bf)
         gemm(tx, W["text_embedding.0.w"], W["text_embedding.0.b"], th, EPI_BF16_GELU)
-        ctx_t = self._buf("ctx_t", (cfg.text_len, cfg.dim), bf)
+        ctx_t = _buf("ctx_t", (cfg.text_len, cfg.dim), bf)
         gemm(th, W["text_embedding.2.w"], W["text_embedding.2.b"], ctx_t, EPI_BF16)
         # image: LayerNorm -> Linear -> GELU(erf) -> Linear -> LayerNorm (model.py:355-358)
         n_img = img.shape[0]
-        i0 = self._buf("img_ln0", (n_img, cfg.img_dim), bf)
+        i0 = _buf("img_ln0", (n_img, cfg.img_dim), bf)
         self._ln(ops.cast(img, f32), W["img_emb.proj.0.w"], W["img_emb.proj.0.b"], i0, 1e-5, plus_one=False)
-        i1 = self._buf("img_h", (n_img, cfg.img_dim), f32)
+        i1 = _buf("img_h", (n_img, cfg.img_dim), f32)
         gemm(i0, W["img_emb.proj.1.w"], W["img_emb.proj.1.b"], i1, EPI_F32)
-        i2 = self._buf("img_o", (n_img, cfg.dim), f32)
+        i2 = _buf("img_o", (n_img, cfg.dim), f32)
         gemm(self._act(i1, None, bf, 1), W["img_emb.proj.3.w"], W["img_emb.proj.3.b"], i2, EPI_F32)
-        ctx_i = self._buf("ctx_i", (n_img, cfg.dim), bf)
+        ctx_i = _buf("ctx_i", (n_img, cfg.dim), bf)
         self._ln(i2, W["img_emb.proj.4.w"], W["img_emb.proj.4.b"], ctx_i, 1e-5, plus_one=False)
         return e, e0.view(6, cfg.dim), ctx_t, ctx_i
 
@@ -367,7 +368,41 @@ class WanTransformer3DModel:
 
     def forward_tokens(self, x_in: torch.Tensor, t_value: float, text: torch.Tensor, img: torch.Tensor) -> torch.Tensor:
         """x_in [in_dim, T, h, w] bf16; text [<=512, text_dim]; img [n_img, img_dim] -> velocity [out_dim, T, h, w] f32."""
+        out = [None]
+        for _ in self._forward_steps(x_in, t_value, text, img, "", out):
+            pass
+        return out[0]
+
+    def forward_tokens_pair(self, x_in: torch.Tensor, t_value: float, text_a: torch.Tensor, text_b: torch.Tensor,
+                            img: torch.Tensor, interleave: Optional[bool] = None):
+        """The two forwards of one classifier-free-guidance evaluation (PIPE:593-610: same latents and timestep, positive then
+        negative prompt).  Under sequence parallelism the two are advanced in lock-step, one layer apart: while branch A's K / V^T
+        all-gather of layer i is in flight on the communication stream, branch B computes its layer i-1 attention / FFN, and vice
+        versa, so every exchange has a whole layer of the other branch to hide under.  Each branch issues exactly the kernels of
+        forward_tokens in the same order on its own buffers: results are bit-identical to two sequential calls."""
+        if interleave is None:
+            interleave = self.comm is not None
+        if not interleave:
+            va = self.forward_tokens(x_in, t_value, text_a, img)
+            return va, self.forward_tokens(x_in, t_value, text_b, img)
+        oa, ob = [None], [None]
+        ga = self._forward_steps(x_in, t_value, text_a, img, "", oa)
+        gb = self._forward_steps(x_in, t_value, text_b, img, "#b", ob)
+        live = [ga, gb]
+        while live:
+            for gen in list(live):
+                try:
+                    next(gen)
+                except StopIteration:
+                    live.remove(gen)
+        return oa[0], ob[0]
+
+    def _forward_steps(self, x_in, t_value, text, img, tag, result):
+        """Generator over one forward: yields once per layer, right after that layer's K / V^T exchange has been launched (the
+        point where another forward can usefully take over the compute stream).  `tag` separates the workspaces of concurrent
+        forwards; the velocity lands in result[0]."""
         cfg, W, dev = self.cfg, self.w, self.device
+        _buf = lambda name, shape, dtype, zero=False: self._buf(name + tag, shape, dtype, zero)  # noqa: E731
         bf, f32 = torch.bfloat16, torch.float32
         Cin, T, Hh, Ww = x_in.shape
         assert Cin == cfg.in_dim
@@ -376,10 +411,10 @@ class WanTransformer3DModel:
         d, H = cfg.dim, cfg.num_heads
         scale = 1.0 / math.sqrt(128.0)
         cos, sin = self._rope_tables(f, h2, w2)
-        e, e0, ctx_t, ctx_i = self._embed_condition(t_value, text, img)
+        e, e0, ctx_t, ctx_i = self._embed_condition(t_value, text, img, tag)
         n_img = ctx_i.shape[0]
         comm = self.comm
-        tok = self._buf("tok", (Lfull, Cin * 4), bf)
+        tok = _buf("tok", (Lfull, Cin * 4), bf)
         call("wf_patchify", x_in.data_ptr(), tok.data_ptr(), Cin, T, Hh, Ww, ops.stream())
         if comm is not None:
             # sequence parallelism: this rank owns a contiguous token shard; K / V^T are exchanged per layer (parallel.py)
@@ -396,28 +431,28 @@ class WanTransformer3DModel:
             L, Lp = Lfull, _pad64(Lfull)
 
         # patch embedding (model.py:534-537) as a GEMM -> fp32 residual stream
-        x = self._buf("x", (L, d), f32)
+        x = _buf("x", (L, d), f32)
         gemm(tok, W["patch.w"], W["patch.b"], x, EPI_F32)
 
-        hbuf = self._buf("h", (L, d), bf)
-        qkv = self._buf("qkv", (L, 3 * d), bf)
-        qh = self._buf("qh", (H, L, 128), bf)
-        kh = self._buf("kh", (H, Lp, 128), bf, zero=True)
-        vt = self._buf("vt", (H, Lp // 64, 128, 64), bf)
+        hbuf = _buf("h", (L, d), bf)
+        qkv = _buf("qkv", (L, 3 * d), bf)
+        qh = _buf("qh", (H, L, 128), bf)
+        kh = _buf("kh", (H, Lp, 128), bf, zero=True)
+        vt = _buf("vt", (H, Lp // 64, 128, 64), bf)
         if comm is not None:
-            kh_all = self._buf("kh_all", (comm.world, H, Lp, 128), bf)
-            vt_all = self._buf("vt_all", (comm.world, H, Lp // 64, 128, 64), bf)
-        ao = self._buf("ao", (L, d), bf)
-        qc = self._buf("qc", (L, d), bf)
-        ffh = self._buf("ffh", (L, cfg.ffn_dim), bf)
+            kh_all = _buf("kh_all", (comm.world, H, Lp, 128), bf)
+            vt_all = _buf("vt_all", (comm.world, H, Lp // 64, 128, 64), bf)
+        ao = _buf("ao", (L, d), bf)
+        qc = _buf("qc", (L, d), bf)
+        ffh = _buf("ffh", (L, cfg.ffn_dim), bf)
         Lt, Li = cfg.text_len, _pad64(n_img)
-        kvt = self._buf("kvt", (cfg.text_len, 2 * d), bf)
-        kvi = self._buf("kvi", (n_img, 2 * d), bf)
-        kth = self._buf("kth", (H, Lt, 128), bf, zero=True)
-        vtt = self._buf("vtt", (H, Lt // 64, 128, 64), bf)
-        kih = self._buf("kih", (H, Li, 128), bf, zero=True)
-        vti = self._buf("vti", (H, Li // 64, 128, 64), bf)
-        emod = self._buf("emod", (6, d), f32)
+        kvt = _buf("kvt", (cfg.text_len, 2 * d), bf)
+        kvi = _buf("kvi", (n_img, 2 * d), bf)
+        kth = _buf("kth", (H, Lt, 128), bf, zero=True)
+        vtt = _buf("vtt", (H, Lt // 64, 128, 64), bf)
+        kih = _buf("kih", (H, Li, 128), bf, zero=True)
+        vti = _buf("vti", (H, Li // 64, 128, 64), bf)
+        emod = _buf("emod", (6, d), f32)
 
         for i in range(cfg.num_layers):
             p = f"blocks.{i}."
@@ -439,6 +474,7 @@ class WanTransformer3DModel:
                 self._vt(qkv, 2 * d, vt, L)
                 ev_k = comm.all_gather_async(kh_all, kh)
                 ev_v = comm.all_gather_async(vt_all, vt)
+                yield i
                 gemm(hbuf, W[p + "qkv.w"][:d], W[p + "qkv.b"][:d], qkv[:, :d], EPI_BF16)
                 self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L)
                 for ev in (ev_k, ev_v):
@@ -465,20 +501,20 @@ class WanTransformer3DModel:
             gemm(ffh, W[p + "ffn.2.w"], W[p + "ffn.2.b"], x, EPI_RESID, gate=emod[5])
 
         # ---- head (model.py:337-347) + unpatchify (:584-607) ----
-        hm = self._buf("hm", (2, d), f32)
+        hm = _buf("hm", (2, d), f32)
         # head modulation (model.py:345): hm[r] = modulation[r] + e
         for r in range(2):
             call("wf_act", W["head.modulation"][r].data_ptr(), WF_F32, e.data_ptr(), WF_F32, hm[r].data_ptr(), WF_F32, 2, d,
                  ops.stream())
         self._ln(x, hm[1], hm[0], hbuf, cfg.eps, plus_one=True)
-        y = self._buf("y", (L, 4 * cfg.out_dim), f32)
+        y = _buf("y", (L, 4 * cfg.out_dim), f32)
         gemm(hbuf, W["head.head.w"], W["head.head.b"], y, EPI_F32)
         if comm is not None:
             from .parallel import gather_rows
             y = gather_rows(comm, y, plan).contiguous()
         out = torch.empty((cfg.out_dim, T, Hh, Ww), dtype=f32, device=dev)
         call("wf_unpatchify", y.data_ptr(), out.data_ptr(), cfg.out_dim, T, Hh, Ww, ops.stream())
-        return out
+        result[0] = out
 
     def __call__(self, hidden_states: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor,
                  encoder_hidden_states_image: Optional[torch.Tensor] = None, attention_kwargs=None, return_dict: bool = False):
@@ -494,3 +530,18 @@ class WanTransformer3DModel:
         if return_dict:
             return SimpleNamespace(sample=out)
         return (out,)
+
+    def forward_cfg_pair(self, hidden_states: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor,
+                         negative_encoder_hidden_states: torch.Tensor, encoder_hidden_states_image: torch.Tensor):
+        """Both transformer calls of PIPE:593-610 (positive, then negative prompt) -> (noise_pred, noise_uncond), each what
+        __call__(...)[0] returns.  See forward_tokens_pair."""
+        if hidden_states.shape[0] != 1:
+            raise NotImplementedError("batch size 1 (the reference path)")
+        t_value = float(torch.as_tensor(timestep).reshape(-1)[0].item())
+        x = hidden_states[0]
+        if x.dtype != torch.bfloat16:
+            x = ops.cast(x.contiguous(), torch.bfloat16)
+        img = encoder_hidden_states_image[0].to(torch.bfloat16).contiguous()
+        va, vb = self.forward_tokens_pair(x.contiguous(), t_value, encoder_hidden_states[0].to(torch.bfloat16).contiguous(),
+                                          negative_encoder_hidden_states[0].to(torch.bfloat16).contiguous(), img)
+        return ops.cast(va, self.dtype).unsqueeze(0), ops.cast(vb, self.dtype).unsqueeze(0)

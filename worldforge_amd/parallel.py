@@ -59,8 +59,14 @@ class Comm:
         """out [P, *inp.shape] <- inp from every rank."""
         assert out.shape[0] == self.world and tuple(out.shape[1:]) == tuple(inp.shape) and out.is_contiguous() and inp.is_contiguous()
         if dist.get_backend(self.group) == "gloo":
-            chunks = [out[i] for i in range(self.world)]
-            dist.all_gather(chunks, inp, group=self.group)
+            if inp.is_cuda:
+                # debug configuration only (several ranks sharing one GPU, WF_COMM_BACKEND=gloo): gloo's all_gather takes host
+                # tensors, so stage through the host
+                host = torch.empty(out.shape, dtype=out.dtype)
+                dist.all_gather([host[i] for i in range(self.world)], inp.cpu(), group=self.group)
+                out.copy_(host)
+            else:
+                dist.all_gather([out[i] for i in range(self.world)], inp, group=self.group)
         else:
             dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.group)
         return out
@@ -97,7 +103,7 @@ def init(world: int, rank: int, local_rank: int, backend: Optional[str] = None) 
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = backend or os.environ.get("WF_COMM_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device(f"cuda:{local_rank}")
