@@ -1,0 +1,17 @@
+"""GPU: the whole guided job (IRR + FLF + DSG sampler, DiT, real-config VAE) on the HIP path against the CPU oracle (fp32) run with
+identical weights, seeds and inputs -- SURVEY 8d's "PSNR vs reference on final frames" (target >= 40 dB).  Tolerance: the
+product computes GEMM / attention / conv operands in bf16 (as the reference does on a GPU), the oracle in fp32."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(dim=256, ffn_dim=512, heads=2, layers=2, Fr=9, H=32, Wd=32, steps=3, guide=2),
+    dict(dim=1024, ffn_dim=2048, heads=8, layers=4, Fr=13, H=64, Wd=96, steps=5, guide=3),
+])
+def test_guided_job_frames_psnr_vs_oracle(cfg):
+    import __graft_entry__ as ge
+    psnr, err = ge.parity_run(**cfg)
+    print(f"PSNR {psnr:.1f} dB, max abs err {err:.4f}")
+    assert psnr >= 40.0, (psnr, err)

@@ -204,3 +204,42 @@ def test_dit_c2_tokens_sharded_and_lockstep_forwards_are_bit_identical():
     for r in range(P):
         assert torch.equal(res[r][0], ref_a), (r, (res[r][0] - ref_a).abs().max())
         assert torch.equal(res[r][1], ref_b), r
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the VAE at the C2 video size: row-sharded (8 simulated ranks) == unsharded, bit for bit, for decode and encode (a-21 / a-22)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_vae_c2_row_sharded_equals_unsharded():
+    import threading
+    from tests.fakes import SimComm
+    from worldforge_amd.vae import AutoencoderKLWan
+    v0 = AutoencoderKLWan(DEV).init_random(seed=1)
+    z = _dev_randn((1, 16, 21, 60, 104), 600, 1.0, F32)
+    g = torch.Generator(device=DEV).manual_seed(601)
+    video = torch.rand((1, 3, 81, 480, 832), generator=g, device=DEV) * 2 - 1
+    ref_dec = v0.decode(z, return_dict=False)[0]
+    assert ref_dec.shape == (1, 3, 81, 480, 832) and torch.isfinite(ref_dec).all()
+    assert ref_dec.min().item() >= -1.0 and ref_dec.max().item() <= 1.0          # autoencoder_kl_wan.py:1222 clamp
+    ref_mu = v0.encode(video).latent_dist.mode()
+    assert ref_mu.shape == (1, 16, 21, 60, 104) and torch.isfinite(ref_mu).all()
+    P = 8
+    shared = {"slots": [None] * P, "bar": threading.Barrier(P)}
+    ok, errs = [False] * P, []
+
+    def worker(r):
+        try:
+            m = AutoencoderKLWan(DEV, comm=SimComm(P, r, shared))
+            m.w = v0.w
+            assert m.can_shard(60)
+            d = m.decode(z, return_dict=False)[0]
+            mu = m.encode(video).latent_dist.mode()
+            ok[r] = torch.equal(d, ref_dec) and torch.equal(mu, ref_mu)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            shared["bar"].abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(P)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert all(ok), ok
