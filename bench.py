@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--width", type=int, default=832)
     ap.add_argument("--layers", type=int, default=40, help="DiT depth (40 = Wan2.1-14B; smaller only for debugging -> flagged)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flow-backend", default="tdiff", choices=["tdiff", "farneback"],
+                    help="FLF motion backend: tdiff = the branch the reference runs without cv2 (golden-pinned); farneback = the "
+                         "GPU restatement of cv2.calcOpticalFlowFarneback (parity with cv2 unpinned)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,7 +130,7 @@ def main():
     t0 = time.time()
     model = wdit.WanTransformer3DModel(cfg, device, comm=comm).init_random(seed=0)
     vae = AutoencoderKLWan(device, comm=comm).init_random(seed=1)  # high-resolution stages row-sharded over the ranks
-    sch = UniPCMultistepScheduler(flow_shift=3.0)
+    sch = UniPCMultistepScheduler(flow_shift=3.0, flow_backend=a.flow_backend)
     pipe = WanImageToVideoPipeline(model, vae, sch, device=device)
     image, ref, mask, text, neg, img_emb = synthetic_inputs(a.frames, a.height, a.width, device)
     torch.cuda.synchronize()
@@ -204,7 +207,7 @@ def main():
                             f"timed steps {start + Wm}..{start + Wm + K - 1} = {len(guided_ms)} guided + {len(plain_ms)} plain",
                 "tokens": L, "dit_layers": cfg.num_layers, "dit_params_bytes": model.param_bytes(),
                 "parallelism": "single" if world == 1 else f"sp{world} (token-sharded DiT with K/V all-gather + row-sharded VAE with halo all-gather, RCCL)",
-                "flow_backend": "tdiff",
+                "flow_backend": a.flow_backend,
             },
             "guided_step_ms": sum(guided_ms) / len(guided_ms) if guided_ms else None,
             "plain_step_ms": sum(plain_ms) / len(plain_ms) if plain_ms else None,

@@ -109,6 +109,15 @@ size_t wf_flow_metrics_workspace_floats(int n_channels);
 int wf_flow_metrics(const float* ref_flow, const float* chan_flow, float* sim, int n_channels, int Tm, int Cr, int Cc,
                     size_t hw, float* ws, void* stream);
 
+/* ---- FLF optical flow (SCHED:156-248) ----------------------------------------------------------------------------------
+ * What `cv2.calcOpticalFlowFarneback(g1, g2, None, 0.5, 3, 15, 3, 5, 1.2, 0)` (SCHED:220-224) computes for every consecutive frame
+ * pair of every channel of a latent tensor, including the reference's preparation of its input: normalisation by the tensor's
+ * global min / range (SCHED:376-388, 462-474), x255, truncation to uint8 (SCHED:175), RGB2GRAY of three equal channels.
+ * x [C,T,h,w] (f32 / bf16) -> flow [C, T-1, 2, h, w] f32 (x then y displacement, the layout of SCHED:240-244).
+ * OpenCV is a third-party dependency absent from the reference tree: parity with a real cv2 is UNPINNED. */
+size_t wf_farneback_workspace_bytes(int C, int T, int h, int w);
+int wf_farneback_flows(const void* x, int dt, float* flow, int C, int T, int h, int w, void* ws, void* stream);
+
 /* ---- DiT (wan/modules/model.py; the in-tree statement of diffusers' WanTransformer3DModel) --------------------------- */
 #define WF_EPI_BF16 0       /* out bf16 = acc + bias */
 #define WF_EPI_BF16_GELU 1  /* out bf16 = gelu_tanh(acc + bias)            (model.py:272) */

@@ -118,10 +118,21 @@ def flow_similarity(ref_motion: torch.Tensor, chan_motion: torch.Tensor) -> floa
 
 def channel_similarities(pred: torch.Tensor, enc: torch.Tensor, flow_backend: str = "tdiff") -> List[float]:
     """SCHED:373-397 + 439-495.  flow_backend 'tdiff' = the branch the reference executes when cv2 is absent."""
-    if flow_backend != "tdiff":
-        raise NotImplementedError("Farneback branch: parity unpinned (no cv2 in this container); see DESIGN.md")
     enc32 = enc.to(torch.float32)
     sims = []
+    if flow_backend == "farneback":
+        # SCHED:376-389, 462-476 with cv2 present; the flow itself is oracle/farneback.py (parity with cv2 UNPINNED)
+        from . import farneback as fb
+        pred32 = pred.to(torch.float32)
+        emin, erange = enc32.min(), enc32.max() - enc32.min() + 1e-8
+        pmin, prange = pred32.min(), pred32.max() - pred32.min() + 1e-8
+        for c in range(pred.shape[1]):
+            ref_m = torch.from_numpy(fb.channel_flow(enc32[0, c].numpy(), emin.numpy(), erange.numpy())).unsqueeze(0)
+            ch_m = torch.from_numpy(fb.channel_flow(pred32[0, c].numpy(), pmin.numpy(), prange.numpy())).unsqueeze(0)
+            sims.append(flow_similarity(ref_m, ch_m))
+        return sims
+    if flow_backend != "tdiff":
+        raise ValueError(f"unknown flow_backend {flow_backend!r}")
     for c in range(pred.shape[1]):
         ref_m = temporal_diff_motion(enc32[:, c:c + 1])
         ch_m = temporal_diff_motion(pred[:, c:c + 1].to(torch.float32))

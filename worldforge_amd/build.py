@@ -28,6 +28,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-r
 SOURCES = {
     "elementwise.hip": ["-ffp-contract=off"],
     "inject.hip": ["-ffp-contract=off"],
+    "flow.hip": ["-ffp-contract=off"],
     "gemm.hip": [],
     "attention.hip": [],
     "dit_ops.hip": [],

@@ -8,9 +8,11 @@ D2H copies and 16 `.item()` syncs per call), and the threshold logic (16 scalars
 flow_backend:
   "tdiff"     -- temporal difference motion (SCHED:391-392 / 478-479): the branch the reference executes whenever
                  `import cv2` fails (SCHED:159-161 -> except at :390), and the one pinned by golden vectors.
-  "farneback" -- OpenCV Farneback (SCHED:220-224).  OpenCV is a third-party dependency absent from /root/reference and
-                 from this image; a GPU Farneback is scheduled and raises NotImplementedError until it
-                 can be pinned -- never a silent fallback.
+  "farneback" -- what the reference computes when OpenCV is installed (SCHED:156-248, cv2.calcOpticalFlowFarneback with the
+                 parameters of :220-224) as a batched GPU implementation (csrc/flow.hip): all 2 x 16 x (T-1) frame pairs in
+                 ~30 small launches, nothing copied to the host.  OpenCV is a third-party dependency absent from
+                 /root/reference and from this image, so this backend is checked against oracle/farneback.py (a restatement
+                 of the published algorithm) only: PARITY WITH A REAL cv2 IS UNPINNED.  It must be chosen explicitly.
 """
 from __future__ import annotations
 
@@ -31,10 +33,14 @@ class VideoMotionPCASelector:
 
     def channel_similarities(self, pred_original_sample: torch.Tensor, video_latents: torch.Tensor) -> np.ndarray:
         """SCHED:373-397 + 439-495 -> numpy float64 array of C similarities."""
-        if self.flow_backend != "tdiff":
-            raise NotImplementedError("flow_backend='farneback' is not built yet (needs a cv2-pinned GPU Farneback)")
         if pred_original_sample.shape[0] != 1:
             raise NotImplementedError("FLF: batch size 1 only (as the reference's squeeze(0) path)")
+        if self.flow_backend == "farneback":
+            ref_f = ops.farneback_flows(video_latents[0])          # [C, T-1, 2, h, w] fp32
+            ch_f = ops.farneback_flows(pred_original_sample[0])
+            sim = ops.flow_metrics(ref_f, ch_f)
+            self.last_similarities = sim.cpu().numpy().astype(np.float64)
+            return self.last_similarities
         ref_m = ops.temporal_diff(video_latents[0])        # [C, T-1, h, w] fp32 (video_latents promoted to fp32 first)
         ch_m = ops.temporal_diff(pred_original_sample[0])  # [C, T-1, h, w] fp32
         sim = ops.flow_metrics(ref_m.unsqueeze(2), ch_m.unsqueeze(2))

@@ -204,6 +204,17 @@ def temporal_diff(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def farneback_flows(x: torch.Tensor) -> torch.Tensor:
+    """SCHED:156-248 for every channel at once: x [C,T,h,w] (f32 / bf16) -> flows [C,T-1,2,h,w] fp32 (device)."""
+    x = _dev(x)
+    C, T, h, w = x.shape
+    nbytes = _ffi.lib().wf_farneback_workspace_bytes(C, T, h, w)
+    ws = _workspace("farneback", (nbytes + 3) // 4, x.device)
+    out = torch.empty((C, T - 1, 2, h, w), dtype=torch.float32, device=x.device)
+    call("wf_farneback_flows", x.data_ptr(), _dt(x), out.data_ptr(), C, T, h, w, ws.data_ptr(), stream())
+    return out
+
+
 def flow_metrics(ref_flow: torch.Tensor, chan_flow: torch.Tensor) -> torch.Tensor:
     """SCHED:497-607 for n channels at once.  ref_flow [n,Tm,Cr,h,w], chan_flow [n,Tm,Cc,h,w] fp32 -> sim [n] (device)."""
     ref_flow, chan_flow = _dev(ref_flow), _dev(chan_flow)
