@@ -23,6 +23,7 @@ LIB = os.path.join(LIBDIR, "libwf_hip.so")
 
 ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result", "-I", os.path.join(ROOT, "include")]
+COMMON += os.environ.get("WF_EXTRA_HIPCC_FLAGS", "").split()  # debug builds (e.g. -DWF_ATTN_TIMING)
 # Per-file extra flags.  The element-wise / injection kernels must round every op separately (no FMA contraction) to
 # reproduce eager PyTorch bit for bit.
 SOURCES = {

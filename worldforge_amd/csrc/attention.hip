@@ -33,6 +33,8 @@
 #include "common.h"
 #include "mfma.h"
 
+#include <cstdlib>
+
 using namespace wf;
 
 namespace {
@@ -54,7 +56,22 @@ struct AttnArgs {
   int n_qblk;
   float scale_log2;  // softmax_scale * log2(e)
   int accumulate;    // O += result (second cross-attention, model.py:227)
+  int prio_mode;     // experiment: 1 = static s_setprio 1 for waves 4-7, 2 = for waves 0-3
 };
+
+#ifdef WF_ATTN_TIMING
+// Per-phase cycle accounting (debug builds only: python -m worldforge_amd.build with WF_EXTRA_HIPCC_FLAGS=-DWF_ATTN_TIMING).
+// Slots: group*8 + {0 qk, 1 wait after qk, 2 softmax, 3 wait after softmax, 4 pv, 5 wait after pv, 6 tiles}.
+__device__ unsigned long long g_attn_cycles[16];
+#define TMARK(slot)                                                      \
+  do {                                                                   \
+    const unsigned long long now__ = __builtin_readcyclecounter();       \
+    if (tim_on) tim[slot] += now__ - tim_last;                           \
+    tim_last = now__;                                                    \
+  } while (0)
+#else
+#define TMARK(slot) do { } while (0)
+#endif
 
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
@@ -130,7 +147,7 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
 
   const int ntiles = (a.kv_len + KB - 1) / KB;
   constexpr int PF = 4;  // fragment prefetch depth (LDS reads in flight ahead of the MFMA that consumes them)
-  constexpr int NBUF = 3;
+  constexpr int NBUF = 4;
 
   // LDS: ring of NBUF tile buffers, each [K tile 16 KiB | V^T tile 16 KiB]; tile j lives in buffer j % NBUF.
   const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_offset(smem));
@@ -156,6 +173,8 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
 
   f32x16 s[2];
   bf16x8 pf[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pf[i] = as_bf16x8(u32x4{0u, 0u, 0u, 0u});
 
   // ---- the three phases of one KV tile (one wave, 32 query rows) ----------------------------------------------------------
   auto phase_qk = [&](int t) {  // S^T = K Q^T: 16 MFMAs, K fragments PF ahead
@@ -255,6 +274,43 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
     }
     __builtin_amdgcn_sched_group_barrier(0x008, PF, 1);
   };
+  // M phase: QK^T(tq) and P.V(tp) with their MFMAs interleaved (s0 o0 s1 o1 s0 o2 s1 o3 ...).  A v_mfma_f32_32x32x16_bf16 that
+  // accumulates into the result of an MFMA issued less than ~4 issue slots (~100 cycles) earlier stalls on it; the QK^T stream has
+  // only two accumulators (distance 2 = 64 cycles: measured 850-1050 cycles per 16 MFMAs instead of 512), interleaving the P.V
+  // stream puts 4 slots between MFMAs on the same score accumulator and 8 on the same output accumulator.
+  auto phase_m = [&](int tq, int tp) {
+    const unsigned char* sKb = smem + (tq % NBUF) * BUF_BYTES;
+    const unsigned char* sVb = smem + (tp % NBUF) * BUF_BYTES + K_TILE_BYTES;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+    constexpr int PFM = 2;
+    u32x4 kring[PFM], vring[PFM];
+#pragma unroll
+    for (int i = 0; i < PFM; ++i) {
+      kring[i] = kread(sKb, i);
+      vring[i] = vread(sVb, i);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const bf16x8 kf = as_bf16x8(kring[i % PFM]);
+      if (i + PFM < 16) kring[i % PFM] = kread(sKb, i + PFM);
+      s[i & 1] = mfma32(kf, qf[i >> 1], s[i & 1]);
+      const bf16x8 vf = as_bf16x8(vring[i % PFM]);
+      if (i + PFM < 16) vring[i % PFM] = vread(sVb, i + PFM);
+      o[i & 3] = mfma32(vf, pf[i >> 2], o[i & 3]);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * PFM, 2);
+#pragma unroll
+    for (int i = 0; i < 16 - PFM; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * PFM, 2);
+  };
   // workgroup barrier WITHOUT the implicit vmcnt(0) drain of __syncthreads(): LDS-DMA stays in flight across it;
   // LDS reads of this wave are complete (their results were consumed by MFMAs), so only lgkmcnt needs draining
   auto bar = [&]() {
@@ -272,35 +328,65 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
   // tile t+1 right after barrier 3t and drain it before barrier 3t+2, whichever phase they are in (ring of 3 buffers:
   // the buffer of tile t+1 was last read two tiles ago by either group).
   const bool groupB = __builtin_amdgcn_readfirstlane(wid) >= 4;
+  if (a.prio_mode == 1 && groupB) __builtin_amdgcn_s_setprio(1);
+  if (a.prio_mode == 2 && !groupB) __builtin_amdgcn_s_setprio(1);
   stage(0);
+  if (ntiles > 1) stage(1);
   drain_dma();
   bar();
+#ifdef WF_ATTN_TIMING
+  unsigned long long tim[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tim_last = __builtin_readcyclecounter();
+  const bool tim_on = lane == 0 && (wid == 0 || wid == 4);
+#endif
+  // Two phases per tile and wave: M(t) = [QK^T(t) then P.V(t-1)] (32 MFMAs + their LDS fragment reads, nothing else) and
+  // S(t) = [online softmax(t) + this wave's LDS-DMA pieces of tile t+2] (VALU / VMEM only).  Group B runs one phase behind
+  // group A, so on every SIMD one wave is always in M and the other in S: the matrix pipe is never shared and never idle by
+  // construction, and the LDS-DMA is issued from the phase where it is cheap (2-4x dearer beside MFMAs + ds_reads).
+  // Ring of 4 tile buffers: the buffer of tile t+2 last held tile t-2, whose V^T was last read in M(t-1) by both groups.
   if (!groupB) {
+    phase_m(0, 0);  // P is still zero: the P.V half adds exact zeros
+    TMARK(0);
+    bar();
+    TMARK(1);
     for (int t = 0; t < ntiles; ++t) {
-      if (t + 1 < ntiles) stage(t + 1);
-      phase_qk(t);
-      bar();  // 3t+1
+      if (t + 2 < ntiles) stage(t + 2);
       phase_softmax(t);
+      TMARK(2);
+      bar();
+      TMARK(3);
+      phase_m(t + 1 < ntiles ? t + 1 : t, t);  // last tile: the QK^T half recomputes scores nobody reads
       drain_dma();
-      bar();  // 3t+2
-      phase_pv(t);
-      bar();  // 3t+3
+      TMARK(0);
+      bar();
+      TMARK(1);
     }
     bar();  // matches group B's last phase
   } else {
-    if (ntiles > 1) stage(1);
-    bar();  // barrier 1: group A did QK^T(0)
+    bar();
+    TMARK(7);
+    phase_m(0, 0);  // P is still zero: the P.V half adds exact zeros
+    TMARK(0);
+    bar();
+    TMARK(1);
     for (int t = 0; t < ntiles; ++t) {
-      phase_qk(t);
-      drain_dma();
-      bar();  // 3t+2
-      phase_softmax(t);
-      bar();  // 3t+3
       if (t + 2 < ntiles) stage(t + 2);
-      phase_pv(t);
-      bar();  // 3t+4
+      phase_softmax(t);
+      TMARK(2);
+      bar();
+      TMARK(3);
+      phase_m(t + 1 < ntiles ? t + 1 : t, t);  // last tile: the QK^T half recomputes scores nobody reads
+      drain_dma();
+      TMARK(0);
+      bar();
+      TMARK(1);
     }
   }
+#ifdef WF_ATTN_TIMING
+  if (tim_on) {
+    tim[6] = ntiles;
+    for (int i = 0; i < 7; ++i) atomicAdd(&g_attn_cycles[(groupB ? 8 : 0) + i], tim[i]);
+  }
+#endif
 
   // ---- finish: combine the two half-wave partial sums, normalise, store ------------------------------------------------
   l_run += __shfl_xor(l_run, 32, 64);
@@ -354,9 +440,13 @@ extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O
   a.n_qblk = ceil_div(Lq, QB);
   a.scale_log2 = softmax_scale * 1.4426950408889634f;
   a.accumulate = accumulate;
+  {
+    const char* e = getenv("WF_ATTN_PRIO");
+    a.prio_mode = e ? atoi(e) : 0;
+  }
   const int hslots = (H + 7) / 8;
   const int grid = hslots * a.n_qblk * 8;
-  const size_t lds = 3 * (K_TILE_BYTES + V_TILE_BYTES);
+  const size_t lds = 4 * (K_TILE_BYTES + V_TILE_BYTES);
   if (Lkp > 1024)
     hipLaunchKernelGGL(k_attn<0>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, a);
   else
@@ -364,3 +454,14 @@ extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O
   WF_LAUNCH_CHECK("wf_attn_fwd");
   return WF_OK;
 }
+
+#ifdef WF_ATTN_TIMING
+extern "C" int wf_debug_attn_cycles(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_attn_cycles), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_cycles), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
