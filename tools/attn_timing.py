@@ -19,15 +19,12 @@ k[:, :L] = torch.randn(H, L, 128, device=dev).to(torch.bfloat16)
 vt = torch.randn(H, Lp // 64, 128, 64, device=dev).to(torch.bfloat16)
 out = torch.empty(L, H * 128, device=dev, dtype=torch.bfloat16)
 lib = _ffi.lib()
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 64)()
 dit.attention(q, k, vt, out, L, 1 / math.sqrt(128))
 torch.cuda.synchronize()
 lib.wf_debug_attn_cycles(buf, 1)
 dit.attention(q, k, vt, out, L, 1 / math.sqrt(128))
 torch.cuda.synchronize()
 lib.wf_debug_attn_cycles(buf, 1)
-names = ["ph0", "wait0", "ph2", "wait2", "ph4", "wait4"]
-for g in range(2):
-    tiles = buf[g * 8 + 6]
-    vals = [buf[g * 8 + i] / max(tiles, 1) for i in range(6)]
-    print(f"group {'AB'[g]}: " + "  ".join(f"{n} {v:7.1f}" for n, v in zip(names, vals)) + f"   sum {sum(vals):7.1f} cycles/tile")
+tiles = max(buf[6], 1)
+print("w4 per tile: gaps0-31 %.1f  gaps32-63 %.1f  commit %.1f  drain %.1f  barrier %.1f cycles" % tuple(buf[i] / tiles for i in range(5)))

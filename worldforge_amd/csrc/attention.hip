@@ -34,6 +34,8 @@
 #include "mfma.h"
 
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 using namespace wf;
 
@@ -414,6 +416,440 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
   }
 }
 
+// ======================================================================================================================================
+// k_attn_w4: one wave per SIMD (4 waves = 256 query rows per workgroup, 64 rows = two 32-row q-blocks a / b per wave, the whole
+// 512-entry register file).  With two waves per SIMD (k_attn) every VALU instruction of the softmax wave costs the MFMA wave issue
+// time (measured: 32 MFMAs take 1300-1500 cycles instead of 1024 beside a partner's softmax).  Here ONE instruction stream carries
+// both: per KV tile two regions, each 32 MFMAs of one q-block with the ~160 VALU instructions of the OTHER q-block's online softmax
+// placed in the MFMA issue shadows (an MFMA occupies the matrix pipe for 32 cycles = ~8 issue slots):
+//     R1(t):  softmax_a(t)   beside   P.V_b(t-1) , QK^T_b(t)        (their MFMAs interleaved: see phase_m of k_attn)
+//     R2(t):  softmax_b(t)   beside   P.V_a(t)   , QK^T_a(t+1)
+// so every dependency (scores -> softmax -> P -> P.V) has a full region of slack, the score registers are single-buffered
+// (S_a is consumed while S_b is produced and vice versa), and there is ONE workgroup barrier per tile (the LDS ring).
+// LDS-DMA: 4 waves x (4 K + 4 V^T) pieces per tile, issued at the head of R1(t) for tile t+2, drained before the tile's barrier.
+// ======================================================================================================================================
+constexpr int NT4 = 256;
+
+// compile-time loop: f(integral_constant<int, 0>), ..., f(integral_constant<int, N-1>) -- the slice placement below needs every
+// index to be a constant (a #pragma unroll that the optimizer declines turns the register arrays into scratch)
+template <class F, int... Is>
+__device__ __forceinline__ void for_const_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void for_const(F&& f) {
+  for_const_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+template <int KIND>
+__global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BUF_BYTES = K_TILE_BYTES + V_TILE_BYTES;
+  constexpr int NBUF = 4;
+
+  const int b = blockIdx.x;
+  const int xcd = b & 7, j = b >> 3;
+  const int hslot = j / a.n_qblk;
+  const int head = hslot * 8 + xcd;
+  const int qblk = j % a.n_qblk;
+  if (head >= a.H) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  int q_row[2];
+  bf16x8 qf[2][8];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    q_row[x] = qblk * QB + wid * 64 + x * 32 + l31;
+    const uint16_t* qp = a.Q + ((size_t)head * a.Lq + min(q_row[x], a.Lq - 1)) * D;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) qf[x][st] = as_bf16x8(*reinterpret_cast<const u32x4*>(qp + 16 * st + 8 * hi));
+  }
+
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  int ksrc[4], vsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wu * 4 + i;
+    const int kr = 4 * piece + (lane >> 4), ks = lane & 15;
+    ksrc[i] = kr * D + ((ks ^ (kr & 15)) << 3);
+    const int vr = 8 * piece + (lane >> 3), vs = lane & 7;
+    vsrc[i] = vr * KB + ((vs ^ ((vr >> 1) & 7)) << 3);
+  }
+  const int tiles_per_seg = a.seg_len / KB;
+  int krow_off[2], krow_sw[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    int kr = kb * 32 + swap23(l31);
+    krow_off[kb] = kr * 256;
+    krow_sw[kb] = kr & 15;
+  }
+  int vrow_off[4], vrow_sw[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    int vr = db * 32 + l31;
+    vrow_off[db] = vr * 128;
+    vrow_sw[db] = (vr >> 1) & 7;
+  }
+
+  // Register homes are chosen by hand through inline-asm MFMAs (hipcc selects ONE accumulator form per function, and with the
+  // AGPR form it shuttles every accumulator the VALU touches through v_accvgpr copies: ~600 per tile):
+  //   O (128 regs)      AGPR  accumulated by "+a" MFMAs, touched by the VALU only in the rare rescale block and the epilogue
+  //   Q (64 regs)       AGPR  MFMA B operand
+  //   S (2 x 64 regs)   VGPR  "+v" MFMAs; double-buffered: the scores of tile t+1 are produced while those of tile t are consumed
+  //   P (32 regs)       VGPR  written by the softmax just in time, MFMA B operand
+  f32x16 o[2][4];
+  f32x16 sb[2][2][2];  // [buffer][q-block][key block]
+  bf16x8 pf[2][4];
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f}, mcq[2] = {0.f, 0.f};
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[x][db][r] = 0.f;
+      asm volatile("" : "+a"(o[x][db]));  // O enters the loop in AGPRs
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pf[x][i] = as_bf16x8(u32x4{0u, 0u, 0u, 0u});
+  }
+  const float c = a.scale_log2;
+  const int ntiles = (a.kv_len + KB - 1) / KB;
+  const bool ragged = (a.kv_len & (KB - 1)) != 0;
+
+  // Global address / LDS slot of the tile being staged (wave-uniform), advanced one tile at a time: no division in the loop.
+  // Past the last tile the pieces are still issued (no branch in the MFMA stream) but land in a 32 KiB trash area behind the ring.
+  const size_t seg_jump = (size_t)(a.H - 1) * tiles_per_seg * (KB * D);  // next K/V segment of the same head (all-gathered shards)
+  const uint16_t* kt_ptr = a.K + (size_t)head * tiles_per_seg * (KB * D);
+  const uint16_t* vt_ptr = a.Vt + (size_t)head * tiles_per_seg * (KB * D);
+  int st_tile = 0, st_in_seg = 0;
+  uint32_t st_base = wu * 4096;
+  auto stage_next = [&]() {  // select tile st_tile + 1
+    ++st_tile;
+    if (st_tile < ntiles) {
+      kt_ptr += KB * D;
+      vt_ptr += KB * D;
+      if (++st_in_seg == tiles_per_seg) {
+        st_in_seg = 0;
+        kt_ptr += seg_jump;
+        vt_ptr += seg_jump;
+      }
+      st_base = (st_tile % NBUF) * BUF_BYTES + wu * 4096;
+    } else {
+      st_base = NBUF * BUF_BYTES + wu * 4096;  // trash
+    }
+  };
+  auto stage_piece = [&](int i) {  // piece i (0..7) of this wave's share of the selected tile: 4 K then 4 V^T pieces
+    if (i < 4)
+      glds16(kt_ptr + ksrc[i], smem + st_base + i * 1024);
+    else
+      glds16(vt_ptr + vsrc[i - 4], smem + st_base + K_TILE_BYTES + (i - 4) * 1024);
+  };
+  auto kread = [&](const unsigned char* sKb, int i) {
+    const int kb = i & 1, st = i >> 1;
+    return *reinterpret_cast<const u32x4*>(sKb + krow_off[kb] + (((2 * st + hi) ^ krow_sw[kb]) << 4));
+  };
+  auto vread = [&](const unsigned char* sVb, int i) {
+    const int db = i & 3, m4 = i >> 2;
+    return *reinterpret_cast<const u32x4*>(sVb + vrow_off[db] + (((2 * m4 + hi) ^ vrow_sw[db]) << 4));
+  };
+  auto mfma_s = [&](f32x16& acc, u32x4 kf, const bf16x8& q, bool first) {
+    if (first)
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(kf), "a"(q));
+    else
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(kf), "a"(q));
+  };
+  auto mfma_o = [&](f32x16& acc, u32x4 vf, const bf16x8& pfr) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(vf), "v"(pfr));
+  };
+  auto bar = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  auto drain_dma = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  // commit of the running max of q-block X given the row max `mloc` of the next tile's scores (already exchanged between the lane
+  // halves); rare path: some row max grew -> rescale O_X, l_X.  O_X lives in AGPRs and must never be a VALU operand in the hot
+  // loop: the copies to VGPRs and back are pinned inside this block by the empty asm statements.
+  auto commit = [&](auto XC, float m_new) {
+    constexpr int X = decltype(XC)::value;
+    // Deferred rescale: the reference max m_run only has to bound the scores well enough for exp2 not to overflow; it is the SAME m
+    // for P and for the row sum, so the result is exact for any m.  O_X / l_X are rescaled only when some row max of the wave grew
+    // by more than 2^8 in the exp2 domain (p <= 256 otherwise) -- almost never after the first tiles, instead of ~1 tile in 4.
+    if (__any(c * (m_new - m_run[X]) > 8.0f)) {
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");  // asm MFMA write -> v_accvgpr_read: 18 wait states
+      const float alpha = __builtin_amdgcn_exp2f(c * (m_run[X] - m_new));
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        f32x16 tmp = o[X][db];
+        asm volatile("" : "+v"(tmp));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmp[r] *= alpha;
+        asm volatile("" : "+v"(tmp));
+        o[X][db] = tmp;
+        asm volatile("" : "+a"(o[X][db]));
+      }
+      l_run[X] *= alpha;
+      m_run[X] = m_new;
+    }
+    mcq[X] = c * m_run[X];
+  };
+  // row max of the 32 scores per lane of q-block X in buffer B, exchanged between the lane halves (un-sliced form: prologue only)
+  auto rowmax_now = [&](auto BC, auto XC) {
+    constexpr int B = decltype(BC)::value, X = decltype(XC)::value;
+    float m = sb[B][X][0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, sb[B][X][kb][r]);
+    const unsigned mu = __float_as_uint(m);
+    auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+    return fmaxf(fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])), m_run[X]);
+  };
+  auto mask_ragged = [&](auto BC, int t) {  // scores of keys >= kv_len -> -inf (last tile only)
+    constexpr int B = decltype(BC)::value;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int key = t * KB + 32 * kb + 16 * (r >> 3) + 8 * hi + (r & 7);
+          if (key >= a.kv_len) sb[B][x][kb][r] = -INFINITY;
+        }
+  };
+
+  // ---- one KV tile t (scores of tile t in buffer B, produced earlier): 64 MFMA gaps -------------------------------------------------
+  //   gaps  0..31  QK^T(t+1) -> buffer 1-B, q-blocks a / b alternating, ONE K fragment read per two MFMAs
+  //   gaps 32..63  P.V(t), q-blocks alternating, one V^T fragment read per two MFMAs
+  //   VALU, <= ~5 issue slots per gap:
+  //     gaps 0..51   the 64 (q-block, element) pairs of softmax(t) in P-fragment order (f0a f0b f1a f1b f2a ...), each through a
+  //                  3-stage pipeline one gap apart (t = c s - c m | p = exp2 t | row sum, bf16 pack) so that nothing waits on the
+  //                  instruction before it; P fragment f is complete before gap 32 + 8 f, where its first MFMA sits
+  //     gaps 52..63  row max of the NEW scores (v_max3 chains); the commit (+ rare rescale) follows the last gap
+  //   LDS-DMA: the 8 pieces of tile t+3 in gaps 2, 6, ..., 30;  fragment rings are refilled across the phase / tile seams.
+  constexpr int PF4 = 4;
+  u32x4 ring[PF4];
+#ifdef WF_ATTN_TIMING
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+#define W4MARK(k) do { const unsigned long long n__ = __builtin_readcyclecounter(); tacc[k] += n__ - tlast; tlast = n__; } while (0)
+#else
+#define W4MARK(k) do { } while (0)
+#endif
+  auto tile = [&](auto BC, int t) {
+    constexpr int B = decltype(BC)::value;
+    const int t1 = t + 1 < ntiles ? t + 1 : t;       // past the end: recompute scores nobody reads
+    const int t2 = t + 2 < ntiles ? t + 2 : t1;
+    const unsigned char* sK1 = smem + (t1 % NBUF) * BUF_BYTES;                 // K(t+1): read now
+    const unsigned char* sV0 = smem + (t % NBUF) * BUF_BYTES + K_TILE_BYTES;   // V^T(t)
+    const unsigned char* sK2 = smem + (t2 % NBUF) * BUF_BYTES;                 // K(t+2): head of the next tile's ring
+    float tq_[64], pq[64];
+    float ls[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    uint32_t pk[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    float mx[2][4];
+    float mn[2] = {0.f, 0.f};
+#ifdef WF_ATTN_TIMING
+    unsigned long long tlast = __builtin_readcyclecounter();
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    for_const<64>([&](auto GC) {
+      auto& sb_ = sb;
+      auto& pf_ = pf;
+      auto& o_ = o;
+      auto& ring_ = ring;
+      auto& tq__ = tq_;
+      auto& pq_ = pq;
+      auto& ls_ = ls;
+      auto& pk_ = pk;
+      auto& mx_ = mx;
+      auto& mcq_ = mcq;
+      constexpr int g = decltype(GC)::value;
+      constexpr int q = g & 1;
+      if constexpr (g < 32) {
+        constexpr int i = g >> 1;  // K fragment i: key block i & 1, k-step i >> 1
+        mfma_s(sb_[1 - B][q][i & 1], ring_[i % PF4], qf[q][i >> 1], i < 2);
+        __builtin_amdgcn_sched_barrier(0);  // the gap's VALU must not be hoisted above its MFMA
+        if constexpr (q == 1) {  // fragment i consumed by both q-blocks: refill its slot
+          if constexpr (i + PF4 < 16)
+            ring_[i % PF4] = kread(sK1, i + PF4);
+          else
+            ring_[i % PF4] = vread(sV0, i + PF4 - 16);
+        }
+      } else {
+        constexpr int i = (g - 32) >> 1;  // V^T fragment i: output block i & 3, key step i >> 2
+        mfma_o(o_[q][i & 3], ring_[i % PF4], pf_[q][i >> 2]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (q == 1) {
+          if constexpr (i + PF4 < 16)
+            ring_[i % PF4] = vread(sV0, i + PF4);
+          else
+            ring_[i % PF4] = kread(sK2, i + PF4 - 16);
+        }
+      }
+      // ---- softmax(t) slices: pair k = 0..63 -> fragment f = k >> 4, q-block (k >> 3) & 1, element e = 8 f + (k & 7) ----
+      for_const<64>([&](auto KC) {
+        (void)&sb_, (void)&pf_, (void)&tq__, (void)&pq_, (void)&ls_, (void)&pk_, (void)&mcq_;
+        constexpr int k = decltype(KC)::value;
+        constexpr int ga = (50 * k) / 64;
+        constexpr int f = k >> 4, x = (k >> 3) & 1, e = 8 * f + (k & 7);
+        if constexpr (ga + 2 == g) {  // stage C
+          ls_[x][e & 3] += pq_[k];
+          asm volatile("" : "+v"(ls_[x][e & 3]));
+          if constexpr ((e & 1) != 0) {
+            pk_[x][(e >> 1) & 3] = pack_bf16x2(pq_[k - 1], pq_[k]);
+            asm volatile("" : "+v"(pk_[x][(e >> 1) & 3]));
+            if constexpr ((e & 7) == 7) {
+              u32x4 v4 = {pk_[x][0], pk_[x][1], pk_[x][2], pk_[x][3]};
+              pf_[x][f] = as_bf16x8(v4);
+            }
+          }
+        }
+      });
+      for_const<64>([&](auto KC) {
+        (void)&sb_, (void)&pf_, (void)&tq__, (void)&pq_, (void)&ls_, (void)&pk_, (void)&mcq_;
+        constexpr int k = decltype(KC)::value;
+        if constexpr ((50 * k) / 64 + 1 == g) {  // stage B
+          pq_[k] = __builtin_amdgcn_exp2f(tq__[k]);
+          asm volatile("" : "+v"(pq_[k]));
+        }
+      });
+      for_const<64>([&](auto KC) {
+        (void)&sb_, (void)&pf_, (void)&tq__, (void)&pq_, (void)&ls_, (void)&pk_, (void)&mcq_;
+        constexpr int k = decltype(KC)::value;
+        constexpr int f = k >> 4, x = (k >> 3) & 1, e = 8 * f + (k & 7);
+        if constexpr ((50 * k) / 64 == g) {  // stage A
+          tq__[k] = c * sb_[B][x][e >> 4][e & 15] - mcq_[x];
+          asm volatile("" : "+v"(tq__[k]));
+        }
+      });
+      // ---- row max of the new scores: 2 q-blocks x 4 chains x 4 v_max3 steps in gaps 52..59 (4 steps per gap); tree, lane-half
+      // exchange and running max in gaps 60..63, so that only the (rare) rescale decision is left after the last MFMA ----
+      if constexpr (g >= 52 && g < 60) {
+        for_const<4>([&](auto JC) {
+          (void)&sb_, (void)&mx_;
+          constexpr int k = 4 * (g - 52) + decltype(JC)::value;  // 0..31
+          constexpr int x = k >> 4, ch = k & 3, st = (k >> 2) & 3;
+          constexpr int kb = ch >> 1, r0 = (ch & 1) + 4 * st;
+          if constexpr (st == 0) {
+            asm volatile("v_max_f32 %0, %1, %2" : "=v"(mx_[x][ch]) : "v"(sb_[1 - B][x][kb][r0]), "v"(sb_[1 - B][x][kb][r0 + 2]));
+          } else {
+            asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mx_[x][ch]) : "v"(sb_[1 - B][x][kb][r0]), "v"(sb_[1 - B][x][kb][r0 + 2]));
+          }
+        });
+      }
+      if constexpr (g == 60 || g == 61) {
+        constexpr int x = g - 60;
+        asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(mn[x]) : "v"(mx_[x][0]), "v"(mx_[x][1]), "v"(mx_[x][2]));
+        asm volatile("v_max_f32 %0, %0, %1" : "+v"(mn[x]) : "v"(mx_[x][3]));
+      }
+      if constexpr (g == 62 || g == 63) {
+        constexpr int x = g - 62;
+        const unsigned mu = __float_as_uint(mn[x]);
+        auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+        asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(mn[x]) : "v"(__uint_as_float(sw[0])), "v"(__uint_as_float(sw[1])), "v"(m_run[x]));
+      }
+      if constexpr (g == 54 || g == 56) {  // the row sums of this tile are complete (last pack at gap 51)
+        constexpr int x = (g - 54) >> 1;
+        l_run[x] += (ls_[x][0] + ls_[x][1]) + (ls_[x][2] + ls_[x][3]);
+        asm volatile("" : "+v"(l_run[x]));
+      }
+#ifdef WF_ATTN_TIMING
+      if constexpr (g == 31) W4MARK(0);
+      if constexpr (g == 63) W4MARK(1);
+#endif
+      if constexpr (g == 0) stage_next();  // tile t + 3 (or trash): scalar bookkeeping, in the shadow of the first MFMA
+      if constexpr (g >= 2 && g < 32 && (g & 3) == 2) stage_piece((g - 2) >> 2);
+      if constexpr (g == 51) {
+        // the new scores were written by asm MFMAs (last one at gap 31): XDL write -> VALU read hazard is long covered; the ragged
+        // mask of the last tile must be in place before its row max
+        if (ragged && t + 1 == ntiles - 1) mask_ragged(std::integral_constant<int, 1 - B>{}, t + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (t + 1 < ntiles) {
+      commit(std::integral_constant<int, 0>{}, mn[0]);
+      commit(std::integral_constant<int, 1>{}, mn[1]);
+    }
+    W4MARK(2);
+    drain_dma();
+    W4MARK(3);
+    bar();
+    W4MARK(4);
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+
+  // prologue: tiles 0, 1, 2 staged by everyone; scores of tile 0 (un-overlapped), their max committed; ring <- head of K(1)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) stage_piece(i);
+  stage_next();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) stage_piece(i);
+  stage_next();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) stage_piece(i);
+  drain_dma();
+  bar();
+  {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const u32x4 kf = kread(smem, i);
+      mfma_s(sb[0][0][i & 1], kf, qf[0][i >> 1], i < 2);
+      mfma_s(sb[0][1][i & 1], kf, qf[1][i >> 1], i < 2);
+    }
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
+    if (ragged && ntiles == 1) mask_ragged(B0{}, 0);
+    const float m0 = rowmax_now(B0{}, std::integral_constant<int, 0>{});
+    const float m1 = rowmax_now(B0{}, std::integral_constant<int, 1>{});
+    commit(std::integral_constant<int, 0>{}, m0);
+    commit(std::integral_constant<int, 1>{}, m1);
+    const unsigned char* sK1 = smem + ((ntiles > 1 ? 1 : 0) % NBUF) * BUF_BYTES;
+#pragma unroll
+    for (int i = 0; i < PF4; ++i) ring[i] = kread(sK1, i);
+  }
+  for (int t = 0; t < ntiles; t += 2) {
+    tile(B0{}, t);
+    if (t + 1 < ntiles) tile(B1{}, t + 1);
+  }
+#ifdef WF_ATTN_TIMING
+  if (lane == 0 && wid == 0) {
+    for (int i = 0; i < 5; ++i) atomicAdd(&g_attn_cycles[i], tacc[i]);
+    atomicAdd(&g_attn_cycles[6], (unsigned long long)ntiles);
+  }
+#endif
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    float l = l_run[x];
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (q_row[x] < a.Lq) {
+      uint16_t* op = a.O + (size_t)q_row[x] * a.ldo + head * D;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        f32x16 ov = o[x][db];
+        asm volatile("" : "+v"(ov));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = db * 32 + 8 * g + 4 * hi;
+          float v0 = ov[4 * g + 0] * inv, v1 = ov[4 * g + 1] * inv, v2 = ov[4 * g + 2] * inv,
+                v3 = ov[4 * g + 3] * inv;
+          if (a.accumulate) {
+            u32x2 old = *reinterpret_cast<const u32x2*>(op + d);
+            v0 += __uint_as_float(old[0] << 16);
+            v1 += __uint_as_float(old[0] & 0xffff0000u);
+            v2 += __uint_as_float(old[1] << 16);
+            v3 += __uint_as_float(old[1] & 0xffff0000u);
+          }
+          u32x2 pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+          *reinterpret_cast<u32x2*>(op + d) = pk;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len,
@@ -447,7 +883,17 @@ extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O
   const int hslots = (H + 7) / 8;
   const int grid = hslots * a.n_qblk * 8;
   const size_t lds = 4 * (K_TILE_BYTES + V_TILE_BYTES);
-  if (Lkp > 1024)
+  const size_t lds_w4 = 5 * (K_TILE_BYTES + V_TILE_BYTES);  // ring of 4 + trash area (160 KiB: the whole LDS of a CU)
+  static const int use_w4 = [] {
+    const char* e = getenv("WF_ATTN_KERNEL");
+    return e && e[0] == 'w' ? 1 : 0;
+  }();
+  if (use_w4) {
+    if (Lkp > 1024)
+      hipLaunchKernelGGL(k_attn_w4<0>, dim3(grid), dim3(NT4), lds_w4, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL(k_attn_w4<1>, dim3(grid), dim3(NT4), lds_w4, (hipStream_t)stream, a);
+  } else if (Lkp > 1024)
     hipLaunchKernelGGL(k_attn<0>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(k_attn<1>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, a);
