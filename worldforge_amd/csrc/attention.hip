@@ -517,33 +517,27 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
   const int ntiles = (a.kv_len + KB - 1) / KB;
   const bool ragged = (a.kv_len & (KB - 1)) != 0;
 
-  // Global address / LDS slot of the tile being staged (wave-uniform), advanced one tile at a time: no division in the loop.
-  // Past the last tile the pieces are still issued (no branch in the MFMA stream) but land in a 32 KiB trash area behind the ring.
-  const size_t seg_jump = (size_t)(a.H - 1) * tiles_per_seg * (KB * D);  // next K/V segment of the same head (all-gathered shards)
-  const uint16_t* kt_ptr = a.K + (size_t)head * tiles_per_seg * (KB * D);
-  const uint16_t* vt_ptr = a.Vt + (size_t)head * tiles_per_seg * (KB * D);
-  int st_tile = 0, st_in_seg = 0;
+  // Element offset / LDS slot of the tile being staged (wave-uniform), advanced one tile at a time: a handful of scalar
+  // instructions, no division.  Past the last tile the pieces are still issued (no branch in the MFMA stream) but re-read the last
+  // tile into a 32 KiB trash area behind the ring.
+  const uint32_t seg_jump = (uint32_t)(a.H - 1) * tiles_per_seg;  // in tiles: next K/V segment of the same head (all-gathered shards)
+  uint32_t st_tile_g = (uint32_t)head * tiles_per_seg;              // global tile index ([segment][head][tile]) of the staged tile
+  int st_tile = 0, st_left = tiles_per_seg;                         // tile number, tiles left in its segment
   uint32_t st_base = wu * 4096;
   auto stage_next = [&]() {  // select tile st_tile + 1
     ++st_tile;
-    if (st_tile < ntiles) {
-      kt_ptr += KB * D;
-      vt_ptr += KB * D;
-      if (++st_in_seg == tiles_per_seg) {
-        st_in_seg = 0;
-        kt_ptr += seg_jump;
-        vt_ptr += seg_jump;
-      }
-      st_base = (st_tile % NBUF) * BUF_BYTES + wu * 4096;
-    } else {
-      st_base = NBUF * BUF_BYTES + wu * 4096;  // trash
-    }
+    const bool live = st_tile < ntiles;
+    const bool wrap = --st_left == 0;
+    st_tile_g += live ? (wrap ? 1u + seg_jump : 1u) : 0u;
+    st_left = wrap ? tiles_per_seg : st_left;
+    st_base = (live ? (uint32_t)(st_tile & (NBUF - 1)) : (uint32_t)NBUF) * BUF_BYTES + wu * 4096;
   };
   auto stage_piece = [&](int i) {  // piece i (0..7) of this wave's share of the selected tile: 4 K then 4 V^T pieces
+    const size_t off = (size_t)st_tile_g * (KB * D);
     if (i < 4)
-      glds16(kt_ptr + ksrc[i], smem + st_base + i * 1024);
+      glds16(a.K + off + ksrc[i], smem + st_base + i * 1024);
     else
-      glds16(vt_ptr + vsrc[i - 4], smem + st_base + K_TILE_BYTES + (i - 4) * 1024);
+      glds16(a.Vt + off + vsrc[i - 4], smem + st_base + K_TILE_BYTES + (i - 4) * 1024);
   };
   auto kread = [&](const unsigned char* sKb, int i) {
     const int kb = i & 1, st = i >> 1;
@@ -644,7 +638,7 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
     const unsigned char* sV0 = smem + (t % NBUF) * BUF_BYTES + K_TILE_BYTES;   // V^T(t)
     const unsigned char* sK2 = smem + (t2 % NBUF) * BUF_BYTES;                 // K(t+2): head of the next tile's ring
     float tq_[64], pq[64];
-    float ls[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float ls[2][4];
     uint32_t pk[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
     float mx[2][4];
     float mn[2] = {0.f, 0.f};
@@ -686,15 +680,30 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
             ring_[i % PF4] = kread(sK2, i + PF4 - 16);
         }
       }
-      // ---- softmax(t) slices: pair k = 0..63 -> fragment f = k >> 4, q-block (k >> 3) & 1, element e = 8 f + (k & 7) ----
+      // ---- softmax(t) slices: pair k = 0..63 -> fragment f = k >> 4, q-block (k >> 3) & 1, element e = 8 f + (k & 7).
+      // Order inside a gap: A (reads only scores), C, B -- so that neither the first VALU after an MFMA nor any VALU directly after a
+      // v_exp consumes that v_exp's result (each would cost a wait state).
+      for_const<64>([&](auto KC) {
+        (void)&sb_, (void)&pf_, (void)&tq__, (void)&pq_, (void)&ls_, (void)&pk_, (void)&mcq_;
+        constexpr int k = decltype(KC)::value;
+        constexpr int f = k >> 4, x = (k >> 3) & 1, e = 8 * f + (k & 7);
+        if constexpr ((50 * k) / 64 == g) {  // stage A
+          tq__[k] = c * sb_[B][x][e >> 4][e & 15] - mcq_[x];
+          asm volatile("" : "+v"(tq__[k]));
+        }
+      });
       for_const<64>([&](auto KC) {
         (void)&sb_, (void)&pf_, (void)&tq__, (void)&pq_, (void)&ls_, (void)&pk_, (void)&mcq_;
         constexpr int k = decltype(KC)::value;
         constexpr int ga = (50 * k) / 64;
         constexpr int f = k >> 4, x = (k >> 3) & 1, e = 8 * f + (k & 7);
         if constexpr (ga + 2 == g) {  // stage C
-          ls_[x][e & 3] += pq_[k];
-          asm volatile("" : "+v"(ls_[x][e & 3]));
+          if constexpr (e < 4) {
+            ls_[x][e & 3] = pq_[k];  // first element of each partial row sum
+          } else {
+            ls_[x][e & 3] += pq_[k];
+            asm volatile("" : "+v"(ls_[x][e & 3]));
+          }
           if constexpr ((e & 1) != 0) {
             pk_[x][(e >> 1) & 3] = pack_bf16x2(pq_[k - 1], pq_[k]);
             asm volatile("" : "+v"(pk_[x][(e >> 1) & 3]));
@@ -711,15 +720,6 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
         if constexpr ((50 * k) / 64 + 1 == g) {  // stage B
           pq_[k] = __builtin_amdgcn_exp2f(tq__[k]);
           asm volatile("" : "+v"(pq_[k]));
-        }
-      });
-      for_const<64>([&](auto KC) {
-        (void)&sb_, (void)&pf_, (void)&tq__, (void)&pq_, (void)&ls_, (void)&pk_, (void)&mcq_;
-        constexpr int k = decltype(KC)::value;
-        constexpr int f = k >> 4, x = (k >> 3) & 1, e = 8 * f + (k & 7);
-        if constexpr ((50 * k) / 64 == g) {  // stage A
-          tq__[k] = c * sb_[B][x][e >> 4][e & 15] - mcq_[x];
-          asm volatile("" : "+v"(tq__[k]));
         }
       });
       // ---- row max of the new scores: 2 q-blocks x 4 chains x 4 v_max3 steps in gaps 52..59 (4 steps per gap); tree, lane-half
@@ -884,9 +884,10 @@ extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O
   const int grid = hslots * a.n_qblk * 8;
   const size_t lds = 4 * (K_TILE_BYTES + V_TILE_BYTES);
   const size_t lds_w4 = 5 * (K_TILE_BYTES + V_TILE_BYTES);  // ring of 4 + trash area (160 KiB: the whole LDS of a CU)
+  // k_attn_w4 (one wave per SIMD) is the default; WF_ATTN_KERNEL=w8 selects the two-waves-per-SIMD ping-pong kernel k_attn
   static const int use_w4 = [] {
     const char* e = getenv("WF_ATTN_KERNEL");
-    return e && e[0] == 'w' ? 1 : 0;
+    return e && e[0] == 'w' && e[1] == '8' ? 0 : 1;
   }();
   if (use_w4) {
     if (Lkp > 1024)
