@@ -445,7 +445,7 @@ template <int KIND>
 __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BUF_BYTES = K_TILE_BYTES + V_TILE_BYTES;
-  constexpr int NBUF = 4;
+  constexpr int NBUF = 5;  // ring of 5 tile buffers = the whole 160 KiB: lets the workgroup barrier run every SECOND tile
 
   const int b = blockIdx.x;
   const int xcd = b & 7, j = b >> 3;
@@ -518,11 +518,11 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
   const bool ragged = (a.kv_len & (KB - 1)) != 0;
 
   // Element offset / LDS slot of the tile being staged (wave-uniform), advanced one tile at a time: a handful of scalar
-  // instructions, no division.  Past the last tile the pieces are still issued (no branch in the MFMA stream) but re-read the last
-  // tile into a 32 KiB trash area behind the ring.
+  // instructions, no division.  Past the last tile the pieces are still issued (no branch in the MFMA stream): they re-read the last
+  // tile into the next ring slots, whose tiles (ntiles-5 ... ntiles-3) are dead by then.
   const uint32_t seg_jump = (uint32_t)(a.H - 1) * tiles_per_seg;  // in tiles: next K/V segment of the same head (all-gathered shards)
   uint32_t st_tile_g = (uint32_t)head * tiles_per_seg;              // global tile index ([segment][head][tile]) of the staged tile
-  int st_tile = 0, st_left = tiles_per_seg;                         // tile number, tiles left in its segment
+  int st_tile = 0, st_left = tiles_per_seg, st_slot = 0;            // tile number, tiles left in its segment, ring slot
   uint32_t st_base = wu * 4096;
   auto stage_next = [&]() {  // select tile st_tile + 1
     ++st_tile;
@@ -530,7 +530,8 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
     const bool wrap = --st_left == 0;
     st_tile_g += live ? (wrap ? 1u + seg_jump : 1u) : 0u;
     st_left = wrap ? tiles_per_seg : st_left;
-    st_base = (live ? (uint32_t)(st_tile & (NBUF - 1)) : (uint32_t)NBUF) * BUF_BYTES + wu * 4096;
+    st_slot = st_slot + 1 == NBUF ? 0 : st_slot + 1;
+    st_base = (uint32_t)st_slot * BUF_BYTES + wu * 4096;
   };
   auto stage_piece = [&](int i) {  // piece i (0..7) of this wave's share of the selected tile: 4 K then 4 V^T pieces
     const size_t off = (size_t)st_tile_g * (KB * D);
@@ -630,13 +631,15 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
 #else
 #define W4MARK(k) do { } while (0)
 #endif
-  auto tile = [&](auto BC, int t) {
+  auto tile = [&](auto BC, int t, int slot0) {  // slot0 = ring slot of tile t
     constexpr int B = decltype(BC)::value;
     const int t1 = t + 1 < ntiles ? t + 1 : t;       // past the end: recompute scores nobody reads
     const int t2 = t + 2 < ntiles ? t + 2 : t1;
-    const unsigned char* sK1 = smem + (t1 % NBUF) * BUF_BYTES;                 // K(t+1): read now
-    const unsigned char* sV0 = smem + (t % NBUF) * BUF_BYTES + K_TILE_BYTES;   // V^T(t)
-    const unsigned char* sK2 = smem + (t2 % NBUF) * BUF_BYTES;                 // K(t+2): head of the next tile's ring
+    const int slot1 = t1 == t ? slot0 : (slot0 + 1 == NBUF ? 0 : slot0 + 1);
+    const int slot2 = t2 == t1 ? slot1 : (slot1 + 1 == NBUF ? 0 : slot1 + 1);
+    const unsigned char* sK1 = smem + slot1 * BUF_BYTES;                 // K(t+1): read now
+    const unsigned char* sV0 = smem + slot0 * BUF_BYTES + K_TILE_BYTES;  // V^T(t)
+    const unsigned char* sK2 = smem + slot2 * BUF_BYTES;                 // K(t+2): head of the next tile's ring
     float tq_[64], pq[64];
     float ls[2][4];
     uint32_t pk[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
@@ -676,7 +679,7 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
         if constexpr (q == 1) {
           if constexpr (i + PF4 < 16)
             ring_[i % PF4] = vread(sV0, i + PF4);
-          else
+          else if constexpr (B == 0)  // an odd tile's successor was staged after the last barrier: its ring is filled behind the next one
             ring_[i % PF4] = kread(sK2, i + PF4 - 16);
         }
       }
@@ -771,10 +774,18 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
       commit(std::integral_constant<int, 1>{}, mn[1]);
     }
     W4MARK(2);
-    drain_dma();
-    W4MARK(3);
-    bar();
-    W4MARK(4);
+    // One barrier per TWO tiles (after the odd ones).  WAR: the pieces of tile t+3 overwrite the slot of tile t-2, whose last reader
+    // ran before the barrier that ended tile t-1 or t-2.  RAW: tile T is staged during tile T-3 and first read for the ring of tile
+    // T-1, i.e. at the tail of tile T-2 -- behind the barrier of tile T-3 when that is odd; when T-3 is even, tile T-2 is odd and
+    // fills the ring after its own barrier instead (every wave drains its own pieces in front of each barrier).
+    if constexpr (B == 1) {
+      drain_dma();
+      W4MARK(3);
+      bar();
+      W4MARK(4);
+#pragma unroll
+      for (int i = 0; i < PF4; ++i) ring[i] = kread(sK2, i);  // K(t+2) was staged during tile t-1: readable only now
+    }
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
@@ -803,13 +814,18 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
     const float m1 = rowmax_now(B0{}, std::integral_constant<int, 1>{});
     commit(std::integral_constant<int, 0>{}, m0);
     commit(std::integral_constant<int, 1>{}, m1);
-    const unsigned char* sK1 = smem + ((ntiles > 1 ? 1 : 0) % NBUF) * BUF_BYTES;
+    const unsigned char* sK1 = smem + (ntiles > 1 ? 1 : 0) * BUF_BYTES;
 #pragma unroll
     for (int i = 0; i < PF4; ++i) ring[i] = kread(sK1, i);
   }
-  for (int t = 0; t < ntiles; t += 2) {
-    tile(B0{}, t);
-    if (t + 1 < ntiles) tile(B1{}, t + 1);
+  {
+    int slot = 0;
+    for (int t = 0; t < ntiles; t += 2) {
+      tile(B0{}, t, slot);
+      slot = slot + 1 == NBUF ? 0 : slot + 1;
+      if (t + 1 < ntiles) tile(B1{}, t + 1, slot);
+      slot = slot + 1 == NBUF ? 0 : slot + 1;
+    }
   }
 #ifdef WF_ATTN_TIMING
   if (lane == 0 && wid == 0) {
@@ -883,7 +899,7 @@ extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O
   const int hslots = (H + 7) / 8;
   const int grid = hslots * a.n_qblk * 8;
   const size_t lds = 4 * (K_TILE_BYTES + V_TILE_BYTES);
-  const size_t lds_w4 = 5 * (K_TILE_BYTES + V_TILE_BYTES);  // ring of 4 + trash area (160 KiB: the whole LDS of a CU)
+  const size_t lds_w4 = 5 * (K_TILE_BYTES + V_TILE_BYTES);  // ring of 5 (160 KiB: the whole LDS of a CU)
   // k_attn_w4 (one wave per SIMD) is the default; WF_ATTN_KERNEL=w8 selects the two-waves-per-SIMD ping-pong kernel k_attn
   static const int use_w4 = [] {
     const char* e = getenv("WF_ATTN_KERNEL");
