@@ -219,10 +219,10 @@ def main():
         if attn_ms:
             avg = sum(attn_ms) / len(attn_ms)
             ach = attn_flop / (avg * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "k_attn (DiT self-attention, model.py:149-154)", "bound": "mfma", "achieved": ach,
+            out["roofline"] = {"kernel": "k_attn_w4<0> (DiT self-attention, model.py:149-154)", "bound": "mfma", "achieved": ach,
                                "peak": MFMA_PEAK_TFLOPS_BF16, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS_BF16,
                                "traffic": ATTN_TRAFFIC_BYTES_C2 if (L == 32760 and world == 1 and cfg.num_heads == 40) else None,
-                               "traffic_source": "rocprofv3 PMC FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, profiles/r1_attn_pmc.md",
+                               "traffic_source": "rocprofv3 PMC FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, profiles/r1_attn_pmc.md (measured on the two-wave kernel k_attn; k_attn_w4 streams the same K / V tiles per 256-row workgroup)",
                                "launches": len(attn_ms), "avg_launch_ms": avg,
                                "flop_per_launch": attn_flop}
         if a.layers != 40:
