@@ -420,6 +420,225 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// One wave per SIMD variant: 256 x 256 tile, 4 waves (2 feature halves x 2 token halves), wave tile 128 features x 128 tokens =
+// 4 x 4 MFMA 32x32x16 tiles = 256 accumulator registers, ALL in AGPRs (inline-asm MFMAs: hipcc picks one accumulator form per
+// function and would otherwise shuttle them through v_accvgpr copies).  With two waves per SIMD (k_gemm_pp) the partner wave's LDS /
+// DMA / address instructions take issue slots from the MFMA wave; here one instruction stream carries 16 MFMAs per k-step with only
+// ~1.3 other instructions per MFMA (8 fragment reads + <= 6 LDS-DMA pieces per 16 MFMAs), all placed in the MFMA issue shadows, so
+// the matrix pipe is paced by itself.  Per K tile (BK = 64 = 4 k-steps): the fragments of k-step s+1 are read during the MFMAs of
+// k-step s; the LDS-DMA pieces of the NEXT tile are issued during k-steps 0-1, drained + workgroup barrier after k-step 2, so
+// that k-step 3 can already prefetch the next tile's first fragments (no MFMA waits on an LDS read after the barrier) and start
+// the pieces of the tile after next (its buffer was last read before that barrier).  Past the last K tile the pieces re-stage
+// the last tile into the dead buffer instead of branching.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int WT = 256;  // threads
+#ifdef WF_GEMM_TIMING
+__device__ unsigned long long g_gemm_cycles[8];
+#endif
+
+template <int EPI>
+__global__ __launch_bounds__(WT, 1) void k_gemm_w4(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int smt = (a.mt + 3) >> 2, snt = (a.nt + 3) >> 2;
+  const int nsuper = smt * snt;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, j = b >> 3;
+  const int gid = (j >> 4) * 8 + xcd;
+  if (gid >= nsuper) return;
+  const int within = j & 15;
+  const int tm = (gid / snt) * 4 + (within >> 2);
+  const int tn = (gid % snt) * 4 + (within & 3);
+  if (tm >= a.mt || tn >= a.nt) return;
+  const int m0 = tm * PM, n0 = tn * PN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wf = wid & 1;   // feature half (128 features)
+  const int wm = wid >> 1;  // token half (128 tokens)
+
+  // LDS-DMA geometry (as k_gemm_pp): operand tile = 256 rows x 128 B = 32 pieces of 1 KiB; wave w moves pieces 8w..8w+7 of W and X
+  const uint16_t* src[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int piece = wid * 8 + i;
+    const int row = 8 * piece + (lane >> 3), slot = lane & 7;
+    const int ch = slot ^ ((row >> 1) & 7);
+    src[i] = a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw + ch * 8;
+    src[8 + i] = a.X + (size_t)min(m0 + row, a.M - 1) * a.ldx + ch * 8;
+  }
+  const int nk = a.K / PK;
+  auto dma_piece = [&](int kt, int i) {  // i in 0..15: W pieces 0..7, X pieces 0..7 of K tile kt (clamped: see header)
+    const int ks = kt < nk ? kt : nk - 1;
+    unsigned char* dst = smem + (kt & 1) * P_BUF + (i < 8 ? 0 : P_TILE) + wid * 8192 + (i & 7) * 1024;
+    glds16(src[i] + (size_t)ks * PK, dst);
+  };
+
+  int offW[4], swW[4], offX[4], swX[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wf * 128 + i * 32 + l31;
+    offW[i] = r * 128;
+    swW[i] = (r >> 1) & 7;
+    const int rx = wm * 128 + i * 32 + l31;
+    offX[i] = P_TILE + rx * 128;
+    swX[i] = (rx >> 1) & 7;
+  }
+  f32x16 acc[4][4];
+  u32x4 fw[2][4], fx[2][4];  // fragment double buffer: k-step parity
+  auto read_frag = [&](int kt, int ks, int which) {  // which 0..3 -> fw[.][which], 4..7 -> fx[.][which-4]
+    const unsigned char* base = smem + (kt & 1) * P_BUF;
+    const int c = 2 * ks + hi;
+    if (which < 4)
+      fw[ks & 1][which] = *reinterpret_cast<const u32x4*>(base + offW[which] + ((c ^ swW[which]) << 4));
+    else
+      fx[ks & 1][which - 4] = *reinterpret_cast<const u32x4*>(base + offX[which - 4] + ((c ^ swX[which - 4]) << 4));
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jx = 0; jx < 4; ++jx) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jx][r] = 0.f;
+      asm volatile("" : "+a"(acc[i][jx]));  // the accumulators enter the loop in AGPRs
+    }
+  auto mma = [&](f32x16& c, const u32x4& wv, const u32x4& xv) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(wv), "v"(xv));
+  };
+  auto bar = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+#ifdef WF_GEMM_TIMING
+  const unsigned long long t_start = __builtin_readcyclecounter();
+#endif
+  // prologue: tile 0 whole, tile 1 pieces 0..7; tile 0 landed -> barrier -> fragments of (tile 0, k-step 0)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dma_piece(0, i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma_piece(1, i);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  bar();
+#pragma unroll
+  for (int q = 0; q < 8; ++q) read_frag(0, 0, q);
+
+#ifdef WF_GEMM_TIMING
+  unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+  const unsigned long long t_loop = tlast;
+#define GMARK(k) do { const unsigned long long n__ = __builtin_readcyclecounter(); tacc[k] += n__ - tlast; tlast = n__; } while (0)
+#else
+#define GMARK(k) do { } while (0)
+#endif
+  for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int idx = 0; idx < 16; ++idx) {
+        const int i = idx >> 2, jx = idx & 3;
+        mma(acc[i][jx], fw[ks & 1][i], fx[ks & 1][jx]);
+        __builtin_amdgcn_sched_barrier(0);
+        // fragments of the next k-step (of the next tile behind the barrier at the end of k-step 2): one read per two MFMAs
+        if ((idx & 1) == 0) {
+          if (ks < 3)
+            read_frag(kt, ks + 1, idx >> 1);
+          else
+            read_frag(kt + 1, 0, idx >> 1);  // past the last tile: reads a dead buffer, never used
+        }
+        // LDS-DMA: k-step 3 -> pieces 0..7 of tile kt+2 (its buffer is free since the barrier), k-step 0 -> pieces 8..15 of tile kt+1
+        if (idx & 1) {
+          const int s_ = idx >> 1;  // 0..7
+          if (ks == 0) dma_piece(kt + 1, 8 + s_);
+          if (ks == 3) dma_piece(kt + 2, s_);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (ks == 2) {
+        GMARK(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1 landed (its last pieces were issued during k-step 0)
+        GMARK(1);
+        bar();
+        GMARK(2);
+      }
+      if (ks == 3) GMARK(3);
+    }
+  }
+#ifdef WF_GEMM_TIMING
+  const unsigned long long t_end_loop = __builtin_readcyclecounter();
+#endif
+
+  // ---- epilogue: lane owns token row m and feature quads (as k_gemm) ------------------------------------------------------
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");  // asm MFMA write -> v_accvgpr_read
+#pragma unroll
+  for (int jx = 0; jx < 4; ++jx) {
+    const int m = m0 + wm * 128 + jx * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x16 av = acc[i][jx];
+      asm volatile("" : "+v"(av));
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wf * 128 + i * 32 + 8 * g + 4 * hi;
+        if (n >= a.N) continue;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = av[4 * g + q];
+        if (a.bias) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += bb[q];
+        }
+        const size_t o = (size_t)m * a.ldo + n;
+        if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+          if constexpr (EPI == EPI_BF16_GELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
+          }
+          u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + o) = pk;
+        } else if constexpr (EPI == EPI_F32) {
+          f32x4 ov = {v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + o) = ov;
+        } else if constexpr (EPI == EPI_F32_ACC) {
+          float* po = reinterpret_cast<float*>(a.out) + o;
+          f32x4 old = *reinterpret_cast<const f32x4*>(po);
+          f32x4 ov = {old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
+          *reinterpret_cast<f32x4*>(po) = ov;
+        } else {
+          float* po = reinterpret_cast<float*>(a.out) + o;
+          f32x4 old = *reinterpret_cast<const f32x4*>(po);
+          f32x4 gg = {1.f, 1.f, 1.f, 1.f};
+          if (a.gate) gg = *reinterpret_cast<const f32x4*>(a.gate + n);
+          f32x4 ov = {old[0] + v[0] * gg[0], old[1] + v[1] * gg[1], old[2] + v[2] * gg[2], old[3] + v[3] * gg[3]};
+          *reinterpret_cast<f32x4*>(po) = ov;
+        }
+      }
+    }
+  }
+#ifdef WF_GEMM_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0 && wid == 0) {
+    const unsigned long long t_end = __builtin_readcyclecounter();
+    for (int q = 0; q < 4; ++q) atomicAdd(&g_gemm_cycles[q], tacc[q]);
+    atomicAdd(&g_gemm_cycles[4], (unsigned long long)nk);
+    atomicAdd(&g_gemm_cycles[5], t_loop - t_start);
+    atomicAdd(&g_gemm_cycles[6], t_end - t_end_loop);
+    atomicAdd(&g_gemm_cycles[7], 1ull);
+  }
+#endif
+}
+
+template <int EPI>
+static void launch_w4(GemmArgs a, hipStream_t s) {
+  a.mt = ceil_div(a.M, PM);
+  a.nt = ceil_div(a.N, PN);
+  const int nsuper = ((a.mt + 3) / 4) * ((a.nt + 3) / 4);
+  const int grid = ((nsuper + 7) / 8) * 8 * 16;
+  hipLaunchKernelGGL(k_gemm_w4<EPI>, dim3(grid), dim3(WT), 2 * P_BUF, s, a);
+}
+
 template <int EPI>
 static void launch_pp(GemmArgs a, hipStream_t s) {
   a.mt = ceil_div(a.M, PM);
@@ -460,6 +679,22 @@ extern "C" int wf_gemm_bf16(const void* X, const void* W, const float* bias, voi
   hipStream_t s = (hipStream_t)stream;
   // large problems with a whole number of 64-wide K tiles take the 256x256 ping-pong kernel
   static const bool no_pp = getenv("WF_GEMM_NO_PP") != nullptr;
+  static const bool use_w4 = [] {
+    const char* e = getenv("WF_GEMM_KERNEL");
+    return e && e[0] == 'w' && e[1] == '4';
+  }();
+  if (use_w4 && !no_pp && K % PK == 0 && M >= 1024 && N >= 256 && (long)M * N >= (1L << 22)) {
+    switch (epilogue) {
+      case EPI_BF16: launch_w4<EPI_BF16>(a, s); break;
+      case EPI_BF16_GELU: launch_w4<EPI_BF16_GELU>(a, s); break;
+      case EPI_F32: launch_w4<EPI_F32>(a, s); break;
+      case EPI_RESID: launch_w4<EPI_RESID>(a, s); break;
+      case EPI_F32_ACC: launch_w4<EPI_F32_ACC>(a, s); break;
+      default: WF_CHECK_ARG(false, "wf_gemm_bf16: unknown epilogue %d", epilogue);
+    }
+    WF_LAUNCH_CHECK("wf_gemm_bf16");
+    return WF_OK;
+  }
   if (!no_pp && K % PK == 0 && M >= 1024 && N >= 256 && (long)M * N >= (1L << 22)) {
     switch (epilogue) {
       case EPI_BF16: launch_pp<EPI_BF16>(a, s); break;
@@ -483,3 +718,14 @@ extern "C" int wf_gemm_bf16(const void* X, const void* W, const float* bias, voi
   WF_LAUNCH_CHECK("wf_gemm_bf16");
   return WF_OK;
 }
+
+#ifdef WF_GEMM_TIMING
+extern "C" int wf_debug_gemm_cycles(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_gemm_cycles), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_cycles), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
