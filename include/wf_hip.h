@@ -171,6 +171,14 @@ int wf_act(const void* a, int dt_a, const void* b, int dt_b, void* out, int dt_o
 int wf_conv3d_cl(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_bf16, int Ti,
                  int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st, int ss, int pt, int ph,
                  int pw, int up2, int tsplit, const void* zero_page, void* stream);
+/* The FLOP-heavy layers (3x3x3, stride 1, causal: every ResidualBlock conv, vae.py:186-220) with the input patch resident in LDS:
+ * an 8 x 64 pixel tile of one output frame x 96 output channels per workgroup, all 27 taps read the (3 x 10 x 66)-pixel patch of a
+ * 16-channel slice from LDS.  Weights in the re-packed layout [27][Cin/16][Cout][16] produced by wf_conv3d_pack333 from
+ * [Cout][27][Cin].  in [T,Hi,Wi,Cin] bf16 (Hi = Ho for ph = 1; row slabs carry their halo rows: Hi = Ho + 2, ph = 0),
+ * out [T,Ho,Wi,Cout]; Cin % 16 == 0, Cout % 32 == 0; zero_page >= 64 bf16 zeros.  Same arithmetic as wf_conv3d_cl. */
+int wf_conv3d_pack333(const void* w, void* w_packed, int Cout, int Cin, void* stream);
+int wf_conv3d_333(const void* in, const void* w_packed, const float* bias, const float* resid, float* out_f32, void* out_bf16, int T,
+                  int Hi, int Wi, int Cin, int Ho, int Cout, int ph, const void* zero_page, void* stream);
 /* Direct convolution for the thin layers (3->96, 16->384, 96->3, 384->32, 1x1x1 quant convs; vae.py:288, 316, 392, 421, 505-506).
  * in f32 or bf16 channels-last, w f32 [taps][Cin][Cout]; clamp > 0 clamps the output (autoencoder_kl_wan.py:1222). */
 int wf_conv3d_small(const void* in, int in_dtype, const float* w, const float* bias, float* out_f32, void* out_bf16, int Ti, int Hi,

@@ -109,9 +109,12 @@ def test_conv3d_c2_sampled_pixels_borders_and_exact_linearity():
     zp = torch.zeros(64, dtype=BF, device=DEV)
     of = torch.empty((T, H, W, C), dtype=F32, device=DEV)
 
-    def run(inp, bias, dst):
-        _ffi.call("wf_conv3d_cl", inp.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None, None, dst.data_ptr(),
-                  None, T, H, W, C, T, H, W, C, 3, 3, 3, 1, 1, 2, 1, 1, 0, 0, zp.data_ptr(), ops.stream())
+    wp = torch.empty((27, C // 16, C, 16), dtype=BF, device=DEV)
+    _ffi.call("wf_conv3d_pack333", wk.data_ptr(), wp.data_ptr(), C, C, ops.stream())
+
+    def run(inp, bias, dst):   # the LDS-resident patch kernel the VAE uses for this layer
+        _ffi.call("wf_conv3d_333", inp.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None, None, dst.data_ptr(),
+                  None, T, H, W, C, H, C, 1, zp.data_ptr(), ops.stream())
 
     run(x, b, of)
     pts = [(0, 0, 0), (0, 0, W - 1), (0, H - 1, 0), (T - 1, H - 1, W - 1), (1, 1, 1), (2, 0, 5), (40, 239, 415), (80, 479, 0),

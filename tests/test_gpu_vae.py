@@ -95,6 +95,49 @@ def test_conv3d_cl_vs_torch(cfg):
     assert (ob.float().cpu() - want).abs().max().item() <= 1e-2 * want.abs().max().item()
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(T=9, H=64, W=64, cin=96, cout=96),        # whole tiles
+    dict(T=5, H=61, W=70, cin=96, cout=192),       # ragged rows and columns, two output-channel blocks
+    dict(T=3, H=24, W=200, cin=192, cout=96),      # several column tiles, last one ragged
+    dict(T=4, H=40, W=104, cin=384, cout=384),     # the 384-wide stage (24 channel slices, 4 output blocks)
+    dict(T=6, H=16, W=64, cin=32, cout=32),        # thin layer: partial output-channel block
+    dict(T=3, H=26, W=66, cin=96, cout=96, halo=True),   # row slab with halo rows (ph = 0, Hi = Ho + 2): the sharded VAE
+])
+def test_conv3d_333_vs_torch(cfg):
+    """wf_conv3d_333 (LDS-resident patch kernel on re-packed weights) against the fp32 reference of the same op."""
+    from worldforge_amd import _ffi, ops
+    g = torch.Generator().manual_seed(5)
+    T, H, W, cin, cout = cfg["T"], cfg["H"], cfg["W"], cfg["cin"], cfg["cout"]
+    halo = cfg.get("halo", False)
+    x = torch.randn(T, H, W, cin, generator=g).to(BF)
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g) / math.sqrt(cin * 27)).to(BF)
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = _conv_ref(x, w.float(), b, (3, 3, 3), 1, 1, 2, 1)          # [T, H, W, cout]
+    if halo:
+        ref = ref[:, 1:-1]                                           # the slab's own rows: input rows 0 and H-1 are halo
+    Ho = ref.shape[1]
+    resid = torch.randn(T, Ho, W, cout, generator=g)
+    wk = w.permute(0, 2, 3, 4, 1).reshape(cout, 27, cin).contiguous().to(DEV)
+    wp = torch.empty((27, cin // 16, cout, 16), dtype=BF, device=DEV)
+    _ffi.call("wf_conv3d_pack333", wk.data_ptr(), wp.data_ptr(), cout, cin, ops.stream())
+    assert torch.equal(wp.permute(2, 0, 1, 3).reshape(cout, 27, cin), wk)
+    xd, bd, rd = x.to(DEV), b.to(DEV), resid.to(DEV)
+    zp = torch.zeros(64, dtype=BF, device=DEV)
+    of = torch.full((T, Ho, W, cout), float("nan"), dtype=F32, device=DEV)
+    ob = torch.empty((T, Ho, W, cout), dtype=BF, device=DEV)
+    _ffi.call("wf_conv3d_333", xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), rd.data_ptr(), of.data_ptr(), ob.data_ptr(), T, H, W, cin, Ho,
+              cout, 0 if halo else 1, zp.data_ptr(), ops.stream())
+    want = ref + resid
+    err = (of.cpu() - want).abs().max().item()
+    assert err <= 2e-3 * max(1.0, want.abs().max().item()), err
+    assert (ob.float().cpu() - want).abs().max().item() <= 1e-2 * want.abs().max().item()
+    # same arithmetic as the generic kernel: fp32 accumulation order differs only within the MFMA k-steps
+    of2 = torch.empty_like(of)
+    _ffi.call("wf_conv3d_cl", xd.data_ptr(), wk.data_ptr(), bd.data_ptr(), rd.data_ptr(), of2.data_ptr(), None, T, H, W, cin, T, Ho, W, cout,
+              3, 3, 3, 1, 1, 2, 0 if halo else 1, 1, 0, 0, zp.data_ptr(), ops.stream())
+    assert (of - of2).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+
+
 def test_conv3d_tsplit_matches_upsample3d_interleave():
     from worldforge_amd import _ffi, ops
     g = torch.Generator().manual_seed(4)

@@ -11,9 +11,15 @@ def bench(T, H, W, cin, cout, k=(3, 3, 3), iters=3):
     b = torch.randn(cout, device=dev)
     out = torch.empty(T, H, W, cout, device=dev)
     zp = torch.zeros(64, dtype=torch.bfloat16, device=dev)
+    wp = torch.empty((27, cin // 16, cout, 16), dtype=torch.bfloat16, device=dev)
+    _ffi.call("wf_conv3d_pack333", w.data_ptr(), wp.data_ptr(), cout, cin, ops.stream())
     def run():
-        _ffi.call("wf_conv3d_cl", x.data_ptr(), w.data_ptr(), b.data_ptr(), None, out.data_ptr(), None, T, H, W, cin, T, H, W, cout,
-                  k[0], k[1], k[2], 1, 1, k[0] - 1, k[1] // 2, k[2] // 2, 0, 0, zp.data_ptr(), ops.stream())
+        if os.environ.get("WF_CONV_NO_W4"):
+            _ffi.call("wf_conv3d_cl", x.data_ptr(), w.data_ptr(), b.data_ptr(), None, out.data_ptr(), None, T, H, W, cin, T, H, W, cout,
+                      k[0], k[1], k[2], 1, 1, k[0] - 1, k[1] // 2, k[2] // 2, 0, 0, zp.data_ptr(), ops.stream())
+        else:
+            _ffi.call("wf_conv3d_333", x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, out.data_ptr(), None, T, H, W, cin, H, cout, 1,
+                      zp.data_ptr(), ops.stream())
     run(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()

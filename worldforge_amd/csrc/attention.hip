@@ -430,17 +430,6 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
 // ======================================================================================================================================
 constexpr int NT4 = 256;
 
-// compile-time loop: f(integral_constant<int, 0>), ..., f(integral_constant<int, N-1>) -- the slice placement below needs every
-// index to be a constant (a #pragma unroll that the optimizer declines turns the register arrays into scratch)
-template <class F, int... Is>
-__device__ __forceinline__ void for_const_impl(F&& f, std::integer_sequence<int, Is...>) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void for_const(F&& f) {
-  for_const_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
-}
-
 template <int KIND>
 __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

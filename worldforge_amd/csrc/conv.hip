@@ -505,6 +505,226 @@ __global__ __launch_bounds__(QT, 2) void k_conv_pp(ConvPPArgs pa) {
 // in: channels-last f32 or bf16; w: [taps][Cin][Cout] f32 (Cout fastest, so consecutive lanes read consecutive weights).
 // One thread per (pixel, co).
 // ------------------------------------------------------------------------------------------------------------------
+// k_conv_w4: 3x3x3 causal convolution (stride 1) with the input patch resident in LDS, one wave per SIMD.
+//
+// The implicit-GEMM kernels above gather every (tap, channel-slice) operand tile from L2, so each input pixel crosses the
+// L2 -> LDS path 27 times: 76 KiB per 1536 MFMA-cycles per CU, ~50 B/clk/CU -- they sit at 650-710 TFLOP/s on every VAE width,
+// bound by that path, not by the matrix pipe.  Here a workgroup computes an 8 x 64 pixel tile of ONE output frame for 96 output
+// channels and keeps, per 16-channel slice, the whole (3 frames) x (8+2 rows) x (64+2 columns) input patch in LDS (63 KiB,
+// double-buffered): all 27 taps read it at shifted addresses (tap offsets are ds_read immediates; 32 consecutive pixels of a
+// fragment are 1 KiB contiguous: no swizzle, no bank conflicts), so a pixel crosses L2 -> LDS ~1.2 times.  Weights never touch
+// LDS: the 96 x 16 weight fragment of a tap is 3 global loads per lane from a re-packed copy [27][Cin/16][Cout][16] (each load is
+// 1 KiB contiguous per wave; from the [Cout][27][Cin] layout the same loads touch 32 cache lines each and the kernel runs at the
+// L2 -> L1 line rate, 3x slower), prefetched 2 taps ahead in a register ring.  4 waves, wave = 2 rows x 64 pixels x 96 channels = 4 x 3 MFMA tiles = 192 accumulator registers in
+// AGPRs (inline-asm MFMAs, see attention.hip); per tap 12 MFMAs with 4 LDS reads + 3 global loads + < 1 LDS-DMA piece in their issue
+// shadows.  Out-of-range taps (causal / spatial padding, ragged tile edges) come from a zeroed page; one barrier per slice.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int WY = 8, WX = 64, W4T = 256;
+constexpr int PR = WY + 2, PC = WX + 2;
+constexpr int PATCH_PX = 3 * PR * PC;      // 1980 pixels of 32 B
+constexpr int PATCH_BUF = 64 * 1024;       // 64 pieces of 1 KiB (1980 * 32 B = 61.9 KiB, the tail of the last piece is padding)
+
+#ifdef WF_CONV_TIMING
+__device__ unsigned long long g_conv_cycles[8];
+#endif
+struct ConvW4Args {
+  ConvArgs c;
+  const uint16_t* zeros;
+  int tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const ConvArgs& a = pa.c;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  // tile: blockIdx.x -> (t, tile_y, tile_x), blockIdx.y -> 96-channel output block
+  int bx = blockIdx.x;
+  const int tx = bx % pa.tiles_x;
+  bx /= pa.tiles_x;
+  const int ty = bx % pa.tiles_y;
+  const int t = bx / pa.tiles_y;
+  const int x0 = tx * WX, y0 = ty * WY;
+  const int n0 = blockIdx.y * 96;
+  const int Cin = a.Cin;
+  const int ns = Cin / 16;
+
+#ifdef WF_CONV_TIMING
+  const unsigned long long tc0 = __builtin_readcyclecounter();
+#endif
+  // ---- LDS-DMA sources of this wave's 16 patch pieces: lane-load q = (16 w + j) * 64 + lane -> patch pixel q >> 1, chunk q & 1 ----
+  const uint16_t* psrc[16];
+  uint32_t pvalid = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int q = (wid * 16 + j) * 64 + lane;
+    const int p = q >> 1, ch = q & 1;
+    const int f = p / (PR * PC), rem = p - f * (PR * PC);
+    const int r = rem / PC, cc = rem - r * PC;
+    const int tt = t - 2 + f, yy = y0 - a.ph + r, xx = x0 - 1 + cc;
+    const bool ok = p < PATCH_PX && tt >= 0 && yy >= 0 && yy < a.Hi && xx >= 0 && xx < a.Wi;
+    psrc[j] = ok ? a.in + (((size_t)tt * a.Hi + yy) * a.Wi + xx) * Cin + ch * 8 : pa.zeros;
+    pvalid |= ok ? (1u << j) : 0u;
+  }
+  const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_offset(smem));
+  auto dma_piece = [&](int cs, int j) {  // piece j of the patch of channel slice cs -> buffer cs & 1
+    const uint16_t* src = psrc[j] + (((pvalid >> j) & 1u) ? cs * 16 : 0);
+    // issued from inline asm: with the builtin hipcc drains vmcnt(0) in front of every later ds_read (it cannot prove that the DMA's
+    // LDS destination does not alias it), i.e. every few MFMAs here.  Ordering is ours: vmcnt + barrier at the end of the slice.
+    glds16_async(src, smem_base + (uint32_t)((cs & 1) * PATCH_BUF + (wid * 16 + j) * 1024));
+  };
+
+  // ---- fragment addressing ----
+  // B (pixels): wave rows 2w, 2w+1 of the tile, two 32-pixel column blocks; patch pixel (dt, row + dy, col + dx), 32 B per pixel
+  uint32_t boff[4];
+#pragma unroll
+  for (int pb = 0; pb < 4; ++pb) {
+    const int rr = pb >> 1, xb = pb & 1;
+    boff[pb] = (uint32_t)(((2 * wid + rr) * PC + xb * 32 + l31) * 32 + hi * 16);
+  }
+  // A (weights): packed [27][Cin/16][Cout][16]; lane row co = n0 + 32 cb + l31, channels 8 hi .. + 7 of the slice
+  const uint32_t aoff = (uint32_t)((l31 * 16 + 8 * hi) * 2);
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.w) + (size_t)n0 * 32;
+  const size_t wslice = (size_t)a.Cout * 32;  // bytes per (tap, slice)
+  auto wload = [&](int cs, int tap, int cb) {
+    const int csc = cs < ns ? cs : ns - 1;  // past the last slice: a valid address whose data is never used
+    const unsigned char* sb = wbase + (size_t)(tap * ns + csc) * wslice + cb * 1024;
+    return *reinterpret_cast<const u32x4*>(sb + aoff);
+  };
+
+  f32x16 acc[4][3];
+#pragma unroll
+  for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[pb][cb][r] = 0.f;
+      asm volatile("" : "+a"(acc[pb][cb]));
+    }
+  auto mma = [&](f32x16& c, const u32x4& wv, const u32x4& xv) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(wv), "v"(xv));
+  };
+  auto bar = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  u32x4 bf[2][4];  // pixel fragments: tap parity (27 taps: tap 26 and the next slice's tap 0 share slot 0, refilled behind the barrier)
+  u32x4 af[3][3];  // weight fragments: ring over taps, 2 ahead (27 = 9 x 3: the slot of a tap is tap % 3 in every slice)
+  auto bread = [&](int buf, int tap, int pb) {
+    const int dt = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+    const unsigned char* base = smem + buf * PATCH_BUF + ((dt * PR + dy) * PC + dx) * 32;
+    return *reinterpret_cast<const u32x4*>(base + boff[pb]);
+  };
+
+  // prologue: patch of slice 0, weights of taps 0, 1, then the pixel fragments of tap 0
+#pragma unroll
+  for (int j = 0; j < 16; ++j) dma_piece(0, j);
+#pragma unroll
+  for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb) af[tp][cb] = wload(0, tp, cb);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // the 16 pieces landed (the 6 weight loads were issued after them)
+  bar();
+#pragma unroll
+  for (int pb = 0; pb < 4; ++pb) bf[0][pb] = bread(0, 0, pb);
+
+#ifdef WF_CONV_TIMING
+  const unsigned long long tc1 = __builtin_readcyclecounter();
+  unsigned long long t_wait = 0;
+#endif
+  for (int cs = 0; cs < ns; ++cs) {
+    const int buf = cs & 1;
+    const int csn = cs + 1 < ns ? cs + 1 : cs;  // last slice: harmless re-stage into the dead buffer
+    for_const<27>([&](auto TC) {
+      constexpr int tap = decltype(TC)::value;
+      constexpr int ntap = tap + 2 < 27 ? tap + 2 : tap + 2 - 27;
+      const int ncs = tap + 2 < 27 ? cs : cs + 1;
+      for_const<12>([&](auto MC) {
+        (void)&acc, (void)&af, (void)&bf;
+        constexpr int m = decltype(MC)::value;
+        constexpr int cb = m % 3, pb = m / 3;
+        mma(acc[pb][cb], af[tap % 3][cb], bf[tap & 1][pb]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (m < 4 && tap < 26) bf[(tap + 1) & 1][m] = bread(buf, tap + 1, m);  // next tap's pixel fragments
+        if constexpr (m >= 4 && m < 7) af[(tap + 2) % 3][m - 4] = wload(ncs, ntap, m - 4);  // weights two taps ahead
+        // next slice's patch, 2 pieces per tap over taps 0..7.  (Measured: the gather -- 32 B per pixel, 32-64 cache lines per piece --
+        // costs ~300 cycles of issue per piece, 30 % of the loop; weights 10 %; the LDS fragment reads nothing.)
+        if constexpr ((m == 8 || m == 10) && tap < 8) dma_piece(csn, 2 * tap + (m - 8) / 2);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+#ifdef WF_CONV_TIMING
+    const unsigned long long tw0 = __builtin_readcyclecounter();
+#endif
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // patch of slice cs+1 landed (only the 6 prefetched weight loads are younger)
+    bar();
+#ifdef WF_CONV_TIMING
+    t_wait += __builtin_readcyclecounter() - tw0;
+#endif
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) bf[0][pb] = bread(buf ^ 1, 0, pb);
+  }
+
+#ifdef WF_CONV_TIMING
+  const unsigned long long tc2 = __builtin_readcyclecounter();
+#endif
+  // ---- epilogue ----
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
+#pragma unroll
+  for (int pb = 0; pb < 4; ++pb) {
+    const int y = y0 + 2 * wid + (pb >> 1), x = x0 + (pb & 1) * 32 + l31;
+    const bool inb = y < a.Ho && x < a.Wo;
+    const size_t m = ((size_t)t * a.Ho + y) * a.Wo + x;
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb) {
+      f32x16 av = acc[pb][cb];
+      asm volatile("" : "+v"(av));
+      if (!inb) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = n0 + cb * 32 + 8 * g + 4 * hi;
+        if (co >= a.Cout) continue;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = av[4 * g + q];
+        if (a.bias) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += bb[q];
+        }
+        const size_t o = m * a.Cout + co;
+        if (a.resid) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(a.resid + o);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += rr[q];
+        }
+        if (a.out_f32) {
+          f32x4 ov = {v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(a.out_f32 + o) = ov;
+        }
+        if (a.out_bf16) {
+          u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(a.out_bf16 + o) = pk;
+        }
+      }
+    }
+  }
+#ifdef WF_CONV_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0 && wid == 0) {
+    const unsigned long long tc3 = __builtin_readcyclecounter();
+    atomicAdd(&g_conv_cycles[0], tc1 - tc0);
+    atomicAdd(&g_conv_cycles[1], tc2 - tc1);
+    atomicAdd(&g_conv_cycles[2], tc3 - tc2);
+    atomicAdd(&g_conv_cycles[3], t_wait);
+    atomicAdd(&g_conv_cycles[4], (unsigned long long)ns);
+    atomicAdd(&g_conv_cycles[5], 1ull);
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 struct SmallConvArgs {
   const void* in;
   int in_bf16;
@@ -607,3 +827,64 @@ extern "C" int wf_conv3d_small(const void* in, int in_dtype, const float* w, con
   WF_LAUNCH_CHECK("wf_conv3d_small");
   return WF_OK;
 }
+
+// weight re-pack for k_conv_w4: [Cout][27][Cin] -> [27][Cin/16][Cout][16]
+namespace {
+__global__ void k_pack333(const uint16_t* __restrict__ w, uint16_t* __restrict__ o, int Cout, int Cin) {
+  const size_t n = (size_t)Cout * 27 * Cin;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin);
+    const int tap = (int)((i / Cin) % 27);
+    const int co = (int)(i / ((size_t)Cin * 27));
+    o[(((size_t)tap * (Cin / 16) + ci / 16) * Cout + co) * 16 + (ci & 15)] = w[i];
+  }
+}
+}  // namespace
+
+extern "C" int wf_conv3d_pack333(const void* w, void* w_packed, int Cout, int Cin, void* stream) {
+  WF_CHECK_ARG(w && w_packed, "wf_conv3d_pack333: null pointer");
+  WF_CHECK_ARG(Cin % 16 == 0 && Cout > 0, "wf_conv3d_pack333: Cin (%d) must be a multiple of 16", Cin);
+  hipLaunchKernelGGL(k_pack333, dim3(512), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)w, (uint16_t*)w_packed, Cout, Cin);
+  WF_LAUNCH_CHECK("wf_conv3d_pack333");
+  return WF_OK;
+}
+
+extern "C" int wf_conv3d_333(const void* in, const void* w_packed, const float* bias, const float* resid, float* out_f32,
+                             void* out_bf16, int T, int Hi, int Wi, int Cin, int Ho, int Cout, int ph, const void* zero_page,
+                             void* stream) {
+  WF_CHECK_ARG(in && w_packed && zero_page && (out_f32 || out_bf16), "wf_conv3d_333: null pointer");
+  WF_CHECK_ARG(Cin % 16 == 0 && Cout % 32 == 0, "wf_conv3d_333: Cin (%d) %% 16 and Cout (%d) %% 32 must be 0", Cin, Cout);
+  WF_CHECK_ARG((long)27 * Cin * Cout * 2 < (1L << 31), "wf_conv3d_333: weight tensor too large");
+  if ((long)T * Ho * Wi == 0) return WF_OK;
+  ConvW4Args wa;
+  ConvArgs& a = wa.c;
+  a.in = (const uint16_t*)in;
+  a.w = (const uint16_t*)w_packed;
+  a.bias = bias;
+  a.resid = resid;
+  a.out_f32 = out_f32;
+  a.out_bf16 = (uint16_t*)out_bf16;
+  a.Ti = T; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin;
+  a.To = T; a.Ho = Ho; a.Wo = Wi; a.Cout = Cout;
+  a.kt = a.kh = a.kw = 3;
+  a.st = a.ss = 1; a.pt = 2; a.ph = ph; a.pw = 1;
+  a.up2 = a.tsplit = a.silu_out = 0;
+  wa.zeros = (const uint16_t*)zero_page;
+  wa.tiles_x = (Wi + WX - 1) / WX;
+  wa.tiles_y = (Ho + WY - 1) / WY;
+  dim3 grid((unsigned)(wa.tiles_x * wa.tiles_y * T), (unsigned)((Cout + 95) / 96));
+  hipLaunchKernelGGL(k_conv_w4, grid, dim3(W4T), 2 * PATCH_BUF, (hipStream_t)stream, wa);
+  WF_LAUNCH_CHECK("wf_conv3d_333");
+  return WF_OK;
+}
+
+#ifdef WF_CONV_TIMING
+extern "C" int wf_debug_conv_cycles(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_conv_cycles), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_conv_cycles), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

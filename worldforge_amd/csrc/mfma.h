@@ -11,6 +11,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 namespace wf {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -70,6 +73,17 @@ __device__ __forceinline__ void glds16_async(const void* gsrc, uint32_t lds_wave
 }
 __device__ __forceinline__ uint32_t lds_offset(const void* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+// compile-time loop: f(integral_constant<int, 0>), ..., f(integral_constant<int, N-1>).  Hand-placed instruction streams need every
+// index to be a constant (a #pragma unroll that the optimizer declines turns register arrays into scratch).
+template <class F, int... Is>
+__device__ __forceinline__ void for_const_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void for_const(F&& f) {
+  for_const_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
 }  // namespace wf

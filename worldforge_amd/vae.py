@@ -15,6 +15,8 @@ two MFMA GEMMs around a row softmax.  fp32 residual stream, bf16 MFMA operands, 
 """
 from __future__ import annotations
 
+import os
+
 import math
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Tuple
@@ -223,12 +225,33 @@ class AutoencoderKLWan:
         of = torch.empty(shape, dtype=F32, device=x.device) if out_f32 else None
         ob = out_bf_tensor if out_bf_tensor is not None else (torch.empty(shape, dtype=BF, device=x.device) if out_bf16 else None)
         W = self.w
-        call("wf_conv3d_cl", x.data_ptr(), W[p + ".w"].data_ptr(), W[p + ".b"].data_ptr(),
-             resid.data_ptr() if resid is not None else None, of.data_ptr() if of is not None else None,
-             ob.data_ptr() if ob is not None else None, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, k[0], k[1], k[2], st, ss, pt,
-             ps if ph is None else ph, ps, 1 if up2 else 0, 1 if tsplit else 0, self._zero_page().data_ptr(), ops.stream())
+        if (tuple(k) == (3, 3, 3) and st == 1 and ss == 1 and pt == 2 and ps == 1 and not up2 and not tsplit and To == Ti and Wo == Wi
+                and Cin % 16 == 0 and Cout % 32 == 0 and not os.environ.get("WF_CONV_NO_W4")):
+            # the FLOP-heavy layers: LDS-resident input patch kernel on re-packed weights (packed once per layer, cached).  Chosen by
+            # layer type only, never by size: a row slab of the sharded VAE must run the same arithmetic as the whole image
+            call("wf_conv3d_333", x.data_ptr(), self._packed333(p, Cout, Cin).data_ptr(), W[p + ".b"].data_ptr(),
+                 resid.data_ptr() if resid is not None else None, of.data_ptr() if of is not None else None,
+                 ob.data_ptr() if ob is not None else None, Ti, Hi, Wi, Cin, Ho, Cout, ps if ph is None else ph,
+                 self._zero_page().data_ptr(), ops.stream())
+        else:
+            call("wf_conv3d_cl", x.data_ptr(), W[p + ".w"].data_ptr(), W[p + ".b"].data_ptr(),
+                 resid.data_ptr() if resid is not None else None, of.data_ptr() if of is not None else None,
+                 ob.data_ptr() if ob is not None else None, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, k[0], k[1], k[2], st, ss, pt,
+                 ps if ph is None else ph, ps, 1 if up2 else 0, 1 if tsplit else 0, self._zero_page().data_ptr(), ops.stream())
         self.flops_last += 2 * To * Ho * Wo * Cout * k[0] * k[1] * k[2] * Cin
         return of, ob
+
+    def _packed333(self, p, Cout, Cin):
+        """[Cout][27][Cin] -> [27][Cin/16][Cout][16] copy of a 3x3x3 weight for wf_conv3d_333 (keyed by the weight tensor's identity so
+        that instances sharing `w` and reloaded weights stay consistent)."""
+        w = self.w[p + ".w"]
+        cache = self.__dict__.setdefault("_packed", {})
+        hit = cache.get(p)
+        if hit is None or hit[0] is not w:
+            out = torch.empty((27, Cin // 16, Cout, 16), dtype=BF, device=w.device)
+            call("wf_conv3d_pack333", w.data_ptr(), out.data_ptr(), Cout, Cin, ops.stream())
+            cache[p] = hit = (w, out)
+        return hit[1]
 
     def _zero_page(self):
         z = getattr(self, "_zeros", None)
