@@ -10,33 +10,49 @@ using namespace wf;
 
 namespace {
 
-// one wave per pixel: C f32 channels (C % 4 == 0, C <= 1024)
+// RMS_norm (+ SiLU) over the C f32 channels of each pixel (C % 4 == 0, C <= 1024).  A pixel is handled by a group of G lanes
+// (G = 8 / 16 / 32 / 64 for C <= 128 / 256 / 512 / 1024: three or four float4 per lane), i.e. 64 / G pixels per wave: with one wave per
+// pixel only 24 of 64 lanes worked at C = 96 and the kernel ran at 2.4 TB/s.  The sum of squares is reduced inside the group by
+// xor-shuffles (fixed order: bit-identical wherever the pixel sits).
+template <int G>
 __global__ __launch_bounds__(256) void k_rms_silu(const float* __restrict__ x, const float* __restrict__ gamma,
                                                   uint16_t* __restrict__ out_bf16, float* __restrict__ out_f32, int C,
                                                   float scale, int silu, size_t npix) {
+  constexpr int PPW = 64 / G;  // pixels per wave
   const int lane = threadIdx.x & 63;
+  const int sub = lane & (G - 1), q = lane / G;
   const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
   const int nvec = C >> 2;
-  for (size_t p = wave; p < npix; p += nwaves) {
-    const float4* xr = reinterpret_cast<const float4*>(x + p * C);
+  float4 g4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = sub + G * i;
+    g4[i] = id < nvec ? reinterpret_cast<const float4*>(gamma)[id] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (size_t p0 = wave * PPW; p0 < npix; p0 += nwaves * PPW) {
+    const size_t p = p0 + q;
+    const bool live = p < npix;
+    const float4* xr = reinterpret_cast<const float4*>(x + (live ? p : 0) * C);
     float4 v[4];
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int id = lane + 64 * i;
+      const int id = sub + G * i;
       if (id < nvec) {
         v[i] = xr[id];
         ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
       }
     }
-    ss = wave_sum(ss);
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     const float inv = scale / fmaxf(sqrtf(ss), 1e-12f);  // F.normalize eps = 1e-12
+    if (!live) continue;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int id = lane + 64 * i;
+      const int id = sub + G * i;
       if (id < nvec) {
-        const float4 g = reinterpret_cast<const float4*>(gamma)[id];
+        const float4 g = g4[i];
         float y[4] = {v[i].x * inv * g.x, v[i].y * inv * g.y, v[i].z * inv * g.z, v[i].w * inv * g.w};
         if (silu) {
 #pragma unroll
@@ -122,10 +138,19 @@ extern "C" int wf_rms_silu_cl(const float* x, const float* gamma, void* out_bf16
   WF_CHECK_ARG(x && gamma && (out_bf16 || out_f32), "wf_rms_silu_cl: null pointer");
   WF_CHECK_ARG(C % 4 == 0 && C > 0 && C <= 1024, "wf_rms_silu_cl: C=%d must be a multiple of 4 and <= 1024", C);
   if (npix == 0) return WF_OK;
-  size_t blocks = (npix + 3) / 4;
+  const int G = C <= 128 ? 8 : (C <= 256 ? 16 : (C <= 512 ? 32 : 64));
+  size_t blocks = (npix + (size_t)(4 * (64 / G)) - 1) / (size_t)(4 * (64 / G));
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(k_rms_silu, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, (uint16_t*)out_bf16,
-                     out_f32, C, sqrtf((float)C), silu, npix);
+  const float sc = sqrtf((float)C);
+  hipStream_t st = (hipStream_t)stream;
+  if (G == 8)
+    hipLaunchKernelGGL(k_rms_silu<8>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix);
+  else if (G == 16)
+    hipLaunchKernelGGL(k_rms_silu<16>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix);
+  else if (G == 32)
+    hipLaunchKernelGGL(k_rms_silu<32>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix);
+  else
+    hipLaunchKernelGGL(k_rms_silu<64>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix);
   WF_LAUNCH_CHECK("wf_rms_silu_cl");
   return WF_OK;
 }
