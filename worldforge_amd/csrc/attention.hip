@@ -10,24 +10,28 @@
 //                                    P.V MFMA reads its A operand (d x keys) with plain 16-byte LDS reads, no transpose
 //   O  [Lq][H*128] bf16 (token-major: the A operand of the o-projection GEMM)
 //
-// Structure: one workgroup = 8 waves = 256 query rows of one head; each wave owns 32 query rows for the whole KV sweep.
+// Two kernels share the layouts and the MFMA formulation below:
+//   k_attn_w4 (default)   one wave per SIMD, 4 waves x 64 query rows, MFMA and softmax hand-placed in ONE instruction stream
+//                         (description at the kernel);
+//   k_attn    (WF_ATTN_KERNEL=w8)  8 waves x 32 query rows, two per SIMD, the first design: two wave groups run
+//                         [M = interleaved QK^T / P.V MFMAs | S = softmax + LDS-DMA issue] one phase apart.
+// Common to both:
 //   * "swapped" QK^T: S^T[key][q] = mfma(A = K tile, B = Q^T), so a lane owns ONE query column and 32 of the 64 scores of
-//     a KV tile: the row max / row sum are in-lane reductions plus one exchange with lane^32;
+//     a KV tile: the row max / row sum are in-lane reductions plus one exchange with lane^32 (v_permlane32_swap);
 //   * the K rows are fed to the MFMA with index bits 2 and 3 swapped, which makes the scores a lane holds in registers
 //     8m..8m+7 exactly the 8 consecutive keys the P^T B-operand of the P.V MFMA needs: P never leaves registers and
 //     needs no cross-lane movement (cvt to bf16 only);
 //   * O^T[d][q] += mfma(A = V^T tile, B = P^T): the lane ends up with quads of consecutive head-dim values of its query
 //     row -> 8-byte stores;
-//   * K and V^T tiles live in a ring of three 32 KiB LDS buffers filled by LDS-DMA (global_load_lds, no staging VGPRs, no
+//   * K and V^T tiles live in a ring of 32 KiB LDS buffers filled by LDS-DMA (global_load_lds, no staging VGPRs, no
 //     ds_write pass); the XOR swizzle of the LDS image -- 16-byte chunk c of row r at c ^ (r & 15) (K, 256-B rows) resp.
 //     c ^ ((r >> 1) & 7) (V^T, 128-B rows), conflict-free for the ds_read_b128 lane groups (SQ_LDS_BANK_CONFLICT = 0) -- is
 //     applied to the per-lane SOURCE address because the DMA destination is lane-linear;
-//   * MFMA operand fragments are read 4 ahead of the MFMA that consumes them and the read/MFMA interleave is pinned with
-//     sched_group_barrier (hipcc otherwise serialises read -> wait -> MFMA through one register quad);
-//   * ping-pong: the 8 waves form two groups (one wave of each per SIMD) that run [QK^T | softmax | P.V] one phase apart,
-//     phase-locked by raw s_barrier, so the VALU-only softmax of one wave coincides with an MFMA phase of the other;
-//   * online softmax in fp32 with exp2 and the 1/sqrt(d)*log2(e) scale folded into one FMA; O is rescaled only when some
-//     row maximum in the wave actually grew (exact, threshold 0);
+//   * QK^T and P.V MFMAs are interleaved: an MFMA that accumulates into the result of one issued < ~4 issue slots earlier stalls
+//     (QK^T alone, two score accumulators: 850-1050 cycles per 16 MFMAs instead of 512);
+//   * online softmax in fp32 with exp2 and the 1/sqrt(d)*log2(e) scale folded into one FMA; k_attn rescales O whenever a row
+//     maximum of the wave grew, k_attn_w4 defers the rescale until it grew by more than 2^8 (the same m is used for P and for the
+//     row sum, so the result is exact for any reference m);
 //   * XCD-aware grid: workgroup b runs on XCD b % 8; all query blocks of a head are given to one XCD so its 32 CUs share
 //     that head's K / V^T stream through their L2.
 #include "common.h"
