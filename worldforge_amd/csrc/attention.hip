@@ -526,12 +526,21 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
     st_slot = st_slot + 1 == NBUF ? 0 : st_slot + 1;
     st_base = (uint32_t)st_slot * BUF_BYTES + wu * 4096;
   };
+  const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_offset(smem));
+  uint32_t kbyte[4], vbyte[4];  // per-lane byte offsets of the pieces inside a tile (constant): uniform base + 32-bit VGPR offset is
+#pragma unroll                   // the saddr form of global_load_lds -- no 64-bit address arithmetic on the VALU per piece
+  for (int i = 0; i < 4; ++i) {
+    kbyte[i] = (uint32_t)ksrc[i] * 2u;
+    vbyte[i] = (uint32_t)vsrc[i] * 2u;
+  }
   auto stage_piece = [&](int i) {  // piece i (0..7) of this wave's share of the selected tile: 4 K then 4 V^T pieces
-    const size_t off = (size_t)st_tile_g * (KB * D);
+    const size_t off = (size_t)st_tile_g * (size_t)(KB * D * 2);
+    const unsigned char* kb_ = reinterpret_cast<const unsigned char*>(a.K) + off;
+    const unsigned char* vb_ = reinterpret_cast<const unsigned char*>(a.Vt) + off;
     if (i < 4)
-      glds16(a.K + off + ksrc[i], smem + st_base + i * 1024);
+      glds16_saddr(kb_, kbyte[i], smem_base + st_base + i * 1024);
     else
-      glds16(a.Vt + off + vsrc[i - 4], smem + st_base + K_TILE_BYTES + (i - 4) * 1024);
+      glds16_saddr(vb_, vbyte[i - 4], smem_base + st_base + K_TILE_BYTES + (i - 4) * 1024);
   };
   auto kread = [&](const unsigned char* sKb, int i) {
     const int kb = i & 1, st = i >> 1;
@@ -762,7 +771,8 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
     });
-    if (t + 1 < ntiles) {
+    // one test for both q-blocks in the hot path; the (rare) commits re-test per q-block
+    if (t + 1 < ntiles && __any(c * fmaxf(mn[0] - m_run[0], mn[1] - m_run[1]) > 8.0f)) {
       commit(std::integral_constant<int, 0>{}, mn[0]);
       commit(std::integral_constant<int, 1>{}, mn[1]);
     }

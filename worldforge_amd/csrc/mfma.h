@@ -71,6 +71,17 @@ __device__ __forceinline__ void glds16_async(const void* gsrc, uint32_t lds_wave
       : "v"(gsrc), "s"(lds_wave_base_byte)
       : "memory");
 }
+// LDS-DMA in the saddr form: wave-uniform 64-bit base in SGPRs + 32-bit per-lane byte offset -- no 64-bit VALU address arithmetic.
+// Inline asm like glds16_async (the caller owns the ordering: s_waitcnt vmcnt + barrier before anyone reads the destination).
+__device__ __forceinline__ void glds16_saddr(const void* base_uniform, uint32_t voff_bytes, uint32_t lds_wave_base_byte) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(voff_bytes), "s"(base_uniform), "s"(lds_wave_base_byte)
+      : "memory", "m0");
+}
 __device__ __forceinline__ uint32_t lds_offset(const void* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
