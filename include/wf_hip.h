@@ -136,6 +136,12 @@ int wf_gemm_bf16(const void* X, const void* W, const float* bias, void* out, con
  * (seg_len % 64 == 0, Lkp = P*seg_len) and key index = seg*seg_len + row. */
 int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len, int ldo,
                 float softmax_scale, int accumulate, void* stream);
+/* The same with the KV sweep split nsplit ways (each split leaves un-normalised partials in the workspace, a merge kernel combines
+ * them exactly): fills the chip when Lq is short, e.g. one rank's token shard of the sequence-parallel DiT (Lq = 4096 at 8 ranks:
+ * 640 workgroups on 256 CUs).  workspace: wf_attn_split_workspace_bytes(H, Lq, nsplit) bytes, 16-byte aligned. */
+size_t wf_attn_split_workspace_bytes(int H, int Lq, int nsplit);
+int wf_attn_fwd_split(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len, int ldo,
+                      float softmax_scale, int accumulate, int nsplit, void* workspace, void* stream);
 
 /* WanLayerNorm (model.py:92-102; eps, no affine) fused with y = ln * (plus_one + mul[c]) + add[c]:
  *   AdaLN modulate (model.py:303, 311, 346): mul = scale e[1]/e[4], add = shift e[0]/e[3], plus_one = 1;

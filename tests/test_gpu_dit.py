@@ -110,6 +110,43 @@ def test_attention(H, Lq, Lk):
     assert _rel(out, 2 * ref) <= 1.5e-2
 
 
+@pytest.mark.parametrize("H,Lq,Lk,nsplit,segs", [(2, 300, 1000, 2, 1), (1, 256, 4524, 3, 1), (3, 77, 640, 2, 1), (2, 500, 1024, 2, 4),
+                                                  (1, 128, 8192 + 37, 8, 1)])
+def test_attention_kv_splits(H, Lq, Lk, nsplit, segs):
+    """wf_attn_fwd_split: KV sweep split nsplit ways + exact merge (used when one rank's token shard is too short to fill the chip).
+    Ragged last tile, spiked keys in the LAST split (its reference max differs from the others'), all-gathered K/V segments."""
+    from worldforge_amd import dit
+    scale = 1 / math.sqrt(128)
+    q = _rand((H, Lq, 128), 30).to(BF)
+    k = _rand((H, Lk, 128), 31)
+    k[:, Lk - 3] = q[:, 5].float() * 4.0     # a late spike: the last split sees a much larger row max for query 5
+    k = k.to(BF)
+    v = _rand((H, Lk, 128), 32).to(BF)
+    Lkp = (Lk + 63) // 64 * 64
+    if segs > 1:
+        assert Lkp % (segs * 64) == 0
+    kp = torch.zeros((H, Lkp, 128), dtype=BF)
+    kp[:, :Lk] = k
+    vp = torch.zeros((H, Lkp, 128), dtype=BF)
+    vp[:, :Lk] = v
+    vt = vp.view(H, Lkp // 64, 64, 128).transpose(2, 3).contiguous()
+    kd, vd = kp.to(DEV), vt.to(DEV)
+    if segs > 1:  # shard-major layout of the sequence-parallel DiT: [P][H][seg][128], [P][H][seg/64][128][64]
+        seg = Lkp // segs
+        kd = kd.view(H, segs, seg, 128).transpose(0, 1).contiguous()
+        vd = vd.view(H, segs, seg // 64, 128, 64).transpose(0, 1).contiguous()
+    ref = _attn_ref(q.float(), k.float(), v.float(), scale)
+    one = torch.empty((Lq, H * 128), dtype=BF, device=DEV)
+    dit.attention(q.to(DEV), kd, vd, one, Lk, scale, nsplit=1)
+    out = torch.full((Lq, H * 128), float("nan"), dtype=BF, device=DEV)
+    dit.attention(q.to(DEV), kd, vd, out, Lk, scale, nsplit=nsplit)
+    assert torch.isfinite(out).all()
+    assert _rel(out, ref) <= 1e-2, _rel(out, ref)
+    assert _rel(out, one.float().cpu()) <= 6e-3        # same math, different association: bf16 output rounding apart
+    dit.attention(q.to(DEV), kd, vd, out, Lk, scale, accumulate=True, nsplit=nsplit)
+    assert _rel(out, 2 * ref) <= 1.5e-2
+
+
 def test_attention_online_softmax_rescale_is_exercised():
     """Spike late keys so the running maximum jumps in the last tiles (forces the O / l rescale branch)."""
     from worldforge_amd import dit

@@ -47,8 +47,11 @@ def bench_attn_shard(L, P, H=40):
     k = torch.randn(P, H, Lp, 128, device=dev).to(torch.bfloat16)
     vt = torch.randn(P, H, Lp // 64, 128, 64, device=dev).to(torch.bfloat16)
     out = torch.empty(Lq, H * 128, device=dev, dtype=torch.bfloat16)
+    ns = dit.kv_splits(H, Lq, L)
     ms = timeit(lambda: dit.attention(q, k, vt, out, L, 1 / math.sqrt(128)))
+    ms1 = timeit(lambda: dit.attention(q, k, vt, out, L, 1 / math.sqrt(128), nsplit=1))
     flop = 4.0 * Lq * L * 128 * H
+    print(f"attn shard P={P} nsplit={ns} (unsplit {ms1:.2f} ms)")
     print(f"attn shard P={P} Lq={Lq} L={L}: {ms:.2f} ms  {flop / ms / 1e9:.1f} TFLOP/s  ({flop / ms / 1e9 / 2500 * 100:.1f}% of 2.5 PF)")
 
 

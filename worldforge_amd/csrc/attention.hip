@@ -63,6 +63,10 @@ struct AttnArgs {
   float scale_log2;  // softmax_scale * log2(e)
   int accumulate;    // O += result (second cross-attention, model.py:227)
   int prio_mode;     // experiment: 1 = static s_setprio 1 for waves 4-7, 2 = for waves 0-3
+  // split-KV (k_attn_w4 only): blockIdx.y = split s works on KV tiles [s * tiles_per_split, ...) and leaves un-normalised partials
+  int nsplit, tiles_per_split;
+  float* o_part;   // [nsplit][Lq][H*128] f32
+  float* ml_part;  // [nsplit][H][Lq][2] f32: reference max m (raw score units), row sum l
 };
 
 #ifdef WF_ATTN_TIMING
@@ -507,15 +511,19 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
     for (int i = 0; i < 4; ++i) pf[x][i] = as_bf16x8(u32x4{0u, 0u, 0u, 0u});
   }
   const float c = a.scale_log2;
-  const int ntiles = (a.kv_len + KB - 1) / KB;
+  const int ntiles_all = (a.kv_len + KB - 1) / KB;
+  const int split = blockIdx.y;
+  const int t_begin = split * a.tiles_per_split;                         // first KV tile of this split (absolute)
+  const int ntiles = min(a.tiles_per_split, ntiles_all - t_begin);       // tiles of this split (>= 1 by construction of the grid)
   const bool ragged = (a.kv_len & (KB - 1)) != 0;
 
   // Element offset / LDS slot of the tile being staged (wave-uniform), advanced one tile at a time: a handful of scalar
   // instructions, no division.  Past the last tile the pieces are still issued (no branch in the MFMA stream): they re-read the last
   // tile into the next ring slots, whose tiles (ntiles-5 ... ntiles-3) are dead by then.
   const uint32_t seg_jump = (uint32_t)(a.H - 1) * tiles_per_seg;  // in tiles: next K/V segment of the same head (all-gathered shards)
-  uint32_t st_tile_g = (uint32_t)head * tiles_per_seg;              // global tile index ([segment][head][tile]) of the staged tile
-  int st_tile = 0, st_left = tiles_per_seg, st_slot = 0;            // tile number, tiles left in its segment, ring slot
+  const int seg0 = t_begin / tiles_per_seg, in0 = t_begin - seg0 * tiles_per_seg;
+  uint32_t st_tile_g = (uint32_t)(seg0 * a.H + head) * tiles_per_seg + in0;  // global tile index ([segment][head][tile]) of the staged tile
+  int st_tile = 0, st_left = tiles_per_seg - in0, st_slot = 0;               // tile number (in the split), tiles left in its segment, ring slot
   uint32_t st_base = wu * 4096;
   auto stage_next = [&]() {  // select tile st_tile + 1
     ++st_tile;
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          int key = t * KB + 32 * kb + 16 * (r >> 3) + 8 * hi + (r & 7);
+          int key = (t_begin + t) * KB + 32 * kb + 16 * (r >> 3) + 8 * hi + (r & 7);
           if (key >= a.kv_len) sb[B][x][kb][r] = -INFINITY;
         }
   };
@@ -767,7 +775,7 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
       if constexpr (g == 51) {
         // the new scores were written by asm MFMAs (last one at gap 31): XDL write -> VALU read hazard is long covered; the ragged
         // mask of the last tile must be in place before its row max
-        if (ragged && t + 1 == ntiles - 1) mask_ragged(std::integral_constant<int, 1 - B>{}, t + 1);
+        if (ragged && t_begin + t + 1 == ntiles_all - 1) mask_ragged(std::integral_constant<int, 1 - B>{}, t + 1);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -812,7 +820,7 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
       mfma_s(sb[0][1][i & 1], kf, qf[1][i >> 1], i < 2);
     }
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
-    if (ragged && ntiles == 1) mask_ragged(B0{}, 0);
+    if (ragged && t_begin == ntiles_all - 1) mask_ragged(B0{}, 0);
     const float m0 = rowmax_now(B0{}, std::integral_constant<int, 0>{});
     const float m1 = rowmax_now(B0{}, std::integral_constant<int, 1>{});
     commit(std::integral_constant<int, 0>{}, m0);
@@ -843,6 +851,27 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
     float l = l_run[x];
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
+    if (a.nsplit > 1) {  // un-normalised partial result of this KV split: O (f32), reference max, row sum -> k_attn_merge
+      if (q_row[x] < a.Lq) {
+        float* op = a.o_part + ((size_t)split * a.Lq + q_row[x]) * (size_t)(a.H * D) + head * D;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          f32x16 ov = o[x][db];
+          asm volatile("" : "+v"(ov));
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 q4 = {ov[4 * g + 0], ov[4 * g + 1], ov[4 * g + 2], ov[4 * g + 3]};
+            *reinterpret_cast<f32x4*>(op + db * 32 + 8 * g + 4 * hi) = q4;
+          }
+        }
+        if (hi == 0) {
+          float* mp = a.ml_part + (((size_t)split * a.H + head) * a.Lq + q_row[x]) * 2;
+          mp[0] = m_run[x];
+          mp[1] = l;
+        }
+      }
+      continue;
+    }
     if (q_row[x] < a.Lq) {
       uint16_t* op = a.O + (size_t)q_row[x] * a.ldo + head * D;
 #pragma unroll
@@ -869,18 +898,54 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
   }
 }
 
+// Merge of the KV splits of k_attn_w4:  O = sum_s O_s 2^(c (m_s - M)) / sum_s l_s 2^(c (m_s - M)),  M = max_s m_s  (exact flash combine).
+// One thread per (row, head, 4 consecutive head-dim values).
+__global__ void k_attn_merge(AttnArgs a) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)a.Lq * a.H * (D / 4);
+  if (i >= n) return;
+  const int d4 = (int)(i % (D / 4));
+  const int h = (int)((i / (D / 4)) % a.H);
+  const size_t q = i / ((size_t)(D / 4) * a.H);
+  float M = -INFINITY;
+  for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, a.ml_part[(((size_t)s * a.H + h) * a.Lq + q) * 2]);
+  float l = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < a.nsplit; ++s) {
+    const float* ml = a.ml_part + (((size_t)s * a.H + h) * a.Lq + q) * 2;
+    const float w = __builtin_amdgcn_exp2f(a.scale_log2 * (ml[0] - M));
+    l += w * ml[1];
+    const f32x4 ov = *reinterpret_cast<const f32x4*>(a.o_part + ((size_t)s * a.Lq + q) * (size_t)(a.H * D) + h * D + 4 * d4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += w * ov[k];
+  }
+  const float inv = 1.0f / l;
+  uint16_t* op = a.O + q * a.ldo + h * D + 4 * d4;
+  float v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = acc[k] * inv;
+  if (a.accumulate) {
+    const u32x2 old = *reinterpret_cast<const u32x2*>(op);
+    v[0] += __uint_as_float(old[0] << 16);
+    v[1] += __uint_as_float(old[0] & 0xffff0000u);
+    v[2] += __uint_as_float(old[1] << 16);
+    v[3] += __uint_as_float(old[1] & 0xffff0000u);
+  }
+  u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  *reinterpret_cast<u32x2*>(op) = pk;
+}
+
 }  // namespace
 
-extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len,
-                           int ldo, float softmax_scale, int accumulate, void* stream) {
-  WF_CHECK_ARG(Q && K && Vt && O, "wf_attn_fwd: null pointer");
-  WF_CHECK_ARG(H > 0 && Lq > 0 && kv_len > 0, "wf_attn_fwd: empty problem");
-  WF_CHECK_ARG(Lkp % KB == 0 && kv_len <= Lkp, "wf_attn_fwd: Lkp (%d) must be a multiple of 64 and >= kv_len (%d)", Lkp,
-               kv_len);
-  WF_CHECK_ARG(seg_len > 0 && seg_len % KB == 0 && Lkp % seg_len == 0, "wf_attn_fwd: seg_len (%d) must be a multiple of 64 dividing Lkp",
+static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len, int ldo,
+                       float softmax_scale, int accumulate, int nsplit, void* workspace, void* stream, const char* who) {
+  WF_CHECK_ARG(Q && K && Vt && O, "%s: null pointer", who);
+  WF_CHECK_ARG(H > 0 && Lq > 0 && kv_len > 0, "%s: empty problem", who);
+  WF_CHECK_ARG(Lkp % KB == 0 && kv_len <= Lkp, "%s: Lkp (%d) must be a multiple of 64 and >= kv_len (%d)", who, Lkp, kv_len);
+  WF_CHECK_ARG(seg_len > 0 && seg_len % KB == 0 && Lkp % seg_len == 0, "%s: seg_len (%d) must be a multiple of 64 dividing Lkp", who,
                seg_len);
-  WF_CHECK_ARG(ldo % 4 == 0 && ldo >= H * D, "wf_attn_fwd: bad ldo %d", ldo);
-  WF_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O) & 15) == 0, "wf_attn_fwd: 16-byte alignment");
+  WF_CHECK_ARG(ldo % 4 == 0 && ldo >= H * D, "%s: bad ldo %d", who, ldo);
+  WF_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O) & 15) == 0, "%s: 16-byte alignment", who);
   AttnArgs a;
   a.Q = (const uint16_t*)Q;
   a.K = (const uint16_t*)K;
@@ -899,6 +964,11 @@ extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O
     const char* e = getenv("WF_ATTN_PRIO");
     a.prio_mode = e ? atoi(e) : 0;
   }
+  const int ntiles = ceil_div(kv_len, KB);
+  a.nsplit = 1;
+  a.tiles_per_split = ntiles;
+  a.o_part = nullptr;
+  a.ml_part = nullptr;
   const int hslots = (H + 7) / 8;
   const int grid = hslots * a.n_qblk * 8;
   const size_t lds = 4 * (K_TILE_BYTES + V_TILE_BYTES);
@@ -908,17 +978,48 @@ extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O
     const char* e = getenv("WF_ATTN_KERNEL");
     return e && e[0] == 'w' && e[1] == '8' ? 0 : 1;
   }();
+  if (nsplit > 1) {
+    WF_CHECK_ARG(use_w4, "%s: KV splits need the k_attn_w4 kernel", who);
+    WF_CHECK_ARG(workspace && (((uintptr_t)workspace) & 15) == 0, "%s: nsplit > 1 needs a 16-byte aligned workspace", who);
+    int tps = ceil_div(ntiles, nsplit);
+    const int ns = ceil_div(ntiles, tps);  // splits that actually get tiles
+    a.nsplit = ns;
+    a.tiles_per_split = tps;
+    a.o_part = (float*)workspace;
+    a.ml_part = a.o_part + (size_t)ns * Lq * H * D;
+  }
   if (use_w4) {
     if (Lkp > 1024)
-      hipLaunchKernelGGL(k_attn_w4<0>, dim3(grid), dim3(NT4), lds_w4, (hipStream_t)stream, a);
+      hipLaunchKernelGGL(k_attn_w4<0>, dim3(grid, a.nsplit), dim3(NT4), lds_w4, (hipStream_t)stream, a);
     else
-      hipLaunchKernelGGL(k_attn_w4<1>, dim3(grid), dim3(NT4), lds_w4, (hipStream_t)stream, a);
+      hipLaunchKernelGGL(k_attn_w4<1>, dim3(grid, a.nsplit), dim3(NT4), lds_w4, (hipStream_t)stream, a);
+    if (a.nsplit > 1) {
+      const size_t n = (size_t)Lq * H * (D / 4);
+      hipLaunchKernelGGL(k_attn_merge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    }
   } else if (Lkp > 1024)
     hipLaunchKernelGGL(k_attn<0>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(k_attn<1>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, a);
-  WF_LAUNCH_CHECK("wf_attn_fwd");
+  WF_LAUNCH_CHECK(who);
   return WF_OK;
+}
+
+extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len,
+                           int ldo, float softmax_scale, int accumulate, void* stream) {
+  return attn_launch(Q, K, Vt, O, H, Lq, Lkp, kv_len, seg_len, ldo, softmax_scale, accumulate, 1, nullptr, stream, "wf_attn_fwd");
+}
+
+extern "C" size_t wf_attn_split_workspace_bytes(int H, int Lq, int nsplit) {
+  if (H <= 0 || Lq <= 0 || nsplit <= 1) return 0;
+  return ((size_t)nsplit * Lq * H * D + (size_t)nsplit * H * Lq * 2) * sizeof(float);
+}
+
+extern "C" int wf_attn_fwd_split(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len,
+                                 int ldo, float softmax_scale, int accumulate, int nsplit, void* workspace, void* stream) {
+  WF_CHECK_ARG(nsplit >= 1 && nsplit <= 8, "wf_attn_fwd_split: nsplit %d out of range 1..8", nsplit);
+  return attn_launch(Q, K, Vt, O, H, Lq, Lkp, kv_len, seg_len, ldo, softmax_scale, accumulate, nsplit, workspace, stream,
+                     "wf_attn_fwd_split");
 }
 
 #ifdef WF_ATTN_TIMING

@@ -16,6 +16,7 @@ diffusers checkpoint.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Dict, Optional, Tuple
@@ -69,8 +70,19 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
 PROFILE_ATTN = None  # bench.py sets this to a list: (start, end) HIP events around every self-attention launch
 
 
+def kv_splits(H: int, Lq: int, kv_len: int, n_cu: int = 256) -> int:
+    """KV splits for the attention launch: the kernel runs one 256-row workgroup per CU, so a launch of W = ceil(Lq/256) * H workgroups
+    takes ceil(W / n_cu) rounds; when Lq is short (one rank's token shard of the sequence-parallel DiT: W = 640 at 8 ranks = 2.5
+    rounds) splitting the KV sweep in two fills the last round.  A function of the shapes only (never of timing)."""
+    if os.environ.get("WF_ATTN_KERNEL", "") == "w8" or kv_len < 128 * 64:
+        return 1
+    w = -(-Lq // 256) * H
+    eff = lambda n: (w * n / n_cu) / -(-(w * n) // n_cu)
+    return 2 if eff(2) > eff(1) + 0.08 else 1
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, kv_len: int, scale: float,
-              accumulate: bool = False, profile: bool = False):
+              accumulate: bool = False, profile: bool = False, nsplit: Optional[int] = None):
     """q [H,Lq,128]; k [H,Lkp,128] and vt [H,Lkp/64,128,64], or their all-gathered per-rank shards k [P,H,S,128],
     vt [P,H,S/64,128,64] (S = shard length, keys in shard-major order) -> out [Lq, H*128] bf16."""
     H, Lq, D = q.shape
@@ -83,11 +95,18 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
         assert vt.shape == (H, Lkp // 64, 128, 64)
     assert D == 128
     prof = PROFILE_ATTN if profile else None
+    if nsplit is None:
+        nsplit = kv_splits(H, Lq, kv_len)
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    call("wf_attn_fwd", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Lq, Lkp, kv_len, seg, out.stride(0),
-         float(scale), 1 if accumulate else 0, ops.stream())
+    if nsplit > 1:
+        ws = ops._workspace("attn_split", (_ffi.lib().wf_attn_split_workspace_bytes(H, Lq, nsplit) + 3) // 4, q.device)
+        call("wf_attn_fwd_split", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Lq, Lkp, kv_len, seg, out.stride(0),
+             float(scale), 1 if accumulate else 0, nsplit, ws.data_ptr(), ops.stream())
+    else:
+        call("wf_attn_fwd", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Lq, Lkp, kv_len, seg, out.stride(0),
+             float(scale), 1 if accumulate else 0, ops.stream())
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1))
