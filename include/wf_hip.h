@@ -92,6 +92,12 @@ int wf_channel_swap(void* enc, int dt_enc, const void* pred, int dt_pred, const 
 int wf_resize_bilinear2d(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, void* stream);
 int wf_resize_nearest2d(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, void* stream);
 
+/* ---- front end: soften_mask (infer_worldforge.py:105-150) -------------------------------------------------------------- */
+/* mask [F,H,W] f32 (any non-zero = inside) -> out [F,H,W]: inside pixels within transition_distance of the zero region get
+ * ramp(d / transition_distance), d = exact Euclidean distance to the nearest zero pixel of the frame (float64 like scipy's EDT);
+ * decay_type 0 linear, 1 exponential (1 - e^-3t), 2 sine, 3 cosine.  mask and out may not alias. */
+int wf_soften_mask(const float* mask, float* out, int F, int H, int W, int transition_distance, int decay_type, void* stream);
+
 /* ---- DSG (PIPE:664-681) ---------------------------------------------------------------------- */
 /* Workspace floats needed by wf_dsg (partials + 8 result floats). */
 size_t wf_dsg_workspace_floats(void);

@@ -196,3 +196,33 @@ def test_errors_are_loud():
         ops.cfg_combine(torch.zeros(4), torch.zeros(4), 1.0)  # CPU tensors: no fallback
     rc = _ffi.lib().wf_latent_affine(None, 0, None, 0, None, None, 0, 1, 16, 4, None)
     assert rc != 0 and b"null" in _ffi.lib().wf_last_error()
+
+
+def test_soften_mask_gpu_matches_reference_goldens(golden_dir):
+    """wf_soften_mask against the goldens recorded from the reference's soften_mask (infer_worldforge.py:105-150): disc and
+    half-plane masks x 4 decay types x 2 transition distances.  The ramp is evaluated in double on both sides; the device sin / cos /
+    exp may differ from libm in the last double bit, i.e. by at most one float32 ulp after the final rounding."""
+    import os
+    import numpy as np
+    from worldforge_amd import ops
+    g = np.load(os.path.join(golden_dir, "g10_harness.npz"))
+    masks = torch.from_numpy(g["masks"].astype(np.float32)).to(DEV)
+    for decay in ("linear", "exponential", "sine", "cosine"):
+        for d in (5, 15):
+            want = torch.from_numpy(g[f"soft_{decay}_{d}"])
+            got = ops.soften_mask(masks, d, decay).cpu()
+            diff = (got - want).abs().max().item()
+            assert diff <= 1.2e-7, (decay, d, diff)
+            if decay == "linear":
+                assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        ops.soften_mask(masks, 5, "bogus")
+    # soft (non-binary) input values, all-ones and all-zeros frames pass through untouched
+    m = torch.ones(3, 40, 50)
+    m[1] = 0
+    m[2] = 0.25
+    m[2, 10:20, 10:20] = 0
+    out = ops.soften_mask(m.to(DEV), 15, "sine").cpu()
+    assert torch.equal(out[0], m[0]) and torch.equal(out[1], m[1])
+    from worldforge_amd import harness
+    assert np.abs(out.numpy() - harness.soften_mask(m.numpy(), 15, "sine")).max() <= 1.2e-7

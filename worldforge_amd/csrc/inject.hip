@@ -269,3 +269,67 @@ extern "C" int wf_resize_bilinear2d(const float* in, float* out, int N, int Hi, 
 extern "C" int wf_resize_nearest2d(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, void* stream) {
   return resize_common("wf_resize_nearest2d", false, in, out, N, Hi, Wi, Ho, Wo, stream);
 }
+
+// ---- soften_mask (infer_worldforge.py:105-150) --------------------------------------------------------------------------------------
+// Inside the ones-region of each frame, pixels within `td` pixels of the zero-region get ramp(d / td), d = Euclidean distance to the
+// nearest zero pixel of the frame (scipy.ndimage.distance_transform_edt in the reference: the exact EDT, float64).  Only d <= td
+// matters, so the nearest zero is searched in the (2 td + 1)^2 window: d^2 is an integer, d = sqrt in double is the value scipy
+// returns; the ramp is evaluated in double and rounded to float once, as numpy does.  Frames that are all ones / all zeros come out
+// unchanged by construction.  One thread per pixel, the window is served from L1 / L2 (0.4 M pixels per frame).
+__global__ void k_soften_mask(const float* __restrict__ mask, float* __restrict__ out, int H, int W, int td, int decay, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % W);
+  const int y = (int)((i / W) % H);
+  const float* fr = mask + (i - (size_t)y * W - x);
+  const float v = fr[(size_t)y * W + x];
+  if (v == 0.0f) {  // .astype(bool): any non-zero value belongs to the ones-region
+    out[i] = v;
+    return;
+  }
+  int best = 0x7fffffff;
+  const int td2 = td * td;
+  for (int dy = -td; dy <= td; ++dy) {
+    const int yy = y + dy;
+    if (yy < 0 || yy >= H) continue;
+    const int rem = td2 - dy * dy;  // dx^2 <= rem
+    const float* row = fr + (size_t)yy * W;
+    for (int dx = 0; dx * dx <= rem; ++dx) {
+      const bool zl = x - dx >= 0 && row[x - dx] == 0.0f;
+      const bool zr = x + dx < W && row[x + dx] == 0.0f;
+      if (zl || zr) {
+        best = min(best, dx * dx + dy * dy);
+        break;  // larger |dx| in this row is farther
+      }
+    }
+  }
+  if (best > td2) {  // distance_from_ones > transition_distance (or no zero in the frame): value kept
+    out[i] = v;
+    return;
+  }
+  const double t = fmin(fmax(sqrt((double)best) / (double)td, 0.0), 1.0);
+  const double kHalfPi = 3.14159265358979323846 / 2;
+  double r;
+  switch (decay) {
+    case 0: r = t; break;                          // linear
+    case 1: r = 1.0 - exp(-3.0 * t); break;        // exponential
+    case 2: r = sin(kHalfPi * t); break;           // sine
+    default: r = 1.0 - cos(kHalfPi * t); break;    // cosine
+  }
+  out[i] = (float)r;
+}
+extern "C" int wf_soften_mask(const float* mask, float* out, int F, int H, int W, int transition_distance, int decay_type,
+                              void* stream) {
+  WF_CHECK_ARG(mask && out, "wf_soften_mask: null pointer");
+  WF_CHECK_ARG(F >= 0 && H > 0 && W > 0, "wf_soften_mask: bad sizes");
+  WF_CHECK_ARG(transition_distance >= 1 && transition_distance <= 64, "wf_soften_mask: transition_distance %d out of range 1..64",
+               transition_distance);
+  WF_CHECK_ARG(decay_type >= 0 && decay_type <= 3, "wf_soften_mask: decay_type %d (0 linear, 1 exponential, 2 sine, 3 cosine)",
+               decay_type);
+  const size_t n = (size_t)F * H * W;
+  if (n == 0) return WF_OK;
+  hipLaunchKernelGGL(k_soften_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask, out, H, W,
+                     transition_distance, decay_type, n);
+  WF_LAUNCH_CHECK("wf_soften_mask");
+  return WF_OK;
+}

@@ -72,10 +72,11 @@ def target_size(image_height: int, image_width: int, max_area: int, mod_value: i
 
 
 def prepare_inputs(directory: str, model: str = "480p", num_frames: int = None, soften: bool = True,
-                   transition_distance: int = 15, decay_type: str = "sine"):
+                   transition_distance: int = 15, decay_type: str = "sine", device=None):
     """INFER:153-254 -> (image PIL, video_ref [1,3,F,H,W] f32 in [0,1], mask [1,1,F,H,W], height, width).
     `num_frames` (not in the reference) truncates the warped sequence: the reference requires #reference frames == the
-    (4k+1) frame count it decodes, otherwise SCHED:1326 raises."""
+    (4k+1) frame count it decodes, otherwise SCHED:1326 raises.  With `device` (a GPU) the mask softening runs there
+    (wf_soften_mask: exact windowed EDT) and video_ref / mask are returned on that device."""
     frames, masks, first = read_frames_from_directory(directory)
     if num_frames is not None:
         frames, masks = frames[:num_frames], masks[:num_frames]
@@ -85,6 +86,12 @@ def prepare_inputs(directory: str, model: str = "480p", num_frames: int = None, 
     video = torch.stack([torch.tensor(np.array(f.resize((w, h)))).permute(2, 0, 1).float() / 255.0 for f in frames])
     video_ref = video.unsqueeze(0).permute(0, 2, 1, 3, 4)
     marr = np.stack([np.array(m.resize((w, h))) / 255.0 for m in masks])
+    if device is not None and torch.device(device).type == "cuda":
+        from . import ops
+        m32 = torch.from_numpy(marr.astype(np.float32)).to(device)
+        if soften:
+            m32 = ops.soften_mask(m32.contiguous(), transition_distance, decay_type)
+        return image, video_ref.to(device), m32.unsqueeze(0).unsqueeze(0), h, w
     if soften:
         marr = soften_mask(marr, transition_distance, decay_type)
     mask = torch.from_numpy(marr).unsqueeze(0).unsqueeze(0)

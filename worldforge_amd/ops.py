@@ -204,6 +204,21 @@ def temporal_diff(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_DECAY = {"linear": 0, "exponential": 1, "sine": 2, "cosine": 3}
+
+
+def soften_mask(mask: torch.Tensor, transition_distance: int = 15, decay_type: str = "sine") -> torch.Tensor:
+    """INFER:105-150 on the device: mask [F,H,W] fp32 -> softened [F,H,W] fp32."""
+    if decay_type not in _DECAY:
+        raise ValueError(f"Unsupported decay type: {decay_type}")
+    mask = _dev(mask)
+    assert mask.dtype == torch.float32 and mask.dim() == 3 and mask.is_contiguous()
+    out = torch.empty_like(mask)
+    F_, H, W = mask.shape
+    call("wf_soften_mask", mask.data_ptr(), out.data_ptr(), F_, H, W, int(transition_distance), _DECAY[decay_type], stream())
+    return out
+
+
 def farneback_flows(x: torch.Tensor) -> torch.Tensor:
     """SCHED:156-248 for every channel at once: x [C,T,h,w] (f32 / bf16) -> flows [C,T-1,2,h,w] fp32 (device)."""
     x = _dev(x)
