@@ -74,3 +74,17 @@ def test_gloo_world2_gather_layout():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), 200, 3, ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_kv_split_choice_depends_on_shapes_only():
+    """dit.kv_splits: two KV splits only when a launch would leave a large part of the last round of workgroups idle
+    (one rank's token shard at 8 ranks), never for the full-length launches; a pure function of the shapes."""
+    from worldforge_amd.dit import kv_splits
+    from worldforge_amd.parallel import shard_plan
+    L = 32760
+    expect = {1: 1, 2: 1, 4: 1, 8: 2}
+    for P, want in expect.items():
+        assert kv_splits(40, shard_plan(L, P).shard_len, L) == want
+    assert kv_splits(40, 75600, 75600) == 1          # 720p, one GPU
+    assert kv_splits(40, 4524, 4524) == 1            # short KV sweep: never split
+    assert kv_splits(40, 32760, 512) == 1            # cross-attention
