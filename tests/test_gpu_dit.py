@@ -286,3 +286,35 @@ def test_sequence_parallel_path_world1_matches_single():
         a, b = m1.forward_tokens_pair(x, 500.0, ctx, ctx_b, clip)
         assert torch.equal(a, ref) and torch.equal(b, ref_b)
     torch.distributed.destroy_process_group()
+
+
+def test_context_kv_cache_is_transparent():
+    """The per-layer cross-attention K / V of a (text, image) context are cached across forwards: results must equal the uncached
+    forward bit for bit, a second context must not hit the first one's entry, and an in-place edit of the embeddings (version
+    counter) must invalidate the entry."""
+    import os
+    from worldforge_amd import dit
+    cfg = dit.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    x = _rand((36, 3, 8, 10), 80).to(BF).to(DEV)
+    ca, cb = _rand((30, 64), 81).to(BF).to(DEV), _rand((30, 64), 82).to(BF).to(DEV)
+    clip = _rand((257, 1280), 83).to(BF).to(DEV)
+    m = dit.WanTransformer3DModel(cfg, DEV).init_random(5)
+    os.environ["WF_NO_CTX_CACHE"] = "1"
+    try:
+        ref_a = m.forward_tokens(x, 500.0, ca, clip).clone()
+        ref_b = m.forward_tokens(x, 500.0, cb, clip).clone()
+    finally:
+        del os.environ["WF_NO_CTX_CACHE"]
+    for _ in range(2):   # second round: served from the cache
+        assert torch.equal(m.forward_tokens(x, 500.0, ca, clip), ref_a)
+        assert torch.equal(m.forward_tokens(x, 250.0, cb, clip), m.forward_tokens(x, 250.0, cb, clip))
+        assert torch.equal(m.forward_tokens(x, 500.0, cb, clip), ref_b)
+    assert len(m._ctx_cache) == 2
+    ca.mul_(0.5)         # in-place edit: same storage, new version -> must not be served from the stale entry
+    os.environ["WF_NO_CTX_CACHE"] = "1"
+    try:
+        ref_c = m.forward_tokens(x, 500.0, ca, clip).clone()
+    finally:
+        del os.environ["WF_NO_CTX_CACHE"]
+    assert not torch.equal(ref_c, ref_a)
+    assert torch.equal(m.forward_tokens(x, 500.0, ca, clip), ref_c)

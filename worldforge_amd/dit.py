@@ -313,6 +313,22 @@ class WanTransformer3DModel:
             self._ws[key] = t
         return t
 
+    def _context_kv(self, text: torch.Tensor, img: torch.Tensor):
+        """Per-layer cross-attention K / V cache for one (text, image) context: {layer: (k_text, vT_text, k_img, vT_img)}.  Keyed by
+        the identity AND version of the embedding storages and of the weight dict, so an in-place edit of the embeddings or a
+        weight reload starts a fresh entry; at most 4 contexts are kept (positive / negative prompt of the last two videos)."""
+        if os.environ.get("WF_NO_CTX_CACHE"):
+            return None
+        key = (text.data_ptr(), text._version, tuple(text.shape), img.data_ptr(), img._version, tuple(img.shape), id(self.w))
+        cache = self.__dict__.setdefault("_ctx_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            while len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+            # the tensors are held so that their storage (and hence data_ptr) cannot be recycled while the entry lives
+            hit = cache[key] = {"_keep": (text, img)}
+        return hit
+
     def _rope_tables(self, f, h, w):
         key = (f, h, w)
         if key not in self._rope:
@@ -473,6 +489,7 @@ class WanTransformer3DModel:
         vti = _buf("vti", (H, Li // 64, 128, 64), bf)
         emod = _buf("emod", (6, d), f32)
 
+        ctx_kv = self._context_kv(text, img)
         for i in range(cfg.num_layers):
             p = f"blocks.{i}."
             # e = modulation + e0 (model.py:298)
@@ -505,12 +522,23 @@ class WanTransformer3DModel:
             self._ln(x, W[p + "norm3.w"], W[p + "norm3.b"], hbuf, cfg.eps, plus_one=False)
             gemm(hbuf, W[p + "cross_attn.q.w"], W[p + "cross_attn.q.b"], qc, EPI_BF16)
             self._heads(qc, 0, W[p + "cross_attn.norm_q"], None, None, qh, L)
-            gemm(ctx_t, W[p + "cross_attn.kv.w"], W[p + "cross_attn.kv.b"], kvt, EPI_BF16)
-            self._heads(kvt, 0, W[p + "cross_attn.norm_k"], None, None, kth, Lt)
-            self._vt(kvt, d, vtt, Lt)
-            gemm(ctx_i, W[p + "cross_attn.kv_img.w"], W[p + "cross_attn.kv_img.b"], kvi, EPI_BF16)
-            self._heads(kvi, 0, W[p + "cross_attn.norm_k_img"], None, None, kih, n_img)
-            self._vt(kvi, d, vti, n_img)
+            # K / V of the text and image context depend on the prompt only, not on the latents or the timestep: computed on
+            # the first forward with a given (text, image) pair and kept (17 MB per layer) -- 130 forwards per video reuse them
+            kv = ctx_kv.get(i) if ctx_kv is not None else None
+            if kv is None:
+                if ctx_kv is not None:  # own buffers per layer
+                    kth, vtt = torch.zeros((H, Lt, 128), dtype=bf, device=dev), torch.empty((H, Lt // 64, 128, 64), dtype=bf, device=dev)
+                    kih, vti = torch.zeros((H, Li, 128), dtype=bf, device=dev), torch.empty((H, Li // 64, 128, 64), dtype=bf, device=dev)
+                gemm(ctx_t, W[p + "cross_attn.kv.w"], W[p + "cross_attn.kv.b"], kvt, EPI_BF16)
+                self._heads(kvt, 0, W[p + "cross_attn.norm_k"], None, None, kth, Lt)
+                self._vt(kvt, d, vtt, Lt)
+                gemm(ctx_i, W[p + "cross_attn.kv_img.w"], W[p + "cross_attn.kv_img.b"], kvi, EPI_BF16)
+                self._heads(kvi, 0, W[p + "cross_attn.norm_k_img"], None, None, kih, n_img)
+                self._vt(kvi, d, vti, n_img)
+                if ctx_kv is not None:
+                    ctx_kv[i] = (kth, vtt, kih, vti)
+            else:
+                kth, vtt, kih, vti = kv
             attention(qh, kih, vti, ao, n_img, scale)
             attention(qh, kth, vtt, ao, Lt, scale, accumulate=True)
             gemm(ao, W[p + "cross_attn.o.w"], W[p + "cross_attn.o.b"], x, EPI_RESID, gate=None)
