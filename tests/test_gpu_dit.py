@@ -299,22 +299,21 @@ def test_context_kv_cache_is_transparent():
     ca, cb = _rand((30, 64), 81).to(BF).to(DEV), _rand((30, 64), 82).to(BF).to(DEV)
     clip = _rand((257, 1280), 83).to(BF).to(DEV)
     m = dit.WanTransformer3DModel(cfg, DEV).init_random(5)
-    os.environ["WF_NO_CTX_CACHE"] = "1"
+    os.environ.pop("WF_CTX_CACHE", None)
+    ref_a = m.forward_tokens(x, 500.0, ca, clip).clone()
+    ref_b = m.forward_tokens(x, 500.0, cb, clip).clone()
+    assert not hasattr(m, "_ctx_cache")      # off by default
+    os.environ["WF_CTX_CACHE"] = "1"
     try:
-        ref_a = m.forward_tokens(x, 500.0, ca, clip).clone()
-        ref_b = m.forward_tokens(x, 500.0, cb, clip).clone()
+        for _ in range(2):   # second round: served from the cache
+            assert torch.equal(m.forward_tokens(x, 500.0, ca, clip), ref_a)
+            assert torch.equal(m.forward_tokens(x, 250.0, cb, clip), m.forward_tokens(x, 250.0, cb, clip))
+            assert torch.equal(m.forward_tokens(x, 500.0, cb, clip), ref_b)
+        assert len(m._ctx_cache) == 2
+        ca.mul_(0.5)         # in-place edit: same storage, new version -> must not be served from the stale entry
+        got_c = m.forward_tokens(x, 500.0, ca, clip).clone()
     finally:
-        del os.environ["WF_NO_CTX_CACHE"]
-    for _ in range(2):   # second round: served from the cache
-        assert torch.equal(m.forward_tokens(x, 500.0, ca, clip), ref_a)
-        assert torch.equal(m.forward_tokens(x, 250.0, cb, clip), m.forward_tokens(x, 250.0, cb, clip))
-        assert torch.equal(m.forward_tokens(x, 500.0, cb, clip), ref_b)
-    assert len(m._ctx_cache) == 2
-    ca.mul_(0.5)         # in-place edit: same storage, new version -> must not be served from the stale entry
-    os.environ["WF_NO_CTX_CACHE"] = "1"
-    try:
-        ref_c = m.forward_tokens(x, 500.0, ca, clip).clone()
-    finally:
-        del os.environ["WF_NO_CTX_CACHE"]
+        del os.environ["WF_CTX_CACHE"]
+    ref_c = m.forward_tokens(x, 500.0, ca, clip)
     assert not torch.equal(ref_c, ref_a)
-    assert torch.equal(m.forward_tokens(x, 500.0, ca, clip), ref_c)
+    assert torch.equal(got_c, ref_c)
