@@ -187,7 +187,7 @@ int wf_conv3d_cl(const void* in, const void* w, const float* bias, const float* 
  * an 8 x 64 pixel tile of one output frame x 96 output channels per workgroup, all 27 taps read the (3 x 10 x 66)-pixel patch of a
  * 16-channel slice from LDS.  Weights in the re-packed layout [27][Cin/16][Cout][16] produced by wf_conv3d_pack333 from
  * [Cout][27][Cin].  in [T,Hi,Wi,Cin] bf16 (Hi = Ho for ph = 1; row slabs carry their halo rows: Hi = Ho + 2, ph = 0),
- * out [T,Ho,Wi,Cout]; Cin % 16 == 0, Cout % 32 == 0; zero_page >= 64 bf16 zeros.  Same arithmetic as wf_conv3d_cl. */
+ * out [T,Ho,Wi,Cout]; Cin % 32 == 0, Cout % 32 == 0; zero_page >= 64 bf16 zeros.  Same arithmetic as wf_conv3d_cl. */
 int wf_conv3d_pack333(const void* w, void* w_packed, int Cout, int Cin, void* stream);
 int wf_conv3d_333(const void* in, const void* w_packed, const float* bias, const float* resid, float* out_f32, void* out_bf16, int T,
                   int Hi, int Wi, int Cin, int Ho, int Cout, int ph, const void* zero_page, void* stream);

@@ -19,6 +19,8 @@
 #include "mfma.h"
 #include <stdlib.h>
 
+#include <algorithm>
+
 using namespace wf;
 
 namespace {
@@ -539,16 +541,21 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  // tile: blockIdx.x -> (t, tile_y, tile_x), blockIdx.y -> 96-channel output block
-  int bx = blockIdx.x;
-  const int tx = bx % pa.tiles_x;
-  bx /= pa.tiles_x;
-  const int ty = bx % pa.tiles_y;
-  const int t = bx / pa.tiles_y;
-  const int x0 = tx * WX, y0 = ty * WY;
+  // persistent: workgroup b walks tiles b, b + gridDim.x, ... ((t, tile_y, tile_x), x fastest); blockIdx.y -> 96-channel output block.
+  // The first patch of the NEXT tile is staged during the last channel slice of the current one, so that only the very first tile
+  // of a workgroup pays the cold-start DMA latency, and the epilogue stores run under that flight.
+  const int ntile = pa.tiles_x * pa.tiles_y * a.To;
   const int n0 = blockIdx.y * 96;
   const int Cin = a.Cin;
-  const int ns = Cin / 16;
+  const int ns = Cin / 16;  // even (Cin % 32 == 0): a tile starts in LDS buffer 0 and ends in buffer 1
+  int t, y0, x0;
+  auto decode = [&](int tile, int& tt, int& yy, int& xx) {
+    const int tx = tile % pa.tiles_x;
+    const int r = tile / pa.tiles_x;
+    xx = tx * WX;
+    yy = (r % pa.tiles_y) * WY;
+    tt = r / pa.tiles_y;
+  };
 
 #ifdef WF_CONV_TIMING
   const unsigned long long tc0 = __builtin_readcyclecounter();
@@ -556,17 +563,22 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   // ---- LDS-DMA sources of this wave's 16 patch pieces: lane-load q = (16 w + j) * 64 + lane -> patch pixel q >> 1, chunk q & 1 ----
   const uint16_t* psrc[16];
   uint32_t pvalid = 0;
+  auto compute_psrc = [&](int tt0, int yy0, int xx0) {
+    pvalid = 0;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int q = (wid * 16 + j) * 64 + lane;
-    const int p = q >> 1, ch = q & 1;
-    const int f = p / (PR * PC), rem = p - f * (PR * PC);
-    const int r = rem / PC, cc = rem - r * PC;
-    const int tt = t - 2 + f, yy = y0 - a.ph + r, xx = x0 - 1 + cc;
-    const bool ok = p < PATCH_PX && tt >= 0 && yy >= 0 && yy < a.Hi && xx >= 0 && xx < a.Wi;
-    psrc[j] = ok ? a.in + (((size_t)tt * a.Hi + yy) * a.Wi + xx) * Cin + ch * 8 : pa.zeros;
-    pvalid |= ok ? (1u << j) : 0u;
-  }
+    for (int j = 0; j < 16; ++j) {
+      const int q = (wid * 16 + j) * 64 + lane;
+      const int p = q >> 1, ch = q & 1;
+      const int f = p / (PR * PC), rem = p - f * (PR * PC);
+      const int r = rem / PC, cc = rem - r * PC;
+      const int tt = tt0 - 2 + f, yy = yy0 - a.ph + r, xx = xx0 - 1 + cc;
+      const bool ok = p < PATCH_PX && tt >= 0 && yy >= 0 && yy < a.Hi && xx >= 0 && xx < a.Wi;
+      psrc[j] = ok ? a.in + (((size_t)tt * a.Hi + yy) * a.Wi + xx) * Cin + ch * 8 : pa.zeros;
+      pvalid |= ok ? (1u << j) : 0u;
+    }
+  };
+  decode(blockIdx.x, t, y0, x0);
+  compute_psrc(t, y0, x0);
   const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_offset(smem));
   auto dma_piece = [&](int cs, int j) {  // piece j of the patch of channel slice cs -> buffer cs & 1
     const uint16_t* src = psrc[j] + (((pvalid >> j) & 1u) ? cs * 16 : 0);
@@ -588,20 +600,12 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.w) + (size_t)n0 * 32;
   const size_t wslice = (size_t)a.Cout * 32;  // bytes per (tap, slice)
   auto wload = [&](int cs, int tap, int cb) {
-    const int csc = cs < ns ? cs : ns - 1;  // past the last slice: a valid address whose data is never used
+    const int csc = cs < ns ? cs : 0;  // past the last slice: slice 0 of the next tile (same weights)
     const unsigned char* sb = wbase + (size_t)(tap * ns + csc) * wslice + cb * 1024;
     return *reinterpret_cast<const u32x4*>(sb + aoff);
   };
 
   f32x16 acc[4][3];
-#pragma unroll
-  for (int pb = 0; pb < 4; ++pb)
-#pragma unroll
-    for (int cb = 0; cb < 3; ++cb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[pb][cb][r] = 0.f;
-      asm volatile("" : "+a"(acc[pb][cb]));
-    }
   auto mma = [&](f32x16& c, const u32x4& wv, const u32x4& xv) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(wv), "v"(xv));
   };
@@ -633,13 +637,30 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   const unsigned long long tc1 = __builtin_readcyclecounter();
   unsigned long long t_wait = 0;
 #endif
+  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+  const int tile_n = tile + (int)gridDim.x;
+  const bool has_next = tile_n < ntile;
+  int tn = t, yn = y0, xn = x0;
+#pragma unroll
+  for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[pb][cb][r] = 0.f;
+      asm volatile("" : "+a"(acc[pb][cb]));
+    }
   for (int cs = 0; cs < ns; ++cs) {
     const int buf = cs & 1;
-    const int csn = cs + 1 < ns ? cs + 1 : cs;  // last slice: harmless re-stage into the dead buffer
+    if (cs == ns - 1 && has_next) {  // the sources of the next tile's first patch replace this tile's (no longer needed)
+      decode(tile_n, tn, yn, xn);
+      compute_psrc(tn, yn, xn);
+    }
+    // next slice's patch; last slice: slice 0 of the next tile into buffer 0 (or a harmless re-stage when there is none)
+    const int csn = cs + 1 < ns ? cs + 1 : (has_next ? 0 : cs);
     for_const<27>([&](auto TC) {
       constexpr int tap = decltype(TC)::value;
       constexpr int ntap = tap + 2 < 27 ? tap + 2 : tap + 2 - 27;
-      const int ncs = tap + 2 < 27 ? cs : cs + 1;
+      const int ncs = tap + 2 < 27 ? cs : cs + 1;  // == ns on the last slice: wload wraps it to slice 0 of the next tile
       for_const<12>([&](auto MC) {
         (void)&acc, (void)&af, (void)&bf;
         constexpr int m = decltype(MC)::value;
@@ -710,6 +731,10 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
       }
     }
   }
+  t = tn;
+  y0 = yn;
+  x0 = xn;
+  }  // tile loop
 #ifdef WF_CONV_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0 && wid == 0) {
@@ -853,7 +878,7 @@ extern "C" int wf_conv3d_333(const void* in, const void* w_packed, const float* 
                              void* out_bf16, int T, int Hi, int Wi, int Cin, int Ho, int Cout, int ph, const void* zero_page,
                              void* stream) {
   WF_CHECK_ARG(in && w_packed && zero_page && (out_f32 || out_bf16), "wf_conv3d_333: null pointer");
-  WF_CHECK_ARG(Cin % 16 == 0 && Cout % 32 == 0, "wf_conv3d_333: Cin (%d) %% 16 and Cout (%d) %% 32 must be 0", Cin, Cout);
+  WF_CHECK_ARG(Cin % 32 == 0 && Cout % 32 == 0, "wf_conv3d_333: Cin (%d) and Cout (%d) must be multiples of 32", Cin, Cout);
   WF_CHECK_ARG((long)27 * Cin * Cout * 2 < (1L << 31), "wf_conv3d_333: weight tensor too large");
   if ((long)T * Ho * Wi == 0) return WF_OK;
   ConvW4Args wa;
@@ -872,7 +897,9 @@ extern "C" int wf_conv3d_333(const void* in, const void* w_packed, const float* 
   wa.zeros = (const uint16_t*)zero_page;
   wa.tiles_x = (Wi + WX - 1) / WX;
   wa.tiles_y = (Ho + WY - 1) / WY;
-  dim3 grid((unsigned)(wa.tiles_x * wa.tiles_y * T), (unsigned)((Cout + 95) / 96));
+  const int ny = (Cout + 95) / 96, ntile = wa.tiles_x * wa.tiles_y * T;
+  const int gx = std::min(ntile, std::max(1, 256 / ny));  // one persistent workgroup per CU
+  dim3 grid((unsigned)gx, (unsigned)ny);
   hipLaunchKernelGGL(k_conv_w4, grid, dim3(W4T), 2 * PATCH_BUF, (hipStream_t)stream, wa);
   WF_LAUNCH_CHECK("wf_conv3d_333");
   return WF_OK;

@@ -226,7 +226,7 @@ class AutoencoderKLWan:
         ob = out_bf_tensor if out_bf_tensor is not None else (torch.empty(shape, dtype=BF, device=x.device) if out_bf16 else None)
         W = self.w
         if (tuple(k) == (3, 3, 3) and st == 1 and ss == 1 and pt == 2 and ps == 1 and not up2 and not tsplit and To == Ti and Wo == Wi
-                and Cin % 16 == 0 and Cout % 32 == 0 and not os.environ.get("WF_CONV_NO_W4")):
+                and Cin % 32 == 0 and Cout % 32 == 0 and not os.environ.get("WF_CONV_NO_W4")):
             # the FLOP-heavy layers: LDS-resident input patch kernel on re-packed weights (packed once per layer, cached).  Chosen by
             # layer type only, never by size: a row slab of the sharded VAE must run the same arithmetic as the whole image
             call("wf_conv3d_333", x.data_ptr(), self._packed333(p, Cout, Cin).data_ptr(), W[p + ".b"].data_ptr(),
