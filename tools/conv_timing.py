@@ -5,6 +5,7 @@ import torch
 from worldforge_amd import _ffi, ops
 lib = _ffi.lib()
 buf = (ctypes.c_ulonglong * 8)()
+sl = (ctypes.c_ulonglong * 32)()
 for (T, H, W, C) in ((81, 480, 832, 96), (41, 120, 208, 384)):
     x = torch.randn(T, H, W, C, device="cuda:0").to(torch.bfloat16)
     w = (torch.randn(C, 27, C, device="cuda:0") / math.sqrt(C * 27)).to(torch.bfloat16)
@@ -15,7 +16,8 @@ for (T, H, W, C) in ((81, 480, 832, 96), (41, 120, 208, 384)):
     def run():
         _ffi.call("wf_conv3d_333", x.data_ptr(), wp.data_ptr(), None, None, out.data_ptr(), None, T, H, W, C, H, C, 1, zp.data_ptr(),
                   ops.stream())
-    run(); torch.cuda.synchronize(); lib.wf_debug_conv_cycles(buf, 1)
-    run(); torch.cuda.synchronize(); lib.wf_debug_conv_cycles(buf, 1)
-    n = max(buf[5], 1)
-    print(f"C={C}: per WG: prologue {buf[0]/n:.0f}  main {buf[1]/n:.0f} ({buf[1]/max(buf[4],1):.0f} per slice, of which wait+barrier {buf[3]/max(buf[4],1):.0f})  epilogue {buf[2]/n:.0f} cycles")
+    run(); torch.cuda.synchronize(); lib.wf_debug_conv_cycles(buf, 1); lib.wf_debug_conv_slices(sl)
+    run(); torch.cuda.synchronize(); lib.wf_debug_conv_cycles(buf, 1); lib.wf_debug_conv_slices(sl)
+    nwg, nt = max(buf[5], 1), max(buf[6], 1)
+    print(f"C={C}: cold start per workgroup {buf[0]/nwg:.0f};  per tile: main {buf[1]/nt:.0f} ({buf[1]/max(buf[4],1):.0f} per slice, of which wait+barrier {buf[3]/max(buf[4],1):.0f})  epilogue {buf[2]/nt:.0f} cycles")
+    print("   per-slice cycles:", " ".join(f"{sl[i] / max(buf[6], 1):.0f}" for i in range(C // 16)))

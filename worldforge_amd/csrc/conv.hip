@@ -528,6 +528,7 @@ constexpr int PATCH_BUF = 64 * 1024;       // 64 pieces of 1 KiB (1980 * 32 B = 
 
 #ifdef WF_CONV_TIMING
 __device__ unsigned long long g_conv_cycles[8];
+__device__ unsigned long long g_conv_slice[32];
 #endif
 struct ConvW4Args {
   ConvArgs c;
@@ -635,9 +636,12 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
 
 #ifdef WF_CONV_TIMING
   const unsigned long long tc1 = __builtin_readcyclecounter();
-  unsigned long long t_wait = 0;
+  unsigned long long t_wait = 0, t_main = 0, t_epi = 0, n_tiles = 0;
 #endif
   for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+#ifdef WF_CONV_TIMING
+  const unsigned long long tt0 = __builtin_readcyclecounter();
+#endif
   const int tile_n = tile + (int)gridDim.x;
   const bool has_next = tile_n < ntile;
   int tn = t, yn = y0, xn = x0;
@@ -650,6 +654,9 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
       asm volatile("" : "+a"(acc[pb][cb]));
     }
   for (int cs = 0; cs < ns; ++cs) {
+#ifdef WF_CONV_TIMING
+    const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
     const int buf = cs & 1;
     if (cs == ns - 1 && has_next) {  // the sources of the next tile's first patch replace this tile's (no longer needed)
       decode(tile_n, tn, yn, xn);
@@ -682,13 +689,14 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
     bar();
 #ifdef WF_CONV_TIMING
     t_wait += __builtin_readcyclecounter() - tw0;
+    if (lane == 0 && wid == 0 && cs < 32) atomicAdd(&g_conv_slice[cs], __builtin_readcyclecounter() - ts0);
 #endif
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb) bf[0][pb] = bread(buf ^ 1, 0, pb);
   }
 
 #ifdef WF_CONV_TIMING
-  const unsigned long long tc2 = __builtin_readcyclecounter();
+  const unsigned long long tt1 = __builtin_readcyclecounter();
 #endif
   // ---- epilogue ----
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
@@ -731,6 +739,11 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
       }
     }
   }
+#ifdef WF_CONV_TIMING
+  t_main += tt1 - tt0;
+  t_epi += __builtin_readcyclecounter() - tt1;
+  ++n_tiles;
+#endif
   t = tn;
   y0 = yn;
   x0 = xn;
@@ -738,12 +751,12 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
 #ifdef WF_CONV_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0 && wid == 0) {
-    const unsigned long long tc3 = __builtin_readcyclecounter();
     atomicAdd(&g_conv_cycles[0], tc1 - tc0);
-    atomicAdd(&g_conv_cycles[1], tc2 - tc1);
-    atomicAdd(&g_conv_cycles[2], tc3 - tc2);
+    atomicAdd(&g_conv_cycles[1], t_main);
+    atomicAdd(&g_conv_cycles[2], t_epi);
     atomicAdd(&g_conv_cycles[3], t_wait);
-    atomicAdd(&g_conv_cycles[4], (unsigned long long)ns);
+    atomicAdd(&g_conv_cycles[4], (unsigned long long)ns * n_tiles);
+    atomicAdd(&g_conv_cycles[6], n_tiles);
     atomicAdd(&g_conv_cycles[5], 1ull);
   }
 #endif
@@ -906,6 +919,11 @@ extern "C" int wf_conv3d_333(const void* in, const void* w_packed, const float* 
 }
 
 #ifdef WF_CONV_TIMING
+extern "C" int wf_debug_conv_slices(unsigned long long* out32) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_conv_slice), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  unsigned long long z[32] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_conv_slice), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
 extern "C" int wf_debug_conv_cycles(unsigned long long* out8, int reset) {
   if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_conv_cycles), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
   if (reset) {
