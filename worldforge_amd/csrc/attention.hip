@@ -520,19 +520,19 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
   // Element offset / LDS slot of the tile being staged (wave-uniform), advanced one tile at a time: a handful of scalar
   // instructions, no division.  Past the last tile the pieces are still issued (no branch in the MFMA stream): they re-read the last
   // tile into the next ring slots, whose tiles (ntiles-5 ... ntiles-3) are dead by then.
-  const uint32_t seg_jump = (uint32_t)(a.H - 1) * tiles_per_seg;  // in tiles: next K/V segment of the same head (all-gathered shards)
+  const size_t tile_bytes = (size_t)(KB * D * 2);
+  const size_t seg_jump = (size_t)(a.H - 1) * tiles_per_seg * tile_bytes;  // to the next K/V segment of the same head (all-gathered shards)
   const int seg0 = t_begin / tiles_per_seg, in0 = t_begin - seg0 * tiles_per_seg;
-  uint32_t st_tile_g = (uint32_t)(seg0 * a.H + head) * tiles_per_seg + in0;  // global tile index ([segment][head][tile]) of the staged tile
-  int st_tile = 0, st_left = tiles_per_seg - in0, st_slot = 0;               // tile number (in the split), tiles left in its segment, ring slot
-  uint32_t st_base = wu * 4096;
+  size_t st_off = ((size_t)(seg0 * a.H + head) * tiles_per_seg + in0) * tile_bytes;  // byte offset of the staged tile in K and in V^T
+  int st_tile = 0, st_left = tiles_per_seg - in0;  // tile number (in the split), tiles left in its segment
+  uint32_t st_base = wu * 4096;                    // LDS byte offset of this wave's pieces in the ring slot of the staged tile
   auto stage_next = [&]() {  // select tile st_tile + 1
     ++st_tile;
     const bool live = st_tile < ntiles;
     const bool wrap = --st_left == 0;
-    st_tile_g += live ? (wrap ? 1u + seg_jump : 1u) : 0u;
+    st_off += live ? (wrap ? tile_bytes + seg_jump : tile_bytes) : 0;
     st_left = wrap ? tiles_per_seg : st_left;
-    st_slot = st_slot + 1 == NBUF ? 0 : st_slot + 1;
-    st_base = (uint32_t)st_slot * BUF_BYTES + wu * 4096;
+    st_base = st_base + BUF_BYTES >= (uint32_t)(NBUF * BUF_BYTES) ? st_base + BUF_BYTES - NBUF * BUF_BYTES : st_base + BUF_BYTES;
   };
   const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_offset(smem));
   uint32_t kbyte[4], vbyte[4];  // per-lane byte offsets of the pieces inside a tile (constant): uniform base + 32-bit VGPR offset is
@@ -542,9 +542,8 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
     vbyte[i] = (uint32_t)vsrc[i] * 2u;
   }
   auto stage_piece = [&](int i) {  // piece i (0..7) of this wave's share of the selected tile: 4 K then 4 V^T pieces
-    const size_t off = (size_t)st_tile_g * (size_t)(KB * D * 2);
-    const unsigned char* kb_ = reinterpret_cast<const unsigned char*>(a.K) + off;
-    const unsigned char* vb_ = reinterpret_cast<const unsigned char*>(a.Vt) + off;
+    const unsigned char* kb_ = reinterpret_cast<const unsigned char*>(a.K) + st_off;
+    const unsigned char* vb_ = reinterpret_cast<const unsigned char*>(a.Vt) + st_off;
     if (i < 4)
       glds16_saddr(kb_, kbyte[i], smem_base + st_base + i * 1024);
     else
