@@ -372,49 +372,98 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
     }
   }
 
-  // ---- epilogue: lane owns token row m and feature quads (as k_gemm) ------------------------------------------------------
+  // ---- epilogue through LDS: row-contiguous global accesses ------------------------------------------------------------------
+  // In the accumulator layout a lane owns one token row and quads of features, so a store instruction touches 32-64 different rows
+  // (8 / 16 bytes each): 64 such instructions per lane made the epilogue ~20 k cycles per tile, 9 % of a K = 5120 GEMM.  Each wave
+  // therefore transposes its 128 x 64 tile through a private 18 KiB LDS region (the operand buffers are free behind the last barrier)
+  // and reads / writes global memory in full 128-byte lines: 8 lanes per token row.  Rows are padded by 16 B (144-byte stride) so
+  // that neither the column-wise writes nor the row-wise reads conflict.  No workgroup barrier: the region is wave-private.
+  {
+    constexpr int RS = 144;  // padded row stride in bytes
+    unsigned char* stg = smem + wid * (128 * RS);
+    const int lrow = lane >> 3, lch = lane & 7;  // row phase: 8 rows x 8 chunks of 16 B per instruction
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+      // one pass: [128 tokens][64 features] bf16 = 128 B per row
 #pragma unroll
-  for (int jx = 0; jx < 4; ++jx) {
-    const int m = m0 + wmh * 128 + jx * 32 + l31;
-    if (m >= a.M) continue;
+      for (int jx = 0; jx < 4; ++jx)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wq * 64 + i * 32 + 8 * g + 4 * hi;
-        if (n >= a.N) continue;
-        float v[4];
+          for (int g = 0; g < 4; ++g) {
+            const int nl = i * 32 + 8 * g + 4 * hi;  // feature within the wave tile
+            const int n = n0 + wq * 64 + nl;
+            float v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = acc[i][jx][4 * g + q];
-        if (a.bias) {
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
+            for (int q = 0; q < 4; ++q) v[q] = acc[i][jx][4 * g + q];
+            if (a.bias && n < a.N) {
+              const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] += bb[q];
-        }
-        const size_t o = (size_t)m * a.ldo + n;
-        if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
-          if constexpr (EPI == EPI_BF16_GELU) {
+              for (int q = 0; q < 4; ++q) v[q] += bb[q];
+            }
+            if constexpr (EPI == EPI_BF16_GELU) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
+              for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
+            }
+            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(stg + (jx * 32 + l31) * RS + nl * 2) = pk;
           }
-          u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + o) = pk;
-        } else if constexpr (EPI == EPI_F32) {
-          f32x4 ov = {v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + o) = ov;
-        } else if constexpr (EPI == EPI_F32_ACC) {
-          float* po = reinterpret_cast<float*>(a.out) + o;
-          f32x4 old = *reinterpret_cast<const f32x4*>(po);
-          f32x4 ov = {old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
-          *reinterpret_cast<f32x4*>(po) = ov;
-        } else {
-          float* po = reinterpret_cast<float*>(a.out) + o;
-          f32x4 old = *reinterpret_cast<const f32x4*>(po);
-          f32x4 gg = {1.f, 1.f, 1.f, 1.f};
-          if (a.gate) gg = *reinterpret_cast<const f32x4*>(a.gate + n);
-          f32x4 ov = {old[0] + v[0] * gg[0], old[1] + v[1] * gg[1], old[2] + v[2] * gg[2], old[3] + v[3] * gg[3]};
-          *reinterpret_cast<f32x4*>(po) = ov;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int r8 = 0; r8 < 16; ++r8) {
+        const int row = r8 * 8 + lrow;
+        const int m = m0 + wmh * 128 + row;
+        const int n = n0 + wq * 64 + lch * 8;
+        const u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * RS + lch * 16);
+        if (m < a.M && n < a.N) {  // N % 4 == 0: a chunk of 8 features may straddle the edge
+          uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
+          if (n + 8 <= a.N)
+            *reinterpret_cast<u32x4*>(op) = val;
+          else
+            *reinterpret_cast<u32x2*>(op) = u32x2{val[0], val[1]};
         }
+      }
+    } else {
+      // fp32 outputs: two passes of [128 tokens][32 features] f32 = 128 B per row
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int nl = 8 * g + 4 * hi;
+            const int n = n0 + wq * 64 + i * 32 + nl;
+            f32x4 v = {acc[i][jx][4 * g + 0], acc[i][jx][4 * g + 1], acc[i][jx][4 * g + 2], acc[i][jx][4 * g + 3]};
+            if (a.bias && n < a.N) {
+              const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] += bb[q];
+            }
+            *reinterpret_cast<f32x4*>(stg + (jx * 32 + l31) * RS + nl * 4) = v;
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r8 = 0; r8 < 16; ++r8) {
+          const int row = r8 * 8 + lrow;
+          const int m = m0 + wmh * 128 + row;
+          const int n = n0 + wq * 64 + i * 32 + lch * 4;
+          f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * RS + lch * 16);
+          if (m < a.M && n < a.N) {
+            float* po = reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n;
+            if constexpr (EPI == EPI_F32) {
+              *reinterpret_cast<f32x4*>(po) = v;
+            } else if constexpr (EPI == EPI_F32_ACC) {
+              const f32x4 old = *reinterpret_cast<const f32x4*>(po);
+              *reinterpret_cast<f32x4*>(po) = f32x4{old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
+            } else {
+              const f32x4 old = *reinterpret_cast<const f32x4*>(po);
+              f32x4 gg = {1.f, 1.f, 1.f, 1.f};
+              if (a.gate) gg = *reinterpret_cast<const f32x4*>(a.gate + n);
+              *reinterpret_cast<f32x4*>(po) =
+                  f32x4{old[0] + v[0] * gg[0], old[1] + v[1] * gg[1], old[2] + v[2] * gg[2], old[3] + v[3] * gg[3]};
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the second pass overwrites the staging rows
       }
     }
   }
@@ -645,7 +694,7 @@ static void launch_pp(GemmArgs a, hipStream_t s) {
   a.nt = ceil_div(a.N, PN);
   const int nsuper = ((a.mt + 3) / 4) * ((a.nt + 3) / 4);
   const int grid = ((nsuper + 7) / 8) * 8 * 16;
-  hipLaunchKernelGGL(k_gemm_pp<EPI>, dim3(grid), dim3(PT), 2 * P_BUF, s, a);
+  hipLaunchKernelGGL(k_gemm_pp<EPI>, dim3(grid), dim3(PT), 8 * 128 * 144, s, a);  // operand double buffer (128 KiB) < epilogue staging (144 KiB)
 }
 
 }  // namespace
