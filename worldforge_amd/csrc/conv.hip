@@ -542,7 +542,7 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  // persistent: workgroup b walks tiles b, b + gridDim.x, ... ((t, tile_y, tile_x), x fastest); blockIdx.y -> 96-channel output block.
+  // persistent: every workgroup walks its own contiguous chunk of the tile list; blockIdx.y -> 96-channel output block.
   // The first patch of the NEXT tile is staged during the last channel slice of the current one, so that only the very first tile
   // of a workgroup pays the cold-start DMA latency, and the epilogue stores run under that flight.
   const int ntile = pa.tiles_x * pa.tiles_y * a.To;
@@ -550,13 +550,17 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   const int Cin = a.Cin;
   const int ns = Cin / 16;  // even (Cin % 32 == 0): a tile starts in LDS buffer 0 and ends in buffer 1
   int t, y0, x0;
+  // tile list in (spatial tile, frame) order, frame fastest, cut into one contiguous chunk per workgroup: consecutive tiles of a
+  // workgroup are consecutive frames of the same 8 x 64 window, so two of the three patch frames were fetched by this CU just before
   auto decode = [&](int tile, int& tt, int& yy, int& xx) {
-    const int tx = tile % pa.tiles_x;
-    const int r = tile / pa.tiles_x;
-    xx = tx * WX;
-    yy = (r % pa.tiles_y) * WY;
-    tt = r / pa.tiles_y;
+    const int sidx = tile / a.To;
+    tt = tile - sidx * a.To;
+    xx = (sidx % pa.tiles_x) * WX;
+    yy = (sidx / pa.tiles_x) * WY;
   };
+  const int chunk = (ntile + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int tile_begin = (int)blockIdx.x * chunk, tile_end = min(ntile, tile_begin + chunk);
+  if (tile_begin >= tile_end) return;
 
 #ifdef WF_CONV_TIMING
   const unsigned long long tc0 = __builtin_readcyclecounter();
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
       pvalid |= ok ? (1u << j) : 0u;
     }
   };
-  decode(blockIdx.x, t, y0, x0);
+  decode(tile_begin, t, y0, x0);
   compute_psrc(t, y0, x0);
   const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_offset(smem));
   auto dma_piece = [&](int cs, int j) {  // piece j of the patch of channel slice cs -> buffer cs & 1
@@ -638,12 +642,12 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   const unsigned long long tc1 = __builtin_readcyclecounter();
   unsigned long long t_wait = 0, t_main = 0, t_epi = 0, n_tiles = 0;
 #endif
-  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
 #ifdef WF_CONV_TIMING
   const unsigned long long tt0 = __builtin_readcyclecounter();
 #endif
-  const int tile_n = tile + (int)gridDim.x;
-  const bool has_next = tile_n < ntile;
+  const int tile_n = tile + 1;
+  const bool has_next = tile_n < tile_end;
   int tn = t, yn = y0, xn = x0;
 #pragma unroll
   for (int pb = 0; pb < 4; ++pb)
