@@ -7,6 +7,8 @@ from __future__ import annotations
 
 from typing import Optional, Sequence
 
+import threading
+
 import torch
 
 from . import _ffi
@@ -177,10 +179,14 @@ _WS = {}
 
 
 def _workspace(key, nfloats, device):
-    t = _WS.get((key, device))
+    """Scratch buffer for the multi-launch entry points (DSG, flow metric, Farneback, split attention), one per calling thread: the
+    launches of one call must not interleave with another thread's launches on the same buffer (the simulated-rank tests run several
+    ranks as threads of one process; a real job has one process per GPU)."""
+    k = (key, device, threading.get_ident())
+    t = _WS.get(k)
     if t is None or t.numel() < nfloats:
         t = torch.empty(int(nfloats), dtype=torch.float32, device=device)
-        _WS[(key, device)] = t
+        _WS[k] = t
     return t
 
 
