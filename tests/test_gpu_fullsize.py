@@ -259,3 +259,32 @@ def test_vae_c2_row_sharded_equals_unsharded():
     [t.join() for t in th]
     assert not errs, errs
     assert all(ok), ok
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the DiT at its real width (d = 5120, 40 heads, FFN 13824, text 4096) against the CPU oracle: two layers on the C1 token grid
+# ---------------------------------------------------------------------------------------------------------------------
+def test_dit_full_width_two_layers_vs_oracle():
+    """Every projection at its production K (5120 / 13824) and all 40 heads, on the tokens of BASELINE configs[0] (9 frames of
+    464 x 832 -> L = 4524): the HIP forward (bf16 MFMA operands, fp32 accumulation / residual stream) against the fp32 oracle run on
+    the same bf16-rounded weights and inputs."""
+    from worldforge_amd import dit
+    ocfg = odit.DiTConfig(num_layers=2)
+    assert (ocfg.dim, ocfg.num_heads, ocfg.ffn_dim, ocfg.text_dim) == (5120, 40, 13824, 4096)
+    W = odit.random_weights(ocfg, seed=21)
+    Wb = {k: (v.to(BF).float() if v.dim() >= 2 else v) for k, v in W.items()}
+    cfg = dit.DiTConfig.wan_i2v_14b()
+    cfg.num_layers = 2
+    model = dit.WanTransformer3DModel(cfg, DEV).load_state_dict(W)
+    g = torch.Generator().manual_seed(22)
+    T, Hh, Ww = 3, 58, 104
+    x = torch.randn(36, T, Hh, Ww, generator=g).to(BF)
+    ctx = (torch.randn(200, 4096, generator=g) * 0.1).to(BF)
+    clip = torch.randn(257, 1280, generator=g).to(BF)
+    out = model.forward_tokens(x.to(DEV), 749.0, ctx.to(DEV), clip.to(DEV)).cpu()
+    with torch.no_grad():
+        orc = odit.forward(Wb, ocfg, x.float(), torch.tensor(749), ctx.float(), clip.float())
+    rel = (out - orc).norm().item() / orc.norm().item()
+    print(f"full-width DiT (2 layers, L = {T * (Hh // 2) * (Ww // 2)}): rel L2 vs oracle {rel:.3e}, max abs {(out - orc).abs().max().item():.3e}")
+    assert torch.isfinite(out).all()
+    assert rel <= 2e-2, rel
