@@ -9,6 +9,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [
     dict(dim=256, ffn_dim=512, heads=2, layers=2, Fr=9, H=32, Wd=32, steps=3, guide=2),
     dict(dim=1024, ffn_dim=2048, heads=8, layers=4, Fr=13, H=64, Wd=96, steps=5, guide=3),
+    dict(dim=5120, ffn_dim=13824, heads=40, layers=2, Fr=9, H=64, Wd=96, steps=4, guide=3),   # the 14B width, two layers
 ])
 def test_guided_job_frames_psnr_vs_oracle(cfg):
     import __graft_entry__ as ge
