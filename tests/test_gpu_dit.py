@@ -53,6 +53,34 @@ def test_gemm(M, N, K, epi):
     assert _rel(out, ref) <= tol, (_rel(out, ref), tol)
 
 
+@pytest.mark.parametrize("M,N,K", [(4095, 5120, 640), (8190, 5120, 128), (4096, 640, 192 * 64)])
+@pytest.mark.parametrize("epi", [0, 1, 3])
+def test_gemm_wide_tile_equals_small_tile_kernel(M, N, K, epi):
+    """Shapes whose last round of workgroups is fuller with 320-feature tiles (N % 320 == 0) take the 256 x 320 variant of the
+    ping-pong kernel.  Every output element is the same sequence of MFMA accumulations over K in all tile shapes, so the result
+    must equal, bit for bit, the same product computed in row chunks small enough for the 128 x 128 kernel."""
+    from worldforge_amd import dit
+    x = _rand((M, K), 21).to(BF).to(DEV)
+    w = (_rand((N, K), 22) / math.sqrt(K)).to(BF).to(DEV)
+    b = _rand((N,), 23, 0.1).to(DEV)
+    gate = _rand((N,), 24).to(DEV) if epi == 3 else None
+    old = _rand((M, N), 25).to(DEV)
+    dt = BF if epi in (0, 1) else F32
+    full = old.clone() if epi == 3 else torch.full((M, N), float("nan"), dtype=dt, device=DEV)
+    dit.gemm(x, w, b, full, epi, gate=gate)
+    parts = old.clone() if epi == 3 else torch.full((M, N), float("nan"), dtype=dt, device=DEV)
+    for r0 in range(0, M, 1000):
+        dit.gemm(x[r0:r0 + 1000], w, b, parts[r0:r0 + 1000], epi, gate=gate)
+    assert torch.isfinite(full.float()).all()
+    assert torch.equal(full, parts), (full.float() - parts.float()).abs().max()
+    ref = x.float() @ w.float().t() + b
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref, approximate="tanh")
+    if epi == 3:
+        ref = old + ref * gate
+    assert _rel(full, ref.cpu()) <= (1e-2 if epi in (0, 1) else 2e-5 * math.sqrt(K) + 1e-5)
+
+
 def test_gemm_strided_views_and_no_bias():
     from worldforge_amd import dit
     big = _rand((200, 512), 6).to(BF).to(DEV)

@@ -227,8 +227,31 @@ constexpr int PM = 256, PN = 256, PK = 64, PT = 512;
 constexpr int P_TILE = PM * PK * 2;  // 32 KiB per operand tile
 constexpr int P_BUF = 2 * P_TILE;    // W tile | X tile
 
-template <int EPI>
+
+// Tile geometry.  NI = 32-feature MFMA tiles per wave, NJ = 32-token MFMA tiles per wave:
+//   NI = 2, NJ = 4: 256 tokens x 256 features; waves = 2 token halves (= ping-pong group) x 4 feature quarters;
+//   NI = 5, NJ = 2: 256 tokens x 320 features; waves = 4 token quarters x 2 feature halves (= ping-pong group).  N = 5120 is
+//   16 x 320: with 4096 / 8192 tokens per rank (8 / 4 ranks) that is exactly 1 / 2 rounds of 256 workgroups where the 256-wide tile
+//   needs 1.25 / 2.5; the wider tile also reads 0.70 fragment quads per MFMA instead of 0.75.
+template <int NI>
+struct PPGeom {
+  static constexpr int NJ = NI == 2 ? 4 : 2;
+  static constexpr int TSPLIT = PM / (NJ * 32);       // waves along tokens
+  static constexpr int FSPLIT = 8 / TSPLIT;           // waves along features
+  static constexpr int PNT = FSPLIT * NI * 32;        // features per workgroup tile
+  static constexpr int W_TILE = PNT * PK * 2;         // bytes
+  static constexpr int X_TILE = PM * PK * 2;
+  static constexpr int BUF = W_TILE + X_TILE;
+  static constexpr int NWP = PNT / 64;                // 1 KiB W pieces per wave
+  static constexpr int NP = NWP + 4;                  // LDS-DMA pieces per wave per K tile
+  static constexpr int STG = NJ * 32 * 144;           // epilogue staging bytes per wave
+  static constexpr int LDS = 2 * BUF > 8 * STG ? 2 * BUF : 8 * STG;
+};
+
+template <int EPI, int NI>
 __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
+  using G = PPGeom<NI>;
+  constexpr int NJ = G::NJ, NWP = G::NWP, NP = G::NP, W_TILE = G::W_TILE, BUF = G::BUF;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // XCD-aware tile assignment (4 x 4 super-tiles of 256 x 256 tiles per XCD pass)
   const int smt = (a.mt + 3) >> 2, snt = (a.nt + 3) >> 2;
@@ -241,92 +264,83 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
   const int tm = (gid / snt) * 4 + (within >> 2);
   const int tn = (gid % snt) * 4 + (within & 3);
   if (tm >= a.mt || tn >= a.nt) return;
-  const int m0 = tm * PM, n0 = tn * PN;
+  const int m0 = tm * PM, n0 = tn * G::PNT;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  const int wq = wid & 3;   // feature quarter (64 features)
-  const int wh = (wid >> 2) ^ 0;  // provisional; group = wid >> 2
   const bool groupB = wid >= 4;
-  const int wmh = wid >> 2;  // token half is tied to the group: A -> tokens 0..127, B -> 128..255
-  (void)wh;
+  const int wfi = NJ == 4 ? (wid & 3) : (wid >> 2);  // wave index along features
+  const int wti = NJ == 4 ? (wid >> 2) : (wid & 3);  // wave index along tokens
+  const int wf0 = wfi * NI * 32, wt0 = wti * NJ * 32;  // wave tile origin inside the workgroup tile
 
-  // ---- LDS-DMA geometry: an operand tile = 256 rows x 128 B = 32 pieces of 1 KiB (8 rows); wave w moves pieces 4w..4w+3 of W
-  // and of X.  lane -> (row = 8*piece + lane/8, slot = lane%8) receives source chunk slot ^ ((row >> 1) & 7).
-  const uint16_t* srcW[4];
+  // ---- LDS-DMA geometry: an operand tile = rows x 128 B = pieces of 1 KiB (8 rows); wave w moves pieces NWP*w.. of W and
+  // 4w..4w+3 of X.  lane -> (row = 8*piece + lane/8, slot = lane%8) receives source chunk slot ^ ((row >> 1) & 7).
+  const uint16_t* srcW[NWP];
   const uint16_t* srcX[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int piece = wid * 4 + i;
-    const int row = 8 * piece + (lane >> 3), slot = lane & 7;
-    const int ch = slot ^ ((row >> 1) & 7);
-    srcW[i] = a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw + ch * 8;
-    srcX[i] = a.X + (size_t)min(m0 + row, a.M - 1) * a.ldx + ch * 8;
+  for (int i = 0; i < NWP; ++i) {
+    const int row = 8 * (wid * NWP + i) + (lane >> 3), slot = lane & 7;
+    srcW[i] = a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw + (slot ^ ((row >> 1) & 7)) * 8;
   }
-  auto dma_piece = [&](int kt, int i) {  // i in 0..7: W pieces 0..3, X pieces 0..3
-    unsigned char* base = smem + (kt & 1) * P_BUF + wid * 4096;
-    if (i < 4)
-      glds16(srcW[i] + (size_t)kt * PK, base + i * 1024);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * (wid * 4 + i) + (lane >> 3), slot = lane & 7;
+    srcX[i] = a.X + (size_t)min(m0 + row, a.M - 1) * a.ldx + (slot ^ ((row >> 1) & 7)) * 8;
+  }
+  auto dma_piece = [&](int kt, int i) {  // i in 0..NP-1: W pieces first, then the 4 X pieces
+    unsigned char* base = smem + (kt & 1) * BUF;
+    if (i < NWP)
+      glds16(srcW[i] + (size_t)kt * PK, base + (wid * NWP + i) * 1024);
     else
-      glds16(srcX[i - 4] + (size_t)kt * PK, base + P_TILE + (i - 4) * 1024);
+      glds16(srcX[i - NWP] + (size_t)kt * PK, base + W_TILE + (wid * 4 + i - NWP) * 1024);
   };
   auto dma = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma_piece(kt, i);
+    for (int i = 0; i < NP; ++i) dma_piece(kt, i);
   };
 
   // ---- fragment addressing ------------------------------------------------------------------------------------------------
-  int offW[2], swW[2], offX[4], swX[4];
+  // every fragment row of a wave is its lane's row l31 plus a multiple of 32: one swizzle term serves all of them
+  const int sw = (l31 >> 1) & 7;
+  const int offW = (wf0 + l31) * 128, offX = W_TILE + (wt0 + l31) * 128;
+  f32x16 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = wq * 64 + i * 32 + l31;
-    offW[i] = r * 128;
-    swW[i] = (r >> 1) & 7;
-  }
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-  for (int jx = 0; jx < 4; ++jx) {
-    const int r = wmh * 128 + jx * 32 + l31;
-    offX[jx] = P_TILE + r * 128;
-    swX[jx] = (r >> 1) & 7;
-  }
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int jx = 0; jx < 4; ++jx)
+    for (int jx = 0; jx < NJ; ++jx)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][jx][r] = 0.f;
 
-  u32x4 fw[2][2], fx[2][4];
+  u32x4 fw[2][NI], fx[2][NJ];
   auto read_half = [&](int kt, int half) {
-    const unsigned char* base = smem + (kt & 1) * P_BUF;
+    const unsigned char* base = smem + (kt & 1) * BUF;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int c = 2 * (2 * half + ks) + hi;
+      const int c = ((2 * (2 * half + ks) + hi) ^ sw) << 4;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fw[ks][i] = *reinterpret_cast<const u32x4*>(base + offW[i] + ((c ^ swW[i]) << 4));
+      for (int i = 0; i < NI; ++i) fw[ks][i] = *reinterpret_cast<const u32x4*>(base + offW + i * 4096 + c);
 #pragma unroll
-      for (int jx = 0; jx < 4; ++jx) fx[ks][jx] = *reinterpret_cast<const u32x4*>(base + offX[jx] + ((c ^ swX[jx]) << 4));
+      for (int jx = 0; jx < NJ; ++jx) fx[ks][jx] = *reinterpret_cast<const u32x4*>(base + offX + jx * 4096 + c);
     }
   };
-  // 16 MFMAs on register operands; optionally the 8 LDS-DMA pieces of tile `dma_kt` are issued in the gaps (one behind every
-  // second MFMA: the MFMA pipe hides their issue cost, and the read phases stay pure LDS reads)
+  // 2*NI*NJ MFMAs on register operands; optionally the NP LDS-DMA pieces of tile `dma_kt` are issued in the gaps (one behind
+  // every second MFMA: the MFMA pipe hides their issue cost, and the read phases stay pure LDS reads)
   auto mma_half = [&](int dma_kt) {
     __builtin_amdgcn_s_setprio(1);  // the MFMA phase outranks the co-resident wave's LDS phase at the issue arbiter
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int jx = 0; jx < 4; ++jx) {
+        for (int jx = 0; jx < NJ; ++jx) {
           acc[i][jx] = mfma32(as_bf16x8(fw[ks][i]), as_bf16x8(fx[ks][jx]), acc[i][jx]);
-          const int idx = ks * 8 + i * 4 + jx;
-          if (dma_kt >= 0 && (idx & 1)) dma_piece(dma_kt, idx >> 1);
+          const int idx = (ks * NI + i) * NJ + jx;
+          if (dma_kt >= 0 && (idx & 1) && (idx >> 1) < NP) dma_piece(dma_kt, idx >> 1);
         }
     if (dma_kt >= 0) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < NP; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
@@ -375,63 +389,75 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
   // ---- epilogue through LDS: row-contiguous global accesses ------------------------------------------------------------------
   // In the accumulator layout a lane owns one token row and quads of features, so a store instruction touches 32-64 different rows
   // (8 / 16 bytes each): 64 such instructions per lane made the epilogue ~20 k cycles per tile, 9 % of a K = 5120 GEMM.  Each wave
-  // therefore transposes its 128 x 64 tile through a private 18 KiB LDS region (the operand buffers are free behind the last barrier)
-  // and reads / writes global memory in full 128-byte lines: 8 lanes per token row.  Rows are padded by 16 B (144-byte stride) so
-  // that neither the column-wise writes nor the row-wise reads conflict.  No workgroup barrier: the region is wave-private.
+  // therefore transposes its tile through a private LDS region (the operand buffers are free behind the last barrier) in passes of
+  // [NJ*32 tokens][128 B]  (64 bf16 features = two MFMA tiles, or 32 fp32 features = one; an odd last bf16 tile makes a 64-byte
+  // pass) and reads / writes global memory in whole rows of a pass.  Rows are padded by 16 B (144-byte stride) so that neither the
+  // column-wise writes nor the row-wise reads conflict.  No workgroup barrier: the region is wave-private.
   {
     constexpr int RS = 144;  // padded row stride in bytes
-    unsigned char* stg = smem + wid * (128 * RS);
-    const int lrow = lane >> 3, lch = lane & 7;  // row phase: 8 rows x 8 chunks of 16 B per instruction
+    constexpr int ROWS = NJ * 32;
+    unsigned char* stg = smem + wid * G::STG;
     if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
-      // one pass: [128 tokens][64 features] bf16 = 128 B per row
 #pragma unroll
-      for (int jx = 0; jx < 4; ++jx)
+      for (int i0 = 0; i0 < NI; i0 += 2) {
+        const int nti = (NI - i0) >= 2 ? 2 : 1;  // feature tiles in this pass (compile-time after unrolling)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int jx = 0; jx < NJ; ++jx)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int nl = i * 32 + 8 * g + 4 * hi;  // feature within the wave tile
-            const int n = n0 + wq * 64 + nl;
-            float v[4];
+          for (int ii = 0; ii < 2; ++ii) {
+            if (ii >= nti) continue;
+            const int i = i0 + ii;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = acc[i][jx][4 * g + q];
-            if (a.bias && n < a.N) {
-              const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
+            for (int g = 0; g < 4; ++g) {
+              const int nl = ii * 32 + 8 * g + 4 * hi;  // feature within the pass
+              const int n = n0 + wf0 + i0 * 32 + nl;
+              float v[4];
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] += bb[q];
+              for (int q = 0; q < 4; ++q) v[q] = acc[i][jx][4 * g + q];
+              if (a.bias && n < a.N) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] += bb[q];
+              }
+              if constexpr (EPI == EPI_BF16_GELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
+              }
+              u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+              *reinterpret_cast<u32x2*>(stg + (jx * 32 + l31) * RS + nl * 2) = pk;
             }
-            if constexpr (EPI == EPI_BF16_GELU) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
-            }
-            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-            *reinterpret_cast<u32x2*>(stg + (jx * 32 + l31) * RS + nl * 2) = pk;
           }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // row phase: 8 (4) lanes x 16 B per token row, 8 (16) rows per instruction
+        const int lpr = nti * 4;
+        const int lrow = lane / lpr, lch = lane % lpr;
 #pragma unroll
-      for (int r8 = 0; r8 < 16; ++r8) {
-        const int row = r8 * 8 + lrow;
-        const int m = m0 + wmh * 128 + row;
-        const int n = n0 + wq * 64 + lch * 8;
-        const u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * RS + lch * 16);
-        if (m < a.M && n < a.N) {  // N % 4 == 0: a chunk of 8 features may straddle the edge
-          uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
-          if (n + 8 <= a.N)
-            *reinterpret_cast<u32x4*>(op) = val;
-          else
-            *reinterpret_cast<u32x2*>(op) = u32x2{val[0], val[1]};
+        for (int r8 = 0; r8 < ROWS * nti / 16; ++r8) {
+          const int row = r8 * (64 / lpr) + lrow;
+          const int m = m0 + wt0 + row;
+          const int n = n0 + wf0 + i0 * 32 + lch * 8;
+          const u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * RS + lch * 16);
+          if (m < a.M && n < a.N) {  // N % 4 == 0: a chunk of 8 features may straddle the edge
+            uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
+            if (n + 8 <= a.N)
+              *reinterpret_cast<u32x4*>(op) = val;
+            else
+              *reinterpret_cast<u32x2*>(op) = u32x2{val[0], val[1]};
+          }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next pass overwrites the staging rows
       }
     } else {
-      // fp32 outputs: two passes of [128 tokens][32 features] f32 = 128 B per row
+      const int lrow = lane >> 3, lch = lane & 7;  // row phase: 8 rows x 8 chunks of 16 B per instruction
+      // fp32 outputs: one pass of [NJ*32 tokens][32 features] f32 = 128 B per row for every feature tile
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NI; ++i) {
 #pragma unroll
-        for (int jx = 0; jx < 4; ++jx)
+        for (int jx = 0; jx < NJ; ++jx)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int nl = 8 * g + 4 * hi;
-            const int n = n0 + wq * 64 + i * 32 + nl;
+            const int n = n0 + wf0 + i * 32 + nl;
             f32x4 v = {acc[i][jx][4 * g + 0], acc[i][jx][4 * g + 1], acc[i][jx][4 * g + 2], acc[i][jx][4 * g + 3]};
             if (a.bias && n < a.N) {
               const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
@@ -442,10 +468,10 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
           }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int r8 = 0; r8 < 16; ++r8) {
+        for (int r8 = 0; r8 < ROWS / 8; ++r8) {
           const int row = r8 * 8 + lrow;
-          const int m = m0 + wmh * 128 + row;
-          const int n = n0 + wq * 64 + i * 32 + lch * 4;
+          const int m = m0 + wt0 + row;
+          const int n = n0 + wf0 + i * 32 + lch * 4;
           f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * RS + lch * 16);
           if (m < a.M && n < a.N) {
             float* po = reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n;
@@ -463,7 +489,7 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
             }
           }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the second pass overwrites the staging rows
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next pass overwrites the staging rows
       }
     }
   }
@@ -688,13 +714,45 @@ static void launch_w4(GemmArgs a, hipStream_t s) {
   hipLaunchKernelGGL(k_gemm_w4<EPI>, dim3(grid), dim3(WT), 2 * P_BUF, s, a);
 }
 
-template <int EPI>
+template <int EPI, int NI>
 static void launch_pp(GemmArgs a, hipStream_t s) {
+  using G = PPGeom<NI>;
   a.mt = ceil_div(a.M, PM);
-  a.nt = ceil_div(a.N, PN);
+  a.nt = ceil_div(a.N, G::PNT);
   const int nsuper = ((a.mt + 3) / 4) * ((a.nt + 3) / 4);
   const int grid = ((nsuper + 7) / 8) * 8 * 16;
-  hipLaunchKernelGGL(k_gemm_pp<EPI>, dim3(grid), dim3(PT), 8 * 128 * 144, s, a);  // operand double buffer (128 KiB) < epilogue staging (144 KiB)
+  hipLaunchKernelGGL((k_gemm_pp<EPI, NI>), dim3(grid), dim3(PT), G::LDS, s, a);
+}
+
+// 256- or 320-feature tiles: whichever leaves fewer idle workgroup slots in the last round of `n_cu` concurrent workgroups
+// (ties go to the wider tile).  The result does not depend on the choice: every output element is the same sequence of MFMA
+// accumulations over K in both.
+static int pp_wide(int M, int N) {
+  if (N % 320 != 0) return 0;
+  static const int force = [] {
+    const char* e = getenv("WF_GEMM_TILE");
+    return e ? atoi(e) : 0;
+  }();
+  if (force == 256) return 0;
+  if (force == 320) return 1;
+  static const int n_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  const long mt = ceil_div(M, PM);
+  const long t256 = mt * ceil_div(N, 256), t320 = mt * (N / 320);
+  const long r256 = (t256 + n_cu - 1) / n_cu, r320 = (t320 + n_cu - 1) / n_cu;
+  // cost ~ rounds x tile width
+  return r320 * 320 <= r256 * 256;
+}
+
+template <int EPI>
+static void launch_pp_any(GemmArgs a, hipStream_t s) {
+  if (pp_wide(a.M, a.N))
+    launch_pp<EPI, 5>(a, s);
+  else
+    launch_pp<EPI, 2>(a, s);
 }
 
 }  // namespace
@@ -746,11 +804,11 @@ extern "C" int wf_gemm_bf16(const void* X, const void* W, const float* bias, voi
   }
   if (!no_pp && K % PK == 0 && M >= 1024 && N >= 256 && (long)M * N >= (1L << 22)) {
     switch (epilogue) {
-      case EPI_BF16: launch_pp<EPI_BF16>(a, s); break;
-      case EPI_BF16_GELU: launch_pp<EPI_BF16_GELU>(a, s); break;
-      case EPI_F32: launch_pp<EPI_F32>(a, s); break;
-      case EPI_RESID: launch_pp<EPI_RESID>(a, s); break;
-      case EPI_F32_ACC: launch_pp<EPI_F32_ACC>(a, s); break;
+      case EPI_BF16: launch_pp_any<EPI_BF16>(a, s); break;
+      case EPI_BF16_GELU: launch_pp_any<EPI_BF16_GELU>(a, s); break;
+      case EPI_F32: launch_pp_any<EPI_F32>(a, s); break;
+      case EPI_RESID: launch_pp_any<EPI_RESID>(a, s); break;
+      case EPI_F32_ACC: launch_pp_any<EPI_F32_ACC>(a, s); break;
       default: WF_CHECK_ARG(false, "wf_gemm_bf16: unknown epilogue %d", epilogue);
     }
     WF_LAUNCH_CHECK("wf_gemm_bf16");
