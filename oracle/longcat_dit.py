@@ -1,0 +1,246 @@
+"""Oracle: LongCat-Video DiT forward in plain torch (CPU, fp32).  TEST INFRASTRUCTURE ONLY.
+
+Restates /root/reference/longcat_for_worldforge/longcat_video/modules/{longcat_video_dit.py, attention.py, blocks.py,
+rope_3d.py} (abbreviated LCD / LCA / LCB / LCR below) for the call the guided image-to-video sampler makes
+(pipeline_longcat_video.py:867-873: one sample, per-frame timesteps with frame 0 clean, num_cond_latents = 1, no KV cache, no
+block-sparse attention).  Weights are a flat dict keyed like the reference state_dict ("blocks.3.attn.qkv.weight", ...).
+Pinned against the imported, unmodified reference module in tests/test_oracle_longcat.py (goldens: tests/golden/g11_longcat_dit.npz,
+written by tools/make_goldens.py longcat; the reference's flash-attn calls are served there by a plain-softmax stand-in for that
+third-party package, tools/refshim/flash_attn).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class LongCatConfig:
+    """LCD:138-158 defaults = the released 13.6B model."""
+    hidden_size: int = 4096
+    depth: int = 48
+    num_heads: int = 32
+    in_channels: int = 16
+    out_channels: int = 16
+    caption_channels: int = 4096
+    mlp_ratio: int = 4
+    adaln_tembed_dim: int = 512
+    frequency_embedding_size: int = 256
+    patch_size: Tuple[int, int, int] = (1, 2, 2)
+    text_tokens_zero_pad: bool = False
+
+    @property
+    def ffn_hidden(self) -> int:
+        """LCB:17-29: SwiGLU width = 2/3 of mlp_ratio * hidden, rounded up to a multiple of 256."""
+        h = int(2 * int(self.hidden_size * self.mlp_ratio) / 3)
+        return 256 * ((h + 255) // 256)
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
+    """LCB:181-199: [cos | sin] of t * exp(-ln(max_period) * i / half), fp32."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+def rope_angles(head_dim: int, f: int, h: int, w: int, base: float = 10000.0) -> torch.Tensor:
+    """LCR:68-99: per-token angles [f*h*w, head_dim], every frequency repeated for the two members of its pair; the first
+    head_dim - 4*(head_dim//6) entries follow the frame index, then 2*(head_dim//6) the row, then the column (fp32)."""
+    d_hw = 2 * (head_dim // 6)
+    d_t = head_dim - 2 * d_hw
+
+    def axis(n, dim):
+        freqs = 1.0 / (base ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))
+        grid = torch.from_numpy(np.linspace(0, n, n, endpoint=False, dtype=np.float32)).float()
+        return torch.outer(grid, freqs).repeat_interleave(2, dim=-1)  # [n, dim]
+
+    at, ah, aw = axis(f, d_t), axis(h, d_hw), axis(w, d_hw)
+    ang = torch.cat([at.view(f, 1, 1, -1).expand(f, h, w, -1), ah.view(1, h, 1, -1).expand(f, h, w, -1),
+                     aw.view(1, 1, w, -1).expand(f, h, w, -1)], dim=-1)
+    return ang.reshape(f * h * w, head_dim)
+
+
+def rope_apply(x: torch.Tensor, ang: torch.Tensor) -> torch.Tensor:
+    """LCR:32-36 + 116-120: x [heads, L, D]; x*cos + rotate_half(x)*sin with interleaved pairs (x0, x1) -> (-x1, x0), fp32."""
+    xf = x.float()
+    cos, sin = ang.cos()[None], ang.sin()[None]
+    x2 = xf.reshape(*xf.shape[:-1], -1, 2)
+    rot = torch.stack((-x2[..., 1], x2[..., 0]), dim=-1).reshape(xf.shape)
+    return (xf * cos + rot * sin).type_as(x)
+
+
+def rms_norm_head(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """LCB:40-52: RMS over the last (head) dimension in fp32, cast back, times weight."""
+    xf = x.float()
+    return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).type_as(x) * weight
+
+
+def layer_norm(x: torch.Tensor, weight=None, bias=None, eps: float = 1e-6) -> torch.Tensor:
+    """LCB:55-68."""
+    return F.layer_norm(x.float(), (x.shape[-1],), None if weight is None else weight.float(),
+                        None if bias is None else bias.float(), eps).to(x.dtype)
+
+
+def modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, tokens_per_frame: int) -> torch.Tensor:
+    """LCB:133-141 with the per-frame [T, C] parameters of LCD:85-91 broadcast over the frame's tokens."""
+    L, C = x.shape
+    xn = layer_norm(x.float()).view(-1, tokens_per_frame, C)
+    return (xn * (scale[:, None, :] + 1) + shift[:, None, :]).view(L, C).to(x.dtype)
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
+    """softmax(q k^T * scale) v per head (what LCA:70-90 asks of flash-attn): q [H, Lq, D], k/v [H, Lk, D] -> [Lq, H*D]."""
+    s = torch.einsum("hqd,hkd->hqk", q.float(), k.float()) * scale
+    o = torch.einsum("hqk,hkd->hqd", torch.softmax(s, dim=-1), v.float())
+    return o.permute(1, 0, 2).reshape(q.shape[1], -1).to(q.dtype)
+
+
+def self_attention(W, p: str, x: torch.Tensor, cfg: LongCatConfig, ang: torch.Tensor, n_cond_tokens: int) -> torch.Tensor:
+    """LCA:105-145: fused qkv -> per-head RMS norm of q, k -> 3D RoPE -> condition tokens attend to condition tokens only, noise
+    tokens to everything -> proj."""
+    L, C = x.shape
+    H = cfg.num_heads
+    D = C // H
+    qkv = F.linear(x, W[p + "qkv.weight"], W[p + "qkv.bias"]).view(L, 3, H, D).permute(1, 2, 0, 3)  # [3, H, L, D]
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    q, k = rms_norm_head(q, W[p + "q_norm.weight"]), rms_norm_head(k, W[p + "k_norm.weight"])
+    q, k = rope_apply(q, ang), rope_apply(k, ang)
+    scale = D ** -0.5
+    if n_cond_tokens > 0:
+        nc = n_cond_tokens
+        o = torch.cat([attention(q[:, :nc], k[:, :nc], v[:, :nc], scale), attention(q[:, nc:], k, v, scale)], dim=0)
+    else:
+        o = attention(q, k, v, scale)
+    return F.linear(o, W[p + "proj.weight"], W[p + "proj.bias"])
+
+
+def cross_attention(W, p: str, x: torch.Tensor, y: torch.Tensor, cfg: LongCatConfig, n_cond_tokens: int) -> torch.Tensor:
+    """LCA:218-276: q from the noise tokens only, k / v from the valid caption tokens, per-head RMS norm of q and k, default
+    softmax scale 1/sqrt(D); condition tokens receive zeros."""
+    L, C = x.shape
+    H = cfg.num_heads
+    D = C // H
+    xn = x[n_cond_tokens:]
+    q = F.linear(xn, W[p + "q_linear.weight"], W[p + "q_linear.bias"]).view(-1, H, D)
+    kv = F.linear(y, W[p + "kv_linear.weight"], W[p + "kv_linear.bias"]).view(-1, 2, H, D)
+    k, v = kv[:, 0], kv[:, 1]
+    q, k = rms_norm_head(q, W[p + "q_norm.weight"]), rms_norm_head(k, W[p + "k_norm.weight"])
+    o = attention(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1), D ** -0.5)
+    o = F.linear(o, W[p + "proj.weight"], W[p + "proj.bias"])
+    return torch.cat([torch.zeros((n_cond_tokens, C), dtype=o.dtype), o], dim=0)
+
+
+def swiglu(W, p: str, x: torch.Tensor) -> torch.Tensor:
+    """LCB:36-37."""
+    return F.linear(F.silu(F.linear(x, W[p + "w1.weight"])) * F.linear(x, W[p + "w3.weight"]), W[p + "w2.weight"])
+
+
+def block(W, i: int, x: torch.Tensor, y: torch.Tensor, t: torch.Tensor, cfg: LongCatConfig, ang: torch.Tensor,
+          tokens_per_frame: int, n_cond_tokens: int) -> torch.Tensor:
+    """LCD:68-121.  x [L, C]; y [n_valid, C]; t [T, C_t] fp32."""
+    p = f"blocks.{i}."
+    C = cfg.hidden_size
+    mod = F.linear(F.silu(t.float()), W[p + "adaLN_modulation.1.weight"].float(), W[p + "adaLN_modulation.1.bias"].float())
+    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = mod.chunk(6, dim=-1)  # each [T, C]
+
+    def gated(x, gate, xs):
+        return (x.float().view(-1, tokens_per_frame, C) + gate[:, None, :] * xs.float().view(-1, tokens_per_frame, C)) \
+            .view(-1, C).to(x.dtype)
+
+    xs = self_attention(W, p + "attn.", modulate(x, shift_msa, scale_msa, tokens_per_frame), cfg, ang, n_cond_tokens)
+    x = gated(x, gate_msa, xs)
+    xn = layer_norm(x, W[p + "pre_crs_attn_norm.weight"], W[p + "pre_crs_attn_norm.bias"])
+    x = x + cross_attention(W, p + "cross_attn.", xn, y, cfg, n_cond_tokens)
+    xs = swiglu(W, p + "ffn.", modulate(x, shift_mlp, scale_mlp, tokens_per_frame))
+    return gated(x, gate_mlp, xs)
+
+
+def forward(W: Dict[str, torch.Tensor], cfg: LongCatConfig, latents: torch.Tensor, timesteps: torch.Tensor, caption: torch.Tensor,
+            caption_mask: torch.Tensor = None, num_cond_latents: int = 0) -> torch.Tensor:
+    """LCD:279-366 for one sample.  latents [C_in, T, H, W]; timesteps [T] (one per latent frame, LCD:299-301); caption
+    [n_tokens, caption_channels]; caption_mask [n_tokens] (0 = padding) or None -> velocity [C_out, T, H, W] fp32."""
+    Cin, T, Hh, Ww = latents.shape
+    pt, ph, pw = cfg.patch_size
+    assert pt == 1
+    nh, nw = Hh // ph, Ww // pw
+    C = cfg.hidden_size
+    # LCB:112 Conv3d with kernel = stride = patch -> tokens in (t, h, w) order
+    x = F.conv3d(latents[None].float(), W["x_embedder.proj.weight"].float(), W["x_embedder.proj.bias"].float(), stride=cfg.patch_size)
+    x = x.flatten(2).transpose(1, 2)[0]  # [L, C]
+    # LCB:201-206 + LCD:310-311
+    tf = timestep_embedding(timesteps.float().flatten(), cfg.frequency_embedding_size)
+    t = F.linear(F.silu(F.linear(tf, W["t_embedder.mlp.0.weight"].float(), W["t_embedder.mlp.0.bias"].float())),
+                 W["t_embedder.mlp.2.weight"].float(), W["t_embedder.mlp.2.bias"].float())  # [T, C_t]
+    # LCB:225-228 + LCD:315-325
+    y = F.linear(F.gelu(F.linear(caption, W["y_embedder.y_proj.0.weight"], W["y_embedder.y_proj.0.bias"]), approximate="tanh"),
+                 W["y_embedder.y_proj.2.weight"], W["y_embedder.y_proj.2.bias"])
+    if caption_mask is not None:
+        if cfg.text_tokens_zero_pad:
+            y = y * caption_mask[:, None].to(y.dtype)
+        else:
+            y = y[caption_mask != 0]
+    ang = rope_angles(C // cfg.num_heads, T, nh, nw)
+    tpf = nh * nw
+    for i in range(cfg.depth):
+        x = block(W, i, x, y, t, cfg, ang, tpf, num_cond_latents * tpf)
+    # LCB:159-168
+    mod = F.linear(F.silu(t), W["final_layer.adaLN_modulation.1.weight"].float(), W["final_layer.adaLN_modulation.1.bias"].float())
+    shift, scale = mod.chunk(2, dim=-1)
+    x = modulate(x, shift, scale, tpf)
+    x = F.linear(x.float(), W["final_layer.linear.weight"].float(), W["final_layer.linear.bias"].float())
+    # LCD:371-392: [L, (ph pw C_out)] -> [C_out, T, H, W]
+    x = x.view(T, nh, nw, ph, pw, cfg.out_channels).permute(5, 0, 1, 3, 2, 4).reshape(cfg.out_channels, T, nh * ph, nw * pw)
+    return x.float()
+
+
+def random_weights(cfg: LongCatConfig, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Synthetic state dict with the reference's names and shapes; values are bf16-representable so that the HIP path (bf16
+    weights) and this fp32 oracle see identical parameters."""
+    g = torch.Generator().manual_seed(seed)
+    C, Ct, Hd = cfg.hidden_size, cfg.adaln_tembed_dim, cfg.ffn_hidden
+    D = C // cfg.num_heads
+    W = {}
+
+    def r(*shape, std=None, base=0.0):
+        std = std if std is not None else 1.0 / math.sqrt(shape[-1])
+        return (torch.randn(*shape, generator=g) * std + base).to(torch.bfloat16).to(dtype)
+
+    def lin(name, o, i, bias=True, std=None):
+        W[name + ".weight"] = r(o, i, std=std)
+        if bias:
+            W[name + ".bias"] = r(o, std=0.02)
+
+    W["x_embedder.proj.weight"] = r(C, cfg.in_channels, *cfg.patch_size, std=1.0 / math.sqrt(cfg.in_channels * 4))
+    W["x_embedder.proj.bias"] = r(C, std=0.02)
+    lin("t_embedder.mlp.0", Ct, cfg.frequency_embedding_size)
+    lin("t_embedder.mlp.2", Ct, Ct)
+    lin("y_embedder.y_proj.0", C, cfg.caption_channels)
+    lin("y_embedder.y_proj.2", C, C)
+    for i in range(cfg.depth):
+        p = f"blocks.{i}."
+        lin(p + "adaLN_modulation.1", 6 * C, Ct, std=0.5 / math.sqrt(Ct))
+        W[p + "pre_crs_attn_norm.weight"] = r(C, std=0.05, base=1.0)
+        W[p + "pre_crs_attn_norm.bias"] = r(C, std=0.02)
+        lin(p + "attn.qkv", 3 * C, C)
+        lin(p + "attn.proj", C, C)
+        lin(p + "cross_attn.q_linear", C, C)
+        lin(p + "cross_attn.kv_linear", 2 * C, C)
+        lin(p + "cross_attn.proj", C, C)
+        for a in ("attn", "cross_attn"):
+            W[p + a + ".q_norm.weight"] = r(D, std=0.05, base=1.0)
+            W[p + a + ".k_norm.weight"] = r(D, std=0.05, base=1.0)
+        lin(p + "ffn.w1", Hd, C, bias=False)
+        lin(p + "ffn.w2", C, Hd, bias=False)
+        lin(p + "ffn.w3", Hd, C, bias=False)
+    lin("final_layer.linear", 4 * cfg.out_channels, C)
+    lin("final_layer.adaLN_modulation.1", 2 * C, Ct, std=0.5 / math.sqrt(Ct))
+    return W

@@ -1,0 +1,42 @@
+"""CPU: oracle/longcat_dit.py against outputs of the unmodified reference LongCatVideoTransformer3DModel (tests/golden/g11_longcat_dit.npz,
+written by tools/make_goldens.py longcat).  The reference ran the CFG pair as a batch of two with caption masks; the oracle runs one
+sample at a time, as the HIP path does."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import longcat_dit as olc
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "g11_longcat_dit.npz"))
+
+
+def _case(name):
+    C, heads, depth, cap, ct, ncond, zpad = (int(v) for v in G[f"{name}_cfg"])
+    cfg = olc.LongCatConfig(hidden_size=C, depth=depth, num_heads=heads, caption_channels=cap, adaln_tembed_dim=ct,
+                            text_tokens_zero_pad=bool(zpad))
+    return cfg, ncond
+
+
+@pytest.mark.parametrize("name", ["tiny", "odd", "zpad"])
+def test_oracle_matches_reference_forward(name):
+    cfg, ncond = _case(name)
+    W = olc.random_weights(cfg, seed=21)
+    x = torch.from_numpy(G[f"{name}_x"])
+    for b in range(2):
+        got = olc.forward(W, cfg, x, torch.from_numpy(G[f"{name}_ts"][b]), torch.from_numpy(G[f"{name}_cap"][b]),
+                          torch.from_numpy(G[f"{name}_mask"][b]), num_cond_latents=ncond)
+        want = torch.from_numpy(G[f"{name}_out"][b])
+        err = (got - want).abs().max().item() / want.abs().max().item()
+        assert err < 2e-5, (name, b, err)
+
+
+def test_ffn_width_and_rope_partition():
+    cfg = olc.LongCatConfig()
+    assert cfg.ffn_hidden == 11008
+    ang = olc.rope_angles(128, 2, 3, 4)
+    assert ang.shape == (24, 128)
+    # 44 temporal, 42 row, 42 column entries; pairs share one frequency
+    assert torch.equal(ang[:, 0::2], ang[:, 1::2])
+    assert ang[0].abs().max() == 0 and ang[1, :44].abs().max() == 0 and ang[1, 86] == 1.0

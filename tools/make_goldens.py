@@ -330,3 +330,54 @@ def g_vae():
 
 if __name__ == "__main__" and "vae" in sys.argv[1:]:
     g_vae()
+
+
+# ------------------------------------------------------------------------------------------------------------
+def g_longcat_dit():
+    """G11: the unmodified LongCatVideoTransformer3DModel (fp32, CPU; its flash-attn calls served by tools/refshim/flash_attn) with
+    the oracle's synthetic weights, called the way generate_i2v calls it (pipeline_longcat_video.py:857-873: cond + uncond batch,
+    per-frame timesteps with frame 0 at t = 0, num_cond_latents = 1, caption masks), plus one call without condition frames."""
+    import warnings
+
+    sys.path.insert(0, "/root/reference/longcat_for_worldforge")
+    from longcat_video.modules.longcat_video_dit import LongCatVideoTransformer3DModel
+    from oracle import longcat_dit as olc
+
+    out = {}
+    cases = {"tiny": dict(C=256, heads=2, depth=2, cap=64, ct=64, T=3, h=8, w=12, ncond=1, zero_pad=False),
+             "odd": dict(C=384, heads=3, depth=1, cap=96, ct=128, T=2, h=6, w=10, ncond=0, zero_pad=False),
+             "zpad": dict(C=256, heads=2, depth=1, cap=64, ct=64, T=2, h=4, w=8, ncond=1, zero_pad=True)}
+    for name, c in cases.items():
+        cfg = olc.LongCatConfig(hidden_size=c["C"], depth=c["depth"], num_heads=c["heads"], caption_channels=c["cap"],
+                                adaln_tembed_dim=c["ct"], text_tokens_zero_pad=c["zero_pad"])
+        W = olc.random_weights(cfg, seed=21)
+        m = LongCatVideoTransformer3DModel(hidden_size=c["C"], depth=c["depth"], num_heads=c["heads"], caption_channels=c["cap"],
+                                           adaln_tembed_dim=c["ct"], enable_flashattn2=True, cp_split_hw=[1, 1],
+                                           text_tokens_zero_pad=c["zero_pad"])
+        sd = m.state_dict()
+        assert set(sd) == set(W), (set(sd) ^ set(W))
+        assert all(tuple(sd[k].shape) == tuple(W[k].shape) for k in sd)
+        m.load_state_dict(W, strict=True)
+        m.eval()
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(1, 16, c["T"], c["h"], c["w"], generator=g)
+        cap = torch.randn(2, 1, 24, c["cap"], generator=g)
+        mask = torch.zeros(2, 24, dtype=torch.int64)
+        mask[0, :9] = 1   # negative prompt: 9 valid tokens
+        mask[1, :17] = 1  # positive prompt: 17 valid tokens
+        ts = torch.full((2, c["T"]), 637.0)
+        if c["ncond"]:
+            ts[:, :1] = 0
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            o = m(hidden_states=torch.cat([x, x]), timestep=ts, encoder_hidden_states=cap, encoder_attention_mask=mask,
+                  num_cond_latents=c["ncond"])
+        out[f"{name}_x"], out[f"{name}_cap"], out[f"{name}_mask"] = x[0].numpy(), cap[:, 0].numpy(), mask.numpy()
+        out[f"{name}_ts"], out[f"{name}_out"] = ts.numpy(), o.numpy()
+        out[f"{name}_cfg"] = np.array([c["C"], c["heads"], c["depth"], c["cap"], c["ct"], c["ncond"], int(c["zero_pad"])])
+        print("g11", name, tuple(o.shape), float(o.abs().mean()))
+    np.savez_compressed(os.path.join(OUT, "g11_longcat_dit.npz"), **out)
+
+
+if __name__ == "__main__" and "longcat" in sys.argv[1:]:
+    g_longcat_dit()
