@@ -1,0 +1,51 @@
+"""LongCat-Video DiT forward at the 480p / 93-frame configuration (latent 24 x 60 x 104 -> 37 440 tokens, 48 blocks, 13.6 B
+parameters, random weights): ms per forward and the self-attention rate.  python tools/longcat_bench.py [--depth N] [--iters K]"""
+import argparse
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from worldforge_amd import dit  # noqa: E402
+from worldforge_amd.longcat_dit import LongCatConfig, LongCatVideoTransformer3DModel  # noqa: E402
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--depth", type=int, default=48)
+    ap.add_argument("--iters", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--h", type=int, default=60)
+    ap.add_argument("--w", type=int, default=104)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    cfg = LongCatConfig(depth=a.depth)
+    t0 = time.time()
+    m = LongCatVideoTransformer3DModel(cfg, dev).init_random(1)
+    torch.cuda.synchronize()
+    print(f"init {time.time() - t0:.1f}s, {m.param_bytes() / 1e9:.1f} GB of weights", flush=True)
+    g = torch.Generator(device=dev).manual_seed(2)
+    x = torch.randn((16, a.frames, a.h, a.w), generator=g, device=dev).bfloat16()
+    cap = torch.randn((512, cfg.caption_channels), generator=g, device=dev).bfloat16()
+    mask = torch.zeros(512, dtype=torch.int64)
+    mask[:180] = 1
+    ts = [0.0] + [700.0] * (a.frames - 1)
+    m.forward_tokens(x, ts, cap, mask, 1)
+    torch.cuda.synchronize()
+    dit.PROFILE_ATTN = []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        out = m.forward_tokens(x, ts, cap, mask, 1)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.iters
+    L = a.frames * (a.h // 2) * (a.w // 2)
+    tpf = (a.h // 2) * (a.w // 2)
+    C, Hd = cfg.hidden_size, cfg.ffn_hidden
+    gemm_flop = 2.0 * L * C * (3 * C + C + C + C + 3 * Hd) * a.depth
+    attn_flop = 4.0 * (L - tpf) * L * C * a.depth
+    att = [s.elapsed_time(e) for s, e in dit.PROFILE_ATTN]
+    att_ms = sum(att) / len(att)
+    print(f"tokens {L}, forward {ms:.1f} ms ({(gemm_flop + attn_flop) / ms / 1e9:.0f} TFLOP/s end to end); noise-token self-attention "
+          f"{att_ms:.2f} ms = {4.0 * (L - tpf) * L * C / att_ms / 1e9:.0f} TFLOP/s; finite={bool(torch.isfinite(out).all())}")

@@ -33,6 +33,7 @@ SOURCES = {
     "gemm.hip": [],
     "attention.hip": [],
     "dit_ops.hip": [],
+    "longcat_ops.hip": ["-ffp-contract=off"],
     "vae_ops.hip": [],
     "conv.hip": [],
     "comm.hip": [],

@@ -1,0 +1,229 @@
+// HBM-bound companions of the GEMM / attention kernels for the LongCat-Video DiT
+// (longcat_for_worldforge/longcat_video/modules: longcat_video_dit.py = LCD, attention.py = LCA, blocks.py = LCB, rope_3d.py = LCR).
+// The LongCat residual stream is bf16 (LCD:104, 120: x.to(x_dtype)) and the AdaLN parameters are per latent FRAME (LCD:85-88), so
+// the Wan kernels of dit_ops.hip (fp32 stream, one modulation vector per forward) do not apply:
+//   wf_lc_ln_modulate   : LayerNorm_FP32 + per-frame modulate (LCB:133-141, LCD:91, 114) or affine (pre_crs_attn_norm, LCD:111)
+//   wf_lc_gate_residual : x = bf16(x + gate[frame] * y)  (LCD:102-104, 117-120), gate NULL: x = x + y (LCD:111)
+//   wf_lc_norm_heads    : RMSNorm_FP32 over each head's 128 channels (LCB:40-52; LCA:111, 231) + interleaved 3D RoPE
+//                         (LCR:32-36, 101-120), written in the attention layout [H][Lout][128]
+//   wf_lc_swiglu        : silu(w1 x) * w3 x (LCB:36-37) on the fused [w1 | w3] projection
+// One pass each, 16-byte accesses, compiled with -ffp-contract=off (the reference's separate torch ops never fuse a multiply-add); rounding points follow the reference's bf16 flow (every torch op on bf16 tensors rounds its result).
+#include "common.h"
+#include "mfma.h"
+
+using namespace wf;
+
+namespace {
+
+__device__ __forceinline__ float block_sum_4(float v, float* sm) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[wid] = v;
+  __syncthreads();
+  return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+__device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f[2 * k] = __uint_as_float(v[k] << 16);
+    f[2 * k + 1] = __uint_as_float(v[k] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4 pack8(const float* y) {
+  return u32x4{pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+}
+
+// x bf16 [L, C] -> out bf16 [L, C]: (x - mean) * rstd * (plus_one + mul[g][c]) + add[g][c], g = row / rows_per_group.
+// Two-pass statistics over register-resident data, biased variance (F.layer_norm).
+template <int VPT>  // chunks of 8 channels per thread: C <= 2048 * VPT
+__global__ __launch_bounds__(256) void k_lc_ln(const uint16_t* __restrict__ x, const float* __restrict__ mul,
+                                               const float* __restrict__ add, long mod_ld, int rows_per_group, float plus_one,
+                                               uint16_t* __restrict__ out, int C, float eps) {
+  __shared__ float sm[4];
+  const size_t row = blockIdx.x;
+  const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * C);
+  const int nch = C >> 3;
+  float v[VPT][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int id = threadIdx.x + 256 * i;
+    if (id < nch) {
+      unpack8(xr[id], v[i]);
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) s += v[i][k] + v[i][k + 1];
+    }
+  }
+  const float mean = block_sum_4(s, sm) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int id = threadIdx.x + 256 * i;
+    if (id < nch) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float d = v[i][k] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(block_sum_4(q, sm) / (float)C + eps);
+  const size_t g = rows_per_group > 0 ? row / rows_per_group : 0;
+  const float* mg = mul ? mul + g * mod_ld : nullptr;
+  const float* ag = add ? add + g * mod_ld : nullptr;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int id = threadIdx.x + 256 * i;
+    if (id < nch) {
+      float m[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, y[8];
+      if (mg) {
+        const float4 m0 = reinterpret_cast<const float4*>(mg)[2 * id], m1 = reinterpret_cast<const float4*>(mg)[2 * id + 1];
+        m[0] = m0.x, m[1] = m0.y, m[2] = m0.z, m[3] = m0.w, m[4] = m1.x, m[5] = m1.y, m[6] = m1.z, m[7] = m1.w;
+      }
+      if (ag) {
+        const float4 a0 = reinterpret_cast<const float4*>(ag)[2 * id], a1 = reinterpret_cast<const float4*>(ag)[2 * id + 1];
+        a[0] = a0.x, a[1] = a0.y, a[2] = a0.z, a[3] = a0.w, a[4] = a1.x, a[5] = a1.y, a[6] = a1.z, a[7] = a1.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) y[k] = (v[i][k] - mean) * rstd * (plus_one + m[k]) + a[k];
+      reinterpret_cast<u32x4*>(out + row * C)[id] = pack8(y);
+    }
+  }
+}
+
+// x[r][c] = bf16(x[r][c] + gate[r / rows_per_group][c] * y[r][c]);  n8 = L * C / 8 chunks
+__global__ void k_lc_gate_resid(uint16_t* __restrict__ x, const uint16_t* __restrict__ y, long ldy, const float* __restrict__ gate,
+                                long gate_ld, int rows_per_group, int C, size_t n8) {
+  const int cpr = C >> 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / cpr;
+    const int ch = (int)(i - row * cpr);
+    float xv[8], yv[8], g[8] = {1, 1, 1, 1, 1, 1, 1, 1}, o[8];
+    u32x4* xp = reinterpret_cast<u32x4*>(x + row * C) + ch;
+    unpack8(*xp, xv);
+    unpack8(reinterpret_cast<const u32x4*>(y + row * ldy)[ch], yv);
+    if (gate) {
+      const float* gp = gate + (row / rows_per_group) * gate_ld + ch * 8;
+      const float4 g0 = reinterpret_cast<const float4*>(gp)[0], g1 = reinterpret_cast<const float4*>(gp)[1];
+      g[0] = g0.x, g[1] = g0.y, g[2] = g0.z, g[3] = g0.w, g[4] = g1.x, g[5] = g1.y, g[6] = g1.z, g[7] = g1.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = xv[k] + g[k] * yv[k];  // two torch ops in the reference: built with -ffp-contract=off
+    *xp = pack8(o);
+  }
+}
+
+// in bf16 [L, ld] (head h at columns h*128) -> out bf16 [H][Lout][128].  16 lanes per (row, head), 8 channels per lane.
+// y = bf16(bf16(x * rsqrt(mean(x^2) + eps)) * w); RoPE on pairs (2p, 2p+1) with angle table entries cos/sin[row][p] in fp32 -> bf16.
+__global__ __launch_bounds__(256) void k_lc_heads(const uint16_t* __restrict__ in, long ld, const float* __restrict__ w,
+                                                  const float* __restrict__ cs, const float* __restrict__ sn,
+                                                  uint16_t* __restrict__ out, int L, int Lout, int H, float eps) {
+  const int row = blockIdx.x;
+  const int head = blockIdx.y * 16 + (threadIdx.x >> 4), within = threadIdx.x & 15;
+  if (head >= H) return;
+  float v[8], y[8];
+  unpack8(*reinterpret_cast<const u32x4*>(in + (size_t)row * ld + head * 128 + within * 8), v);
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ss += v[k] * v[k];
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
+  const float rinv = rsqrtf(ss * (1.0f / 128.0f) + eps);
+  const float4 w0 = reinterpret_cast<const float4*>(w)[2 * within], w1 = reinterpret_cast<const float4*>(w)[2 * within + 1];
+  const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) y[k] = rbf(rbf(v[k] * rinv) * ww[k]);
+  if (cs) {
+    const float4 c4 = reinterpret_cast<const float4*>(cs + (size_t)row * 64)[within];
+    const float4 s4 = reinterpret_cast<const float4*>(sn + (size_t)row * 64)[within];
+    const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float re = y[2 * k] * cc[k] - y[2 * k + 1] * sv[k];
+      const float im = y[2 * k + 1] * cc[k] + y[2 * k] * sv[k];
+      y[2 * k] = re;
+      y[2 * k + 1] = im;
+    }
+  }
+  *reinterpret_cast<u32x4*>(out + ((size_t)head * Lout + row) * 128 + within * 8) = pack8(y);
+}
+
+// in bf16 [L, ld]: columns [0, Hd) = w1 x, [Hd, 2 Hd) = w3 x -> out bf16 [L, Hd] = bf16(bf16(silu(a)) * b)
+__global__ void k_lc_swiglu(const uint16_t* __restrict__ in, long ld, uint16_t* __restrict__ out, int Hd, size_t n8) {
+  const int cpr = Hd >> 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / cpr;
+    const int ch = (int)(i - row * cpr);
+    float a[8], b[8], o[8];
+    unpack8(reinterpret_cast<const u32x4*>(in + row * ld)[ch], a);
+    unpack8(reinterpret_cast<const u32x4*>(in + row * ld + Hd)[ch], b);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = rbf(a[k] / (1.0f + __expf(-a[k]))) * b[k];
+    reinterpret_cast<u32x4*>(out + row * (size_t)Hd)[ch] = pack8(o);
+  }
+}
+
+}  // namespace
+
+extern "C" int wf_lc_ln_modulate(const void* x, const float* mul, const float* add, int64_t mod_ld, int rows_per_group, int plus_one,
+                                 void* out, int L, int C, float eps, void* stream) {
+  WF_CHECK_ARG(x && out, "wf_lc_ln_modulate: null pointer");
+  WF_CHECK_ARG(C % 8 == 0 && C > 0 && C <= 8192, "wf_lc_ln_modulate: C=%d must be a multiple of 8 and <= 8192", C);
+  WF_CHECK_ARG(rows_per_group >= 0 && mod_ld % 4 == 0, "wf_lc_ln_modulate: rows_per_group >= 0, mod_ld %% 4 == 0");
+  WF_CHECK_ARG((((uintptr_t)x | (uintptr_t)out | (uintptr_t)mul | (uintptr_t)add) & 15) == 0, "wf_lc_ln_modulate: 16-byte alignment");
+  if (L == 0) return WF_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const float p1 = plus_one ? 1.0f : 0.0f;
+  const uint16_t* xi = (const uint16_t*)x;
+  uint16_t* oo = (uint16_t*)out;
+  if (C <= 2048)
+    hipLaunchKernelGGL(k_lc_ln<1>, dim3(L), dim3(256), 0, s, xi, mul, add, mod_ld, rows_per_group, p1, oo, C, eps);
+  else if (C <= 4096)
+    hipLaunchKernelGGL(k_lc_ln<2>, dim3(L), dim3(256), 0, s, xi, mul, add, mod_ld, rows_per_group, p1, oo, C, eps);
+  else
+    hipLaunchKernelGGL(k_lc_ln<4>, dim3(L), dim3(256), 0, s, xi, mul, add, mod_ld, rows_per_group, p1, oo, C, eps);
+  WF_LAUNCH_CHECK("wf_lc_ln_modulate");
+  return WF_OK;
+}
+
+extern "C" int wf_lc_gate_residual(void* x, const void* y, int64_t ldy, const float* gate, int64_t gate_ld, int rows_per_group, int L, int C,
+                                   void* stream) {
+  WF_CHECK_ARG(x && y, "wf_lc_gate_residual: null pointer");
+  WF_CHECK_ARG(C % 8 == 0 && ldy % 8 == 0 && gate_ld % 4 == 0, "wf_lc_gate_residual: C, ldy %% 8, gate_ld %% 4");
+  WF_CHECK_ARG(!gate || rows_per_group > 0, "wf_lc_gate_residual: rows_per_group must be positive with a gate");
+  WF_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gate) & 15) == 0, "wf_lc_gate_residual: 16-byte alignment");
+  const size_t n8 = (size_t)L * (C / 8);
+  if (n8 == 0) return WF_OK;
+  hipLaunchKernelGGL(k_lc_gate_resid, dim3(grid_for(n8, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)x,
+                     (const uint16_t*)y, ldy, gate, gate_ld, rows_per_group > 0 ? rows_per_group : 1, C, n8);
+  WF_LAUNCH_CHECK("wf_lc_gate_residual");
+  return WF_OK;
+}
+
+extern "C" int wf_lc_norm_heads(const void* in, int64_t ld, const float* weight, const float* cos_tab, const float* sin_tab, void* out,
+                                int L, int Lout, int H, float eps, void* stream) {
+  WF_CHECK_ARG(in && weight && out, "wf_lc_norm_heads: null pointer");
+  WF_CHECK_ARG(H > 0 && ld % 8 == 0 && Lout >= L, "wf_lc_norm_heads: H > 0, ld %% 8 == 0, Lout >= L");
+  WF_CHECK_ARG((cos_tab == nullptr) == (sin_tab == nullptr), "wf_lc_norm_heads: cos/sin must both be given or both null");
+  WF_CHECK_ARG((((uintptr_t)in | (uintptr_t)out | (uintptr_t)weight | (uintptr_t)cos_tab | (uintptr_t)sin_tab) & 15) == 0,
+               "wf_lc_norm_heads: 16-byte alignment");
+  if (L == 0) return WF_OK;
+  hipLaunchKernelGGL(k_lc_heads, dim3(L, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in, ld, weight, cos_tab,
+                     sin_tab, (uint16_t*)out, L, Lout, H, eps);
+  WF_LAUNCH_CHECK("wf_lc_norm_heads");
+  return WF_OK;
+}
+
+extern "C" int wf_lc_swiglu(const void* in, int64_t ld, void* out, int L, int Hd, void* stream) {
+  WF_CHECK_ARG(in && out, "wf_lc_swiglu: null pointer");
+  WF_CHECK_ARG(Hd % 8 == 0 && ld % 8 == 0 && ld >= 2 * (int64_t)Hd, "wf_lc_swiglu: Hd %% 8, ld %% 8, ld >= 2 Hd");
+  WF_CHECK_ARG((((uintptr_t)in | (uintptr_t)out) & 15) == 0, "wf_lc_swiglu: 16-byte alignment");
+  const size_t n8 = (size_t)L * (Hd / 8);
+  if (n8 == 0) return WF_OK;
+  hipLaunchKernelGGL(k_lc_swiglu, dim3(grid_for(n8, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in, ld,
+                     (uint16_t*)out, Hd, n8);
+  WF_LAUNCH_CHECK("wf_lc_swiglu");
+  return WF_OK;
+}

@@ -1,0 +1,338 @@
+"""LongCat-Video DiT (LongCatVideoTransformer3DModel) on hand-written HIP kernels.
+
+Speaks the call protocol of the reference sampler (longcat_video/pipeline_longcat_video.py:867-873):
+    dit(hidden_states[B,16,T,H,W], timestep[B,T], encoder_hidden_states[B,1,N,4096], encoder_attention_mask[B,N],
+        num_cond_latents=1) -> fp32 [B,16,T,H,W]
+and follows longcat_video/modules/longcat_video_dit.py (LCD), attention.py (LCA), blocks.py (LCB), rope_3d.py (LCR); file:line
+citations are on the kernels (csrc/longcat_ops.hip, gemm.hip, attention.hip) and below.  Every FLOP of the token path runs in
+libwf_hip.so; PyTorch owns the buffers.  The samples of a batch (the CFG pair of pipeline:857-866) are run one after the other:
+the reference's varlen / block-diagonal cross-attention (LCA:236-262) never mixes samples.
+
+Numerics: bf16 weights, bf16 residual stream (LCD:104, 120), bf16 GEMM / attention operands with fp32 accumulation, fp32 timestep
+embedding and AdaLN parameters (LCD:84-88, 310-311: the fp32 activations are fed to the bf16 MFMA GEMM as a hi + lo bf16 pair, which
+keeps 16 mantissa bits), fp32 LayerNorm statistics, fp32 final projection (LCB:162-167).
+
+Not covered here (next rows of SURVEY section 8f): KV-cache continuation (LCA:147-181), block-sparse attention (LCA:57-66), runtime LoRA
+(LCD:189-268; fold `W + multiplier * alpha/r * up @ down` into the loaded weights instead), sequence parallelism.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from ._ffi import WF_BF16, WF_F32, call
+from .dit import EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_F32_ACC, _pad64, attention, gemm
+
+
+@dataclass
+class LongCatConfig:
+    """LCD:138-158 defaults = the released model."""
+    hidden_size: int = 4096
+    depth: int = 48
+    num_heads: int = 32
+    in_channels: int = 16
+    out_channels: int = 16
+    caption_channels: int = 4096
+    mlp_ratio: int = 4
+    adaln_tembed_dim: int = 512
+    frequency_embedding_size: int = 256
+    patch_size: Tuple[int, int, int] = (1, 2, 2)
+    text_tokens_zero_pad: bool = False
+    eps: float = 1e-6
+
+    @property
+    def ffn_hidden(self) -> int:
+        """LCB:17-29."""
+        h = int(2 * int(self.hidden_size * self.mlp_ratio) / 3)
+        return 256 * ((h + 255) // 256)
+
+
+def timestep_embedding(ts, dim: int, max_period: float = 10000.0) -> torch.Tensor:
+    """LCB:181-199 on the host in fp32: [cos | sin] -> [len(ts), dim]."""
+    half = dim // 2
+    freqs = np.exp(np.float32(-math.log(max_period)) * np.arange(half, dtype=np.float32) / np.float32(half)).astype(np.float32)
+    args = np.asarray(ts, dtype=np.float32)[:, None] * freqs[None]
+    emb = np.concatenate([np.cos(args), np.sin(args)], axis=-1).astype(np.float32)
+    if dim % 2:
+        emb = np.concatenate([emb, np.zeros_like(emb[:, :1])], axis=-1)
+    return torch.from_numpy(emb)
+
+
+def rope_tables(head_dim: int, f: int, h: int, w: int, base: float = 10000.0):
+    """LCR:68-99 + 113-115: cos / sin [f*h*w, head_dim/2] fp32, one entry per rotation pair (2p, 2p+1): the first
+    (head_dim - 4*(head_dim//6))/2 pairs turn with the frame index, the next head_dim//6 with the row, the last with the column."""
+    d_hw = 2 * (head_dim // 6)
+    d_t = head_dim - 2 * d_hw
+
+    def axis(n, dim):
+        freqs = 1.0 / (base ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))
+        grid = torch.from_numpy(np.linspace(0, n, n, endpoint=False, dtype=np.float32)).float()
+        return torch.outer(grid, freqs)  # [n, dim/2]
+
+    at, ah, aw = axis(f, d_t), axis(h, d_hw), axis(w, d_hw)
+    ang = torch.cat([at.view(f, 1, 1, -1).expand(f, h, w, -1), ah.view(1, h, 1, -1).expand(f, h, w, -1),
+                     aw.view(1, 1, w, -1).expand(f, h, w, -1)], dim=-1).reshape(f * h * w, head_dim // 2)
+    return ang.cos().contiguous(), ang.sin().contiguous()
+
+
+class LongCatVideoTransformer3DModel:
+    dtype = torch.bfloat16
+
+    def __init__(self, cfg: LongCatConfig, device="cuda:0"):
+        assert cfg.hidden_size // cfg.num_heads == 128 and cfg.hidden_size % cfg.num_heads == 0, "attention kernel is built for head_dim 128"
+        assert cfg.patch_size == (1, 2, 2)
+        self.cfg = cfg
+        self.config = SimpleNamespace(in_channels=cfg.in_channels, out_channels=cfg.out_channels, patch_size=cfg.patch_size)
+        self.cp_split_hw = None
+        self.device = torch.device(device)
+        self.w: Dict[str, torch.Tensor] = {}
+        self._ws = {}
+        self._rope = {}
+
+    # ------------------------------------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        """Reference-keyed state dict (any dtype / device) -> device tensors: matrices bf16, vectors fp32; the AdaLN projections of
+        all blocks stacked into one matrix, w1 | w3 fused."""
+        cfg, dev = self.cfg, self.device
+        W = {}
+        mat = lambda k: sd[k].to(device=dev, dtype=torch.bfloat16).contiguous()  # noqa: E731
+        vec = lambda k: sd[k].to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+        W["patch.w"] = mat("x_embedder.proj.weight").reshape(cfg.hidden_size, -1).contiguous()
+        W["patch.b"] = vec("x_embedder.proj.bias")
+        for n in ("t_embedder.mlp.0", "t_embedder.mlp.2", "y_embedder.y_proj.0", "y_embedder.y_proj.2", "final_layer.linear",
+                  "final_layer.adaLN_modulation.1"):
+            W[n + ".w"], W[n + ".b"] = mat(n + ".weight"), vec(n + ".bias")
+        W["ada.w"] = torch.cat([mat(f"blocks.{i}.adaLN_modulation.1.weight") for i in range(cfg.depth)], 0).contiguous()
+        W["ada.b"] = torch.cat([vec(f"blocks.{i}.adaLN_modulation.1.bias") for i in range(cfg.depth)], 0).contiguous()
+        for i in range(cfg.depth):
+            p = f"blocks.{i}."
+            W[p + "norm.w"], W[p + "norm.b"] = vec(p + "pre_crs_attn_norm.weight"), vec(p + "pre_crs_attn_norm.bias")
+            for n in ("attn.qkv", "attn.proj", "cross_attn.q_linear", "cross_attn.kv_linear", "cross_attn.proj"):
+                W[p + n + ".w"], W[p + n + ".b"] = mat(p + n + ".weight"), vec(p + n + ".bias")
+            for n in ("attn.q_norm", "attn.k_norm", "cross_attn.q_norm", "cross_attn.k_norm"):
+                W[p + n] = vec(p + n + ".weight")
+            W[p + "ffn.w13"] = torch.cat([mat(p + "ffn.w1.weight"), mat(p + "ffn.w3.weight")], 0).contiguous()
+            W[p + "ffn.w2"] = mat(p + "ffn.w2.weight")
+        self.w = W
+        return self
+
+    def init_random(self, seed: int = 0):
+        """Synthetic weights of the right shapes, generated on the device (there are no checkpoints offline)."""
+        cfg, dev = self.cfg, self.device
+        g = torch.Generator(device=dev).manual_seed(seed)
+        C, Ct, Hd = cfg.hidden_size, cfg.adaln_tembed_dim, cfg.ffn_hidden
+
+        def mat(n, k, std=None):
+            std = std if std is not None else 1.0 / math.sqrt(k)
+            return (torch.randn(n, k, generator=g, device=dev, dtype=torch.float32) * std).to(torch.bfloat16)
+
+        def vec(n, std=0.02, base=0.0):
+            return (torch.randn(n, generator=g, device=dev, dtype=torch.float32) * std + base).to(torch.bfloat16).float()
+
+        W = {"patch.w": mat(C, cfg.in_channels * 4), "patch.b": vec(C)}
+        for n, (o, i) in {"t_embedder.mlp.0": (Ct, cfg.frequency_embedding_size), "t_embedder.mlp.2": (Ct, Ct),
+                          "y_embedder.y_proj.0": (C, cfg.caption_channels), "y_embedder.y_proj.2": (C, C),
+                          "final_layer.linear": (4 * cfg.out_channels, C)}.items():
+            W[n + ".w"], W[n + ".b"] = mat(o, i), vec(o)
+        W["final_layer.adaLN_modulation.1.w"], W["final_layer.adaLN_modulation.1.b"] = mat(2 * C, Ct, 0.5 / math.sqrt(Ct)), vec(2 * C)
+        W["ada.w"], W["ada.b"] = mat(cfg.depth * 6 * C, Ct, 0.5 / math.sqrt(Ct)), vec(cfg.depth * 6 * C)
+        for i in range(cfg.depth):
+            p = f"blocks.{i}."
+            W[p + "norm.w"], W[p + "norm.b"] = vec(C, 0.05, 1.0), vec(C)
+            for n, o in (("attn.qkv", 3 * C), ("attn.proj", C), ("cross_attn.q_linear", C), ("cross_attn.kv_linear", 2 * C),
+                         ("cross_attn.proj", C)):
+                W[p + n + ".w"], W[p + n + ".b"] = mat(o, C), vec(o)
+            for n in ("attn.q_norm", "attn.k_norm", "cross_attn.q_norm", "cross_attn.k_norm"):
+                W[p + n] = vec(128, 0.05, 1.0)
+            W[p + "ffn.w13"], W[p + "ffn.w2"] = mat(2 * Hd, C), mat(C, Hd)
+        self.w = W
+        return self
+
+    def param_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.w.values())
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _buf(self, name, shape, dtype, zero=False):
+        key = (name, tuple(shape), dtype)
+        t = self._ws.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self._ws[key] = t
+        return t
+
+    def _rope_tables(self, f, h, w):
+        key = (f, h, w)
+        if key not in self._rope:
+            c, s = rope_tables(128, f, h, w)
+            self._rope[key] = (c.to(self.device), s.to(self.device))
+        return self._rope[key]
+
+    def _act(self, a, out_dtype, mode):
+        out = torch.empty(a.shape, dtype=out_dtype, device=a.device)
+        dt = {torch.float32: WF_F32, torch.bfloat16: WF_BF16}
+        call("wf_act", a.data_ptr(), dt[a.dtype], None, 0, out.data_ptr(), dt[out_dtype], mode, a.numel(), ops.stream())
+        return out
+
+    def _gemm_f32(self, a: torch.Tensor, w, b, out):
+        """out f32 = a f32 @ w^T + b with the fp32 activation split into a hi + lo bf16 pair (two MFMA GEMMs accumulating in fp32):
+        what the reference's fp32 autocast regions compute from bf16-valued weights, to ~2^-17 relative."""
+        hi = ops.cast(a, torch.bfloat16)
+        lo = ops.cast(a - hi.float(), torch.bfloat16)
+        gemm(hi, w, b, out, EPI_F32)
+        gemm(lo, w, None, out, EPI_F32_ACC)
+        return out
+
+    def _ln(self, x, mul, add, mod_ld, rows_per_group, plus_one, out):
+        L, C = x.shape
+        call("wf_lc_ln_modulate", x.data_ptr(), mul.data_ptr(), add.data_ptr(), mod_ld, rows_per_group, 1 if plus_one else 0,
+             out.data_ptr(), L, C, float(self.cfg.eps), ops.stream())
+
+    def _resid(self, x, y, gate, gate_ld, rows_per_group):
+        L, C = x.shape
+        call("wf_lc_gate_residual", x.data_ptr(), y.data_ptr(), y.stride(0), gate.data_ptr() if gate is not None else None, gate_ld,
+             rows_per_group, L, C, ops.stream())
+
+    def _heads(self, src, col0, weight, cos, sin, out, r0, r1):
+        """Rows [r0, r1) of columns [col0, col0 + C) of src -> out [H, Lout, 128] rows [0, r1 - r0)."""
+        if r1 <= r0:
+            return
+        view = src[r0:r1, col0:col0 + self.cfg.hidden_size]
+        call("wf_lc_norm_heads", view.data_ptr(), src.stride(0), weight.data_ptr(),
+             cos[r0:r1].data_ptr() if cos is not None else None, sin[r0:r1].data_ptr() if sin is not None else None,
+             out.data_ptr(), r1 - r0, out.shape[1], self.cfg.num_heads, float(self.cfg.eps), ops.stream())
+
+    def _vt(self, src, col0, out, L):
+        view = src[:, col0:col0 + self.cfg.hidden_size]
+        call("wf_v_transpose", view.data_ptr(), src.stride(0), out.data_ptr(), L, out.shape[1] * 64, self.cfg.num_heads, ops.stream())
+
+    # ------------------------------------------------------------------------------------------------------------
+    def forward_tokens(self, x_in: torch.Tensor, timesteps, caption: torch.Tensor, caption_mask: Optional[torch.Tensor] = None,
+                       num_cond_latents: int = 0) -> torch.Tensor:
+        """One sample.  x_in [16, T, Hh, Ww] bf16; timesteps: T host floats; caption [N, caption_channels] bf16; caption_mask [N]
+        host / device ints (0 = padding) or None -> velocity [16, T, Hh, Ww] fp32  (LCD:279-366)."""
+        cfg, W, dev = self.cfg, self.w, self.device
+        bf, f32 = torch.bfloat16, torch.float32
+        Cin, T, Hh, Ww = x_in.shape
+        assert Cin == cfg.in_channels and len(timesteps) == T
+        C, H, Hd, Ct = cfg.hidden_size, cfg.num_heads, cfg.ffn_hidden, cfg.adaln_tembed_dim
+        h2, w2 = Hh // 2, Ww // 2
+        tpf = h2 * w2
+        L, Lp = T * tpf, _pad64(T * tpf)
+        nc = int(num_cond_latents or 0) * tpf
+        assert 0 <= nc < L
+        scale = 1.0 / math.sqrt(128.0)
+        cos, sin = self._rope_tables(T, h2, w2)
+        _buf = self._buf
+
+        # ---- embeddings ----
+        tok = _buf("tok", (L, Cin * 4), bf)
+        call("wf_patchify", x_in.data_ptr(), tok.data_ptr(), Cin, T, Hh, Ww, ops.stream())
+        x = _buf("x", (L, C), bf)
+        gemm(tok, W["patch.w"], W["patch.b"], x, EPI_BF16)  # LCB:112 (Conv3d with kernel = stride = patch)
+        tf = timestep_embedding(timesteps, cfg.frequency_embedding_size).to(dev)  # LCB:201-206
+        t0 = self._gemm_f32(tf, W["t_embedder.mlp.0.w"], W["t_embedder.mlp.0.b"], _buf("t0", (T, Ct), f32))
+        t = self._gemm_f32(self._act(t0, f32, 0), W["t_embedder.mlp.2.w"], W["t_embedder.mlp.2.b"], _buf("t", (T, Ct), f32))
+        st = self._act(t, f32, 0)  # SiLU(t), shared by every adaLN_modulation (LCD:40-43, LCB:156)
+        ada = self._gemm_f32(st, W["ada.w"], W["ada.b"], _buf("ada", (T, cfg.depth * 6 * C), f32))
+        fmod = self._gemm_f32(st, W["final_layer.adaLN_modulation.1.w"], W["final_layer.adaLN_modulation.1.b"], _buf("fmod", (T, 2 * C), f32))
+        # caption: Linear -> GELU(tanh) -> Linear (LCB:225-228), valid tokens only (LCD:319-325)
+        cap = caption
+        if caption_mask is not None:
+            keep = torch.as_tensor(caption_mask).reshape(-1).to("cpu") != 0
+            if not cfg.text_tokens_zero_pad:
+                cap = caption[keep.to(caption.device)]
+        n_txt = cap.shape[0]
+        assert n_txt > 0, "empty caption"
+        yh = _buf("yh", (n_txt, C), bf)
+        gemm(cap.contiguous(), W["y_embedder.y_proj.0.w"], W["y_embedder.y_proj.0.b"], yh, EPI_BF16_GELU)
+        y = _buf("y", (n_txt, C), bf)
+        gemm(yh, W["y_embedder.y_proj.2.w"], W["y_embedder.y_proj.2.b"], y, EPI_BF16)
+        if caption_mask is not None and cfg.text_tokens_zero_pad:
+            y[(~keep).to(dev)] = 0  # LCD:315-317
+        Ltp = _pad64(n_txt)
+
+        hbuf = _buf("h", (L, C), bf)
+        qkv = _buf("qkv", (L, 3 * C), bf)
+        qh_c = _buf("qh_c", (H, max(nc, 1), 128), bf)
+        qh_n = _buf("qh_n", (H, L - nc, 128), bf)
+        kh = _buf("kh", (H, Lp, 128), bf, zero=True)
+        vt = _buf("vt", (H, Lp // 64, 128, 64), bf)
+        ao = _buf("ao", (L, C), bf)
+        ys = _buf("ys", (L, C), bf)
+        qc = _buf("qc", (L, C), bf)
+        kvt = _buf("kvt", (n_txt, 2 * C), bf)
+        kth = _buf("kth", (H, Ltp, 128), bf, zero=True)
+        vtt = _buf("vtt", (H, Ltp // 64, 128, 64), bf)
+        ffh = _buf("ffh", (L, 2 * Hd), bf)
+        ffg = _buf("ffg", (L, Hd), bf)
+        ald = ada.stride(0)
+
+        for i in range(cfg.depth):
+            p = f"blocks.{i}."
+            m = ada[:, i * 6 * C:(i + 1) * 6 * C]
+            shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = (m[:, j * C:(j + 1) * C] for j in range(6))
+            # ---- self-attention (LCD:91-104, LCA:105-145) ----
+            self._ln(x, scale_msa, shift_msa, ald, tpf, True, hbuf)
+            gemm(hbuf, W[p + "attn.qkv.w"], W[p + "attn.qkv.b"], qkv, EPI_BF16)
+            self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_c, 0, nc)
+            self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_n, nc, L)
+            self._heads(qkv, C, W[p + "attn.k_norm"], cos, sin, kh, 0, L)
+            self._vt(qkv, 2 * C, vt, L)
+            if nc > 0:
+                attention(qh_c, kh, vt, ao[:nc], nc, scale)  # condition tokens see condition tokens only (LCA:127-131)
+            attention(qh_n, kh, vt, ao[nc:], L, scale, profile=True)  # noise tokens see everything (LCA:133-134)
+            gemm(ao, W[p + "attn.proj.w"], W[p + "attn.proj.b"], ys, EPI_BF16)
+            self._resid(x, ys, gate_msa, ald, tpf)
+            # ---- cross-attention on the noise tokens (LCD:108-111, LCA:218-276) ----
+            self._ln(x[nc:], W[p + "norm.w"], W[p + "norm.b"], 0, 0, False, hbuf[nc:])
+            gemm(hbuf[nc:], W[p + "cross_attn.q_linear.w"], W[p + "cross_attn.q_linear.b"], qc[nc:], EPI_BF16)
+            self._heads(qc, 0, W[p + "cross_attn.q_norm"], None, None, qh_n, nc, L)
+            gemm(y, W[p + "cross_attn.kv_linear.w"], W[p + "cross_attn.kv_linear.b"], kvt, EPI_BF16)
+            self._heads(kvt, 0, W[p + "cross_attn.k_norm"], None, None, kth, 0, n_txt)
+            self._vt(kvt, C, vtt, n_txt)
+            attention(qh_n, kth, vtt, ao[nc:], n_txt, scale)
+            gemm(ao[nc:], W[p + "cross_attn.proj.w"], W[p + "cross_attn.proj.b"], ys[nc:], EPI_BF16)
+            self._resid(x[nc:], ys[nc:], None, 0, 0)
+            # ---- SwiGLU FFN (LCD:113-120, LCB:36-37) ----
+            self._ln(x, scale_mlp, shift_mlp, ald, tpf, True, hbuf)
+            gemm(hbuf, W[p + "ffn.w13"], None, ffh, EPI_BF16)
+            call("wf_lc_swiglu", ffh.data_ptr(), ffh.stride(0), ffg.data_ptr(), L, Hd, ops.stream())
+            gemm(ffg, W[p + "ffn.w2"], None, ys, EPI_BF16)
+            self._resid(x, ys, gate_mlp, ald, tpf)
+
+        # ---- final layer (LCB:159-168) + unpatchify (LCD:371-392) ----
+        self._ln(x, fmod[:, C:], fmod[:, :C], fmod.stride(0), tpf, True, hbuf)
+        yo = _buf("yo", (L, 4 * cfg.out_channels), f32)
+        gemm(hbuf, W["final_layer.linear.w"], W["final_layer.linear.b"], yo, EPI_F32)
+        out = torch.empty((cfg.out_channels, T, Hh, Ww), dtype=f32, device=dev)
+        call("wf_unpatchify", yo.data_ptr(), out.data_ptr(), cfg.out_channels, T, Hh, Ww, ops.stream())
+        return out
+
+    def __call__(self, hidden_states: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
+                 encoder_attention_mask: Optional[torch.Tensor] = None, num_cond_latents: int = 0, return_kv: bool = False,
+                 kv_cache_dict=None, skip_crs_attn: bool = False, offload_kv_cache: bool = False) -> torch.Tensor:
+        if return_kv or kv_cache_dict or skip_crs_attn:
+            raise NotImplementedError("KV-cache continuation (LCA:147-181) is not built; the guided i2v path does not use it")
+        B, _, T, _, _ = hidden_states.shape
+        ts = torch.as_tensor(timestep)
+        if ts.dim() == 1:
+            ts = ts.unsqueeze(1).expand(-1, T)  # LCD:299-301
+        # LCD:304-306: the reference casts the timesteps to the model dtype (bf16) before embedding them
+        ts = ts.to(self.dtype).float().cpu()
+        cap = encoder_hidden_states
+        if cap.dim() == 4:
+            cap = cap[:, 0]
+        outs = []
+        for b in range(B):
+            x = hidden_states[b]
+            if x.dtype != torch.bfloat16:
+                x = ops.cast(x.contiguous(), torch.bfloat16)
+            mask = encoder_attention_mask[b] if encoder_attention_mask is not None else None
+            outs.append(self.forward_tokens(x.contiguous(), ts[b].tolist(), cap[b].to(torch.bfloat16).contiguous(), mask, num_cond_latents))
+        return torch.stack(outs)
