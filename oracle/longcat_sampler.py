@@ -1,0 +1,242 @@
+"""Oracle: the LongCat-Video guided image-to-video sampling loop (torch CPU).  TEST INFRASTRUCTURE ONLY.
+
+Restates, from /root/reference/longcat_for_worldforge/longcat_video:
+  pipeline_longcat_video.py (PIPE)  : get_timesteps_sigmas :317-331, prepare_latents :214-286, optimized_scale :374-383,
+                                      the loop of generate_i2v :823-994, the decode tail :998-1004
+  modules/scheduling_flow_match_euler_discrete.py (SCHED): set_timesteps :610-716, step :740-912, add_noise :1041-1070,
+                                      fuse_latents :1072-1233, the channel selector :165-170, 172-243, 245-381 (temporal-difference
+                                      branch: the one the reference executes when `import cv2` fails, SCHED:45-51, 307-309)
+Pinned against trajectories recorded from the imported, unmodified reference pipeline + scheduler with deterministic stand-ins for
+the DiT / VAE / text encoder (tests/golden/g12_longcat_pipe_*.npz, tools/make_goldens.py longcat_pipe).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import inject
+
+
+@dataclass
+class LongCatSamplerConfig:
+    num_inference_steps: int = 50
+    guidance_scale: float = 4.0
+    shift: float = 1.0               # scheduler config (SCHED:447)
+    use_distill: bool = False
+    guided: bool = False
+    resample_steps: int = 3
+    guide_steps: int = 20
+    resample_round: int = 20
+    omega: float = 1.8
+    omega_resample: float = 1.0
+    use_pca_channel_selection: bool = False
+    max_replace_threshold: Optional[int] = None
+    dit_dtype: torch.dtype = torch.bfloat16
+
+
+# ---- schedule ---------------------------------------------------------------------------------------------------------------
+def timesteps_sigmas(sampling_steps: int, use_distill: bool = False, num_timesteps: int = 1000, num_distill: int = 50) -> torch.Tensor:
+    """PIPE:317-331."""
+    if use_distill:
+        idx = torch.arange(1, num_distill + 1, dtype=torch.float32)
+        idx = (idx * (num_timesteps // num_distill)).round().long()
+        inf = np.floor(np.linspace(0, num_distill, num=sampling_steps, endpoint=False)).astype(np.int64)
+        sigmas = torch.flip(idx, [0])[inf].float() / num_timesteps
+        sigmas = sigmas - sigmas[-1]
+    else:
+        sigmas = torch.linspace(0.999, 0.000, sampling_steps)
+    return sigmas.to(torch.float32)
+
+
+def make_schedule(sigmas_in: torch.Tensor, shift: float, num_train_timesteps: int = 1000):
+    """SCHED:664-709 for the static-shift configuration: sigmas [n+1] (terminal 0 appended), timesteps [n], fp32."""
+    s = (sigmas_in.numpy() if isinstance(sigmas_in, torch.Tensor) else np.array(sigmas_in)).astype(np.float32)
+    s = shift * s / (1 + (shift - 1) * s)
+    sig = torch.from_numpy(s).to(torch.float32)
+    return torch.cat([sig, torch.zeros(1)]), sig * num_train_timesteps
+
+
+# ---- latents ----------------------------------------------------------------------------------------------------------------
+def normalize(z, mean, std):
+    """PIPE:385-394: (z - mean) * (1 / std) with the constants in z's dtype."""
+    m = torch.tensor(mean).view(1, -1, 1, 1, 1).to(z.device, z.dtype)
+    s = 1.0 / torch.tensor(std).view(1, -1, 1, 1, 1).to(z.device, z.dtype)
+    return (z - m) * s
+
+
+def denormalize(z, mean, std):
+    """PIPE:396-405."""
+    m = torch.tensor(mean).view(1, -1, 1, 1, 1).to(z.device, z.dtype)
+    s = 1.0 / torch.tensor(std).view(1, -1, 1, 1, 1).to(z.device, z.dtype)
+    return z / s + m
+
+
+def prepare_latents(image: torch.Tensor, num_frames: int, encode_sample: Callable, mean, std, generator, dit_dtype=torch.bfloat16):
+    """PIPE:774-792 + 236-286 with num_cond_frames = 1: noise latents (fp32, drawn first), first latent frame <- normalised posterior
+    SAMPLE of the conditioning image (cast to the DiT dtype first, PIPE:772).  image [B,3,H,W] in [-1,1]."""
+    B, _, H, W = image.shape
+    image = image.to(dit_dtype)
+    T = (num_frames - 1) // 4 + 1
+    latents = torch.randn((B, 16, T, H // 8, W // 8), generator=generator).to(torch.float32)
+    cond = torch.cat([encode_sample(image[i].unsqueeze(0).unsqueeze(2), generator) for i in range(B)], dim=0).to(torch.float32)
+    latents[:, :, :1] = normalize(cond, mean, std)
+    return latents
+
+
+# ---- FLF, LongCat variant ---------------------------------------------------------------------------------------------------
+def flow_similarity(ref_motion: torch.Tensor, cand_motion: torch.Tensor) -> float:
+    """SCHED:172-243: like the Wan metric but outliers are epe > 3 OR epe > 5 % of |ref|, and the weights are 0.4 / 0.4 / 0.2."""
+    n = min(ref_motion.shape[1], cand_motion.shape[1])
+    if n <= 0:
+        return 0.0
+    r, c = ref_motion.float()[:, :n], cand_motion.float()[:, :n]
+    r = r[:, :, :2] if r.shape[2] >= 2 else r.repeat(1, 1, 2, 1, 1)[:, :, :2]
+    c = c[:, :, :2] if c.shape[2] >= 2 else c.repeat(1, 1, 2, 1, 1)[:, :, :2]
+    d = r - c
+    epe = torch.sqrt((d ** 2).sum(dim=2) + 1e-8)
+    dot = (r * c).sum(dim=2)
+    rn = torch.sqrt((r ** 2).sum(dim=2) + 1e-8)
+    cn = torch.sqrt((c ** 2).sum(dim=2) + 1e-8)
+    ae = torch.acos(torch.clamp(dot / (rn * cn + 1e-8), -1.0, 1.0)) * 180.0 / torch.pi
+    outl = (epe > 3.0) | (epe > rn * 0.05)
+    m_epe, m_ae, fl = epe.mean(), ae.mean(), outl.float().mean()
+    werr = 0.4 * torch.clamp(m_epe / 10.0, 0.0, 1.0) + 0.4 * torch.clamp(fl / 0.5, 0.0, 1.0) + 0.2 * torch.clamp(m_ae / 30.0, 0.0, 1.0)
+    return torch.clamp(1.0 - werr, 0.0, 1.0).item()
+
+
+def channel_similarities(pred: torch.Tensor, enc: torch.Tensor) -> List[float]:
+    """SCHED:281-316, temporal-difference branch (SCHED:165-170)."""
+    enc = enc.to(pred.device, dtype=pred.dtype)
+    sims = []
+    for c in range(pred.shape[1]):
+        pm = inject.temporal_diff_motion(pred[:, c:c + 1].to(torch.float32))
+        rm = inject.temporal_diff_motion(enc[:, c:c + 1].to(torch.float32))
+        sims.append(flow_similarity(rm, pm))
+    return sims
+
+
+def select_from_similarities(sims: Sequence[float], current_step: int, use_distill: bool = False,
+                             max_replace_threshold: Optional[int] = None) -> List[int]:
+    """SCHED:269-270, 330-381."""
+    if current_step < 2:
+        return []
+    corr = np.array(sims)
+    mean, std = np.mean(corr), np.std(corr)
+    early = 3 if use_distill else 5
+    if current_step <= early:
+        chans = np.argsort(corr)[:1].tolist()
+    else:
+        max_replace = max_replace_threshold if max_replace_threshold is not None else (3 if use_distill else 1)
+        thr = mean - 0.625 * std
+        below = [i for i, s in enumerate(corr) if s < thr]
+        if len(below) < 1:
+            chans = np.argsort(corr)[:1].tolist()
+        elif len(below) > max_replace:
+            sc = sorted([(i, corr[i]) for i in below], key=lambda x: x[1])
+            chans = [i for i, _ in sc[:max_replace]]
+        else:
+            chans = below
+    return sorted(chans)
+
+
+def fuse_latents(x0_full: torch.Tensor, ref: torch.Tensor, mask: torch.Tensor, *, decode: Callable, encode_mode: Callable, mean, std,
+                 use_flf: bool, current_step: int, use_distill: bool = False, max_replace_threshold: Optional[int] = None) -> torch.Tensor:
+    """SCHED:1072-1233: de-normalise -> decode -> ref*mask + dec*(1-mask) at the exact decoded size (no alignment: a shape mismatch
+    raises inside the reference's try block and returns the prediction unchanged) -> encode (mode) -> normalise -> FLF."""
+    dec = decode(denormalize(x0_full, mean, std))
+    if ref.shape != dec.shape or mask.shape[1] != 1 or tuple(mask.shape[2:]) != tuple(dec.shape[2:]):
+        return x0_full
+    r = 2.0 * ref.to(dec.dtype) - 1.0
+    m = mask.to(dec.dtype)
+    if m.shape[1] != dec.shape[1]:
+        m = m.repeat(1, dec.shape[1], 1, 1, 1)
+    fused = r * m + dec * (1 - m)
+    enc = encode_mode(fused)
+    if enc.shape != x0_full.shape:
+        return x0_full
+    enc = normalize(enc, mean, std)
+    if use_flf:
+        for c in select_from_similarities(channel_similarities(x0_full, enc), current_step, use_distill, max_replace_threshold):
+            if 0 <= c < enc.shape[1]:
+                enc[:, c] = x0_full[:, c]
+    return enc.to(x0_full.dtype)
+
+
+# ---- CFG-zero ---------------------------------------------------------------------------------------------------------------
+def cfg_zero(cond: torch.Tensor, uncond: torch.Tensor, g: float) -> torch.Tensor:
+    """PIPE:374-383 + 875-885: st* = <cond, uncond> / (|uncond|^2 + 1e-8) per sample; uncond*st* + g*(cond - uncond*st*)."""
+    B = cond.shape[0]
+    pos, neg = cond.reshape(B, -1), uncond.reshape(B, -1)
+    st = (torch.sum(pos * neg, dim=1, keepdim=True) / (torch.sum(neg ** 2, dim=1, keepdim=True) + 1e-8)).view(B, 1, 1, 1, 1)
+    return uncond * st + g * (cond - uncond * st)
+
+
+# ---- the loop ---------------------------------------------------------------------------------------------------------------
+def run(cfg: LongCatSamplerConfig, *, latents: torch.Tensor, dit: Callable, prompt_embeds: torch.Tensor, prompt_mask: torch.Tensor,
+        video_ref: Optional[torch.Tensor], mask: Optional[torch.Tensor], decode: Callable, encode_mode: Callable, mean, std,
+        generator: Optional[torch.Generator] = None, trace: Optional[list] = None) -> torch.Tensor:
+    """PIPE:823-994.  latents [B,16,T,h,w] fp32 with the clean condition frame at index 0 (edited in place, as the reference);
+    prompt_embeds [2B,1,N,C] = (negative, positive) when guidance_scale > 1, else [B,1,N,C]; dit(hidden_states, timestep[B,T],
+    encoder_hidden_states, encoder_attention_mask, num_cond_latents) -> fp32."""
+    sigmas, timesteps = make_schedule(timesteps_sigmas(cfg.num_inference_steps, cfg.use_distill), cfg.shift)
+    do_cfg = cfg.guidance_scale > 1.0
+    for i, t in enumerate(timesteps):
+        history = []
+        sigma, dt = sigmas[i], sigmas[i + 1] - sigmas[i]
+        pred_x0 = None
+        prev = None
+
+        def euler(model_output, sample, fuse):
+            x0 = sample - sigma * model_output  # SCHED:836
+            if fuse is not None:
+                x0_full = latents - sigma * torch.cat([torch.zeros_like(model_output[:, :, 0:1]), model_output], dim=2)
+                x0 = fuse(x0_full)[:, :, 1:]
+            history.append(model_output)
+            return (sample + dt * model_output).to(model_output.dtype), x0  # SCHED:894, 901
+
+        rounds = cfg.resample_steps if (cfg.guided and i < cfg.resample_round) else 1
+        for r in range(rounds):
+            ts = t.expand(latents.shape[0]).to(cfg.dit_dtype)
+            x_in = (torch.cat([latents] * 2) if do_cfg else latents).to(cfg.dit_dtype)
+            if do_cfg:
+                ts = torch.cat([ts] * 2)
+            ts = ts.unsqueeze(-1).repeat(1, x_in.shape[2])
+            ts[:, :1] = 0
+            v = dit(hidden_states=x_in, timestep=ts, encoder_hidden_states=prompt_embeds, encoder_attention_mask=prompt_mask,
+                    num_cond_latents=1)
+            if do_cfg:
+                v_un, v_c = v.chunk(2)
+                v = cfg_zero(v_c, v_un, cfg.guidance_scale)
+            v = -v
+            fuse = None
+            if cfg.guided and i < cfg.guide_steps and video_ref is not None and r == 0:
+                def fuse(x0_full):
+                    return fuse_latents(x0_full, video_ref, mask, decode=decode, encode_mode=encode_mode, mean=mean, std=std,
+                                        use_flf=cfg.use_pca_channel_selection, current_step=i, use_distill=cfg.use_distill,
+                                        max_replace_threshold=cfg.max_replace_threshold)
+            prev, pred_x0 = euler(v[:, :, 1:], latents[:, :, 1:].to(torch.float32), fuse)
+            if trace is not None:
+                trace.append(("step", i, r, prev.clone(), pred_x0.clone()))
+            if i >= cfg.resample_round:
+                break
+            if r < cfg.resample_steps - 1 and pred_x0 is not None:
+                noise = torch.randn(pred_x0.shape, generator=generator).to(dtype=pred_x0.dtype)
+                latents[:, :, 1:] = (1.0 - sigma) * pred_x0 + sigma * noise  # SCHED:1041-1070 at the current timestep
+        if i < cfg.resample_round and len(history) > 1 and cfg.guided:
+            omega = cfg.omega_resample if i >= cfg.guide_steps else cfg.omega
+            better = inject.dsg(history[-1], history[0], omega)
+            latents[:, :, 1:] = euler(better, latents[:, :, 1:].to(torch.float32), None)[0]
+        else:
+            latents[:, :, 1:] = prev
+        if trace is not None:
+            trace.append(("latents", i, latents.clone()))
+    return latents
+
+
+def decode_final(latents: torch.Tensor, decode: Callable, mean, std):
+    """PIPE:998-1004: de-normalise, decode, (x/2+0.5).clamp(0,1) -> [B,F,H,W,C]."""
+    video = decode(denormalize(latents.to(torch.float32), mean, std))
+    return (video / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 4, 1)

@@ -55,6 +55,43 @@ class _Dist:
     def mode(self):
         return self._mu
 
+    def sample(self, generator=None):
+        """Posterior sample with a fixed small std (LongCat's prepare_latents draws it: pipeline_longcat_video.py:278)."""
+        noise = torch.randn(self._mu.shape, generator=generator, dtype=torch.float32)
+        return self._mu + noise.to(self._mu.device) * 0.05
+
+
+class FakeLongCatDiT:
+    """LongCat call protocol (pipeline_longcat_video.py:867-873): batch of CFG samples, per-frame timesteps, caption masks.
+    v[b,c] = a_c * (0.5 + t[b,frame]/1000) * x[b,c] + g_c * x[b,(c+5)%16] + 0.25 * ctx[b,c%4] + 0.01 * n_valid[b]  -> fp32."""
+
+    def __init__(self, dtype=torch.bfloat16):
+        self.dtype = dtype
+        self.config = SimpleNamespace(in_channels=16, out_channels=16, patch_size=(1, 2, 2))
+        self.cp_split_hw = None
+        self.coef = _coef(16, 3, 4321, 0.8)
+        self.calls = 0
+
+    def __call__(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask=None, num_cond_latents=0, **kw):
+        self.calls += 1
+        x = hidden_states.float()
+        B, _, T = x.shape[:3]
+        ts = timestep.float()
+        if ts.dim() == 1:
+            ts = ts.unsqueeze(1).expand(-1, T)
+        fac = (ts.to(x.device) / 1000.0 + 0.5).view(B, T, 1, 1)
+        ctx = encoder_hidden_states.float().reshape(B, -1, encoder_hidden_states.shape[-1])[:, 0, :4].cpu().tolist()
+        nval = [float(v) for v in encoder_attention_mask.sum(dim=-1).reshape(-1).cpu().tolist()] if encoder_attention_mask is not None else [0.0] * B
+        outs = []
+        for c in range(16):
+            a, _, g = [float(v) for v in self.coef[c]]
+            o = x[:, c] * fac * a
+            o = o + x[:, (c + 5) % 16] * g
+            bias = torch.tensor([ctx[b][c % 4] * 0.25 + 0.01 * nval[b] for b in range(B)], dtype=torch.float32, device=x.device)
+            o = o + bias.view(B, 1, 1, 1)
+            outs.append(o)
+        return torch.stack(outs, dim=1)
+
 
 class FakeVAE:
     """decode: channel mix 16->3, nearest x8 spatial, latent frame t -> output frames (1 + 4(T-1)), clamp(-1,1);
@@ -62,7 +99,7 @@ class FakeVAE:
 
     def __init__(self):
         self.dtype = torch.float32
-        self.config = SimpleNamespace(z_dim=16, latents_mean=VAE_MEAN, latents_std=VAE_STD)
+        self.config = SimpleNamespace(z_dim=16, latents_mean=VAE_MEAN, latents_std=VAE_STD, scale_factor_temporal=4, scale_factor_spatial=8)
         self.temperal_downsample = [False, True, True]
         self.wd = _coef(3, 16, 77, 0.3)
         self.we = _coef(16, 3, 78, 1.2)
@@ -86,7 +123,7 @@ class FakeVAE:
 
     def encode(self, x):
         self.n_enc += 1
-        s = x[:, :, ::4, ::8, ::8]
+        s = x.float()[:, :, ::4, ::8, ::8]
         chans = []
         for o in range(16):
             acc = s[:, 0] * float(self.we[o, 0])

@@ -381,3 +381,84 @@ def g_longcat_dit():
 
 if __name__ == "__main__" and "longcat" in sys.argv[1:]:
     g_longcat_dit()
+
+
+# ------------------------------------------------------------------------------------------------------------
+LC_PIPE_CASES = {
+    "irr_flf": dict(steps=9, R=2, guide=8, rnd=8, flf=True, omega=1.8, omega_r=1.0, cfg=4.0, F=9, H=32, W=32, guided=True, shift=1.0,
+                    distill=False, maxrep=None),
+    "dsg_shift": dict(steps=6, R=3, guide=3, rnd=5, flf=False, omega=2.5, omega_r=1.5, cfg=3.0, F=5, H=32, W=48, guided=True, shift=8.0,
+                      distill=False, maxrep=None),
+    "plain": dict(steps=5, R=3, guide=0, rnd=0, flf=False, omega=1.8, omega_r=1.0, cfg=4.0, F=5, H=32, W=32, guided=False, shift=3.0,
+                  distill=False, maxrep=None),
+    "nocfg_distill": dict(steps=6, R=2, guide=6, rnd=6, flf=True, omega=1.8, omega_r=1.0, cfg=1.0, F=9, H=32, W=32, guided=True,
+                          shift=1.0, distill=True, maxrep=2),
+}
+
+
+def lc_case_inputs(c):
+    g = torch.Generator().manual_seed(17)
+    image = torch.rand(3, c["H"], c["W"], generator=g)
+    ref, mask = synthetic_ref_and_mask(c["F"], c["H"], c["W"], seed=6)
+    pe = torch.randn(1, 1, 12, 32, generator=g).to(torch.bfloat16)
+    ne = torch.randn(1, 1, 12, 32, generator=g).to(torch.bfloat16)
+    pm = torch.zeros(1, 12, dtype=torch.int64)
+    pm[:, :9] = 1
+    nm = torch.zeros(1, 12, dtype=torch.int64)
+    nm[:, :4] = 1
+    return image, ref, mask, pe, pm, ne, nm
+
+
+def g_longcat_pipe():
+    """G12: LongCatVideoPipeline.generate_i2v + FlowMatchEulerDiscreteScheduler, unmodified, with deterministic stand-ins for the DiT,
+    the VAE and the text encoder (encode_prompt) and a fixed target size instead of the resolution-bucket lookup."""
+    from tests.fakes import FakeLongCatDiT
+
+    sys.path.insert(0, "/root/reference/longcat_for_worldforge")
+    from longcat_video.modules.scheduling_flow_match_euler_discrete import FlowMatchEulerDiscreteScheduler
+    from longcat_video.pipeline_longcat_video import LongCatVideoPipeline
+
+    for name, c in LC_PIPE_CASES.items():
+        image, ref, mask, pe, pm, ne, nm = lc_case_inputs(c)
+        dit, vae = FakeLongCatDiT(), FakeVAE()
+        sch = FlowMatchEulerDiscreteScheduler(shift=c["shift"])
+        pipe = LongCatVideoPipeline(tokenizer=None, text_encoder=None, vae=vae, scheduler=sch, dit=dit)
+        pipe.device = "cpu"
+        pipe.encode_prompt = lambda **kw: (pe, pm, ne if kw["do_classifier_free_guidance"] else None,
+                                           nm if kw["do_classifier_free_guidance"] else None)
+        pipe.get_condition_shape = lambda *a, **k: (c["H"], c["W"])
+        rec, calls = {}, []
+        orig_step = sch.step
+
+        def wrapped(*a, **k):
+            o = orig_step(*a, **k)
+            calls.append((t2n(o.prev_sample), t2n(o.pred_x0)))
+            return o
+
+        sch.step = wrapped
+        orig_prep = pipe.prepare_latents
+
+        def prep(*a, **k):
+            lat = orig_prep(*a, **k)
+            rec["latents0"] = t2n(lat).copy()
+            return lat
+
+        pipe.prepare_latents = prep
+        gen = torch.manual_seed(42)
+        frames = pipe.generate_i2v(image=image, prompt="p", negative_prompt="n", resolution="480p", num_frames=c["F"],
+                                   num_inference_steps=c["steps"], use_distill=c["distill"], guidance_scale=c["cfg"], generator=gen,
+                                   output_type="np", video_ref=ref, mask=mask, guided=c["guided"], resample_steps=c["R"],
+                                   guide_steps=c["guide"], resample_round=c["rnd"], omega=c["omega"], omega_resample=c["omega_r"],
+                                   use_pca_channel_selection=c["flf"], static=True, max_replace_threshold=c["maxrep"])
+        rec["frames"] = np.asarray(frames, dtype=np.float32)
+        rec["n_calls"] = np.array([dit.calls, vae.n_enc, vae.n_dec])
+        rec["sigmas"], rec["timesteps"] = sch.sigmas.numpy(), sch.timesteps.numpy()
+        for j, (p, x0) in enumerate(calls):
+            rec[f"call{j}_prev"], rec[f"call{j}_x0"] = p, x0
+        rec["n_step_calls"] = np.array([len(calls)])
+        np.savez_compressed(os.path.join(OUT, f"g12_longcat_pipe_{name}.npz"), **rec)
+        print("g12", name, "dit/enc/dec calls", rec["n_calls"], "step calls", len(calls), "frames", rec["frames"].shape)
+
+
+if __name__ == "__main__" and "longcat_pipe" in sys.argv[1:]:
+    g_longcat_pipe()

@@ -1,2 +1,6 @@
 class WanLoraLoaderMixin:
     pass
+
+
+class FromOriginalModelMixin:
+    pass

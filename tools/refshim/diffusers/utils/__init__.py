@@ -31,3 +31,18 @@ class _Logging:
 
 
 logging = _Logging()
+
+
+class BaseOutput:
+    """diffusers.utils.BaseOutput: a dataclass base whose fields can also be read by index / key."""
+
+    def __getitem__(self, k):
+        import dataclasses
+        vals = [getattr(self, f.name) for f in dataclasses.fields(self)]
+        if isinstance(k, str):
+            return getattr(self, k)
+        return [v for v in vals if v is not None][k]
+
+    def to_tuple(self):
+        import dataclasses
+        return tuple(getattr(self, f.name) for f in dataclasses.fields(self) if getattr(self, f.name) is not None)

@@ -80,11 +80,23 @@ def decoder_plan() -> List[Tuple]:
 
 
 class _LatentDist:
-    def __init__(self, mean):
+    """diffusers' DiagonalGaussianDistribution surface the samplers use: mode() (Wan path, PIPE retrieve_latents "argmax") and
+    sample(generator) (LongCat prepare_latents, pipeline_longcat_video.py:278: mean + std * randn, logvar clamped to [-30, 20])."""
+
+    def __init__(self, mean, logvar=None):
         self._mean = mean
+        self._logvar = logvar
 
     def mode(self):
         return self._mean
+
+    def sample(self, generator=None):
+        std = torch.exp(0.5 * torch.clamp(self._logvar, -30.0, 20.0))
+        if generator is not None and generator.device.type != self._mean.device.type:
+            noise = torch.randn(self._mean.shape, generator=generator, dtype=self._mean.dtype).to(self._mean.device)
+        else:
+            noise = torch.randn(self._mean.shape, generator=generator, dtype=self._mean.dtype, device=self._mean.device)
+        return self._mean + std * noise
 
 
 class AutoencoderKLWan:
@@ -549,7 +561,7 @@ class AutoencoderKLWan:
         q = self._small_conv(y, "conv1", T, h, w, 2 * Z_DIM, (1, 1, 1))
         out = torch.empty((2 * Z_DIM, T, h, w), dtype=F32, device=self.device)
         call("wf_cl_to_ncthw", q.data_ptr(), out.data_ptr(), 2 * Z_DIM, 2 * Z_DIM, T * h * w, 0.0, ops.stream())
-        return out[:Z_DIM]
+        return out  # [mean | logvar]
 
     # ------------------------------------------------------------------------------------------------------------
     # diffusers protocol
@@ -571,7 +583,7 @@ class AutoencoderKLWan:
         q = self._small_conv(y, "conv1", T, h, w, 2 * Z_DIM, (1, 1, 1))
         out = torch.empty((2 * Z_DIM, T, h, w), dtype=F32, device=self.device)
         call("wf_cl_to_ncthw", q.data_ptr(), out.data_ptr(), 2 * Z_DIM, 2 * Z_DIM, T * h * w, 0.0, ops.stream())
-        return out[:Z_DIM]
+        return out  # [mean | logvar]
 
     def _decode_one(self, z: torch.Tensor) -> torch.Tensor:
         """[16,T,h,w] f32 -> [3, 4T-3, 8h, 8w] f32 clamped to [-1,1] (vae.py:544-568, autoencoder_kl_wan.py:1222)."""
@@ -591,8 +603,8 @@ class AutoencoderKLWan:
     @torch.no_grad()
     def encode(self, x: torch.Tensor, return_dict: bool = True):
         x = x.to(device=self.device, dtype=F32).contiguous()
-        mean = torch.stack([self._encode_one(v) for v in x])
-        post = _LatentDist(mean)
+        moments = torch.stack([self._encode_one(v) for v in x])
+        post = _LatentDist(moments[:, :Z_DIM].contiguous(), moments[:, Z_DIM:])
         if not return_dict:
             return (post,)
         return SimpleNamespace(latent_dist=post)
