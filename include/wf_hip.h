@@ -105,6 +105,10 @@ size_t wf_dsg_workspace_floats(void);
  *   better = g + omega*sin(theta) * (g - (|g|/(|w|+1e-8))*cos(theta) * w).   g = "good" (post-injection), w = "worse".
  * ws: wf_dsg_workspace_floats() floats; ws[0..7] afterwards = {dot, ng2, nw2, cos, sin, ratio, 0, 0} for inspection. */
 int wf_dsg(const void* g, const void* w, void* out, int dt, float omega, size_t n, float* ws, void* stream);
+/* CFG-zero (LongCat pipeline_longcat_video.py:374-383 optimized_scale + :875-888): st = <cond,uncond> / (|uncond|^2 + 1e-8) over the
+ * whole sample; out = uncond*st + guidance*(cond - uncond*st), negated when negate != 0 (the sign flip of :888).  fp32;
+ * ws: wf_dsg_workspace_floats() floats, ws[0..3] afterwards = {dot, |cond|^2, |uncond|^2, st}. */
+int wf_cfg_zero(const float* cond, const float* uncond, float* out, float guidance, int negate, size_t n, float* ws, void* stream);
 
 /* ---- FLF metric (SCHED:497-607) ------------------------------------------------------------------ */
 /* Temporal-difference motion (SCHED:391-392, 478-479): out[c,t,:] = x[c,t+1,:] - x[c,t,:];  x [C,T,hw] -> out [C,T-1,hw] f32. */
@@ -114,6 +118,11 @@ size_t wf_flow_metrics_workspace_floats(int n_channels);
  * similarity = 1 - (.45*clamp(mEPE/10) + .45*clamp(Fl/.5) + .1*clamp(mAE/30))  -> sim[n_channels] (device floats). */
 int wf_flow_metrics(const float* ref_flow, const float* chan_flow, float* sim, int n_channels, int Tm, int Cr, int Cc,
                     size_t hw, float* ws, void* stream);
+/* The same with the metric variant selectable: 0 = the Wan scheduler's (above); 1 = the LongCat scheduler's
+ * (longcat_video/modules/scheduling_flow_match_euler_discrete.py:172-243): outlier = (epe > 3) OR (epe > 5 % |ref|),
+ * similarity = 1 - (.4*clamp(mEPE/10) + .4*clamp(Fl/.5) + .2*clamp(mAE/30)). */
+int wf_flow_metrics_variant(const float* ref_flow, const float* chan_flow, float* sim, int n_channels, int Tm, int Cr, int Cc,
+                            size_t hw, int variant, float* ws, void* stream);
 
 /* ---- FLF optical flow (SCHED:156-248) ----------------------------------------------------------------------------------
  * What `cv2.calcOpticalFlowFarneback(g1, g2, None, 0.5, 3, 15, 3, 5, 1.2, 0)` (SCHED:220-224) computes for every consecutive frame

@@ -136,11 +136,55 @@ extern "C" int wf_temporal_diff(const void* x, int dt, float* out, int C, int T,
 }
 
 // ------------------------------------------------------------------------------------------------
+// CFG-zero (LongCat pipeline_longcat_video.py:374-383, 875-888): st = <c,u> / (|u|^2 + 1e-8);
+// out = +-(u*st + g*(c - u*st)), every product / sum rounded separately as the reference's torch ops.  fp32.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_cfgz_coeff(float* ws, int nblk) {
+  __shared__ float sm[12];
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+    acc[0] += ws[8 + 3 * i + 0];
+    acc[1] += ws[8 + 3 * i + 1];
+    acc[2] += ws[8 + 3 * i + 2];
+  }
+  block_sum<3>(acc, sm);
+  if (threadIdx.x == 0) {
+    ws[0] = acc[0];
+    ws[1] = acc[1];
+    ws[2] = acc[2];
+    ws[3] = acc[0] / (acc[2] + 1e-8f);
+  }
+}
+__global__ void k_cfgz_apply(const float* __restrict__ c, const float* __restrict__ u, float* __restrict__ o, const float* ws, float g,
+                             int negate, size_t n) {
+  const float st = ws[3];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float us = u[i] * st;
+    const float d = c[i] - us;
+    const float r = us + g * d;
+    o[i] = negate ? -r : r;
+  }
+}
+extern "C" int wf_cfg_zero(const float* cond, const float* uncond, float* out, float guidance, int negate, size_t n, float* ws,
+                           void* stream) {
+  WF_CHECK_ARG(cond && uncond && out && ws, "wf_cfg_zero: null pointer");
+  WF_CHECK_ARG(n > 0, "wf_cfg_zero: empty tensor");
+  TView cv{(void*)cond, WF_F32}, uv{(void*)uncond, WF_F32};
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = grid_for(n, RED_BLOCK, RED_NBLK);
+  hipLaunchKernelGGL(k_dsg_reduce<false>, dim3(nblk), dim3(RED_BLOCK), 0, s, cv, uv, ws, n);
+  hipLaunchKernelGGL(k_cfgz_coeff, dim3(1), dim3(RED_BLOCK), 0, s, ws, nblk);
+  hipLaunchKernelGGL(k_cfgz_apply, dim3(grid_for(n, RED_BLOCK)), dim3(RED_BLOCK), 0, s, cond, uncond, out, ws, guidance, negate, n);
+  WF_LAUNCH_CHECK("wf_cfg_zero");
+  return WF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // SCHED:497-607 _compute_flow_metrics (mask=None path): per channel three means -> similarity
 // ------------------------------------------------------------------------------------------------
 #define FM_NBLK 32
 __global__ void k_flow_partial(const float* __restrict__ ref, const float* __restrict__ chan, float* ws, int Tm, int Cr,
-                               int Cc, size_t hw) {
+                               int Cc, size_t hw, int outlier_or) {
   __shared__ float sm[12];
   const int ch = blockIdx.y;
   const size_t npix = (size_t)Tm * hw;
@@ -161,7 +205,8 @@ __global__ void k_flow_partial(const float* __restrict__ ref, const float* __res
     float ca = dot / (rn * cn + 1e-8f);
     ca = fminf(fmaxf(ca, -1.0f), 1.0f);
     float ae = acosf(ca) * 180.0f / 3.14159265358979323846f;
-    bool outl = (epe > 3.0f) && (epe > rn * 0.05f);
+    const bool o_abs = epe > 3.0f, o_rel = epe > rn * 0.05f;
+    bool outl = outlier_or ? (o_abs || o_rel) : (o_abs && o_rel);
     acc[0] += epe;
     acc[1] += ae;
     acc[2] += outl ? 1.0f : 0.0f;
@@ -174,7 +219,7 @@ __global__ void k_flow_partial(const float* __restrict__ ref, const float* __res
     o[2] = acc[2];
   }
 }
-__global__ void k_flow_final(const float* ws, float* sim, int Tm, size_t hw) {
+__global__ void k_flow_final(const float* ws, float* sim, int Tm, size_t hw, float w_epe, float w_fl, float w_ae) {
   const int ch = blockIdx.x;
   // 64 threads, FM_NBLK (=32) partials: fixed-order wave tree
   float a[3] = {0.f, 0.f, 0.f};
@@ -193,22 +238,31 @@ __global__ void k_flow_final(const float* ws, float* sim, int Tm, size_t hw) {
     float ne = fminf(fmaxf(m_epe / 10.0f, 0.f), 1.f);
     float nf = fminf(fmaxf(fl / 0.5f, 0.f), 1.f);
     float na = fminf(fmaxf(m_ae / 30.0f, 0.f), 1.f);
-    float werr = (0.45f * ne + 0.45f * nf) + 0.1f * na;
+    float werr = (w_epe * ne + w_fl * nf) + w_ae * na;
     float s = 1.0f - werr;
     sim[ch] = fminf(fmaxf(s, 0.f), 1.f);
   }
 }
 extern "C" size_t wf_flow_metrics_workspace_floats(int n_channels) { return (size_t)n_channels * FM_NBLK * 3; }
-extern "C" int wf_flow_metrics(const float* ref_flow, const float* chan_flow, float* sim, int n_channels, int Tm, int Cr,
-                               int Cc, size_t hw, float* ws, void* stream) {
+extern "C" int wf_flow_metrics_variant(const float* ref_flow, const float* chan_flow, float* sim, int n_channels, int Tm, int Cr,
+                                       int Cc, size_t hw, int variant, float* ws, void* stream) {
   WF_CHECK_ARG(ref_flow && chan_flow && sim && ws, "wf_flow_metrics: null pointer");
   WF_CHECK_ARG((Cr == 1 || Cr == 2) && (Cc == 1 || Cc == 2), "wf_flow_metrics: flow components must be 1 or 2");
   WF_CHECK_ARG(n_channels > 0 && Tm > 0 && hw > 0, "wf_flow_metrics: empty input");
+  WF_CHECK_ARG(variant == 0 || variant == 1, "wf_flow_metrics: variant must be 0 (Wan) or 1 (LongCat)");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_flow_partial, dim3(FM_NBLK, n_channels), dim3(RED_BLOCK), 0, s, ref_flow, chan_flow, ws, Tm, Cr, Cc, hw);
-  hipLaunchKernelGGL(k_flow_final, dim3(n_channels), dim3(64), 0, s, ws, sim, Tm, hw);
+  // variant 1 = the LongCat scheduler's metric (scheduling_flow_match_euler_discrete.py:172-243): outlier = abs OR rel, weights .4/.4/.2
+  hipLaunchKernelGGL(k_flow_partial, dim3(FM_NBLK, n_channels), dim3(RED_BLOCK), 0, s, ref_flow, chan_flow, ws, Tm, Cr, Cc, hw, variant);
+  if (variant == 0)
+    hipLaunchKernelGGL(k_flow_final, dim3(n_channels), dim3(64), 0, s, ws, sim, Tm, hw, 0.45f, 0.45f, 0.1f);
+  else
+    hipLaunchKernelGGL(k_flow_final, dim3(n_channels), dim3(64), 0, s, ws, sim, Tm, hw, 0.4f, 0.4f, 0.2f);
   WF_LAUNCH_CHECK("wf_flow_metrics");
   return WF_OK;
+}
+extern "C" int wf_flow_metrics(const float* ref_flow, const float* chan_flow, float* sim, int n_channels, int Tm, int Cr,
+                               int Cc, size_t hw, float* ws, void* stream) {
+  return wf_flow_metrics_variant(ref_flow, chan_flow, sim, n_channels, Tm, Cr, Cc, hw, 0, ws, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,192 @@
+"""The LongCat-Video guided image-to-video sampler (IRR re-noising, FLF gate, DSG auto-guidance, CFG-zero), HIP-backed.
+
+Host-side mirror of `LongCatVideoPipeline.generate_i2v` (PIPE = longcat_for_worldforge/longcat_video/pipeline_longcat_video.py:619-1006):
+same sampling knobs, same control flow (PIPE:823-994), same RNG draw order (CPU generator: noise latents PIPE:256, the posterior sample
+of the conditioning frame PIPE:278, the re-noise draws PIPE:925), same dtype hand-offs (fp32 latents, DiT input / timesteps in the
+DiT dtype).  The DiT, the VAE and the scheduler are objects speaking the reference's call protocol, so the MI355X-native modules of
+this package (longcat_dit.LongCatVideoTransformer3DModel, vae.AutoencoderKLWan, longcat_scheduler.FlowMatchEulerDiscreteScheduler)
+and test doubles are interchangeable.  The UMT5 text encoder runs once per video outside the loop and is out of scope: its outputs
+are taken as tensors (`prompt_embeds` [1,1,N,C] + `prompt_attention_mask` [1,N], and the negative pair).  The target size is given
+explicitly (`height`, `width`): the resolution-bucket lookup of PIPE:358-372 belongs to the front-end.
+"""
+from __future__ import annotations
+
+from typing import Optional, Union
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class LongCatVideoPipeline:
+    def __init__(self, vae, scheduler, dit, device: Union[str, torch.device] = "cuda:0"):
+        self.vae, self.scheduler, self.dit = vae, scheduler, dit
+        self.device = torch.device(device)
+        cfg = getattr(vae, "config", None)
+        self.vae_scale_factor_temporal = getattr(cfg, "scale_factor_temporal", 4)  # PIPE:83-84
+        self.vae_scale_factor_spatial = getattr(cfg, "scale_factor_spatial", 8)
+        self._num_timesteps = 1000
+        self._num_distill_sample_steps = 50
+        self._guidance_scale = 1.0
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def do_classifier_free_guidance(self):
+        return self._guidance_scale > 1.0
+
+    # ---- PIPE:317-331 ---------------------------------------------------------------------------------------------------
+    def get_timesteps_sigmas(self, sampling_steps: int, use_distill: bool = False) -> torch.Tensor:
+        if use_distill:
+            idx = torch.arange(1, self._num_distill_sample_steps + 1, dtype=torch.float32)
+            idx = (idx * (self._num_timesteps // self._num_distill_sample_steps)).round().long()
+            inf = np.floor(np.linspace(0, self._num_distill_sample_steps, num=sampling_steps, endpoint=False)).astype(np.int64)
+            sigmas = torch.flip(idx, [0])[inf].float() / self._num_timesteps
+            sigmas = sigmas - sigmas[-1]
+        else:
+            sigmas = torch.linspace(0.999, 0.000, sampling_steps)
+        return sigmas.to(torch.float32)
+
+    def _preprocess_image(self, image, height, width) -> torch.Tensor:
+        """diffusers VideoProcessor.preprocess: -> [1,3,H,W] fp32 in [-1,1]."""
+        if isinstance(image, torch.Tensor):
+            t = (image if image.dim() == 4 else image.unsqueeze(0)).to(torch.float32)
+        else:
+            if image.size != (width, height):
+                image = image.resize((width, height))
+            t = torch.from_numpy(np.array(image).astype(np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
+        if t.shape[-2:] != (height, width):
+            raise ValueError(f"image tensor is {tuple(t.shape[-2:])}, expected {(height, width)}")
+        return 2.0 * t - 1.0
+
+    def _randn(self, shape, generator):
+        # diffusers / the reference draw on the CPU generator and move (RNG parity)
+        if generator is not None and generator.device.type == "cpu":
+            return torch.randn(shape, generator=generator).to(self.device)
+        return torch.randn(shape, generator=generator, device=self.device)
+
+    # ---- PIPE:214-286 with num_cond_frames = 1 ----------------------------------------------------------------------------
+    def prepare_latents(self, image: torch.Tensor, batch_size: int, num_channels_latents: int, height: int, width: int,
+                        num_frames: int, generator=None, latents: Optional[torch.Tensor] = None) -> torch.Tensor:
+        T = (num_frames - 1) // self.vae_scale_factor_temporal + 1
+        shape = (batch_size, num_channels_latents, T, height // self.vae_scale_factor_spatial, width // self.vae_scale_factor_spatial)
+        latents = self._randn(shape, generator).to(torch.float32) if latents is None else latents.to(self.device, torch.float32)
+        cond = []
+        for i in range(batch_size):
+            post = self.vae.encode(image[i].unsqueeze(0).unsqueeze(2)).latent_dist
+            cond.append(post.sample(generator))  # PIPE:278 retrieve_latents(..., sample_mode="sample")
+        cond = torch.cat(cond, dim=0).to(self.device, torch.float32)
+        latents[:, :, :1] = ops.latent_norm(cond, self.vae.config.latents_mean, self.vae.config.latents_std)
+        return latents
+
+    # ---- PIPE:619-1006 ----------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate_i2v(self, image, height: int, width: int, prompt_embeds: torch.Tensor, prompt_attention_mask: torch.Tensor,
+                     negative_prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_attention_mask: Optional[torch.Tensor] = None,
+                     num_frames: int = 93, num_inference_steps: int = 50, use_distill: bool = False, guidance_scale: float = 4.0,
+                     generator=None, latents: Optional[torch.Tensor] = None, output_type: str = "np",
+                     video_ref: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None, guided: bool = False,
+                     resample_steps: int = 3, guide_steps: int = 20, resample_round: int = 20, omega: float = 1.8,
+                     omega_resample: float = 1.0, use_pca_channel_selection: bool = False, static: bool = False,
+                     max_replace_threshold: Optional[int] = None, step_hook=None):
+        dev, sch = self.device, self.scheduler
+        ssp = self.vae_scale_factor_spatial * 2
+        if height % ssp != 0 or width % ssp != 0:
+            raise ValueError(f"`height and width` have to be divisible by {ssp} but are {height} and {width}.")  # PIPE:199-201
+        if num_frames % self.vae_scale_factor_temporal != 1:
+            num_frames = num_frames // self.vae_scale_factor_temporal * self.vae_scale_factor_temporal + 1  # PIPE:700-704
+        num_frames = max(num_frames, 1)
+        self._guidance_scale = guidance_scale
+        do_cfg = self.do_classifier_free_guidance
+        dit_dtype = self.dit.dtype
+        pe = prompt_embeds.to(dev, dit_dtype)
+        pm = prompt_attention_mask.to(dev)
+        if do_cfg:
+            if negative_prompt_embeds is None:
+                raise ValueError("classifier-free guidance (guidance_scale > 1) needs the negative prompt embeddings")
+            pe = torch.cat([negative_prompt_embeds.to(dev, dit_dtype), pe], dim=0)  # PIPE:760-762
+            pm = torch.cat([negative_prompt_attention_mask.to(dev), pm], dim=0)
+        # PIPE:764-767
+        sch.set_timesteps(num_inference_steps, sigmas=self.get_timesteps_sigmas(num_inference_steps, use_distill=use_distill), device=dev)
+        timesteps = sch.timesteps
+        # PIPE:769-789
+        img = self._preprocess_image(image, height, width).to(dev, dit_dtype)
+        latents = self.prepare_latents(img, 1, self.dit.config.in_channels, height, width, num_frames, generator, latents)
+        if video_ref is not None and guided:
+            video_ref = torch.as_tensor(video_ref).to(dev, torch.float32)  # PIPE:792-801
+        if mask is not None and guided:  # PIPE:803-817
+            mask = torch.from_numpy(mask) if isinstance(mask, np.ndarray) else mask
+            if mask.dim() == 3:
+                mask = mask.unsqueeze(0).unsqueeze(1)
+            elif mask.dim() == 4 and mask.shape[1] != 1:
+                mask = mask[:, 0:1, :, :].unsqueeze(0)
+            elif mask.dim() == 4 and mask.shape[0] == 1:
+                mask = mask.unsqueeze(1)
+            elif mask.dim() == 5 and mask.shape[1] != 1:
+                mask = mask[:, 0:1, :, :, :]
+            mask = mask.to(dev, torch.float32)
+        sch.derivative_history = []
+
+        for i, t in enumerate(timesteps):
+            if step_hook is not None:
+                step_hook(i, "start")
+            sch.derivative_history = []
+            pred_x0 = None
+            scheduler_output = None
+            for r in range(resample_steps if (guided and i < resample_round) else 1):
+                if r > 0:
+                    sch.set_resample_mode(True)
+                    sch._step_index -= 1
+                else:
+                    sch.set_resample_mode(False)
+                # PIPE:852-865: the timestep in the DiT dtype, one per latent frame, the condition frame at t = 0
+                ts = t.expand(latents.shape[0]).to(dit_dtype)
+                x_in = ops.cast(latents, dit_dtype)
+                if do_cfg:
+                    x_in = torch.cat([x_in] * 2)
+                    ts = torch.cat([ts] * 2)
+                ts = ts.unsqueeze(-1).repeat(1, x_in.shape[2])
+                ts[:, :1] = 0
+                noise_pred = self.dit(hidden_states=x_in, timestep=ts, encoder_hidden_states=pe, encoder_attention_mask=pm,
+                                      num_cond_latents=1)
+                if do_cfg:
+                    # CFG-zero (PIPE:875-885) and the sign flip of PIPE:888 in one launch per sample
+                    u, c = noise_pred.chunk(2)
+                    noise_pred = torch.stack([ops.cfg_zero(c[b], u[b], guidance_scale, negate=True) for b in range(c.shape[0])])
+                else:
+                    noise_pred = -noise_pred
+                scheduler_output = sch.step(
+                    noise_pred[:, :, 1:], t, latents[:, :, 1:], video_ref=video_ref, mask=mask, guided=guided and i < guide_steps,
+                    resampling=r > 0, vae=self.vae, use_pca_channel_selection=use_pca_channel_selection, static=static,
+                    current_step=i, total_steps=len(timesteps), sample_full=latents, use_distill=use_distill,
+                    max_replace_threshold=max_replace_threshold, return_dict=True)
+                if scheduler_output.pred_x0 is not None:
+                    pred_x0 = scheduler_output.pred_x0
+                if i >= resample_round:
+                    break
+                if r < resample_steps - 1 and pred_x0 is not None:
+                    noise = self._randn(tuple(pred_x0.shape), generator).to(pred_x0.dtype)
+                    latents[:, :, 1:] = sch.add_noise(pred_x0, noise, t.expand(pred_x0.shape[0]), use_resample_sigma=False)
+            sch.set_resample_mode(False)
+            if i < resample_round and len(sch.derivative_history) > 1 and guided:
+                # DSG (PIPE:945-976): cosine-corrected extrapolation from the first to the last prediction of this step
+                current_omega = omega_resample if i >= guide_steps else omega
+                better = ops.dsg(sch.derivative_history[-1].contiguous(), sch.derivative_history[0].contiguous(), current_omega)
+                sch._step_index -= 1
+                out = sch.step(better, t, latents[:, :, 1:], guided=False, resampling=False, vae=self.vae, sample_full=latents,
+                               use_distill=use_distill, return_dict=True)
+                latents[:, :, 1:] = out.prev_sample
+            elif scheduler_output is not None:
+                latents[:, :, 1:] = scheduler_output.prev_sample
+            if step_hook is not None:
+                step_hook(i, "end")
+
+        if output_type == "latent":
+            return latents
+        z = ops.latent_denorm(ops.cast(latents, torch.float32), self.vae.config.latents_mean, self.vae.config.latents_std)
+        video = self.vae.decode(z, return_dict=False)[0]
+        video = torch.stack([ops.postprocess_video(v) for v in video])  # [B,F,H,W,C] in [0,1]
+        return video.cpu().numpy() if output_type == "np" else video

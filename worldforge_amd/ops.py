@@ -201,6 +201,17 @@ def dsg(good: torch.Tensor, worse: torch.Tensor, omega: float) -> torch.Tensor:
     return out
 
 
+def cfg_zero(cond: torch.Tensor, uncond: torch.Tensor, guidance: float, negate: bool = False) -> torch.Tensor:
+    """LongCat CFG-zero (pipeline_longcat_video.py:374-383, 875-888) for one sample, one fused call, no host sync."""
+    cond, uncond = _dev(cond).contiguous(), _dev(uncond).contiguous()
+    assert cond.dtype == uncond.dtype == torch.float32 and cond.shape == uncond.shape
+    ws = _workspace("dsg", _ffi.lib().wf_dsg_workspace_floats(), cond.device)
+    out = torch.empty_like(cond)
+    call("wf_cfg_zero", cond.data_ptr(), uncond.data_ptr(), out.data_ptr(), float(guidance), 1 if negate else 0, cond.numel(),
+         ws.data_ptr(), stream())
+    return out
+
+
 def temporal_diff(x: torch.Tensor) -> torch.Tensor:
     """SCHED:391-392: x [C,T,h,w] -> [C,T-1,h,w] fp32."""
     x = _dev(x)
@@ -236,8 +247,9 @@ def farneback_flows(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def flow_metrics(ref_flow: torch.Tensor, chan_flow: torch.Tensor) -> torch.Tensor:
-    """SCHED:497-607 for n channels at once.  ref_flow [n,Tm,Cr,h,w], chan_flow [n,Tm,Cc,h,w] fp32 -> sim [n] (device)."""
+def flow_metrics(ref_flow: torch.Tensor, chan_flow: torch.Tensor, variant: int = 0) -> torch.Tensor:
+    """SCHED:497-607 (variant 0) or the LongCat scheduler's metric (variant 1) for n channels at once.
+    ref_flow [n,Tm,Cr,h,w], chan_flow [n,Tm,Cc,h,w] fp32 -> sim [n] (device)."""
     ref_flow, chan_flow = _dev(ref_flow), _dev(chan_flow)
     assert ref_flow.dtype == chan_flow.dtype == torch.float32
     n, Tm, Cr, h, w = ref_flow.shape
@@ -245,6 +257,6 @@ def flow_metrics(ref_flow: torch.Tensor, chan_flow: torch.Tensor) -> torch.Tenso
     assert chan_flow.shape == (n, Tm, Cc, h, w)
     ws = _workspace("flow", _ffi.lib().wf_flow_metrics_workspace_floats(n), ref_flow.device)
     sim = torch.empty(n, dtype=torch.float32, device=ref_flow.device)
-    call("wf_flow_metrics", ref_flow.data_ptr(), chan_flow.data_ptr(), sim.data_ptr(), n, Tm, Cr, Cc, h * w, ws.data_ptr(),
-         stream())
+    call("wf_flow_metrics_variant", ref_flow.data_ptr(), chan_flow.data_ptr(), sim.data_ptr(), n, Tm, Cr, Cc, h * w, variant,
+         ws.data_ptr(), stream())
     return sim
