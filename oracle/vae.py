@@ -223,6 +223,16 @@ def encode_mode(W, video: torch.Tensor) -> torch.Tensor:
     return mu
 
 
+def encode_sample(W, video: torch.Tensor, generator=None) -> torch.Tensor:
+    """vae.encode(x).latent_dist.sample(generator) (LongCat prepare_latents, pipeline_longcat_video.py:278; diffusers'
+    DiagonalGaussianDistribution: logvar clamped to [-30, 20], mean + exp(logvar / 2) * randn)."""
+    assert (video.shape[2] - 1) % 4 == 0
+    out = run_plan(video.float(), W, encoder_plan())
+    mu, logvar = causal_conv3d(out, W, "conv1").chunk(2, dim=1)
+    std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+    return mu + std * torch.randn(mu.shape, generator=generator, dtype=mu.dtype)
+
+
 def decode(W, z: torch.Tensor) -> torch.Tensor:
     """vae.decode(z)[0] (SCHED:1285, PIPE:743): [1,16,T,h,w] (de-normalised) -> [1,3,4T-3,8h,8w], clamped to [-1,1]."""
     x = causal_conv3d(z.float(), W, "conv2")  # vae.py:553

@@ -16,3 +16,16 @@ def test_guided_job_frames_psnr_vs_oracle(cfg):
     psnr, err = ge.parity_run(**cfg)
     print(f"PSNR {psnr:.1f} dB, max abs err {err:.4f}")
     assert psnr >= 40.0, (psnr, err)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(hidden=256, heads=2, depth=2, Fr=9, H=32, Wd=32, steps=4, guide=3),
+    dict(hidden=1024, heads=8, depth=3, Fr=13, H=64, Wd=96, steps=5, guide=4, resample=3),
+    dict(hidden=4096, heads=32, depth=1, Fr=9, H=64, Wd=64, steps=4, guide=3),   # the released width, one block
+])
+def test_longcat_guided_job_frames_psnr_vs_oracle(cfg):
+    """LongCat-Video config of SURVEY section 8f-1: Euler flow-match sampler + IRR / FLF / DSG / CFG-zero + LongCat DiT + VAE."""
+    import __graft_entry__ as ge
+    psnr, err = ge.longcat_parity_run(**cfg)
+    print(f"LongCat PSNR {psnr:.1f} dB, max abs err {err:.4f}")
+    assert psnr >= 40.0, (psnr, err)
