@@ -244,3 +244,29 @@ def random_weights(cfg: LongCatConfig, seed: int = 0, dtype=torch.float32) -> Di
     lin("final_layer.linear", 4 * cfg.out_channels, C)
     lin("final_layer.adaLN_modulation.1", 2 * C, Ct, std=0.5 / math.sqrt(Ct))
     return W
+
+
+def fold_lora(W: Dict[str, torch.Tensor], lora: Dict[str, torch.Tensor], multiplier: float = 1.0, network_dim: int = 128,
+              network_alpha: float = 64.0) -> Dict[str, torch.Tensor]:
+    """Runtime LoRA of LCD:189-247 + lora_utils.py:27-78 as a weight update: for every `<name>.lora_down.weight` in the LoRA state dict
+    (name = "lora___lorahyphen___" + module path with "." written "___lorahyphen___"), the wrapped Linear computes
+    org(x) + multiplier * alpha_scale * up(down(x)), i.e. W' = W + multiplier * alpha_scale * U @ D, where U is `lora_up.weight`
+    or, for n separate up-blocks (lora_utils.py:15-24), the block-diagonal stack of `lora_up.blocks.i.weight` acting on the i-th
+    rank-slice of D.  alpha_scale = the stored buffer if present, else alpha / dim."""
+    out = dict(W)
+    for key in lora:
+        if not key.endswith(".lora_down.weight"):
+            continue
+        name = key[: -len(".lora_down.weight")]
+        module = name.replace("lora___lorahyphen___", "").replace("___lorahyphen___", ".")
+        down = lora[key].float()
+        scale = float(lora[name + ".alpha_scale"]) if name + ".alpha_scale" in lora else (network_alpha or network_dim) / network_dim
+        if name + ".lora_up.weight" in lora:
+            delta = lora[name + ".lora_up.weight"].float() @ down
+        else:
+            blocks = sorted((k for k in lora if k.startswith(name + ".lora_up.blocks.")), key=lambda k: int(k.split(".")[-2]))
+            r = down.shape[0] // len(blocks)
+            delta = torch.cat([lora[k].float() @ down[i * r:(i + 1) * r] for i, k in enumerate(blocks)], dim=0)
+        wk = module + ".weight"
+        out[wk] = (W[wk].float() + multiplier * scale * delta).to(W[wk].dtype)
+    return out

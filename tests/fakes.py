@@ -169,3 +169,25 @@ class SimComm:
     def all_gather_async(self, out, inp):
         self.all_gather(out, inp)
         return None
+
+
+def lora_state(cfg, seed=33, dim=8):
+    """Synthetic LoRA state dict in the reference's naming (lora_utils.py:83-145): fused qkv with 3 up-blocks, kv_linear with 2,
+    plain up-projections elsewhere; alpha_scale buffers as LoRAModule registers them."""
+    g = torch.Generator().manual_seed(seed)
+    C, Hd = cfg.hidden_size, cfg.ffn_hidden
+    sd = {}
+    H = "___lorahyphen___"
+    for i in range(cfg.depth):
+        for mod, (o, k, nsep) in {f"blocks.{i}.attn.qkv": (3 * C, C, 3), f"blocks.{i}.attn.proj": (C, C, 1),
+                                  f"blocks.{i}.cross_attn.kv_linear": (2 * C, C, 2), f"blocks.{i}.ffn.w1": (Hd, C, 1),
+                                  f"blocks.{i}.ffn.w2": (C, Hd, 1)}.items():
+            name = "lora" + H + mod.replace(".", H)
+            sd[name + ".lora_down.weight"] = torch.randn(nsep * dim, k, generator=g) / k ** 0.5
+            if nsep > 1:
+                for b in range(nsep):
+                    sd[name + f".lora_up.blocks.{b}.weight"] = torch.randn(o // nsep, dim, generator=g) * 0.3
+            else:
+                sd[name + ".lora_up.weight"] = torch.randn(o, dim, generator=g) * 0.3
+            sd[name + ".alpha_scale"] = torch.tensor(0.5)
+    return sd

@@ -185,3 +185,20 @@ def test_full_width_block_matches_oracle():
     want = olc.forward(W, ocfg, x.float(), torch.tensor(ts), cap.float(), mask, num_cond_latents=1)
     got = m.forward_tokens(x.to(DEV), ts, cap.to(DEV), mask, 1)
     assert _rel_l2(got, want) <= 2e-2, _rel_l2(got, want)
+
+
+def test_lora_fold_matches_reference_runtime_lora():
+    """fold_lora at load vs the reference's run-time LoRA (golden g13), through the HIP forward."""
+    from tests.fakes import lora_state
+    from worldforge_amd.longcat_dit import LongCatVideoTransformer3DModel, fold_lora
+    L = np.load(os.path.join(os.path.dirname(__file__), "golden", "g13_longcat_lora.npz"))
+    cfg, ocfg = _cfg(256, 2, 2, 64, 64)
+    W = olc.random_weights(ocfg, seed=21)
+    m = LongCatVideoTransformer3DModel(cfg, DEV).load_state_dict(fold_lora(W, lora_state(ocfg), multiplier=0.8, network_dim=8,
+                                                                           network_alpha=4))
+    got = m.forward_tokens(torch.from_numpy(L["x"]).to(BF).to(DEV), L["ts"].tolist(), torch.from_numpy(L["cap"]).to(BF).to(DEV),
+                           torch.from_numpy(L["mask"]), 1)
+    assert _rel_l2(got, torch.from_numpy(L["out"])) <= 2e-2
+    assert _rel_l2(got, torch.from_numpy(L["out_base"])) > 5e-2   # and not the base model
+    with pytest.raises(KeyError):
+        fold_lora(W, {"lora___lorahyphen___blocks___lorahyphen___9___lorahyphen___attn___lorahyphen___proj.lora_down.weight": torch.zeros(8, 256)})

@@ -40,3 +40,20 @@ def test_ffn_width_and_rope_partition():
     # 44 temporal, 42 row, 42 column entries; pairs share one frequency
     assert torch.equal(ang[:, 0::2], ang[:, 1::2])
     assert ang[0].abs().max() == 0 and ang[1, :44].abs().max() == 0 and ang[1, 86] == 1.0
+
+
+def test_lora_fold_equals_reference_runtime_lora():
+    """G13: the reference with a LoRA network enabled at run time (5 wrapped Linears per block, fused qkv / kv with separate up-blocks,
+    multiplier 0.8, stored alpha_scale 0.5) == the oracle forward on the folded weights."""
+    from tests.fakes import lora_state
+    L = np.load(os.path.join(os.path.dirname(__file__), "golden", "g13_longcat_lora.npz"))
+    cfg = olc.LongCatConfig(hidden_size=256, depth=2, num_heads=2, caption_channels=64, adaln_tembed_dim=64)
+    W = olc.random_weights(cfg, seed=21)
+    args = (torch.from_numpy(L["x"]), torch.from_numpy(L["ts"]), torch.from_numpy(L["cap"]), torch.from_numpy(L["mask"]))
+    base = olc.forward(W, cfg, *args, num_cond_latents=1)
+    assert (base - torch.from_numpy(L["out_base"])).abs().max() / np.abs(L["out_base"]).max() < 2e-5
+    Wf = olc.fold_lora(W, lora_state(cfg), multiplier=0.8, network_dim=8, network_alpha=4)
+    got = olc.forward(Wf, cfg, *args, num_cond_latents=1)
+    want = torch.from_numpy(L["out"])
+    assert (got - want).abs().max() / want.abs().max() < 2e-5
+    assert (want - torch.from_numpy(L["out_base"])).abs().mean() > 0.05  # the LoRA really changes the output

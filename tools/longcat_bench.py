@@ -17,7 +17,49 @@ if __name__ == "__main__":
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--h", type=int, default=60)
     ap.add_argument("--w", type=int, default=104)
+    ap.add_argument("--job", action="store_true", help="time guided / plain sampler steps of the whole i2v job instead of one forward")
     a = ap.parse_args()
+    if a.job:
+        from worldforge_amd.longcat_pipeline import LongCatVideoPipeline
+        from worldforge_amd.longcat_scheduler import FlowMatchEulerDiscreteScheduler
+        from worldforge_amd.vae import AutoencoderKLWan
+
+        dev = torch.device("cuda:0")
+        m = LongCatVideoTransformer3DModel(LongCatConfig(depth=a.depth), dev).init_random(1)
+        vae = AutoencoderKLWan(dev).init_random(seed=1)
+        pipe = LongCatVideoPipeline(vae, FlowMatchEulerDiscreteScheduler(shift=12.0), m, device=dev)
+        Fr, H, Wd = 4 * (a.frames - 1) + 1, a.h * 8, a.w * 8
+        g = torch.Generator().manual_seed(3)
+        image = torch.rand(3, H, Wd, generator=g)
+        ref = torch.rand(1, 3, Fr, H, Wd, generator=g)
+        mask = (torch.rand(1, 1, Fr, H // 8, Wd // 8, generator=g) > 0.4).float().repeat_interleave(8, 3).repeat_interleave(8, 4)
+        pe, ne = (torch.randn(2, 1, 1, 512, 4096, generator=g) * 0.5).bfloat16()
+        pm, nm = torch.zeros(1, 512, dtype=torch.int64), torch.zeros(1, 512, dtype=torch.int64)
+        pm[:, :180] = 1
+        nm[:, :120] = 1
+        marks = []
+
+        class _Stop(Exception):
+            pass
+
+        def hook(i, what):
+            torch.cuda.synchronize()
+            marks.append((i, what, time.time()))
+            if what == "end" and i == 3:
+                raise _Stop
+
+        try:
+            pipe.generate_i2v(image=image, height=H, width=Wd, prompt_embeds=pe, prompt_attention_mask=pm, negative_prompt_embeds=ne,
+                              negative_prompt_attention_mask=nm, num_frames=Fr, num_inference_steps=50, guidance_scale=4.0,
+                              generator=torch.manual_seed(1), video_ref=ref, mask=mask, guided=True, resample_steps=3, guide_steps=3,
+                              resample_round=3, use_pca_channel_selection=True, static=True, step_hook=hook)
+        except _Stop:
+            pass
+        t = {(i, w): ts for i, w, ts in marks}
+        for i in range(4):
+            print(f"step {i} ({'guided: 3 CFG evaluations + injection + DSG' if i < 3 else 'plain: 1 CFG evaluation'}): "
+                  f"{t[(i, 'end')] - t[(i, 'start')]:.2f} s", flush=True)
+        sys.exit(0)
     dev = torch.device("cuda:0")
     cfg = LongCatConfig(depth=a.depth)
     t0 = time.time()

@@ -462,3 +462,46 @@ def g_longcat_pipe():
 
 if __name__ == "__main__" and "longcat_pipe" in sys.argv[1:]:
     g_longcat_pipe()
+
+
+# ------------------------------------------------------------------------------------------------------------
+def g_longcat_lora():
+    """G13: the reference DiT with a LoRA network enabled the reference's way (create_lora_network + enable_loras, LCD:189-247)."""
+    import warnings
+
+    sys.path.insert(0, "/root/reference/longcat_for_worldforge")
+    from longcat_video.modules.longcat_video_dit import LongCatVideoTransformer3DModel
+    from longcat_video.modules.lora_utils import create_lora_network
+    from oracle import longcat_dit as olc
+    from tests.fakes import lora_state
+
+    cfg = olc.LongCatConfig(hidden_size=256, depth=2, num_heads=2, caption_channels=64, adaln_tembed_dim=64)
+    W = olc.random_weights(cfg, seed=21)
+    m = LongCatVideoTransformer3DModel(hidden_size=256, depth=2, num_heads=2, caption_channels=64, adaln_tembed_dim=64,
+                                       enable_flashattn2=True, cp_split_hw=[1, 1])
+    m.load_state_dict(W, strict=True)
+    m.eval()
+    lsd = lora_state(cfg)
+    net = create_lora_network(transformer=m, lora_network_state_dict_loaded=lsd, multiplier=0.8, network_dim=8, network_alpha=4)
+    net.load_state_dict(lsd, strict=True)
+    m.lora_dict["k"] = net
+    m.enable_loras(["k"])
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 16, 3, 8, 12, generator=g)
+    cap = torch.randn(1, 1, 24, 64, generator=g)
+    mask = torch.zeros(1, 24, dtype=torch.int64)
+    mask[0, :17] = 1
+    ts = torch.full((1, 3), 500.0)
+    ts[:, :1] = 0
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        o = m(hidden_states=x, timestep=ts, encoder_hidden_states=cap, encoder_attention_mask=mask, num_cond_latents=1)
+        m.disable_all_loras()
+        o0 = m(hidden_states=x, timestep=ts, encoder_hidden_states=cap, encoder_attention_mask=mask, num_cond_latents=1)
+    np.savez_compressed(os.path.join(OUT, "g13_longcat_lora.npz"), x=x[0].numpy(), cap=cap[0, 0].numpy(), mask=mask[0].numpy(),
+                        ts=ts[0].numpy(), out=o[0].numpy(), out_base=o0[0].numpy())
+    print("g13", tuple(o.shape), float((o - o0).abs().mean()), float(o0.abs().mean()))
+
+
+if __name__ == "__main__" and "longcat_lora" in sys.argv[1:]:
+    g_longcat_lora()

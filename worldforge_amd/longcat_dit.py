@@ -12,8 +12,8 @@ Numerics: bf16 weights, bf16 residual stream (LCD:104, 120), bf16 GEMM / attenti
 embedding and AdaLN parameters (LCD:84-88, 310-311: the fp32 activations are fed to the bf16 MFMA GEMM as a hi + lo bf16 pair, which
 keeps 16 mantissa bits), fp32 LayerNorm statistics, fp32 final projection (LCB:162-167).
 
-Not covered here (next rows of SURVEY section 8f): KV-cache continuation (LCA:147-181), block-sparse attention (LCA:57-66), runtime LoRA
-(LCD:189-268; fold `W + multiplier * alpha/r * up @ down` into the loaded weights instead), sequence parallelism.
+Runtime LoRA (LCD:189-268) is offered as a weight fold at load (`fold_lora`).  Not covered here (next rows of SURVEY section 8f):
+KV-cache continuation (LCA:147-181), block-sparse attention (LCA:57-66), sequence parallelism.
 """
 from __future__ import annotations
 
@@ -79,6 +79,42 @@ def rope_tables(head_dim: int, f: int, h: int, w: int, base: float = 10000.0):
     ang = torch.cat([at.view(f, 1, 1, -1).expand(f, h, w, -1), ah.view(1, h, 1, -1).expand(f, h, w, -1),
                      aw.view(1, 1, w, -1).expand(f, h, w, -1)], dim=-1).reshape(f * h * w, head_dim // 2)
     return ang.cos().contiguous(), ang.sin().contiguous()
+
+
+def fold_lora(sd: Dict[str, torch.Tensor], lora_sd: Dict[str, torch.Tensor], multiplier: float = 1.0, network_dim: int = 128,
+              network_alpha: float = 64.0) -> Dict[str, torch.Tensor]:
+    """The reference applies LoRA at run time (LCD:189-247, lora_utils.py:27-78): every wrapped Linear returns
+    org(x) + multiplier * alpha_scale * up(down(x)).  Here the update is folded into the weights once, at load (fp32 accumulate, then
+    the usual bf16 storage): W' = W + multiplier * alpha_scale * U @ D, with U block-diagonal over the rank slices of D when the
+    up-projection is stored as n separate blocks (fused qkv / kv).  A weight-load step, not part of the sampling path; the forward then
+    costs exactly what the base model costs.  Returns a new reference-keyed state dict for load_state_dict."""
+    out = dict(sd)
+    for key in lora_sd:
+        if not key.endswith(".lora_down.weight"):
+            continue
+        name = key[: -len(".lora_down.weight")]
+        module = name.replace("lora___lorahyphen___", "").replace("___lorahyphen___", ".")
+        wk = module + ".weight"
+        if wk not in sd:
+            raise KeyError(f"LoRA entry {name} has no Linear {wk} in the model")
+        dev = sd[wk].device
+        down = lora_sd[key].to(dev, torch.float32)
+        if name + ".alpha_scale" in lora_sd:
+            scale = float(lora_sd[name + ".alpha_scale"])
+        else:
+            scale = (network_alpha or network_dim) / network_dim
+        if name + ".lora_up.weight" in lora_sd:
+            delta = lora_sd[name + ".lora_up.weight"].to(dev, torch.float32) @ down
+        else:
+            blocks = sorted((k for k in lora_sd if k.startswith(name + ".lora_up.blocks.")), key=lambda k: int(k.split(".")[-2]))
+            if not blocks:
+                raise KeyError(f"LoRA entry {name} has no up-projection")
+            r = down.shape[0] // len(blocks)
+            delta = torch.cat([lora_sd[k].to(dev, torch.float32) @ down[i * r:(i + 1) * r] for i, k in enumerate(blocks)], dim=0)
+        if tuple(delta.shape) != tuple(sd[wk].shape):
+            raise ValueError(f"LoRA update for {wk} has shape {tuple(delta.shape)}, weight is {tuple(sd[wk].shape)}")
+        out[wk] = sd[wk].to(torch.float32) + (multiplier * scale) * delta
+    return out
 
 
 class LongCatVideoTransformer3DModel:
