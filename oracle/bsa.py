@@ -1,0 +1,66 @@
+"""Oracle: LongCat-Video block-sparse attention (the 720p refine pass) in plain torch (CPU).  TEST INFRASTRUCTURE ONLY.
+
+Restates /root/reference/longcat_for_worldforge/longcat_video/block_sparse_attention/bsa_interface.py (BSA):
+  rearrange_THW_to_3d_block / rearrange_3d_block_to_THW :600-610, mean_pooling_compression :169-179, cal_score :181-185,
+  get_select_indices_topk_from_score :211-224, _attention_bsa.forward :538-560, flash_attn_bsa_3d :612-659.
+The permutes, the pooling and the top-k selection are pinned against those functions imported from the reference
+(tests/golden/g14_bsa.npz, tools/make_goldens.py bsa).  The sparse attention itself is a Triton GPU kernel in the reference
+(flash_attn_bsa_varlen_mask.py:174-285, not runnable here): it is restated from its source as what it computes -- for every query
+block, softmax(q k^T * sm_scale) over the keys of the selected key blocks only -- PARITY OF THAT STEP WITH THE TRITON KERNEL IS UNPINNED.
+"""
+from __future__ import annotations
+
+from typing import Sequence, Tuple
+
+import torch
+
+
+def block_permutation(T: int, H: int, W: int, t: int, h: int, w: int) -> torch.Tensor:
+    """BSA:600-604: index tensor `perm` with x_blocks = x[perm]: tokens of each (t x h x w) brick made contiguous, bricks in
+    (Nt, Nh, Nw) order, tokens inside a brick in (t, h, w) order."""
+    assert T % t == 0 and H % h == 0 and W % w == 0
+    idx = torch.arange(T * H * W).view(T // t, t, H // h, h, W // w, w)
+    return idx.permute(0, 2, 4, 1, 3, 5).reshape(-1)
+
+
+def mean_pool(x: torch.Tensor, block: int) -> torch.Tensor:
+    """BSA:169-179: [heads, S, D] -> [heads, S / block, D] in x's dtype (S is a multiple of the block on this path)."""
+    Hh, S, D = x.shape
+    assert S % block == 0
+    return x.view(Hh, S // block, block, D).mean(dim=2)
+
+
+def select_topk(q_cmp: torch.Tensor, k_cmp: torch.Tensor, sparsity: float) -> torch.Tensor:
+    """BSA:181-185 + 211-224: score = q_cmp k_cmp^T (input dtype); the int((1 - sparsity) * n_k) best key blocks per query block."""
+    score = torch.matmul(q_cmp, k_cmp.transpose(-1, -2))
+    n = int((1 - sparsity) * score.shape[-1])
+    return torch.topk(score, n)[1]
+
+
+def sparse_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_indices: torch.Tensor, block_q: int, block_k: int,
+                     scale: float) -> torch.Tensor:
+    """flash_attn_bsa_varlen_mask.py:236-285 as a masked dense softmax: q [heads, Sq, D], k / v [heads, Sk, D] (block order),
+    block_indices [heads, Sq / block_q, n_sel] -> [heads, Sq, D] in q's dtype."""
+    Hh, Sq, D = q.shape
+    Sk = k.shape[1]
+    nq, nk = Sq // block_q, Sk // block_k
+    allow = torch.zeros((Hh, nq, nk), dtype=torch.bool)
+    allow.scatter_(2, block_indices.long(), True)
+    mask = allow.repeat_interleave(block_q, dim=1).repeat_interleave(block_k, dim=2)
+    s = torch.einsum("hqd,hkd->hqk", q.float(), k.float()) * scale
+    s = s.masked_fill(~mask, float("-inf"))
+    return torch.einsum("hqk,hkd->hqd", torch.softmax(s, dim=-1), v.float()).to(q.dtype)
+
+
+def flash_attn_bsa_3d(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, shape_q: Tuple[int, int, int], shape_k: Tuple[int, int, int],
+                      sparsity: float = 0.875, chunk_q: Sequence[int] = (4, 4, 8), chunk_k: Sequence[int] = (4, 4, 8),
+                      return_indices: bool = False):
+    """BSA:612-659 for one sample: q [heads, Sq, D], k / v [heads, Sk, D] in (T, H, W) token order -> [heads, Sq, D]."""
+    pq, pk = block_permutation(*shape_q, *chunk_q), block_permutation(*shape_k, *chunk_k)
+    bq, bk = chunk_q[0] * chunk_q[1] * chunk_q[2], chunk_k[0] * chunk_k[1] * chunk_k[2]
+    qb, kb, vb = q[:, pq], k[:, pk], v[:, pk]
+    idx = select_topk(mean_pool(qb, bq), mean_pool(kb, bk), sparsity)
+    ob = sparse_attention(qb, kb, vb, idx, bq, bk, q.shape[-1] ** -0.5)
+    out = torch.empty_like(ob)
+    out[:, pq] = ob  # BSA:606-610
+    return (out, idx) if return_indices else out

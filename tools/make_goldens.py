@@ -505,3 +505,35 @@ def g_longcat_lora():
 
 if __name__ == "__main__" and "longcat_lora" in sys.argv[1:]:
     g_longcat_lora()
+
+
+# ------------------------------------------------------------------------------------------------------------
+def g_bsa():
+    """G14: the reference's own BSA helper functions (permutes, mean pooling, top-k block selection; eager: TORCHDYNAMO_DISABLE=1)."""
+    sys.path.insert(0, "/root/reference/longcat_for_worldforge")
+    from longcat_video.block_sparse_attention import bsa_interface as B
+
+    g = torch.Generator().manual_seed(9)
+    out = {}
+    for name, (T, H, W, t, h, w) in {"a": (8, 8, 16, 4, 4, 8), "b": (4, 12, 8, 2, 4, 4)}.items():
+        x = torch.arange(T * H * W, dtype=torch.float32).view(1, 1, -1, 1)
+        xb = B.rearrange_THW_to_3d_block(x, T // t, H // h, W // w, t, h, w, 1)
+        out[f"{name}_perm"] = xb.flatten().long().numpy()
+        assert torch.equal(B.rearrange_3d_block_to_THW(xb, T // t, H // h, W // w, t, h, w, 1), x)
+        out[f"{name}_shape"] = np.array([T, H, W, t, h, w])
+    for name, (Hh, Sq, Sk, blk, sp, dt) in {"f32": (3, 1024, 1536, 128, 0.75, torch.float32),
+                                            "bf16": (2, 768, 768, 128, 0.5, torch.bfloat16)}.items():
+        q = torch.randn(1, Hh, Sq, 128, generator=g).to(dt)
+        k = (torch.randn(1, Hh, Sk, 128, generator=g) + 0.3 * torch.randn(1, Hh, 1, 128, generator=g)).to(dt)
+        qc, kc = B.mean_pooling_compression(q, blk), B.mean_pooling_compression(k, blk)
+        idx, lens = B.get_select_indices(qc, kc, sp, None)
+        out[f"{name}_q"], out[f"{name}_k"] = q[0].float().numpy(), k[0].float().numpy()
+        out[f"{name}_qc"], out[f"{name}_kc"] = qc[0].float().numpy(), kc[0].float().numpy()
+        out[f"{name}_idx"], out[f"{name}_lens"] = idx[0].numpy(), lens[0].numpy()
+        out[f"{name}_cfg"] = np.array([Hh, Sq, Sk, blk, int(sp * 1000)])
+    np.savez_compressed(os.path.join(OUT, "g14_bsa.npz"), **out)
+    print("g14", {k: v.shape for k, v in out.items() if k.endswith("_idx")})
+
+
+if __name__ == "__main__" and "bsa" in sys.argv[1:]:
+    g_bsa()
