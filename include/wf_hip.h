@@ -195,12 +195,27 @@ int wf_lc_gate_residual(void* x, const void* y, int64_t ldy, const float* gate, 
                         void* stream);
 /* RMSNorm_FP32 over each head's 128 channels (LCB:40-52 as used at LCA:111 and LCA:231) + optional interleaved 3D RoPE
  * (LCR:32-36, 101-120; cos/sin tables [L][64] f32 per rotation pair, NULL -> none), written head-major for wf_attn_fwd:
- * in bf16 [L, ld] (head h at columns h*128) -> out bf16 [H][Lout][128] (rows L..Lout untouched); weight f32 [128]. */
+ * in bf16 [L, ld] (head h at columns h*128) -> out bf16 [H][Lout][128] (rows L..Lout untouched); weight f32 [128].
+ * row_map (int32 [L], may be NULL): input row r is written to output row row_map[r] -- the (T,H,W) -> 3D-block token order of the
+ * block-sparse refine attention (block_sparse_attention/bsa_interface.py:600-604) applied for free on the way out. */
 int wf_lc_norm_heads(const void* in, int64_t ld, const float* weight, const float* cos_tab, const float* sin_tab, void* out, int L,
-                     int Lout, int H, float eps, void* stream);
+                     int Lout, int H, float eps, const int* row_map, void* stream);
 /* FeedForwardSwiGLU gate (LCB:36-37): in bf16 [L, ld] with w1 x in columns [0, Hd) and w3 x in [Hd, 2 Hd) ->
  * out bf16 [L, Hd] = silu(w1 x) * w3 x. */
 int wf_lc_swiglu(const void* in, int64_t ld, void* out, int L, int Hd, void* stream);
+
+/* ---- LongCat block-sparse attention of the 720p refine pass (longcat_video/block_sparse_attention/bsa_interface.py = BSA) --------- */
+/* mean_pooling_compression (BSA:169-179): in bf16 [H][L][128] -> out bf16 [H][L/128][128], mean of each 128-token block. */
+int wf_lc_mean_pool_blocks(const void* in, void* out, int H, int L, void* stream);
+/* out[i][:C] = in[index[i]][:C], bf16 rows: the token permutes of BSA:600-610 where they cannot ride on another kernel's store. */
+int wf_gather_rows_bf16(const void* in, int64_t ld_in, const int* index, void* out, int64_t ld_out, int n_rows, int C, void* stream);
+/* The sparse attention of BSA:538-560 (flash_attn_bsa_varlen_mask.py:174-285): Q [H][Lq][128], K [H][Lkp][128], Vt [H][Lkp/64][128][64]
+ * in 3D-block token order, 128 tokens per block; every query block attends to its selected key blocks only.  The selection is given
+ * per GROUP of two consecutive query blocks (the 256 query rows of one workgroup): group_lists [H][ceil(Lq/256)][max_entries] int32,
+ * entry = key_block * 4 + flags (bit 0 / 1: selected by the first / second query block of the group), the union of both lists in any
+ * order; group_counts [H][ceil(Lq/256)] entries used.  O [Lq][ldo] bf16 (block order), head h at columns h*128. */
+int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int ldo, float softmax_scale,
+                    const int* group_lists, const int* group_counts, int max_entries, void* stream);
 
 /* ---- 3D causal VAE (wan/modules/vae.py; the in-tree statement of diffusers' AutoencoderKLWan), channels-last ----------- */
 /* CausalConv3d / Conv2d as implicit GEMM on MFMA (vae.py:17-36, 76-96, 186-220).  in bf16 [Ti,Hi,Wi,Cin] (Cin % 32 == 0),

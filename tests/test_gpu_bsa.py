@@ -1,0 +1,100 @@
+"""GPU: block-sparse attention of the LongCat refine pass (worldforge_amd/bsa.py, wf_attn_bsa_fwd) against oracle/bsa.py.
+Tolerances: attention |err| <= 1e-2 * max|ref| (bf16 output, fp32 accumulation order); mean pooling <= 1 bf16 ulp; block scores
+<= 1 bf16 ulp of the fp32 product, and the selection must be identical wherever the oracle's top-k margin exceeds that."""
+import math
+
+import pytest
+import torch
+
+from oracle import bsa as obsa
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+BF = torch.bfloat16
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def _layouts(k, v):
+    """k, v [H, S, 128] bf16 (cpu) -> device K [H, S, 128], Vt [H, S/64, 128, 64]."""
+    from worldforge_amd._ffi import call
+    from worldforge_amd import ops
+    Hh, S, _ = k.shape
+    kd = k.to(DEV).contiguous()
+    vd = v.permute(1, 0, 2).reshape(S, Hh * 128).to(DEV).contiguous()
+    vt = torch.empty((Hh, S // 64, 128, 64), dtype=BF, device=DEV)
+    call("wf_v_transpose", vd.data_ptr(), vd.stride(0), vt.data_ptr(), S, S, Hh, ops.stream())
+    return kd, vt
+
+
+@pytest.mark.parametrize("Hh,Sq,Sk,nsel", [(2, 256, 512, 2), (3, 384, 1024, 3), (1, 128, 128, 1), (8, 1024, 2048, 5), (2, 640, 640, 5)])
+def test_sparse_attention_kernel(Hh, Sq, Sk, nsel):
+    from worldforge_amd import bsa
+    q, k, v = _rand((Hh, Sq, 128), 1).to(BF), _rand((Hh, Sk, 128), 2).to(BF), _rand((Hh, Sk, 128), 3).to(BF)
+    nq, nk = Sq // 128, Sk // 128
+    g = torch.Generator().manual_seed(4)
+    idx = torch.stack([torch.stack([torch.randperm(nk, generator=g)[:nsel] for _ in range(nq)]) for _ in range(Hh)])
+    want = obsa.sparse_attention(q.float(), k.float(), v.float(), idx, 128, 128, 128 ** -0.5)  # [H, Sq, 128]
+    kd, vt = _layouts(k, v)
+    out = torch.full((Sq, Hh * 128), float("nan"), dtype=BF, device=DEV)
+    bsa.sparse_attention(q.to(DEV).contiguous(), kd, vt, out, idx.to(DEV), 128 ** -0.5, nk)
+    got = out.float().cpu().view(Sq, Hh, 128).permute(1, 0, 2)
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max().item() <= 1e-2 * want.abs().max().item()
+
+
+def test_all_blocks_selected_equals_dense_kernel():
+    from worldforge_amd import bsa, dit
+    Hh, S = 2, 768
+    q, k, v = _rand((Hh, S, 128), 5).to(BF), _rand((Hh, S, 128), 6).to(BF), _rand((Hh, S, 128), 7).to(BF)
+    kd, vt = _layouts(k, v)
+    idx = torch.arange(S // 128).view(1, 1, -1).expand(Hh, S // 128, -1).contiguous()
+    sparse = torch.empty((S, Hh * 128), dtype=BF, device=DEV)
+    dense = torch.empty((S, Hh * 128), dtype=BF, device=DEV)
+    bsa.sparse_attention(q.to(DEV).contiguous(), kd, vt, sparse, idx.to(DEV), 128 ** -0.5, S // 128)
+    dit.attention(q.to(DEV).contiguous(), kd, vt, dense, S, 128 ** -0.5)
+    assert (sparse.float() - dense.float()).abs().max().item() <= 4e-3 * dense.float().abs().max().item()
+
+
+def test_gating_pool_scores_selection():
+    from worldforge_amd import bsa
+    Hh, Sq, Sk = 3, 1024, 1536 + 128  # 13 key blocks: exercises the padded score buffer
+    q = _rand((Hh, Sq, 128), 8).to(BF)
+    k = (_rand((Hh, Sk, 128), 9) + 0.4 * _rand((Hh, 1, 128), 10)).to(BF)
+    qc, kc = bsa.mean_pool(q.to(DEV).contiguous()), bsa.mean_pool(k.to(DEV).contiguous())
+    wq, wk = obsa.mean_pool(q, 128), obsa.mean_pool(k, 128)
+    assert (qc.float().cpu() - wq.float()).abs().max() <= 2.0 ** -8 * wq.float().abs().max()
+    sc = bsa.block_scores(qc, kc)
+    assert sc.shape == (Hh, Sq // 128, Sk // 128)
+    ref = torch.matmul(qc.float().cpu(), kc.float().cpu().transpose(-1, -2))
+    assert (sc.float().cpu() - ref).abs().max() <= 2.0 ** -7 * ref.abs().max()
+    idx = bsa.select_topk(sc, 0.75).cpu()
+    assert idx.shape[-1] == int(0.25 * 13)
+    # a valid top-k of these scores (bf16 scores tie often; which of two equal blocks is taken is not defined by torch.topk either)
+    scf = sc.float().cpu()
+    kth = torch.topk(scf, idx.shape[-1])[0][..., -1:]
+    picked = scf.gather(-1, idx)
+    assert (picked >= kth).all()
+    assert ((scf > kth).sum(-1) <= idx.shape[-1]).all() and ((scf > kth) & ~torch.zeros_like(scf, dtype=torch.bool).scatter_(-1, idx, True)).sum() == 0
+
+
+def test_group_lists_encoding():
+    from worldforge_amd import bsa
+    idx = torch.tensor([[[0, 3], [3, 5], [1, 2]]], device=DEV)  # 3 query blocks -> 2 groups (the second has one block)
+    lists, counts, mx = bsa.group_lists(idx, 6)
+    assert mx == 4 and counts.cpu().tolist() == [[3, 2]]
+    l = lists.cpu()[0]
+    assert l[0, :3].tolist() == [0 * 4 + 1, 3 * 4 + 3, 5 * 4 + 2]
+    assert l[1, :2].tolist() == [1 * 4 + 1, 2 * 4 + 1]
+
+
+def test_block_permutation_matches_oracle():
+    from worldforge_amd import bsa
+    perm, pos = bsa.block_permutation(8, 8, 16, (4, 4, 8), DEV)
+    want = obsa.block_permutation(8, 8, 16, 4, 4, 8)
+    assert torch.equal(perm.cpu().long(), want)
+    assert torch.equal(pos.cpu().long()[want], torch.arange(want.numel()))
+    with pytest.raises(ValueError):
+        bsa.block_permutation(6, 8, 16, (4, 4, 8), DEV)

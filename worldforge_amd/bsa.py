@@ -1,0 +1,99 @@
+"""Block-sparse attention of the LongCat-Video 720p refine pass, HIP-backed.
+
+Mirror of longcat_video/block_sparse_attention/bsa_interface.py (BSA): `flash_attn_bsa_3d` :612-659 = 3D-block token permute (:600-610)
+-> mean-pool gating (:169-179) -> block scores (:181-185) -> top-k block selection (:211-224) -> sparse attention (:538-560, the Triton
+kernel of flash_attn_bsa_varlen_mask.py:174-285) -> inverse permute.  Token-sized work runs in libwf_hip.so (`wf_lc_mean_pool_blocks`,
+`wf_gemm_bf16` for the block scores, `wf_attn_bsa_fwd`, the permutes ride on `wf_lc_norm_heads` / `wf_gather_rows_bf16`); the
+selection itself -- a top-k over a [heads, n_q_blocks, n_k_blocks] score table and the index bookkeeping that turns it into
+per-workgroup block lists -- is a few small integer tensor ops left to torch on the device (no host sync).
+"""
+from __future__ import annotations
+
+from typing import Dict, Sequence, Tuple
+
+import torch
+
+from . import ops
+from ._ffi import call
+from .dit import EPI_BF16, gemm
+
+BLOCK = 128
+_PERM: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def block_permutation(T: int, H: int, W: int, chunk: Sequence[int], device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """BSA:600-604.  Returns (perm, pos) int32 on the device: x_blocks[i] = x[perm[i]], pos[token] = its row in block order."""
+    t, h, w = chunk
+    if T % t or H % h or W % w:
+        raise ValueError(f"latent grid {(T, H, W)} is not a whole number of {tuple(chunk)} blocks")
+    if t * h * w != BLOCK:
+        raise NotImplementedError("the sparse attention kernel is built for 128-token blocks (4 x 4 x 8)")
+    key = (T, H, W, t, h, w, str(device))
+    if key not in _PERM:
+        idx = torch.arange(T * H * W).view(T // t, t, H // h, h, W // w, w).permute(0, 2, 4, 1, 3, 5).reshape(-1)
+        pos = torch.empty_like(idx)
+        pos[idx] = torch.arange(idx.numel())
+        _PERM[key] = (idx.to(device=device, dtype=torch.int32), pos.to(device=device, dtype=torch.int32))
+    return _PERM[key]
+
+
+def mean_pool(x: torch.Tensor) -> torch.Tensor:
+    """BSA:169-179: [heads, L, 128] bf16 -> [heads, L / 128, 128] bf16."""
+    Hh, L, D = x.shape
+    assert D == 128 and x.dtype == torch.bfloat16 and x.is_contiguous()
+    out = torch.empty((Hh, L // BLOCK, D), dtype=torch.bfloat16, device=x.device)
+    call("wf_lc_mean_pool_blocks", x.data_ptr(), out.data_ptr(), Hh, L, ops.stream())
+    return out
+
+
+def block_scores(q_cmp: torch.Tensor, k_cmp: torch.Tensor) -> torch.Tensor:
+    """BSA:181-185: per head q_cmp k_cmp^T in bf16 -> view [heads, n_q, n_k] (of a buffer padded to a multiple of 8 columns)."""
+    Hh, nq, D = q_cmp.shape
+    nk = k_cmp.shape[1]
+    nkp = (nk + 7) // 8 * 8
+    kp = k_cmp
+    if nkp != nk:
+        kp = torch.zeros((Hh, nkp, D), dtype=k_cmp.dtype, device=k_cmp.device)
+        kp[:, :nk] = k_cmp
+    sc = torch.empty((Hh, nq, nkp), dtype=torch.bfloat16, device=q_cmp.device)
+    for h in range(Hh):
+        gemm(q_cmp[h], kp[h], None, sc[h], EPI_BF16)
+    return sc[:, :, :nk]
+
+
+def select_topk(scores: torch.Tensor, sparsity: float) -> torch.Tensor:
+    """BSA:211-224: indices of the int((1 - sparsity) * n_k) best key blocks per query block."""
+    n = int((1 - sparsity) * scores.shape[-1])
+    if n < 1:
+        raise ValueError(f"sparsity {sparsity} leaves no key block of {scores.shape[-1]}")
+    return torch.topk(scores, n)[1]
+
+
+def group_lists(block_indices: torch.Tensor, n_k: int):
+    """[heads, n_q, n_sel] selected key blocks per query block -> the per-workgroup lists `wf_attn_bsa_fwd` walks: one list per pair of
+    consecutive query blocks (2 x 128 = the 256 query rows of a workgroup) holding the union of the pair's blocks in ascending order,
+    entry = block * 4 + (selected by the first) + 2 * (selected by the second).  Returns (lists int32 [heads, n_groups, max_entries],
+    counts int32 [heads, n_groups], max_entries); max_entries = min(2 * n_sel, n_k) is a shape-only bound: no host sync."""
+    Hh, nq, nsel = block_indices.shape
+    allow = torch.zeros((Hh, nq + (nq & 1), n_k), dtype=torch.bool, device=block_indices.device)
+    allow[:, :nq].scatter_(2, block_indices.long(), True)
+    a, b = allow[:, 0::2], allow[:, 1::2]
+    union = a | b
+    counts = union.sum(dim=-1).to(torch.int32)
+    order = torch.sort((~union).to(torch.uint8), dim=-1, stable=True)[1]  # selected blocks first, ascending
+    max_entries = min(2 * nsel, n_k)
+    order = order[..., :max_entries]
+    entries = order * 4 + a.gather(2, order).long() + 2 * b.gather(2, order).long()
+    return entries.to(torch.int32).contiguous(), counts.contiguous(), max_entries
+
+
+def sparse_attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, block_indices: torch.Tensor, scale: float,
+                     n_k_blocks: int):
+    """q [heads, Lq, 128], k [heads, Lkp, 128], vt [heads, Lkp/64, 128, 64] in block order; block_indices [heads, Lq/128, n_sel] over the
+    first n_k_blocks key blocks -> out [Lq, ld] bf16 (block order)."""
+    Hh, Lq, _ = q.shape
+    Lkp = k.shape[1]
+    lists, counts, mx = group_lists(block_indices, n_k_blocks)
+    call("wf_attn_bsa_fwd", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), Hh, Lq, Lkp, out.stride(0), float(scale),
+         lists.data_ptr(), counts.data_ptr(), mx, ops.stream())
+    return out

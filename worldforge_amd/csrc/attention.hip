@@ -67,6 +67,11 @@ struct AttnArgs {
   int nsplit, tiles_per_split;
   float* o_part;   // [nsplit][Lq][H*128] f32
   float* ml_part;  // [nsplit][H][Lq][2] f32: reference max m (raw score units), row sum l
+  // block-sparse attention (k_attn<2>): per (head, 256-row query group) a list of 128-key blocks to visit, entry = block * 4 + flags,
+  // flags bit 0 / 1 = the block is selected by the first / second 128-row query block of the group
+  const int* bsa_list;  // [H][n_qblk][bsa_max]
+  const int* bsa_cnt;   // [H][n_qblk]
+  int bsa_max;
 };
 
 #ifdef WF_ATTN_TIMING
@@ -85,8 +90,14 @@ __device__ unsigned long long g_attn_cycles[16];
 
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
-// KIND only names the launch for profilers: 0 = long K/V (self-attention), 1 = short K/V (<= 1024 keys: the text / image
+// KIND 0 / 1 only name the launch for profilers: 0 = long K/V (self-attention), 1 = short K/V (<= 1024 keys: the text / image
 // cross-attentions).  Same code; rocprofv3 then reports the two populations separately.
+// KIND 2 = block-sparse attention of the LongCat refine pass (block_sparse_attention/bsa_interface.py:538-560 +
+// flash_attn_bsa_varlen_mask.py:236-285): queries and keys are in 3D-block order, every 128-row query block attends to its own
+// selected 128-key blocks only.  A workgroup holds TWO query blocks (waves 0-3 / 4-7 = the two ping-pong groups); it walks the UNION
+// of their block lists (built on the host side of the C-ABI from the top-k indices), two 64-key tiles per entry, and a wave group
+// sets the scores of a block its query block did not select to -inf (exactly zero probability).  The running max starts at a large
+// finite negative value instead of -inf so that a leading run of masked blocks cannot produce inf - inf.
 template <int KIND>
 __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -152,18 +163,26 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
   for (int db = 0; db < 4; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = KIND == 2 ? -1e30f : -INFINITY, l_run = 0.f;
   const float c = a.scale_log2;
 
-  const int ntiles = (a.kv_len + KB - 1) / KB;
+  const int* bsa = nullptr;
+  int ntiles = (a.kv_len + KB - 1) / KB;
+  if constexpr (KIND == 2) {
+    bsa = a.bsa_list + ((size_t)head * a.n_qblk + qblk) * a.bsa_max;
+    ntiles = 2 * a.bsa_cnt[head * a.n_qblk + qblk];
+    if (ntiles == 0) return;  // nothing selected by either query block (cannot happen with top-k >= 1)
+  }
   constexpr int PF = 4;  // fragment prefetch depth (LDS reads in flight ahead of the MFMA that consumes them)
   constexpr int NBUF = 4;
 
   // LDS: ring of NBUF tile buffers, each [K tile 16 KiB | V^T tile 16 KiB]; tile j lives in buffer j % NBUF.
   const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_offset(smem));
   auto stage = [&](int t) {
-    const int seg = t / tiles_per_seg;
-    const size_t tile_off = ((size_t)(seg * a.H + head) * tiles_per_seg + (t - seg * tiles_per_seg)) * (KB * D);
+    int kt = t;  // KV tile held by ring slot t
+    if constexpr (KIND == 2) kt = (__builtin_amdgcn_readfirstlane(bsa[t >> 1]) >> 2) * 2 + (t & 1);
+    const int seg = kt / tiles_per_seg;
+    const size_t tile_off = ((size_t)(seg * a.H + head) * tiles_per_seg + (kt - seg * tiles_per_seg)) * (KB * D);
     const uint32_t base = smem_base + (t % NBUF) * BUF_BYTES + wu * 2048;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -179,7 +198,7 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
     const int db = i & 3, m4 = i >> 2;  // rotate over the four output accumulators
     return *reinterpret_cast<const u32x4*>(sVb + vrow_off[db] + (((2 * m4 + hi) ^ vrow_sw[db]) << 4));
   };
-  const bool ragged = (a.kv_len & (KB - 1)) != 0;
+  const bool ragged = KIND != 2 && (a.kv_len & (KB - 1)) != 0;
 
   f32x16 s[2];
   bf16x8 pf[4];
@@ -211,6 +230,15 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
     __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
   };
   auto phase_softmax = [&](int t) {  // online softmax of the 64 scores per query row held by the lane pair (l, l^32)
+    if constexpr (KIND == 2) {
+      const int flags = __builtin_amdgcn_readfirstlane(bsa[t >> 1]) & 3;
+      if (!((flags >> (wu >> 2)) & 1)) {  // this key block is not in the list of this wave's query block
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[kb][r] = -INFINITY;
+      }
+    }
     if (ragged && t == ntiles - 1) {
       // lane holds, for query column l31: register r of block kb  <->  key  t*64 + 32*kb + 16*(r>>3) + 8*hi + (r&7)
 #pragma unroll
@@ -968,6 +996,9 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
   a.tiles_per_split = ntiles;
   a.o_part = nullptr;
   a.ml_part = nullptr;
+  a.bsa_list = nullptr;
+  a.bsa_cnt = nullptr;
+  a.bsa_max = 0;
   const int hslots = (H + 7) / 8;
   const int grid = hslots * a.n_qblk * 8;
   const size_t lds = 4 * (K_TILE_BYTES + V_TILE_BYTES);
@@ -1007,6 +1038,41 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
 extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len,
                            int ldo, float softmax_scale, int accumulate, void* stream) {
   return attn_launch(Q, K, Vt, O, H, Lq, Lkp, kv_len, seg_len, ldo, softmax_scale, accumulate, 1, nullptr, stream, "wf_attn_fwd");
+}
+
+extern "C" int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int ldo, float softmax_scale,
+                               const int* group_lists, const int* group_counts, int max_entries, void* stream) {
+  WF_CHECK_ARG(Q && K && Vt && O && group_lists && group_counts, "wf_attn_bsa_fwd: null pointer");
+  WF_CHECK_ARG(H > 0 && Lq > 0 && Lkp > 0 && max_entries > 0, "wf_attn_bsa_fwd: empty problem");
+  WF_CHECK_ARG(Lq % 128 == 0 && Lkp % 128 == 0, "wf_attn_bsa_fwd: Lq (%d) and Lkp (%d) must be whole 128-token blocks", Lq, Lkp);
+  WF_CHECK_ARG(ldo % 4 == 0 && ldo >= H * D, "wf_attn_bsa_fwd: bad ldo %d", ldo);
+  WF_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O) & 15) == 0, "wf_attn_bsa_fwd: 16-byte alignment");
+  AttnArgs a;
+  a.Q = (const uint16_t*)Q;
+  a.K = (const uint16_t*)K;
+  a.Vt = (const uint16_t*)Vt;
+  a.O = (uint16_t*)O;
+  a.H = H;
+  a.Lq = Lq;
+  a.Lkp = Lkp;
+  a.kv_len = Lkp;
+  a.seg_len = Lkp;
+  a.ldo = ldo;
+  a.n_qblk = ceil_div(Lq, QB);
+  a.scale_log2 = softmax_scale * 1.4426950408889634f;
+  a.accumulate = 0;
+  a.prio_mode = 0;
+  a.nsplit = 1;
+  a.tiles_per_split = 0;
+  a.o_part = nullptr;
+  a.ml_part = nullptr;
+  a.bsa_list = group_lists;
+  a.bsa_cnt = group_counts;
+  a.bsa_max = max_entries;
+  const int grid = ((H + 7) / 8) * a.n_qblk * 8;
+  hipLaunchKernelGGL(k_attn<2>, dim3(grid), dim3(NT), 4 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream, a);
+  WF_LAUNCH_CHECK("wf_attn_bsa_fwd");
+  return WF_OK;
 }
 
 extern "C" size_t wf_attn_split_workspace_bytes(int H, int Lq, int nsplit) {

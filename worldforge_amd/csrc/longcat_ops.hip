@@ -119,7 +119,8 @@ __global__ void k_lc_gate_resid(uint16_t* __restrict__ x, const uint16_t* __rest
 // y = bf16(bf16(x * rsqrt(mean(x^2) + eps)) * w); RoPE on pairs (2p, 2p+1) with angle table entries cos/sin[row][p] in fp32 -> bf16.
 __global__ __launch_bounds__(256) void k_lc_heads(const uint16_t* __restrict__ in, long ld, const float* __restrict__ w,
                                                   const float* __restrict__ cs, const float* __restrict__ sn,
-                                                  uint16_t* __restrict__ out, int L, int Lout, int H, float eps) {
+                                                  uint16_t* __restrict__ out, int L, int Lout, int H, float eps,
+                                                  const int* __restrict__ row_map) {
   const int row = blockIdx.x;
   const int head = blockIdx.y * 16 + (threadIdx.x >> 4), within = threadIdx.x & 15;
   if (head >= H) return;
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(256) void k_lc_heads(const uint16_t* __restrict__ i
       y[2 * k + 1] = im;
     }
   }
-  *reinterpret_cast<u32x4*>(out + ((size_t)head * Lout + row) * 128 + within * 8) = pack8(y);
+  const int orow = row_map ? row_map[row] : row;
+  *reinterpret_cast<u32x4*>(out + ((size_t)head * Lout + orow) * 128 + within * 8) = pack8(y);
 }
 
 // in bf16 [L, ld]: columns [0, Hd) = w1 x, [Hd, 2 Hd) = w3 x -> out bf16 [L, Hd] = bf16(bf16(silu(a)) * b)
@@ -165,7 +167,65 @@ __global__ void k_lc_swiglu(const uint16_t* __restrict__ in, long ld, uint16_t* 
   }
 }
 
+// in bf16 [H][L][128] -> out bf16 [H][L / 128][128]: mean over each block of 128 consecutive rows, fp32 accumulation, one rounding
+// (torch's mean on a bf16 tensor; bsa_interface.py:169-179).  grid (L / 128, H), 256 threads = 16 row groups x 16 column chunks.
+__global__ __launch_bounds__(256) void k_lc_mean_pool(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int L) {
+  __shared__ float sm[16][128];
+  const int blk = blockIdx.x, head = blockIdx.y;
+  const int ch = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const uint16_t* base = in + ((size_t)head * L + (size_t)blk * 128) * 128 + ch * 8;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float v[8];
+    unpack8(*reinterpret_cast<const u32x4*>(base + (size_t)(grp + 16 * i) * 128), v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += v[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sm[grp][ch * 8 + k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += sm[g][threadIdx.x];
+    out[((size_t)head * (L / 128) + blk) * 128 + threadIdx.x] = f32_to_bf16(t * (1.0f / 128.0f));
+  }
+}
+
+// out[i][:] = in[idx[i]][:]  (bf16 rows of C elements, 16-byte chunks)
+__global__ void k_gather_rows(const uint16_t* __restrict__ in, int64_t ld_in, const int* __restrict__ idx, uint16_t* __restrict__ out,
+                              int64_t ld_out, int C, size_t n8) {
+  const int cpr = C >> 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / cpr;
+    const int ch = (int)(i - row * cpr);
+    reinterpret_cast<u32x4*>(out + row * ld_out)[ch] = reinterpret_cast<const u32x4*>(in + (size_t)idx[row] * ld_in)[ch];
+  }
+}
+
 }  // namespace
+
+extern "C" int wf_lc_mean_pool_blocks(const void* in, void* out, int H, int L, void* stream) {
+  WF_CHECK_ARG(in && out, "wf_lc_mean_pool_blocks: null pointer");
+  WF_CHECK_ARG(H > 0 && L > 0 && L % 128 == 0, "wf_lc_mean_pool_blocks: L (%d) must be whole 128-token blocks", L);
+  hipLaunchKernelGGL(k_lc_mean_pool, dim3(L / 128, H), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in, (uint16_t*)out, L);
+  WF_LAUNCH_CHECK("wf_lc_mean_pool_blocks");
+  return WF_OK;
+}
+
+extern "C" int wf_gather_rows_bf16(const void* in, int64_t ld_in, const int* index, void* out, int64_t ld_out, int n_rows, int C,
+                                   void* stream) {
+  WF_CHECK_ARG(in && out && index, "wf_gather_rows_bf16: null pointer");
+  WF_CHECK_ARG(C % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0, "wf_gather_rows_bf16: C, ld_in, ld_out must be multiples of 8");
+  WF_CHECK_ARG((((uintptr_t)in | (uintptr_t)out) & 15) == 0, "wf_gather_rows_bf16: 16-byte alignment");
+  const size_t n8 = (size_t)n_rows * (C / 8);
+  if (n8 == 0) return WF_OK;
+  hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(n8, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in, ld_in, index,
+                     (uint16_t*)out, ld_out, C, n8);
+  WF_LAUNCH_CHECK("wf_gather_rows_bf16");
+  return WF_OK;
+}
 
 extern "C" int wf_lc_ln_modulate(const void* x, const float* mul, const float* add, int64_t mod_ld, int rows_per_group, int plus_one,
                                  void* out, int L, int C, float eps, void* stream) {
@@ -203,7 +263,7 @@ extern "C" int wf_lc_gate_residual(void* x, const void* y, int64_t ldy, const fl
 }
 
 extern "C" int wf_lc_norm_heads(const void* in, int64_t ld, const float* weight, const float* cos_tab, const float* sin_tab, void* out,
-                                int L, int Lout, int H, float eps, void* stream) {
+                                int L, int Lout, int H, float eps, const int* row_map, void* stream) {
   WF_CHECK_ARG(in && weight && out, "wf_lc_norm_heads: null pointer");
   WF_CHECK_ARG(H > 0 && ld % 8 == 0 && Lout >= L, "wf_lc_norm_heads: H > 0, ld %% 8 == 0, Lout >= L");
   WF_CHECK_ARG((cos_tab == nullptr) == (sin_tab == nullptr), "wf_lc_norm_heads: cos/sin must both be given or both null");
@@ -211,7 +271,7 @@ extern "C" int wf_lc_norm_heads(const void* in, int64_t ld, const float* weight,
                "wf_lc_norm_heads: 16-byte alignment");
   if (L == 0) return WF_OK;
   hipLaunchKernelGGL(k_lc_heads, dim3(L, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in, ld, weight, cos_tab,
-                     sin_tab, (uint16_t*)out, L, Lout, H, eps);
+                     sin_tab, (uint16_t*)out, L, Lout, H, eps, row_map);
   WF_LAUNCH_CHECK("wf_lc_norm_heads");
   return WF_OK;
 }
