@@ -54,12 +54,17 @@ def sparse_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_in
 
 def flash_attn_bsa_3d(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, shape_q: Tuple[int, int, int], shape_k: Tuple[int, int, int],
                       sparsity: float = 0.875, chunk_q: Sequence[int] = (4, 4, 8), chunk_k: Sequence[int] = (4, 4, 8),
-                      return_indices: bool = False):
+                      return_indices: bool = False, gate_dtype=None, block_indices=None):
     """BSA:612-659 for one sample: q [heads, Sq, D], k / v [heads, Sk, D] in (T, H, W) token order -> [heads, Sq, D]."""
     pq, pk = block_permutation(*shape_q, *chunk_q), block_permutation(*shape_k, *chunk_k)
     bq, bk = chunk_q[0] * chunk_q[1] * chunk_q[2], chunk_k[0] * chunk_k[1] * chunk_k[2]
     qb, kb, vb = q[:, pq], k[:, pk], v[:, pk]
-    idx = select_topk(mean_pool(qb, bq), mean_pool(kb, bk), sparsity)
+    if block_indices is not None:
+        idx = block_indices
+    elif gate_dtype is not None:  # the reference's q / k are bf16 on the GPU: pooled means and block scores are rounded to it
+        idx = select_topk(mean_pool(qb.to(gate_dtype), bq), mean_pool(kb.to(gate_dtype), bk), sparsity)
+    else:
+        idx = select_topk(mean_pool(qb, bq), mean_pool(kb, bk), sparsity)
     ob = sparse_attention(qb, kb, vb, idx, bq, bk, q.shape[-1] ** -0.5)
     out = torch.empty_like(ob)
     out[:, pq] = ob  # BSA:606-610

@@ -104,7 +104,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -
     return o.permute(1, 0, 2).reshape(q.shape[1], -1).to(q.dtype)
 
 
-def self_attention(W, p: str, x: torch.Tensor, cfg: LongCatConfig, ang: torch.Tensor, n_cond_tokens: int) -> torch.Tensor:
+def self_attention(W, p: str, x: torch.Tensor, cfg: LongCatConfig, ang: torch.Tensor, n_cond_tokens: int, grid=None, bsa=None,
+                   picked=None) -> torch.Tensor:
     """LCA:105-145: fused qkv -> per-head RMS norm of q, k -> 3D RoPE -> condition tokens attend to condition tokens only, noise
     tokens to everything -> proj."""
     L, C = x.shape
@@ -115,7 +116,26 @@ def self_attention(W, p: str, x: torch.Tensor, cfg: LongCatConfig, ang: torch.Te
     q, k = rms_norm_head(q, W[p + "q_norm.weight"]), rms_norm_head(k, W[p + "k_norm.weight"])
     q, k = rope_apply(q, ang), rope_apply(k, ang)
     scale = D ** -0.5
-    if n_cond_tokens > 0:
+    if bsa is not None and grid[0] > 1:
+        # LCA:57-66: block-sparse attention (oracle/bsa.py); the gating runs in `gate_dtype` (bf16 in the reference's bf16 model)
+        from . import bsa as obsa
+        T, gh, gw = grid
+        tpf = gh * gw
+        gd = bsa.get("gate_dtype", torch.float32)
+
+        def part(qq, kk, vv):
+            sq, sk = (qq.shape[1] // tpf, gh, gw), (kk.shape[1] // tpf, gh, gw)
+            if picked is None:
+                out, idx = obsa.flash_attn_bsa_3d(qq, kk, vv, sq, sk, bsa["sparsity"], bsa["chunk_3d_shape_q"], bsa["chunk_3d_shape_k"],
+                                                  return_indices=True, gate_dtype=gd)
+            else:
+                out = obsa.flash_attn_bsa_3d(qq, kk, vv, sq, sk, bsa["sparsity"], bsa["chunk_3d_shape_q"], bsa["chunk_3d_shape_k"],
+                                             block_indices=picked.pop(0))
+            return out.permute(1, 0, 2).reshape(qq.shape[1], -1)
+
+        nc = n_cond_tokens
+        o = torch.cat([part(q[:, :nc], k[:, :nc], v[:, :nc]), part(q[:, nc:], k, v)], dim=0) if nc > 0 else part(q, k, v)
+    elif n_cond_tokens > 0:
         nc = n_cond_tokens
         o = torch.cat([attention(q[:, :nc], k[:, :nc], v[:, :nc], scale), attention(q[:, nc:], k, v, scale)], dim=0)
     else:
@@ -145,7 +165,7 @@ def swiglu(W, p: str, x: torch.Tensor) -> torch.Tensor:
 
 
 def block(W, i: int, x: torch.Tensor, y: torch.Tensor, t: torch.Tensor, cfg: LongCatConfig, ang: torch.Tensor,
-          tokens_per_frame: int, n_cond_tokens: int) -> torch.Tensor:
+          tokens_per_frame: int, n_cond_tokens: int, grid=None, bsa=None, picked=None) -> torch.Tensor:
     """LCD:68-121.  x [L, C]; y [n_valid, C]; t [T, C_t] fp32."""
     p = f"blocks.{i}."
     C = cfg.hidden_size
@@ -156,7 +176,7 @@ def block(W, i: int, x: torch.Tensor, y: torch.Tensor, t: torch.Tensor, cfg: Lon
         return (x.float().view(-1, tokens_per_frame, C) + gate[:, None, :] * xs.float().view(-1, tokens_per_frame, C)) \
             .view(-1, C).to(x.dtype)
 
-    xs = self_attention(W, p + "attn.", modulate(x, shift_msa, scale_msa, tokens_per_frame), cfg, ang, n_cond_tokens)
+    xs = self_attention(W, p + "attn.", modulate(x, shift_msa, scale_msa, tokens_per_frame), cfg, ang, n_cond_tokens, grid, bsa, picked)
     x = gated(x, gate_msa, xs)
     xn = layer_norm(x, W[p + "pre_crs_attn_norm.weight"], W[p + "pre_crs_attn_norm.bias"])
     x = x + cross_attention(W, p + "cross_attn.", xn, y, cfg, n_cond_tokens)
@@ -165,7 +185,7 @@ def block(W, i: int, x: torch.Tensor, y: torch.Tensor, t: torch.Tensor, cfg: Lon
 
 
 def forward(W: Dict[str, torch.Tensor], cfg: LongCatConfig, latents: torch.Tensor, timesteps: torch.Tensor, caption: torch.Tensor,
-            caption_mask: torch.Tensor = None, num_cond_latents: int = 0) -> torch.Tensor:
+            caption_mask: torch.Tensor = None, num_cond_latents: int = 0, bsa: dict = None, bsa_indices=None) -> torch.Tensor:
     """LCD:279-366 for one sample.  latents [C_in, T, H, W]; timesteps [T] (one per latent frame, LCD:299-301); caption
     [n_tokens, caption_channels]; caption_mask [n_tokens] (0 = padding) or None -> velocity [C_out, T, H, W] fp32."""
     Cin, T, Hh, Ww = latents.shape
@@ -191,7 +211,10 @@ def forward(W: Dict[str, torch.Tensor], cfg: LongCatConfig, latents: torch.Tenso
     ang = rope_angles(C // cfg.num_heads, T, nh, nw)
     tpf = nh * nw
     for i in range(cfg.depth):
-        x = block(W, i, x, y, t, cfg, ang, tpf, num_cond_latents * tpf)
+        # bsa: dict(sparsity, chunk_3d_shape_q, chunk_3d_shape_k[, gate_dtype]) enables the block-sparse self-attention of the refine
+        # pass (LCD:270-272); bsa_indices: per block a list of block-index tensors to use instead of the oracle's own top-k
+        x = block(W, i, x, y, t, cfg, ang, tpf, num_cond_latents * tpf, (T, nh, nw), bsa,
+                  list(bsa_indices[i]) if bsa_indices is not None else None)
     # LCB:159-168
     mod = F.linear(F.silu(t), W["final_layer.adaLN_modulation.1.weight"].float(), W["final_layer.adaLN_modulation.1.bias"].float())
     shift, scale = mod.chunk(2, dim=-1)

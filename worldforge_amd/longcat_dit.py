@@ -120,7 +120,7 @@ def fold_lora(sd: Dict[str, torch.Tensor], lora_sd: Dict[str, torch.Tensor], mul
 class LongCatVideoTransformer3DModel:
     dtype = torch.bfloat16
 
-    def __init__(self, cfg: LongCatConfig, device="cuda:0"):
+    def __init__(self, cfg: LongCatConfig, device="cuda:0", enable_bsa: bool = False, bsa_params: Optional[dict] = None):
         assert cfg.hidden_size // cfg.num_heads == 128 and cfg.hidden_size % cfg.num_heads == 0, "attention kernel is built for head_dim 128"
         assert cfg.patch_size == (1, 2, 2)
         self.cfg = cfg
@@ -130,6 +130,21 @@ class LongCatVideoTransformer3DModel:
         self.w: Dict[str, torch.Tensor] = {}
         self._ws = {}
         self._rope = {}
+        # block-sparse self-attention of the 720p refine pass (LCA:57-66, LCD:270-276); bsa_params as in the reference's config:
+        # sparsity, chunk_3d_shape_q, chunk_3d_shape_k (cdf_threshold is not built)
+        self._bsa = bool(enable_bsa)
+        self.bsa_params = dict(bsa_params) if bsa_params else dict(sparsity=0.9375, chunk_3d_shape_q=[4, 4, 8], chunk_3d_shape_k=[4, 4, 8])
+        if self.bsa_params.get("cdf_threshold") is not None:
+            raise NotImplementedError("cdf-threshold block selection (bsa_interface.py:226-263) is not built; top-k only")
+        self.last_bsa_indices = None
+
+    def enable_bsa(self):
+        """LCD:270-272."""
+        self._bsa = True
+
+    def disable_bsa(self):
+        """LCD:274-276."""
+        self._bsa = False
 
     # ------------------------------------------------------------------------------------------------------------
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
@@ -309,6 +324,22 @@ class LongCatVideoTransformer3DModel:
         ffh = _buf("ffh", (L, 2 * Hd), bf)
         ffg = _buf("ffg", (L, Hd), bf)
         ald = ada.stride(0)
+        use_bsa = self._bsa and T > 1  # LCA:57: "bsa will not be used in image training / sampling"
+        if use_bsa:
+            from . import bsa
+            cq, ck = self.bsa_params["chunk_3d_shape_q"], self.bsa_params["chunk_3d_shape_k"]
+            if list(cq) != list(ck):
+                raise NotImplementedError("different query / key block shapes")
+            ncl = int(num_cond_latents or 0)
+            if ncl % cq[0] or (T - ncl) % cq[0]:
+                raise ValueError(f"block-sparse attention needs the condition ({ncl}) and noise ({T - ncl}) latent frames to be "
+                                 f"multiples of {cq[0]} (the reference pads them: pipeline_longcat_video.py:1417-1419)")
+            perm, pos = bsa.block_permutation(T, h2, w2, cq, dev)   # the first nc rows of the block order are the condition tokens
+            pos_n = (pos[nc:] - nc).contiguous()
+            vperm = _buf("vperm", (L, C), bf)
+            aob = _buf("aob", (L, C), bf)
+            sparsity = float(self.bsa_params["sparsity"])
+            self.last_bsa_indices = []
 
         for i in range(cfg.depth):
             p = f"blocks.{i}."
@@ -317,13 +348,35 @@ class LongCatVideoTransformer3DModel:
             # ---- self-attention (LCD:91-104, LCA:105-145) ----
             self._ln(x, scale_msa, shift_msa, ald, tpf, True, hbuf)
             gemm(hbuf, W[p + "attn.qkv.w"], W[p + "attn.qkv.b"], qkv, EPI_BF16)
-            self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_c, 0, nc)
-            self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_n, nc, L)
-            self._heads(qkv, C, W[p + "attn.k_norm"], cos, sin, kh, 0, L)
-            self._vt(qkv, 2 * C, vt, L)
-            if nc > 0:
-                attention(qh_c, kh, vt, ao[:nc], nc, scale)  # condition tokens see condition tokens only (LCA:127-131)
-            attention(qh_n, kh, vt, ao[nc:], L, scale, profile=True)  # noise tokens see everything (LCA:133-134)
+            if use_bsa:
+                # LCA:57-66 + bsa_interface.py:612-659.  q / k are written straight into 3D-block token order (row_map), V is gathered
+                # into it, the output is gathered back; gating = mean-pooled q / k blocks -> bf16 block scores -> top-k per query block
+                self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_c, 0, nc, row_map=pos)
+                self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_n, nc, L, row_map=pos_n)
+                self._heads(qkv, C, W[p + "attn.k_norm"], cos, sin, kh, 0, L, row_map=pos)
+                vsrc = qkv[:, 2 * C:]
+                call("wf_gather_rows_bf16", vsrc.data_ptr(), qkv.stride(0), perm.data_ptr(), vperm.data_ptr(), vperm.stride(0), L, C,
+                     ops.stream())
+                self._vt(vperm, 0, vt, L)
+                kcmp = bsa.mean_pool(kh)
+                picked = []
+                if nc > 0:
+                    idx = bsa.select_topk(bsa.block_scores(bsa.mean_pool(qh_c), kcmp[:, :nc // 128]), sparsity)
+                    bsa.sparse_attention(qh_c, kh, vt, aob[:nc], idx, scale, nc // 128)
+                    picked.append(idx)
+                idx = bsa.select_topk(bsa.block_scores(bsa.mean_pool(qh_n), kcmp), sparsity)
+                bsa.sparse_attention(qh_n, kh, vt, aob[nc:], idx, scale, L // 128)
+                picked.append(idx)
+                self.last_bsa_indices.append(picked)
+                call("wf_gather_rows_bf16", aob.data_ptr(), aob.stride(0), pos.data_ptr(), ao.data_ptr(), ao.stride(0), L, C, ops.stream())
+            else:
+                self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_c, 0, nc)
+                self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_n, nc, L)
+                self._heads(qkv, C, W[p + "attn.k_norm"], cos, sin, kh, 0, L)
+                self._vt(qkv, 2 * C, vt, L)
+                if nc > 0:
+                    attention(qh_c, kh, vt, ao[:nc], nc, scale)  # condition tokens see condition tokens only (LCA:127-131)
+                attention(qh_n, kh, vt, ao[nc:], L, scale, profile=True)  # noise tokens see everything (LCA:133-134)
             gemm(ao, W[p + "attn.proj.w"], W[p + "attn.proj.b"], ys, EPI_BF16)
             self._resid(x, ys, gate_msa, ald, tpf)
             # ---- cross-attention on the noise tokens (LCD:108-111, LCA:218-276) ----
