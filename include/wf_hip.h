@@ -204,6 +204,11 @@ int wf_lc_norm_heads(const void* in, int64_t ld, const float* weight, const floa
  * out bf16 [L, Hd] = silu(w1 x) * w3 x. */
 int wf_lc_swiglu(const void* in, int64_t ld, void* out, int L, int Hd, void* stream);
 
+/* LongCat refine pass input (pipeline_longcat_video.py:1407-1413): stage-1 frames uint8 [F][H0][W0][3] -> bilinear (align_corners) to
+ * (H, W) -> / 255 -> linear along the frame axis (the trilinear of :1412 with H, W unchanged) to Fo frames -> * 2 - 1, every step
+ * rounded to bf16 as the reference's bf16 tensors.  out f32 [3][Fo][H][W]. */
+int wf_refine_upsample_u8(const void* frames_u8, float* out, int F, int H0, int W0, int Fo, int H, int W, void* stream);
+
 /* ---- LongCat block-sparse attention of the 720p refine pass (longcat_video/block_sparse_attention/bsa_interface.py = BSA) --------- */
 /* mean_pooling_compression (BSA:169-179): in bf16 [H][L][128] -> out bf16 [H][L/128][128], mean of each 128-token block. */
 int wf_lc_mean_pool_blocks(const void* in, void* out, int H, int L, void* stream);

@@ -240,3 +240,80 @@ def decode_final(latents: torch.Tensor, decode: Callable, mean, std):
     """PIPE:998-1004: de-normalise, decode, (x/2+0.5).clamp(0,1) -> [B,F,H,W,C]."""
     video = decode(denormalize(latents.to(torch.float32), mean, std))
     return (video / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 4, 1)
+
+
+# ---- 720p refine pass (PIPE:1271-1511) --------------------------------------------------------------------------------------
+def refine_upsample(stage1_frames: torch.Tensor, height: int, width: int, new_frame_size: int, dtype=torch.bfloat16,
+                    gpu_semantics: bool = False) -> torch.Tensor:
+    """PIPE:1404-1413: uint8 frames [F, H0, W0, 3] -> [1, 3, new_frame_size, height, width] in [-1, 1], every step in `dtype`.
+    gpu_semantics=False runs torch's CPU bf16 interpolation kernels (what the golden recorded here contains: they round intermediate
+    passes to bf16, up to 1.5 grey levels off); gpu_semantics=True restates what the reference executes on a GPU, where torch's
+    upsample kernels interpolate in fp32 (accscalar_t) and round once per op -- the semantics the HIP kernel implements."""
+    import torch.nn.functional as F
+    if gpu_semantics:
+        rb = lambda x: x.to(dtype).float()  # noqa: E731
+        v = stage1_frames.permute(0, 3, 1, 2).float()
+        down = rb(F.interpolate(v, size=(height, width), mode="bilinear", align_corners=True))
+        down = rb(down.permute(1, 0, 2, 3).unsqueeze(0) / 255.0)
+        up = rb(F.interpolate(down, size=(new_frame_size, height, width), mode="trilinear", align_corners=True))
+        return rb(rb(up * 2) - 1).to(dtype)
+    v = stage1_frames.permute(0, 3, 1, 2).to(dtype)
+    down = F.interpolate(v, size=(height, width), mode="bilinear", align_corners=True)
+    down = down.permute(1, 0, 2, 3).unsqueeze(0) / 255.0
+    up = F.interpolate(down, size=(new_frame_size, height, width), mode="trilinear", align_corners=True)
+    return up * 2 - 1
+
+
+def refine_plan(n_frames_up: int, num_cond_frames: int, t_scale: int = 4, granularity: int = 4):
+    """PIPE:1415-1431: latent-frame counts padded to the block-sparse granularity -> (num_cond_latents, num_cond_frames_added,
+    num_noise_frames_added, num_cond_frames after padding)."""
+    import math
+    num_noise_frames = n_frames_up - num_cond_frames
+    ncl = added_c = 0
+    if num_cond_frames > 0:
+        ncl = 1 + math.ceil((num_cond_frames - 1) / t_scale)
+        ncl = math.ceil(ncl / granularity) * granularity
+        added_c = 1 + (ncl - 1) * t_scale - num_cond_frames
+        num_cond_frames = num_cond_frames + added_c
+    nnl = math.ceil(math.ceil(num_noise_frames / t_scale) / granularity) * granularity
+    return ncl, added_c, nnl * t_scale - num_noise_frames, num_cond_frames
+
+
+def refine_schedule(num_inference_steps: int, shift: float, t_thresh: float):
+    """PIPE:1394-1402: the usual schedule, cut to [t_thresh * 1000] + the timesteps below it; sigmas = timesteps / 1000 + [0]."""
+    _, ts = make_schedule(timesteps_sigmas(num_inference_steps), shift)
+    if t_thresh:
+        tt = torch.tensor(t_thresh * 1000, dtype=ts.dtype)
+        ts = torch.cat([tt.unsqueeze(0), ts[ts < tt]])
+    return torch.cat([ts / 1000, torch.zeros(1)]), ts
+
+
+def run_refine(*, stage1_frames: torch.Tensor, image: torch.Tensor, height: int, width: int, dit: Callable, prompt_embeds, prompt_mask,
+               encode_sample: Callable, decode: Callable, mean, std, generator, num_inference_steps: int = 50, shift: float = 1.0,
+               t_thresh: float = 0.5, spatial_refine_only: bool = False, num_cond_frames: int = 1, dit_dtype=torch.bfloat16,
+               trace: Optional[list] = None, gpu_upsample: bool = False):
+    """PIPE:1394-1503 for one sample with an image condition.  image [1,3,H,W] in [-1,1] or None.  Returns frames [1,F,H,W,3]."""
+    sigmas, timesteps = refine_schedule(num_inference_steps, shift, t_thresh)
+    nf = stage1_frames.shape[0]
+    new_frame_size = nf if spatial_refine_only else 2 * nf
+    up = refine_upsample(stage1_frames, height, width, new_frame_size, dit_dtype, gpu_semantics=gpu_upsample)
+    ncl, added_c, added_n, ncf = refine_plan(up.shape[2], num_cond_frames if image is not None else 0)
+    up = torch.cat([up[:, :, 0:1].repeat(1, 1, added_c, 1, 1), up, up[:, :, -1:].repeat(1, 1, added_n, 1, 1)], dim=2)
+    lat = normalize(encode_sample(up, generator), mean, std)
+    noise = torch.randn(lat.shape, generator=generator, dtype=lat.dtype)
+    latents = ((1 - t_thresh) * lat + t_thresh * noise).to(torch.float32)
+    if image is not None:  # PIPE:262-284
+        enc_in = image.to(dit_dtype)[0].unsqueeze(0).unsqueeze(2)
+        enc_in = torch.cat([enc_in[:, :, 0:1].repeat(1, 1, added_c, 1, 1), enc_in], dim=2)
+        assert enc_in.shape[2] == ncf
+        latents[:, :, :ncl] = normalize(encode_sample(enc_in, generator).to(torch.float32), mean, std)
+    for i, t in enumerate(timesteps):
+        ts = t.expand(latents.shape[0]).to(dit_dtype).unsqueeze(-1).repeat(1, latents.shape[2])
+        ts[:, :ncl] = 0
+        v = -dit(hidden_states=latents.to(dit_dtype), timestep=ts, encoder_hidden_states=prompt_embeds, encoder_attention_mask=prompt_mask,
+                 num_cond_latents=ncl)
+        latents[:, :, ncl:] = (latents[:, :, ncl:].to(torch.float32) + (sigmas[i + 1] - sigmas[i]) * v[:, :, ncl:]).to(v.dtype)
+        if trace is not None:
+            trace.append(latents.clone())
+    frames = decode_final(latents, decode, mean, std)
+    return frames[:, added_c: new_frame_size + added_c]

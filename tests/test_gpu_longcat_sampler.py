@@ -105,3 +105,51 @@ def test_pipeline_matches_reference_trajectory(name):
         np.testing.assert_allclose(prev, G[f"call{j}_prev"], rtol=0, atol=2e-4, err_msg=f"{name} call {j} prev")
         np.testing.assert_allclose(x0, G[f"call{j}_x0"], rtol=0, atol=2e-4, err_msg=f"{name} call {j} x0")
     np.testing.assert_allclose(frames, G["frames"], rtol=0, atol=1e-3)
+
+
+@pytest.mark.parametrize("name", ["spatial", "spatiotemporal"])
+def test_refine_pass_matches_reference(name):
+    """generate_refine (PIPE:1271-1511) on the HIP path.  The reference trajectory recorded here (golden g15) went through torch's CPU
+    bf16 interpolation kernels, which round between passes (up to 1.5 grey levels off the fp32 interpolation); on a GPU the reference
+    interpolates in fp32 and rounds once per op, which is what wf_refine_upsample_u8 implements.  So: (1) the up-sampled video must equal
+    the oracle's GPU-semantics restatement (|err| <= 2^-7 = one bf16 ulp of the [0, 1] video through 2x - 1; >= 99 % identical); (2) the whole pass must match the oracle -- pinned to the
+    reference on every other step by g15 -- run on that up-sampled video to 2e-4; (3) and the recorded reference trajectory to 3e-2."""
+    from tests.test_oracle_longcat_sampler import REFINE_CASES, refine_inputs
+    from worldforge_amd.longcat_pipeline import LongCatVideoPipeline
+    from worldforge_amd.longcat_scheduler import FlowMatchEulerDiscreteScheduler
+    c = REFINE_CASES[name]
+    G = np.load(os.path.join(GOLD, f"g15_longcat_refine_{name}.npz"))
+    frames, image, pe, pm = refine_inputs(c)
+    dit, vae = FakeLongCatDiT(), FakeVAE()
+    sch = FlowMatchEulerDiscreteScheduler(shift=c["shift"])
+    pipe = LongCatVideoPipeline(vae, sch, dit, device=DEV)
+    ups, lats = [], []
+    orig_enc = vae.encode
+    vae.encode = lambda x: (ups.append(x.float().cpu()), orig_enc(x))[1]
+    orig_step = sch.step
+    sch.step = lambda *a, **k: (lambda o: (lats.append(o[0].cpu().numpy()), o)[1])(orig_step(*a, **k))
+    out = pipe.generate_refine(stage1_video=[f.numpy() for f in frames], height=c["H"], width=c["W"], prompt_embeds=pe,
+                               prompt_attention_mask=pm, image=image, num_cond_frames=1, num_inference_steps=c["steps"],
+                               generator=torch.manual_seed(42), t_thresh=c["t"], spatial_refine_only=c["sro"])
+    assert np.array_equal(sch.timesteps.numpy(), G["timesteps"]) and np.array_equal(sch.sigmas.numpy(), G["sigmas"])
+    nf = c["F0"] if c["sro"] else 2 * c["F0"]
+    want_up = ols.refine_upsample(frames, c["H"], c["W"], nf, gpu_semantics=True).float()
+    up = ups[0][:, :, 12:12 + nf]
+    assert ups[0].shape == G["video_up"].shape
+    assert (up - want_up).abs().max().item() <= 2.0 ** -7, (up - want_up).abs().max().item()  # one bf16 ulp of the [0, 1] video, doubled by 2x - 1
+    assert (up != want_up).float().mean().item() < 0.01
+    assert torch.equal(ups[0][:, :, :12], ups[0][:, :, 12:13].expand(-1, -1, 12, -1, -1))  # front padding repeats the first frame
+    # (2) the oracle on the GPU-semantics up-sampling
+    dit2, vae2 = FakeLongCatDiT(), FakeVAE()
+    trace = []
+    want = ols.run_refine(stage1_frames=frames, image=(2.0 * image - 1.0)[None], height=c["H"], width=c["W"], dit=dit2, prompt_embeds=pe,
+                          prompt_mask=pm, encode_sample=lambda x, g: vae2.encode(x).latent_dist.sample(g),
+                          decode=lambda z: vae2.decode(z)[0], mean=vae2.config.latents_mean, std=vae2.config.latents_std,
+                          generator=torch.manual_seed(42), num_inference_steps=c["steps"], shift=c["shift"], t_thresh=c["t"],
+                          spatial_refine_only=c["sro"], trace=trace, gpu_upsample=True)
+    assert [len(lats), dit.calls, vae.n_enc, vae.n_dec] == G["n"].tolist()
+    for j, l in enumerate(lats):
+        np.testing.assert_allclose(l, trace[j][:, :, 4:].numpy(), rtol=0, atol=2e-3)
+        np.testing.assert_allclose(l, G[f"step{j}"], rtol=0, atol=3e-2)
+    np.testing.assert_allclose(out, want.numpy(), rtol=0, atol=2e-3)
+    np.testing.assert_allclose(out, G["frames"], rtol=0, atol=3e-2)

@@ -89,3 +89,44 @@ def test_longcat_selection_rule():
     assert ols.select_from_similarities(sims, 3, use_distill=True) == [3]
     assert ols.select_from_similarities(sims, 4, use_distill=True) == [1, 3, 6]  # distill default: up to 3
     assert ols.select_from_similarities([0.5] * 8, 9) == [0]                  # nothing below the threshold -> the argmin
+
+
+REFINE_CASES = {"spatial": dict(F0=5, H0=32, W0=48, H=64, W=128, steps=8, shift=1.0, t=0.5, sro=True),
+                "spatiotemporal": dict(F0=3, H0=24, W0=40, H=64, W=64, steps=6, shift=4.0, t=0.6, sro=False)}
+
+
+def refine_inputs(c):
+    g = torch.Generator().manual_seed(23)
+    frames = (torch.rand(c["F0"], c["H0"], c["W0"], 3, generator=g) * 255).to(torch.uint8)
+    image = torch.rand(3, c["H"], c["W"], generator=g)
+    pe = torch.randn(1, 1, 12, 32, generator=g).to(torch.bfloat16)
+    pm = torch.zeros(1, 12, dtype=torch.int64)
+    pm[:, :9] = 1
+    return frames, image, pe, pm
+
+
+@pytest.mark.parametrize("name", list(REFINE_CASES))
+def test_refine_pass_matches_reference(name):
+    """G15: the unmodified generate_refine (schedule truncation, bf16 upsampling chain, granularity padding, noise mixing, condition
+    latents, Euler loop without CFG, frame slicing)."""
+    c = REFINE_CASES[name]
+    G = np.load(os.path.join(GOLD, f"g15_longcat_refine_{name}.npz"))
+    frames, image, pe, pm = refine_inputs(c)
+    dit, vae = FakeLongCatDiT(), FakeVAE()
+    mean, std = vae.config.latents_mean, vae.config.latents_std
+    sig, ts = ols.refine_schedule(c["steps"], c["shift"], c["t"])
+    assert np.array_equal(sig.numpy(), G["sigmas"]) and np.array_equal(ts.numpy(), G["timesteps"])
+    nf = c["F0"] if c["sro"] else 2 * c["F0"]
+    up = ols.refine_upsample(frames, c["H"], c["W"], nf)
+    ncl, ac, an, ncf = ols.refine_plan(nf, 1)
+    assert (ncl, ac, ncf) == (4, 12, 13)
+    assert np.array_equal(up.float().numpy(), G["video_up"][:, :, ac:ac + nf])
+    trace = []
+    out = ols.run_refine(stage1_frames=frames, image=(2.0 * image - 1.0)[None], height=c["H"], width=c["W"], dit=dit, prompt_embeds=pe,
+                         prompt_mask=pm, encode_sample=lambda x, g: vae.encode(x).latent_dist.sample(g),
+                         decode=lambda z: vae.decode(z)[0], mean=mean, std=std, generator=torch.manual_seed(42),
+                         num_inference_steps=c["steps"], shift=c["shift"], t_thresh=c["t"], spatial_refine_only=c["sro"], trace=trace)
+    assert len(trace) == int(G["n"][0])
+    for j, lat in enumerate(trace):
+        np.testing.assert_allclose(lat[:, :, ncl:].numpy(), G[f"step{j}"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out.numpy(), G["frames"], rtol=0, atol=2e-5)

@@ -17,6 +17,7 @@ if __name__ == "__main__":
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--h", type=int, default=60)
     ap.add_argument("--w", type=int, default=104)
+    ap.add_argument("--bsa", action="store_true", help="refine-pass configuration: block-sparse self-attention, 4 condition latents, no CFG")
     ap.add_argument("--job", action="store_true", help="time guided / plain sampler steps of the whole i2v job instead of one forward")
     a = ap.parse_args()
     if a.job:
@@ -63,7 +64,7 @@ if __name__ == "__main__":
     dev = torch.device("cuda:0")
     cfg = LongCatConfig(depth=a.depth)
     t0 = time.time()
-    m = LongCatVideoTransformer3DModel(cfg, dev).init_random(1)
+    m = LongCatVideoTransformer3DModel(cfg, dev, enable_bsa=a.bsa).init_random(1)
     torch.cuda.synchronize()
     print(f"init {time.time() - t0:.1f}s, {m.param_bytes() / 1e9:.1f} GB of weights", flush=True)
     g = torch.Generator(device=dev).manual_seed(2)
@@ -71,14 +72,31 @@ if __name__ == "__main__":
     cap = torch.randn((512, cfg.caption_channels), generator=g, device=dev).bfloat16()
     mask = torch.zeros(512, dtype=torch.int64)
     mask[:180] = 1
-    ts = [0.0] + [700.0] * (a.frames - 1)
-    m.forward_tokens(x, ts, cap, mask, 1)
+    ncl = 4 if a.bsa else 1
+    ts = [0.0] * ncl + [700.0] * (a.frames - ncl)
+    if a.bsa:
+        import worldforge_amd.bsa as wbsa
+        ev = []
+        orig = wbsa.sparse_attention
+
+        def timed(*aa, **kk):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*aa, **kk)
+            e1.record()
+            ev.append((e0, e1, aa[0].shape[1], kk.get("n_k_blocks", aa[-1] if isinstance(aa[-1], int) else 0)))
+            return r
+
+        wbsa.sparse_attention = timed
+    m.forward_tokens(x, ts, cap, mask, ncl)
     torch.cuda.synchronize()
     dit.PROFILE_ATTN = []
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
+    if a.bsa:
+        ev.clear()
     for _ in range(a.iters):
-        out = m.forward_tokens(x, ts, cap, mask, 1)
+        out = m.forward_tokens(x, ts, cap, mask, ncl)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
@@ -87,6 +105,15 @@ if __name__ == "__main__":
     C, Hd = cfg.hidden_size, cfg.ffn_hidden
     gemm_flop = 2.0 * L * C * (3 * C + C + C + C + 3 * Hd) * a.depth
     attn_flop = 4.0 * (L - tpf) * L * C * a.depth
+    if a.bsa:
+        big = [(s.elapsed_time(e), lq, nk) for s, e, lq, nk in ev if lq > 4 * tpf]
+        ms_b = sum(b[0] for b in big) / len(big)
+        lq, nk = big[0][1], big[0][2]
+        nsel = int(0.125 * nk)
+        print(f"tokens {L}, forward {ms:.1f} ms; noise-token block-sparse attention {ms_b:.2f} ms per launch: {lq // 128} query blocks x {nsel} of {nk} "
+              f"key blocks = {4.0 * lq * nsel * 128 * C / ms_b / 1e9:.0f} TFLOP/s of selected work (dense would be {4.0 * lq * nk * 128 * C / 1e12:.0f} TFLOP); "
+              f"finite={bool(torch.isfinite(out).all())}")
+        sys.exit(0)
     att = [s.elapsed_time(e) for s, e in dit.PROFILE_ATTN]
     att_ms = sum(att) / len(att)
     print(f"tokens {L}, forward {ms:.1f} ms ({(gemm_flop + attn_flop) / ms / 1e9:.0f} TFLOP/s end to end); noise-token self-attention "

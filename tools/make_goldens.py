@@ -537,3 +537,70 @@ def g_bsa():
 
 if __name__ == "__main__" and "bsa" in sys.argv[1:]:
     g_bsa()
+
+
+# ------------------------------------------------------------------------------------------------------------
+LC_REFINE_CASES = {"spatial": dict(F0=5, H0=32, W0=48, H=64, W=128, steps=8, shift=1.0, t=0.5, sro=True),
+                   "spatiotemporal": dict(F0=3, H0=24, W0=40, H=64, W=64, steps=6, shift=4.0, t=0.6, sro=False)}
+
+
+def lc_refine_inputs(c):
+    g = torch.Generator().manual_seed(23)
+    frames = (torch.rand(c["F0"], c["H0"], c["W0"], 3, generator=g) * 255).to(torch.uint8)
+    image = torch.rand(3, c["H"], c["W"], generator=g)
+    pe = torch.randn(1, 1, 12, 32, generator=g).to(torch.bfloat16)
+    pm = torch.zeros(1, 12, dtype=torch.int64)
+    pm[:, :9] = 1
+    return frames, image, pe, pm
+
+
+def g_longcat_refine():
+    """G15: LongCatVideoPipeline.generate_refine, unmodified, with the deterministic DiT / VAE / text-encoder stand-ins."""
+    from tests.fakes import FakeLongCatDiT
+
+    sys.path.insert(0, "/root/reference/longcat_for_worldforge")
+    from longcat_video.modules.scheduling_flow_match_euler_discrete import FlowMatchEulerDiscreteScheduler
+    import longcat_video.pipeline_longcat_video as lcp
+    from longcat_video.pipeline_longcat_video import LongCatVideoPipeline
+
+    lcp.torch_gc = lambda: None  # memory housekeeping that calls torch.cuda.ipc_collect() unconditionally (no GPU here); no arithmetic
+
+    for name, c in LC_REFINE_CASES.items():
+        frames, image, pe, pm = lc_refine_inputs(c)
+        dit, vae = FakeLongCatDiT(), FakeVAE()
+        sch = FlowMatchEulerDiscreteScheduler(shift=c["shift"])
+        pipe = LongCatVideoPipeline(tokenizer=None, text_encoder=None, vae=vae, scheduler=sch, dit=dit)
+        pipe.device = "cpu"
+        pipe.encode_prompt = lambda **kw: (pe, pm, None, None)
+        pipe.get_condition_shape = lambda *a, **k: (c["H"], c["W"])
+        rec, lats = {}, []
+        orig_step = sch.step
+
+        def wrapped(*a, **k):
+            o = orig_step(*a, **k)
+            lats.append(t2n(o[0]))
+            return o
+
+        sch.step = wrapped
+        orig_enc, ups = vae.encode, []
+
+        def enc(x):
+            ups.append(t2n(x))
+            return orig_enc(x)
+
+        vae.encode = enc
+        out = pipe.generate_refine(image=image, prompt="p", stage1_video=[f.numpy() for f in frames], num_cond_frames=1,
+                                   num_inference_steps=c["steps"], generator=torch.manual_seed(42), output_type="np", t_thresh=c["t"],
+                                   spatial_refine_only=c["sro"])
+        rec["frames"] = np.asarray(out, dtype=np.float32)
+        rec["video_up"] = ups[0]
+        rec["timesteps"], rec["sigmas"] = sch.timesteps.numpy(), sch.sigmas.numpy()
+        for j, l in enumerate(lats):
+            rec[f"step{j}"] = l
+        rec["n"] = np.array([len(lats), dit.calls, vae.n_enc, vae.n_dec])
+        np.savez_compressed(os.path.join(OUT, f"g15_longcat_refine_{name}.npz"), **rec)
+        print("g15", name, rec["n"], rec["frames"].shape, rec["video_up"].shape)
+
+
+if __name__ == "__main__" and "longcat_refine" in sys.argv[1:]:
+    g_longcat_refine()

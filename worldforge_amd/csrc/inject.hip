@@ -266,6 +266,50 @@ extern "C" int wf_flow_metrics(const float* ref_flow, const float* chan_flow, fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// LongCat refine pass, stage-1 video -> model input (pipeline_longcat_video.py:1407-1413): uint8 frames [F][H0][W0][3]
+//   -> bf16 -> F.interpolate(bilinear, align_corners=True) to (H, W)              (bf16 result)
+//   -> / 255                                                                        (bf16 result)
+//   -> F.interpolate(trilinear, align_corners=True) to (Fo, H, W): H, W unchanged, so only the frame axis interpolates (bf16 result)
+//   -> * 2 - 1                                                                      (two bf16 roundings)
+// out f32 [3][Fo][H][W] (bf16-valued).  Index / weight arithmetic as PyTorch's upsample kernels: scale = (in-1)/(out-1) in fp32,
+// src = scale * dst, i0 = (int)src, lambda1 = src - i0.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float refine_tap(const unsigned char* __restrict__ frame, int H0, int W0, int c, int y0, int y1, float ly1,
+                                            int x0, int x1, float lx1) {
+  const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+  const float v00 = frame[((size_t)y0 * W0 + x0) * 3 + c], v01 = frame[((size_t)y0 * W0 + x1) * 3 + c];
+  const float v10 = frame[((size_t)y1 * W0 + x0) * 3 + c], v11 = frame[((size_t)y1 * W0 + x1) * 3 + c];
+  const float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+  return rbf(rbf(v) / 255.0f);
+}
+__global__ void k_refine_upsample(const unsigned char* __restrict__ in, float* __restrict__ out, int F, int H0, int W0, int Fo, int H,
+                                  int W, float sf, float sy, float sx, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), fo = (int)((i / ((size_t)W * H)) % Fo), c = (int)(i / ((size_t)W * H * Fo));
+    const float fy = sy * y, fx = sx * x, ff = sf * fo;
+    const int y0 = (int)fy, x0 = (int)fx, f0 = (int)ff;
+    const int y1 = y0 + (y0 < H0 - 1 ? 1 : 0), x1 = x0 + (x0 < W0 - 1 ? 1 : 0), f1 = f0 + (f0 < F - 1 ? 1 : 0);
+    const float ly1 = fy - y0, lx1 = fx - x0, lf1 = ff - f0;
+    const float a = refine_tap(in + (size_t)f0 * H0 * W0 * 3, H0, W0, c, y0, y1, ly1, x0, x1, lx1);
+    const float b = refine_tap(in + (size_t)f1 * H0 * W0 * 3, H0, W0, c, y0, y1, ly1, x0, x1, lx1);
+    const float t = rbf((1.0f - lf1) * a + lf1 * b);
+    out[i] = rbf(rbf(t * 2.0f) - 1.0f);
+  }
+}
+extern "C" int wf_refine_upsample_u8(const void* frames_u8, float* out, int F, int H0, int W0, int Fo, int H, int W, void* stream) {
+  WF_CHECK_ARG(frames_u8 && out, "wf_refine_upsample_u8: null pointer");
+  WF_CHECK_ARG(F > 0 && H0 > 0 && W0 > 0 && Fo > 0 && H > 0 && W > 0, "wf_refine_upsample_u8: empty shape");
+  const size_t n = (size_t)3 * Fo * H * W;
+  const float sf = Fo > 1 ? (float)(F - 1) / (float)(Fo - 1) : 0.0f;
+  const float sy = H > 1 ? (float)(H0 - 1) / (float)(H - 1) : 0.0f;
+  const float sx = W > 1 ? (float)(W0 - 1) / (float)(W - 1) : 0.0f;
+  hipLaunchKernelGGL(k_refine_upsample, dim3(grid_for(n, 256, 16384)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned char*)frames_u8, out, F, H0, W0, Fo, H, W, sf, sy, sx, n);
+  WF_LAUNCH_CHECK("wf_refine_upsample_u8");
+  return WF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Resize: PyTorch upsample_bilinear2d (align_corners=False) and legacy 'nearest'
 // ------------------------------------------------------------------------------------------------
 __global__ void k_bilinear(const float* __restrict__ in, float* __restrict__ out, int Hi, int Wi, int Ho, int Wo, float rh,

@@ -133,7 +133,7 @@ class LongCatVideoTransformer3DModel:
         # block-sparse self-attention of the 720p refine pass (LCA:57-66, LCD:270-276); bsa_params as in the reference's config:
         # sparsity, chunk_3d_shape_q, chunk_3d_shape_k (cdf_threshold is not built)
         self._bsa = bool(enable_bsa)
-        self.bsa_params = dict(bsa_params) if bsa_params else dict(sparsity=0.9375, chunk_3d_shape_q=[4, 4, 8], chunk_3d_shape_k=[4, 4, 8])
+        self.bsa_params = dict(bsa_params) if bsa_params else dict(sparsity=0.875, chunk_3d_shape_q=[4, 4, 8], chunk_3d_shape_k=[4, 4, 8])  # bsa_interface.py:618-621 defaults
         if self.bsa_params.get("cdf_threshold") is not None:
             raise NotImplementedError("cdf-threshold block selection (bsa_interface.py:226-263) is not built; top-k only")
         self.last_bsa_indices = None

@@ -1,6 +1,7 @@
 """The LongCat-Video guided image-to-video sampler (IRR re-noising, FLF gate, DSG auto-guidance, CFG-zero), HIP-backed.
 
-Host-side mirror of `LongCatVideoPipeline.generate_i2v` (PIPE = longcat_for_worldforge/longcat_video/pipeline_longcat_video.py:619-1006):
+Host-side mirror of `LongCatVideoPipeline.generate_i2v` (PIPE = longcat_for_worldforge/longcat_video/pipeline_longcat_video.py:619-1006)
+and of `generate_refine` (PIPE:1271-1511, the 720p refine pass):
 same sampling knobs, same control flow (PIPE:823-994), same RNG draw order (CPU generator: noise latents PIPE:256, the posterior sample
 of the conditioning frame PIPE:278, the re-noise draws PIPE:925), same dtype hand-offs (fp32 latents, DiT input / timesteps in the
 DiT dtype).  The DiT, the VAE and the scheduler are objects speaking the reference's call protocol, so the MI355X-native modules of
@@ -81,6 +82,87 @@ class LongCatVideoPipeline:
         cond = torch.cat(cond, dim=0).to(self.device, torch.float32)
         latents[:, :, :1] = ops.latent_norm(cond, self.vae.config.latents_mean, self.vae.config.latents_std)
         return latents
+
+    # ---- PIPE:1271-1511 ---------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate_refine(self, stage1_video, height: int, width: int, prompt_embeds: torch.Tensor, prompt_attention_mask: torch.Tensor,
+                        image=None, num_cond_frames: int = 0, num_inference_steps: int = 50, generator=None, output_type: str = "np",
+                        t_thresh: float = 0.5, spatial_refine_only: bool = False, step_hook=None):
+        """The 720p refine pass: the stage-1 (480p) video is up-sampled, encoded, mixed with noise at t_thresh and denoised from there
+        without CFG, the DiT running with block-sparse self-attention (enable it on the DiT, with the refinement LoRA folded in, as
+        run_longcat_worldforge_single.py:447-451 does).  stage1_video: uint8 frames [F, H0, W0, 3] (tensor / array / list of arrays);
+        image: the conditioning first frame at the target size or None.  Returns frames [1, F', H, W, 3] in [0, 1]."""
+        import math
+
+        from ._ffi import call
+        dev, sch = self.device, self.scheduler
+        ssp = self.vae_scale_factor_spatial * 2 * 4  # PIPE:1336
+        if height % ssp != 0 or width % ssp != 0:
+            raise ValueError(f"`height and width` have to be divisible by {ssp} but are {height} and {width}.")
+        dit_dtype = self.dit.dtype
+        pe, pm = prompt_embeds.to(dev, dit_dtype), prompt_attention_mask.to(dev)
+        # PIPE:1394-1402: the schedule, cut at t_thresh
+        sch.set_timesteps(num_inference_steps, sigmas=self.get_timesteps_sigmas(num_inference_steps), device=dev)
+        timesteps = sch.timesteps
+        if t_thresh:
+            tt = torch.tensor(t_thresh * 1000, dtype=timesteps.dtype)
+            timesteps = torch.cat([tt.unsqueeze(0), timesteps[timesteps < tt]])
+            sch.timesteps = timesteps
+            sch.sigmas = torch.cat([timesteps / 1000, torch.zeros(1)])
+        # PIPE:1404-1413: up-sampling chain in the DiT dtype, one kernel
+        frames = torch.as_tensor(np.array(stage1_video)) if not isinstance(stage1_video, torch.Tensor) else stage1_video
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
+            raise ValueError("stage1_video must be uint8 frames [F, H, W, 3]")
+        if dit_dtype != torch.bfloat16:
+            raise NotImplementedError("the up-sampling kernel rounds as a bf16 model does")
+        frames = frames.to(dev).contiguous()
+        nf, H0, W0, _ = frames.shape
+        new_frame_size = nf if spatial_refine_only else 2 * nf
+        up = torch.empty((1, 3, new_frame_size, height, width), dtype=torch.float32, device=dev)
+        call("wf_refine_upsample_u8", frames.data_ptr(), up.data_ptr(), nf, H0, W0, new_frame_size, height, width, ops.stream())
+        # PIPE:1415-1435: pad to the block-sparse granularity (4 latent frames), encode, mix with noise
+        gran, tsc = 4, self.vae_scale_factor_temporal
+        num_noise_frames = new_frame_size - num_cond_frames
+        ncl = added_c = 0
+        if num_cond_frames > 0:
+            ncl = 1 + math.ceil((num_cond_frames - 1) / tsc)
+            ncl = math.ceil(ncl / gran) * gran
+            added_c = 1 + (ncl - 1) * tsc - num_cond_frames
+            num_cond_frames = num_cond_frames + added_c
+        nnl = math.ceil(math.ceil(num_noise_frames / tsc) / gran) * gran
+        added_n = nnl * tsc - num_noise_frames
+        up = torch.cat([up[:, :, 0:1].repeat(1, 1, added_c, 1, 1), up, up[:, :, -1:].repeat(1, 1, added_n, 1, 1)], dim=2)
+        mean, std = self.vae.config.latents_mean, self.vae.config.latents_std
+        lat = ops.latent_norm(self.vae.encode(up).latent_dist.sample(generator).to(dev, torch.float32), mean, std)
+        noise = self._randn(tuple(lat.shape), generator).to(lat.dtype)
+        latents = ops.add_noise(lat, noise, 1 - t_thresh, t_thresh)  # (1 - t) * latent + t * noise
+        del up, lat, noise
+        if image is not None:  # PIPE:262-284: the condition frame, front-padded, encoded (posterior sample), normalised
+            img = self._preprocess_image(image, height, width).to(dev, dit_dtype)
+            enc_in = img[0].unsqueeze(0).unsqueeze(2)
+            enc_in = torch.cat([enc_in[:, :, 0:1].repeat(1, 1, added_c, 1, 1), enc_in], dim=2)
+            assert enc_in.shape[2] == num_cond_frames
+            cond = self.vae.encode(enc_in).latent_dist.sample(generator).to(dev, torch.float32)
+            latents[:, :, :ncl] = ops.latent_norm(cond, mean, std)
+        elif num_cond_frames > 0:
+            raise ValueError("num_cond_frames > 0 needs the conditioning image (video conditioning is not built)")
+        # PIPE:1464-1497
+        for i, t in enumerate(timesteps):
+            if step_hook is not None:
+                step_hook(i, "start")
+            ts = t.expand(latents.shape[0]).to(dit_dtype).unsqueeze(-1).repeat(1, latents.shape[2])
+            ts[:, :ncl] = 0
+            noise_pred = -self.dit(hidden_states=ops.cast(latents, dit_dtype), timestep=ts, encoder_hidden_states=pe,
+                                   encoder_attention_mask=pm, num_cond_latents=ncl)
+            latents[:, :, ncl:] = sch.step(noise_pred[:, :, ncl:], t, latents[:, :, ncl:], return_dict=False)[0]
+            if step_hook is not None:
+                step_hook(i, "end")
+        if output_type == "latent":
+            return latents
+        z = ops.latent_denorm(ops.cast(latents, torch.float32), mean, std)
+        video = self.vae.decode(z, return_dict=False)[0]
+        video = torch.stack([ops.postprocess_video(v) for v in video])[:, added_c: new_frame_size + added_c]  # PIPE:1505
+        return video.cpu().numpy() if output_type == "np" else video
 
     # ---- PIPE:619-1006 ----------------------------------------------------------------------------------------------------
     @torch.no_grad()
