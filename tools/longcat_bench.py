@@ -18,8 +18,46 @@ if __name__ == "__main__":
     ap.add_argument("--h", type=int, default=60)
     ap.add_argument("--w", type=int, default=104)
     ap.add_argument("--bsa", action="store_true", help="refine-pass configuration: block-sparse self-attention, 4 condition latents, no CFG")
+    ap.add_argument("--refine", action="store_true", help="time the 720p refine pass (704 x 1280, 93 stage-1 frames): prepare, 2 steps")
     ap.add_argument("--job", action="store_true", help="time guided / plain sampler steps of the whole i2v job instead of one forward")
     a = ap.parse_args()
+    if a.refine:
+        from worldforge_amd.longcat_pipeline import LongCatVideoPipeline
+        from worldforge_amd.longcat_scheduler import FlowMatchEulerDiscreteScheduler
+        from worldforge_amd.vae import AutoencoderKLWan
+
+        dev = torch.device("cuda:0")
+        m = LongCatVideoTransformer3DModel(LongCatConfig(depth=a.depth), dev, enable_bsa=True).init_random(1)
+        vae = AutoencoderKLWan(dev).init_random(seed=1)
+        pipe = LongCatVideoPipeline(vae, FlowMatchEulerDiscreteScheduler(shift=12.0), m, device=dev)
+        g = torch.Generator().manual_seed(3)
+        frames = (torch.rand(93, 480, 832, 3, generator=g) * 255).to(torch.uint8)
+        image = torch.rand(3, 704, 1280, generator=g)
+        pe = (torch.randn(1, 1, 512, 4096, generator=g) * 0.5).bfloat16()
+        pm = torch.zeros(1, 512, dtype=torch.int64)
+        pm[:, :180] = 1
+        marks = [("t0", "", time.time())]
+
+        class _Stop(Exception):
+            pass
+
+        def hook(i, what):
+            torch.cuda.synchronize()
+            marks.append((i, what, time.time()))
+            if what == "end" and i == 1:
+                raise _Stop
+
+        try:
+            pipe.generate_refine(stage1_video=frames, height=704, width=1280, prompt_embeds=pe, prompt_attention_mask=pm, image=image,
+                                 num_cond_frames=1, num_inference_steps=50, generator=torch.manual_seed(1), t_thresh=0.5,
+                                 spatial_refine_only=True, step_hook=hook)
+        except _Stop:
+            pass
+        t = {(i, w): ts for i, w, ts in marks}
+        print(f"refine 704x1280, 93 frames (109 after padding = 28 latent frames = 98 560 tokens), {len(pipe.scheduler.timesteps)} steps "
+              f"at t_thresh 0.5: prepare (up-sample + 2 VAE encodes + noise mix) {t[(0, 'start')] - t[('t0', '')]:.2f} s; "
+              f"step 0 {t[(0, 'end')] - t[(0, 'start')]:.2f} s, step 1 {t[(1, 'end')] - t[(1, 'start')]:.2f} s", flush=True)
+        sys.exit(0)
     if a.job:
         from worldforge_amd.longcat_pipeline import LongCatVideoPipeline
         from worldforge_amd.longcat_scheduler import FlowMatchEulerDiscreteScheduler
