@@ -46,12 +46,12 @@ def test_ln_modulate(L, C, tpf, affine):
     xd = x.to(DEV)
     if affine:
         w, b = (_rand((C,), 2, 0.1) + 1).to(DEV), _rand((C,), 3, 0.1).to(DEV)
-        call("wf_lc_ln_modulate", xd.data_ptr(), w.data_ptr(), b.data_ptr(), 0, 0, 0, out.data_ptr(), L, C, 1e-6, ops.stream())
+        call("wf_lc_ln_modulate", xd.data_ptr(), w.data_ptr(), b.data_ptr(), 0, 0, 0, 0, out.data_ptr(), L, C, 1e-6, ops.stream())
         want = olc.layer_norm(x, w.cpu(), b.cpu())
     else:
         mod = _rand((T, 3 * C), 4, 0.3).to(DEV)  # [shift | scale | unused] rows 3C apart
         shift, scale = mod[:, :C], mod[:, C:2 * C]
-        call("wf_lc_ln_modulate", xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mod.stride(0), tpf, 1, out.data_ptr(), L, C, 1e-6,
+        call("wf_lc_ln_modulate", xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mod.stride(0), tpf, 0, 1, out.data_ptr(), L, C, 1e-6,
              ops.stream())
         want = olc.modulate(x, shift.cpu(), scale.cpu(), tpf)
     assert torch.isfinite(out.float()).all()
@@ -67,7 +67,7 @@ def test_gate_residual(L, C, tpf, gated):
     xd, yd = x.to(DEV), y.to(DEV)
     yv = yd[:, C:]
     call("wf_lc_gate_residual", xd.data_ptr(), yv.data_ptr(), yd.stride(0), gate[:, C:].data_ptr() if gated else None, gate.stride(0),
-         tpf if gated else 0, L, C, ops.stream())
+         tpf if gated else 0, 0, L, C, ops.stream())
     g = gate[:, C:].cpu().repeat_interleave(tpf, dim=0) if gated else 1.0
     want = (x.float() + g * y[:, C:].float()).to(BF)
     assert torch.equal(xd.cpu(), want)
@@ -202,3 +202,24 @@ def test_lora_fold_matches_reference_runtime_lora():
     assert _rel_l2(got, torch.from_numpy(L["out_base"])) > 5e-2   # and not the base model
     with pytest.raises(KeyError):
         fold_lora(W, {"lora___lorahyphen___blocks___lorahyphen___9___lorahyphen___attn___lorahyphen___proj.lora_down.weight": torch.zeros(8, 256)})
+
+
+def test_row_offset_of_a_token_shard():
+    """row0: the per-frame parameters are selected by the GLOBAL token index when the rows are one rank's shard."""
+    from worldforge_amd._ffi import call
+    from worldforge_amd import ops
+    L, C, tpf, lo = 40, 256, 8, 13
+    x, y = _rand((L, C), 1, 2.0).to(BF), _rand((L, C), 2).to(BF)
+    mod = _rand((L // tpf, 3 * C), 4, 0.3).to(DEV)
+    shift, scale, gate = mod[:, :C], mod[:, C:2 * C], mod[:, 2 * C:]
+    full = torch.empty((L, C), dtype=BF, device=DEV)
+    part = torch.empty((L - lo, C), dtype=BF, device=DEV)
+    xd = x.to(DEV)
+    call("wf_lc_ln_modulate", xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mod.stride(0), tpf, 0, 1, full.data_ptr(), L, C, 1e-6, ops.stream())
+    call("wf_lc_ln_modulate", xd[lo:].data_ptr(), scale.data_ptr(), shift.data_ptr(), mod.stride(0), tpf, lo, 1, part.data_ptr(), L - lo, C, 1e-6,
+         ops.stream())
+    assert torch.equal(full[lo:], part)
+    xa, xb, yd = x.to(DEV).clone(), x.to(DEV).clone(), y.to(DEV)
+    call("wf_lc_gate_residual", xa.data_ptr(), yd.data_ptr(), yd.stride(0), gate.data_ptr(), mod.stride(0), tpf, 0, L, C, ops.stream())
+    call("wf_lc_gate_residual", xb[lo:].data_ptr(), yd[lo:].data_ptr(), yd.stride(0), gate.data_ptr(), mod.stride(0), tpf, lo, L - lo, C, ops.stream())
+    assert torch.equal(xa[lo:], xb[lo:])

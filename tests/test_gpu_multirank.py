@@ -127,3 +127,70 @@ def test_cfg_pair_lockstep_equals_two_sequential_forwards(P):
     for r, (a, b) in enumerate(results):
         assert torch.equal(a, ref_a), (r, (a - ref_a).abs().max())
         assert torch.equal(b, ref_b), (r, (b - ref_b).abs().max())
+
+
+@pytest.mark.parametrize("P,thw,ncl", [(2, (3, 16, 20), 1), (3, (5, 16, 24), 1), (4, (5, 16, 24), 0), (8, (8, 16, 32), 2)])
+def test_token_sharded_longcat_dit_equals_single(P, thw, ncl):
+    """LongCat DiT, sequence parallel: per-frame AdaLN selected by the global token index (row0), condition / noise split by global
+    index (a shard may hold both kinds of rows, or only one), K / V^T shards all-gathered and consumed in place.  Every rank must
+    return the single-rank velocity, bit for bit."""
+    from oracle import longcat_dit as olc
+    from worldforge_amd.longcat_dit import LongCatConfig, LongCatVideoTransformer3DModel
+    kw = dict(hidden_size=256, depth=2, num_heads=2, caption_channels=64, adaln_tembed_dim=64)
+    W = olc.random_weights(olc.LongCatConfig(**kw), seed=5)
+    T, Hh, Ww = thw
+    x = _rand((16, T, Hh, Ww), 60).to(BF).to(DEV)
+    cap = _rand((30, 64), 61).to(BF).to(DEV)
+    mask = torch.zeros(30, dtype=torch.int64)
+    mask[:21] = 1
+    ts = [0.0] * ncl + [500.0] * (T - ncl)
+    m0 = LongCatVideoTransformer3DModel(LongCatConfig(**kw), DEV).load_state_dict(W)
+    ref = m0.forward_tokens(x, ts, cap, mask, ncl).clone()
+
+    def rank_fn(comm):
+        m = LongCatVideoTransformer3DModel(LongCatConfig(**kw), DEV, comm=comm)
+        m.w = m0.w
+        return m.forward_tokens(x, ts, cap, mask, ncl).clone()
+
+    for r, got in enumerate(_run_ranks(P, rank_fn)):
+        assert torch.equal(got, ref), (r, (got - ref).abs().max())
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_longcat_guided_sampler_on_sharded_dit_and_vae_equals_single(P):
+    """The whole LongCat guided i2v job (Euler sampler, CFG-zero, IRR re-noise, FLF, DSG) with the DiT token-sharded and the VAE
+    row-sharded: every rank draws the same CPU-generator noise and must produce the single-rank frames."""
+    from oracle import longcat_dit as olc
+    from worldforge_amd.longcat_dit import LongCatConfig, LongCatVideoTransformer3DModel
+    from worldforge_amd.longcat_pipeline import LongCatVideoPipeline
+    from worldforge_amd.longcat_scheduler import FlowMatchEulerDiscreteScheduler
+    from worldforge_amd.vae import AutoencoderKLWan
+    kw = dict(hidden_size=256, depth=2, num_heads=2, caption_channels=64, adaln_tembed_dim=64)
+    W = olc.random_weights(olc.LongCatConfig(**kw), seed=5)
+    Fr, H, Wd = 9, 128, 160
+    g = torch.Generator().manual_seed(3)
+    image = torch.rand(3, H, Wd, generator=g)
+    ref = torch.rand(1, 3, Fr, H, Wd, generator=g)
+    mask = (torch.rand(1, 1, Fr, H, Wd, generator=g) > 0.3).float()
+    pe, ne = _rand((1, 1, 20, 64), 7).to(BF), _rand((1, 1, 20, 64), 8).to(BF)
+    pm, nm = torch.ones(1, 20, dtype=torch.int64), torch.ones(1, 20, dtype=torch.int64)
+    nm[:, 9:] = 0
+    m0 = LongCatVideoTransformer3DModel(LongCatConfig(**kw), DEV).load_state_dict(W)
+    v0 = AutoencoderKLWan(DEV).init_random(seed=1)
+
+    def run(comm):
+        m = LongCatVideoTransformer3DModel(LongCatConfig(**kw), DEV, comm=comm)
+        m.w = m0.w
+        v = AutoencoderKLWan(DEV, comm=comm)
+        v.w = v0.w
+        pipe = LongCatVideoPipeline(v, FlowMatchEulerDiscreteScheduler(shift=3.0), m, device=DEV)
+        out = pipe.generate_i2v(image=image, height=H, width=Wd, prompt_embeds=pe, prompt_attention_mask=pm, negative_prompt_embeds=ne,
+                                negative_prompt_attention_mask=nm, num_frames=Fr, num_inference_steps=4, guidance_scale=4.0,
+                                generator=torch.Generator().manual_seed(42), video_ref=ref, mask=mask, guided=True, resample_steps=2,
+                                guide_steps=3, resample_round=3, use_pca_channel_selection=True, static=True)
+        return torch.from_numpy(out).clone()
+
+    want = run(None)
+    assert torch.isfinite(want).all()
+    for r, got in enumerate(_run_ranks(P, run)):
+        assert torch.equal(got, want), (r, (got - want).abs().max())

@@ -120,12 +120,13 @@ def fold_lora(sd: Dict[str, torch.Tensor], lora_sd: Dict[str, torch.Tensor], mul
 class LongCatVideoTransformer3DModel:
     dtype = torch.bfloat16
 
-    def __init__(self, cfg: LongCatConfig, device="cuda:0", enable_bsa: bool = False, bsa_params: Optional[dict] = None):
+    def __init__(self, cfg: LongCatConfig, device="cuda:0", enable_bsa: bool = False, bsa_params: Optional[dict] = None, comm=None):
         assert cfg.hidden_size // cfg.num_heads == 128 and cfg.hidden_size % cfg.num_heads == 0, "attention kernel is built for head_dim 128"
         assert cfg.patch_size == (1, 2, 2)
         self.cfg = cfg
         self.config = SimpleNamespace(in_channels=cfg.in_channels, out_channels=cfg.out_channels, patch_size=cfg.patch_size)
         self.cp_split_hw = None
+        self.comm = comm  # parallel.Comm (or a stand-in): sequence parallelism over contiguous token shards, see forward_tokens
         self.device = torch.device(device)
         self.w: Dict[str, torch.Tensor] = {}
         self._ws = {}
@@ -239,15 +240,19 @@ class LongCatVideoTransformer3DModel:
         gemm(lo, w, None, out, EPI_F32_ACC)
         return out
 
-    def _ln(self, x, mul, add, mod_ld, rows_per_group, plus_one, out):
+    def _ln(self, x, mul, add, mod_ld, rows_per_group, plus_one, out, row0=0):
         L, C = x.shape
-        call("wf_lc_ln_modulate", x.data_ptr(), mul.data_ptr(), add.data_ptr(), mod_ld, rows_per_group, 1 if plus_one else 0,
+        if L == 0:
+            return
+        call("wf_lc_ln_modulate", x.data_ptr(), mul.data_ptr(), add.data_ptr(), mod_ld, rows_per_group, row0, 1 if plus_one else 0,
              out.data_ptr(), L, C, float(self.cfg.eps), ops.stream())
 
-    def _resid(self, x, y, gate, gate_ld, rows_per_group):
+    def _resid(self, x, y, gate, gate_ld, rows_per_group, row0=0):
         L, C = x.shape
+        if L == 0:
+            return
         call("wf_lc_gate_residual", x.data_ptr(), y.data_ptr(), y.stride(0), gate.data_ptr() if gate is not None else None, gate_ld,
-             rows_per_group, L, C, ops.stream())
+             rows_per_group, row0, L, C, ops.stream())
 
     def _heads(self, src, col0, weight, cos, sin, out, r0, r1, row_map=None):
         """Rows [r0, r1) of columns [col0, col0 + C) of src -> out [H, Lout, 128] rows [0, r1 - r0)."""
@@ -267,7 +272,12 @@ class LongCatVideoTransformer3DModel:
     def forward_tokens(self, x_in: torch.Tensor, timesteps, caption: torch.Tensor, caption_mask: Optional[torch.Tensor] = None,
                        num_cond_latents: int = 0) -> torch.Tensor:
         """One sample.  x_in [16, T, Hh, Ww] bf16; timesteps: T host floats; caption [N, caption_channels] bf16; caption_mask [N]
-        host / device ints (0 = padding) or None -> velocity [16, T, Hh, Ww] fp32  (LCD:279-366)."""
+        host / device ints (0 = padding) or None -> velocity [16, T, Hh, Ww] fp32  (LCD:279-366).
+
+        With `comm` (one process per GPU) the tokens are split into contiguous shards, weights replicated: every rank runs the row-wise
+        work on its shard, K and blocked V^T shards are all-gathered once per block and consumed in place by the attention kernel
+        (segment addressing), the 64-column output rows are gathered at the end.  The condition / noise split of LCA:123-138 is by GLOBAL
+        token index: a rank's rows below the first frame boundary are condition queries (keys < nc), the rest noise queries."""
         cfg, W, dev = self.cfg, self.w, self.device
         bf, f32 = torch.bfloat16, torch.float32
         Cin, T, Hh, Ww = x_in.shape
@@ -281,10 +291,28 @@ class LongCatVideoTransformer3DModel:
         scale = 1.0 / math.sqrt(128.0)
         cos, sin = self._rope_tables(T, h2, w2)
         _buf = self._buf
+        comm = self.comm
+        if comm is not None:
+            from .parallel import gather_rows, shard_plan
+            plan = shard_plan(L, comm.world)
+            lo, hi = plan.bounds(comm.rank)
+            Lr, Sp = hi - lo, plan.shard_len
+            if Lr <= 0:
+                raise ValueError(f"sequence-parallel plan leaves rank {comm.rank} of {comm.world} without tokens ({L} tokens in shards "
+                                 f"of {Sp}); use fewer ranks for this size")
+            if self._bsa and T > 1:
+                raise NotImplementedError("block-sparse attention is single-GPU for now")
+        else:
+            plan, lo, Lr, Sp = None, 0, L, Lp
+        ncr = min(max(nc - lo, 0), Lr)  # this rank's condition rows
+        cos, sin = cos[lo:lo + Lr], sin[lo:lo + Lr]
 
         # ---- embeddings ----
         tok = _buf("tok", (L, Cin * 4), bf)
         call("wf_patchify", x_in.data_ptr(), tok.data_ptr(), Cin, T, Hh, Ww, ops.stream())
+        tok = tok[lo:lo + Lr]
+        L_all, nc_all = L, nc
+        L, nc = Lr, ncr  # from here on L / nc are this rank's row counts; L_all / nc_all the key counts
         x = _buf("x", (L, C), bf)
         gemm(tok, W["patch.w"], W["patch.b"], x, EPI_BF16)  # LCB:112 (Conv3d with kernel = stride = patch)
         tf = timestep_embedding(timesteps, cfg.frequency_embedding_size).to(dev)  # LCB:201-206
@@ -312,9 +340,12 @@ class LongCatVideoTransformer3DModel:
         hbuf = _buf("h", (L, C), bf)
         qkv = _buf("qkv", (L, 3 * C), bf)
         qh_c = _buf("qh_c", (H, max(nc, 1), 128), bf)
-        qh_n = _buf("qh_n", (H, L - nc, 128), bf)
-        kh = _buf("kh", (H, Lp, 128), bf, zero=True)
-        vt = _buf("vt", (H, Lp // 64, 128, 64), bf)
+        qh_n = _buf("qh_n", (H, max(L - nc, 1), 128), bf)[:, :L - nc] if L - nc == 0 else _buf("qh_n", (H, L - nc, 128), bf)
+        kh = _buf("kh", (H, Sp, 128), bf, zero=True)
+        vt = _buf("vt", (H, Sp // 64, 128, 64), bf)
+        if comm is not None:
+            kh_all = _buf("kh_all", (comm.world, H, Sp, 128), bf)
+            vt_all = _buf("vt_all", (comm.world, H, Sp // 64, 128, 64), bf)
         ao = _buf("ao", (L, C), bf)
         ys = _buf("ys", (L, C), bf)
         qc = _buf("qc", (L, C), bf)
@@ -346,7 +377,7 @@ class LongCatVideoTransformer3DModel:
             m = ada[:, i * 6 * C:(i + 1) * 6 * C]
             shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = (m[:, j * C:(j + 1) * C] for j in range(6))
             # ---- self-attention (LCD:91-104, LCA:105-145) ----
-            self._ln(x, scale_msa, shift_msa, ald, tpf, True, hbuf)
+            self._ln(x, scale_msa, shift_msa, ald, tpf, True, hbuf, row0=lo)
             gemm(hbuf, W[p + "attn.qkv.w"], W[p + "attn.qkv.b"], qkv, EPI_BF16)
             if use_bsa:
                 # LCA:57-66 + bsa_interface.py:612-659.  q / k are written straight into 3D-block token order (row_map), V is gathered
@@ -374,32 +405,43 @@ class LongCatVideoTransformer3DModel:
                 self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_n, nc, L)
                 self._heads(qkv, C, W[p + "attn.k_norm"], cos, sin, kh, 0, L)
                 self._vt(qkv, 2 * C, vt, L)
+                kk, vv = kh, vt
+                if comm is not None:
+                    evs = (comm.all_gather_async(kh_all, kh), comm.all_gather_async(vt_all, vt))
+                    for ev in evs:
+                        if ev is not None:
+                            torch.cuda.current_stream().wait_event(ev)
+                    kk, vv = kh_all, vt_all
                 if nc > 0:
-                    attention(qh_c, kh, vt, ao[:nc], nc, scale)  # condition tokens see condition tokens only (LCA:127-131)
-                attention(qh_n, kh, vt, ao[nc:], L, scale, profile=True)  # noise tokens see everything (LCA:133-134)
+                    attention(qh_c, kk, vv, ao[:nc], nc_all, scale)  # condition tokens see condition tokens only (LCA:127-131)
+                if L - nc > 0:
+                    attention(qh_n, kk, vv, ao[nc:], L_all, scale, profile=True)  # noise tokens see everything (LCA:133-134)
             gemm(ao, W[p + "attn.proj.w"], W[p + "attn.proj.b"], ys, EPI_BF16)
-            self._resid(x, ys, gate_msa, ald, tpf)
+            self._resid(x, ys, gate_msa, ald, tpf, row0=lo)
             # ---- cross-attention on the noise tokens (LCD:108-111, LCA:218-276) ----
-            self._ln(x[nc:], W[p + "norm.w"], W[p + "norm.b"], 0, 0, False, hbuf[nc:])
-            gemm(hbuf[nc:], W[p + "cross_attn.q_linear.w"], W[p + "cross_attn.q_linear.b"], qc[nc:], EPI_BF16)
-            self._heads(qc, 0, W[p + "cross_attn.q_norm"], None, None, qh_n, nc, L)
-            gemm(y, W[p + "cross_attn.kv_linear.w"], W[p + "cross_attn.kv_linear.b"], kvt, EPI_BF16)
-            self._heads(kvt, 0, W[p + "cross_attn.k_norm"], None, None, kth, 0, n_txt)
-            self._vt(kvt, C, vtt, n_txt)
-            attention(qh_n, kth, vtt, ao[nc:], n_txt, scale)
-            gemm(ao[nc:], W[p + "cross_attn.proj.w"], W[p + "cross_attn.proj.b"], ys[nc:], EPI_BF16)
-            self._resid(x[nc:], ys[nc:], None, 0, 0)
+            if L - nc > 0:
+                self._ln(x[nc:], W[p + "norm.w"], W[p + "norm.b"], 0, 0, False, hbuf[nc:])
+                gemm(hbuf[nc:], W[p + "cross_attn.q_linear.w"], W[p + "cross_attn.q_linear.b"], qc[nc:], EPI_BF16)
+                self._heads(qc, 0, W[p + "cross_attn.q_norm"], None, None, qh_n, nc, L)
+                gemm(y, W[p + "cross_attn.kv_linear.w"], W[p + "cross_attn.kv_linear.b"], kvt, EPI_BF16)
+                self._heads(kvt, 0, W[p + "cross_attn.k_norm"], None, None, kth, 0, n_txt)
+                self._vt(kvt, C, vtt, n_txt)
+                attention(qh_n, kth, vtt, ao[nc:], n_txt, scale)
+                gemm(ao[nc:], W[p + "cross_attn.proj.w"], W[p + "cross_attn.proj.b"], ys[nc:], EPI_BF16)
+                self._resid(x[nc:], ys[nc:], None, 0, 0)
             # ---- SwiGLU FFN (LCD:113-120, LCB:36-37) ----
-            self._ln(x, scale_mlp, shift_mlp, ald, tpf, True, hbuf)
+            self._ln(x, scale_mlp, shift_mlp, ald, tpf, True, hbuf, row0=lo)
             gemm(hbuf, W[p + "ffn.w13"], None, ffh, EPI_BF16)
             call("wf_lc_swiglu", ffh.data_ptr(), ffh.stride(0), ffg.data_ptr(), L, Hd, ops.stream())
             gemm(ffg, W[p + "ffn.w2"], None, ys, EPI_BF16)
-            self._resid(x, ys, gate_mlp, ald, tpf)
+            self._resid(x, ys, gate_mlp, ald, tpf, row0=lo)
 
         # ---- final layer (LCB:159-168) + unpatchify (LCD:371-392) ----
-        self._ln(x, fmod[:, C:], fmod[:, :C], fmod.stride(0), tpf, True, hbuf)
+        self._ln(x, fmod[:, C:], fmod[:, :C], fmod.stride(0), tpf, True, hbuf, row0=lo)
         yo = _buf("yo", (L, 4 * cfg.out_channels), f32)
         gemm(hbuf, W["final_layer.linear.w"], W["final_layer.linear.b"], yo, EPI_F32)
+        if comm is not None:
+            yo = gather_rows(comm, yo, plan).contiguous()
         out = torch.empty((cfg.out_channels, T, Hh, Ww), dtype=f32, device=dev)
         call("wf_unpatchify", yo.data_ptr(), out.data_ptr(), cfg.out_channels, T, Hh, Ww, ops.stream())
         return out
