@@ -91,6 +91,151 @@ def cpu_baseline(budget_s=25.0):
                        f"encode+decode of {Fs}x{Hs}x{Ws} in {t_vae:.2f}s; extrapolated by algorithmic FLOPs to the timed step mix")
 
 
+def cpu_baseline_longcat():
+    """Oracle (CPU port, fp32) timed on this host: one LongCat block at the released width on a bounded token sample + the VAE sample
+    of cpu_baseline(); returns flop rates."""
+    from oracle import longcat_dit as olc
+    from oracle import vae as ovae
+
+    torch.manual_seed(0)
+    cfg = olc.LongCatConfig(depth=1)
+    W = olc.random_weights(cfg, seed=1)
+    T, h, w = 2, 32, 32  # 512 tokens
+    Ls = T * (h // 2) * (w // 2)
+    x, cap = torch.randn(16, T, h, w), torch.randn(64, cfg.caption_channels)
+    with torch.no_grad():
+        t0 = time.time()
+        olc.forward(W, cfg, x, torch.tensor([0.0, 500.0]), cap, None, num_cond_latents=1)
+        t_blk = time.time() - t0
+    C, Hd = cfg.hidden_size, cfg.ffn_hidden
+    flop_blk = 2.0 * Ls * C * (6 * C + 3 * Hd) + 4.0 * Ls * Ls * C
+    del W
+    Wv = ovae.random_weights(seed=2)
+    Fs, Hs, Ws = 5, 64, 64
+    with torch.no_grad():
+        t0 = time.time()
+        ovae.decode(Wv, ovae.encode_mode(Wv, torch.rand(1, 3, Fs, Hs, Ws) * 2 - 1))
+        t_vae = time.time() - t0
+    return dict(cores=torch.get_num_threads(), dit_flops_per_s=flop_blk / t_blk, vae_flops_per_s=(5.19e6 + 8.70e6) * Fs * Hs * Ws / t_vae,
+                sample=f"oracle fp32: 1 LongCat block (d=4096, 32 heads, SwiGLU 11008) + embeddings at L={Ls} tokens in {t_blk:.2f}s + VAE "
+                       f"encode+decode of {Fs}x{Hs}x{Ws} in {t_vae:.2f}s; extrapolated by algorithmic FLOPs to the timed step mix")
+
+
+def main_longcat(a):
+    """`--workload longcat`: BASELINE config 4's model on the same contract -- LongCat-Video (13.6 B) guided i2v, 93 frames x 480 x 832,
+    50-step schedule, IRR (3 rounds) + FLF + DSG + CFG-zero for the first 20 steps.  The timed window holds guided and plain steps in the
+    job's 20 : 30 proportion."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("WF_SHARE_GPU"):
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    device = torch.device(f"cuda:{local_rank}")
+    from worldforge_amd import dit as wdit
+    from worldforge_amd import parallel
+    from worldforge_amd.longcat_dit import LongCatConfig, LongCatVideoTransformer3DModel
+    from worldforge_amd.longcat_pipeline import LongCatVideoPipeline
+    from worldforge_amd.longcat_scheduler import FlowMatchEulerDiscreteScheduler
+    from worldforge_amd.vae import AutoencoderKLWan
+
+    comm = parallel.init(world, rank, local_rank) if world > 1 else None
+    cfg = LongCatConfig(depth=a.layers if a.layers != 40 else 48)
+    frames = a.frames if a.frames != 81 else 93
+    t0 = time.time()
+    model = LongCatVideoTransformer3DModel(cfg, device, comm=comm).init_random(seed=0)
+    vae = AutoencoderKLWan(device, comm=comm).init_random(seed=1)
+    pipe = LongCatVideoPipeline(vae, FlowMatchEulerDiscreteScheduler(shift=12.0), model, device=device)
+    g = torch.Generator().manual_seed(42)
+    image = torch.rand(3, a.height, a.width, generator=g)
+    ref = torch.rand(1, 3, frames, a.height, a.width, generator=g)
+    mask = (torch.rand(1, 1, frames, a.height // 8, a.width // 8, generator=g) > 0.4).float().repeat_interleave(8, 3).repeat_interleave(8, 4)
+    pe, ne = (torch.randn(2, 1, 1, 512, cfg.caption_channels, generator=g) * 0.5).bfloat16()
+    pm, nm = torch.zeros(1, 512, dtype=torch.int64), torch.zeros(1, 512, dtype=torch.int64)
+    pm[:, :180] = 1
+    nm[:, :120] = 1
+    torch.cuda.synchronize()
+    t_setup = time.time() - t0
+    K, Wm = a.steps, a.warmup
+    n_g = min(K, max(1, round(0.4 * K))) if K > 1 else 1
+    guide = Wm + n_g
+    marks = {}
+
+    class _Stop(Exception):
+        pass
+
+    def barrier():
+        torch.cuda.synchronize()
+        if comm is not None:
+            comm.barrier()
+        torch.cuda.synchronize()
+
+    def hook(i, phase):
+        if phase == "start" and i == Wm:
+            barrier()
+            marks["t0"] = time.perf_counter()
+            wdit.PROFILE_ATTN = []
+        torch.cuda.synchronize()
+        marks[(phase[0], i)] = time.perf_counter()
+        if phase == "end" and i == Wm + K - 1:
+            barrier()
+            marks["t1"] = time.perf_counter()
+            raise _Stop
+
+    try:
+        pipe.generate_i2v(image=image, height=a.height, width=a.width, prompt_embeds=pe, prompt_attention_mask=pm, negative_prompt_embeds=ne,
+                          negative_prompt_attention_mask=nm, num_frames=frames, num_inference_steps=50, guidance_scale=4.0,
+                          generator=torch.manual_seed(42), output_type="latent", video_ref=ref, mask=mask, guided=True, resample_steps=3,
+                          guide_steps=guide, resample_round=guide, omega=1.8, omega_resample=1.0, use_pca_channel_selection=True,
+                          static=True, step_hook=hook)
+    except _Stop:
+        pass
+    el = torch.tensor([marks["t1"] - marks["t0"]], dtype=torch.float64, device=device)
+    if comm is not None:
+        comm.all_reduce_max(el)
+    elapsed = el.item()
+    prof = wdit.PROFILE_ATTN or []
+    wdit.PROFILE_ATTN = None
+    torch.cuda.synchronize()
+    attn_ms = [s.elapsed_time(e) for s, e in prof]
+    T = (frames - 1) // 4 + 1
+    tpf = (a.height // 16) * (a.width // 16)
+    L = T * tpf
+    if rank == 0:
+        gms = [1e3 * (marks[("e", i)] - marks[("s", i)]) for i in range(Wm, Wm + K) if i < guide]
+        pms = [1e3 * (marks[("e", i)] - marks[("s", i)]) for i in range(Wm, Wm + K) if i >= guide]
+        out = {"metric": "denoising steps/sec (93f x 480p, LongCat-Video 13.6B)", "value": K / elapsed, "unit": "steps/s", "n_gpus": world,
+               "steps": K, "warmup": Wm, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"LongCat-Video i2v, {frames}f {a.height}x{a.width}, 50-step schedule, IRR x3 + FLF + DSG + CFG-zero 4; timed "
+                                      f"steps {Wm}..{Wm + K - 1} = {len(gms)} guided + {len(pms)} plain",
+                          "tokens": L, "dit_layers": cfg.depth, "dit_params_bytes": model.param_bytes(),
+                          "parallelism": "single" if world == 1 else f"sp{world} (token-sharded DiT + row-sharded VAE, RCCL)"},
+               "guided_step_ms": sum(gms) / len(gms) if gms else None, "plain_step_ms": sum(pms) / len(pms) if pms else None,
+               "setup_s": t_setup}
+        if gms and pms:
+            out["job50_steps_per_s"] = 50.0 / ((20 * out["guided_step_ms"] + 30 * out["plain_step_ms"]) / 1e3)
+        if attn_ms and world == 1:
+            avg = sum(attn_ms) / len(attn_ms)
+            flop = 4.0 * (L - tpf) * L * 128 * cfg.num_heads
+            ach = flop / (avg * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "k_attn_w4<0> (LongCat noise-token self-attention, attention.py:133-134)", "bound": "mfma",
+                               "achieved": ach, "peak": MFMA_PEAK_TFLOPS_BF16, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS_BF16,
+                               "traffic": None, "launches": len(attn_ms), "avg_launch_ms": avg, "flop_per_launch": flop}
+        if cfg.depth != 48:
+            out["invalid_reason"] = f"debug run with {cfg.depth} DiT blocks (the named model has 48)"
+        if not a.no_cpu_baseline and world == 1:
+            cb = cpu_baseline_longcat()
+            C, Hd = cfg.hidden_size, cfg.ffn_hidden
+            fwd = cfg.depth * (2.0 * L * C * (6 * C + 3 * Hd) + 4.0 * L * L * C)
+            vae_flop = (5.19e6 + 8.70e6) * frames * a.height * a.width
+            t_cpu = (len(gms) * 6 + len(pms) * 2) * fwd / cb["dit_flops_per_s"] + len(gms) * vae_flop / cb["vae_flops_per_s"]
+            out["cpu_baseline"] = {"value": K / t_cpu, "unit": "steps/s", "cores": cb["cores"], "kind": "port", "sample": cb["sample"]}
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.barrier()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,7 +249,11 @@ def main():
     ap.add_argument("--flow-backend", default="tdiff", choices=["tdiff", "farneback"],
                     help="FLF motion backend: tdiff = the branch the reference runs without cv2 (golden-pinned); farneback = the "
                          "GPU restatement of cv2.calcOpticalFlowFarneback (parity with cv2 unpinned)")
+    ap.add_argument("--workload", default="wan", choices=["wan", "longcat"],
+                    help="wan = the BASELINE metric (default); longcat = the same contract on LongCat-Video 13.6B guided i2v (config 4's model)")
     a = ap.parse_args()
+    if a.workload == "longcat":
+        return main_longcat(a)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
