@@ -37,19 +37,40 @@ def select_topk(q_cmp: torch.Tensor, k_cmp: torch.Tensor, sparsity: float) -> to
     return torch.topk(score, n)[1]
 
 
+def select_cdf(q_cmp: torch.Tensor, k_cmp: torch.Tensor, cdf_threshold: float, sparsity=None):
+    """BSA:226-263 (get_select_indices_cdf / _cdf_topk): block weights = softmax(score / sqrt(D)); blocks in descending weight order,
+    as many as it takes for the cumulative weight to pass cdf_threshold (searchsorted right), at least the top-k count when sparsity is
+    given too.  Returns (sorted block indices [heads, n_q, n_k], number selected [heads, n_q])."""
+    score = torch.matmul(q_cmp, k_cmp.transpose(-1, -2))
+    w = torch.softmax(score * (1 / q_cmp.shape[-1] ** 0.5), dim=-1)
+    ws = torch.sort(w, dim=-1, descending=True)
+    cdf = torch.cumsum(ws.values, dim=-1)
+    thr = torch.full(cdf.shape[:-1] + (1,), cdf_threshold, dtype=cdf.dtype)
+    num = torch.searchsorted(cdf, thr, right=True).squeeze(-1)
+    if sparsity is not None:
+        num = num.clamp_min(int((1 - sparsity) * score.shape[-1]))
+    return ws.indices, num
+
+
 def sparse_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_indices: torch.Tensor, block_q: int, block_k: int,
-                     scale: float) -> torch.Tensor:
+                     scale: float, block_lens: torch.Tensor = None) -> torch.Tensor:
     """flash_attn_bsa_varlen_mask.py:236-285 as a masked dense softmax: q [heads, Sq, D], k / v [heads, Sk, D] (block order),
     block_indices [heads, Sq / block_q, n_sel] -> [heads, Sq, D] in q's dtype."""
     Hh, Sq, D = q.shape
     Sk = k.shape[1]
     nq, nk = Sq // block_q, Sk // block_k
     allow = torch.zeros((Hh, nq, nk), dtype=torch.bool)
-    allow.scatter_(2, block_indices.long(), True)
+    if block_lens is None:
+        allow.scatter_(2, block_indices.long(), True)
+    else:  # variable-length lists: the first block_lens entries of each (sorted) index row
+        use = torch.arange(block_indices.shape[-1]).view(1, 1, -1) < block_lens.unsqueeze(-1)
+        allow.scatter_(2, block_indices.long(), use)
     mask = allow.repeat_interleave(block_q, dim=1).repeat_interleave(block_k, dim=2)
     s = torch.einsum("hqd,hkd->hqk", q.float(), k.float()) * scale
     s = s.masked_fill(~mask, float("-inf"))
-    return torch.einsum("hqk,hkd->hqd", torch.softmax(s, dim=-1), v.float()).to(q.dtype)
+    p = torch.softmax(s, dim=-1)
+    p = torch.where(mask.any(dim=-1, keepdim=True), p, torch.zeros_like(p))  # empty selection: acc / l = 0 / 1 in the reference's kernel
+    return torch.einsum("hqk,hkd->hqd", p, v.float()).to(q.dtype)
 
 
 def flash_attn_bsa_3d(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, shape_q: Tuple[int, int, int], shape_k: Tuple[int, int, int],

@@ -147,3 +147,36 @@ def test_longcat_dit_with_block_sparse_attention(ncl):
                 same += set(a[hh, q].tolist()) == set(b[hh, q].tolist())
                 total += 1
     assert same / total >= 0.8, (same, total)
+
+
+def test_cdf_threshold_selection_with_empty_and_variable_lists():
+    """bsa_interface.py:226-263 on the device vs the oracle (pinned to the reference's functions, golden g14b), and the kernel on the
+    variable-length lists it produces -- including query blocks whose selection is EMPTY (a dominant block already passes the
+    threshold, searchsorted(right) returns 0): the reference's kernel then yields zeros."""
+    from worldforge_amd import bsa
+    Hh, Sq, Sk = 2, 768, 1024
+    g = torch.Generator().manual_seed(3)
+    q = (torch.randn(Hh, Sq, 128, generator=g) * 0.3).to(BF)
+    k = (torch.randn(Hh, Sk, 128, generator=g) * 0.3).to(BF)
+    v = torch.randn(Hh, Sk, 128, generator=g).to(BF)
+    u = torch.randn(Hh, 1, 128, generator=g)
+    q[:, :128] += u.to(BF)          # query block 0 has a common direction ...
+    k[:, 128:256] += (2 * u).to(BF)  # ... that key block 1 shares: its block weight alone passes the threshold
+    qc, kc = bsa.mean_pool(q.to(DEV).contiguous()), bsa.mean_pool(k.to(DEV).contiguous())
+    sc = bsa.block_scores(qc, kc)
+    for thr, sp in ((0.5, None), (0.3, 0.75)):
+        idx, lens = bsa.select_cdf(sc.float(), thr, sp)
+        widx, wlens = obsa.select_cdf(qc.float().cpu(), kc.float().cpu(), thr, sp)
+        # same scores up to bf16 rounding of the block scores: counts agree except at exact threshold crossings
+        assert (lens.cpu() - wlens).abs().max() <= 1
+        kd, vt = _layouts(k, v)
+        out = torch.full((Sq, Hh * 128), float("nan"), dtype=BF, device=DEV)
+        bsa.sparse_attention(q.to(DEV).contiguous(), kd, vt, out, idx, 128 ** -0.5, Sk // 128, lens)
+        want = obsa.sparse_attention(q.float(), k.float(), v.float(), idx.cpu(), 128, 128, 128 ** -0.5, block_lens=lens.cpu())
+        got = out.float().cpu().view(Sq, Hh, 128).permute(1, 0, 2)
+        assert torch.isfinite(got).all()
+        assert (got - want).abs().max().item() <= 1e-2 * want.abs().max().item()
+        if sp is None:
+            assert (lens == 0).any()  # the empty-selection path is exercised
+            empty = (lens.cpu() == 0).repeat_interleave(128, dim=1)
+            assert got[empty].abs().max().item() == 0

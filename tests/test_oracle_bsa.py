@@ -38,3 +38,19 @@ def test_sparse_attention_with_all_blocks_is_dense_and_3d_wrapper_round_trips():
     assert (out - dense).abs().max() < 1e-5
     sp, idx = obsa.flash_attn_bsa_3d(q, k, v, (T, H, W), (T, H, W), sparsity=0.75, chunk_q=(2, 2, 4), chunk_k=(2, 2, 4), return_indices=True)
     assert idx.shape == (Hh, 8, 2) and (sp - dense).abs().max() > 1e-3
+
+
+def test_cdf_selection_equals_reference():
+    C = np.load(os.path.join(os.path.dirname(__file__), "golden", "g14b_bsa_cdf.npz"))
+    for name in ("cdf", "cdf_topk"):
+        thr, sp = (float(v) for v in C[f"{name}_cfg"])
+        idx, lens = obsa.select_cdf(torch.from_numpy(C[f"{name}_qc"]), torch.from_numpy(C[f"{name}_kc"]), thr, None if sp < 0 else sp)
+        assert np.array_equal(lens.numpy(), C[f"{name}_lens"])
+        assert np.array_equal(idx.numpy(), C[f"{name}_idx"])
+    # variable-length lists in the masked attention: only the first `lens` entries of a row count
+    g = torch.Generator().manual_seed(2)
+    q, k, v = (torch.randn(1, 256, 128, generator=g) for _ in range(3))
+    idx = torch.tensor([[[1, 0], [0, 1]]])
+    a = obsa.sparse_attention(q, k, v, idx, 128, 128, 0.1, block_lens=torch.tensor([[1, 2]]))
+    b = obsa.sparse_attention(q, k, v, torch.tensor([[[1], [0]]]), 128, 128, 0.1)
+    assert torch.equal(a[:, :128], b[:, :128]) and not torch.equal(a[:, 128:], b[:, 128:])

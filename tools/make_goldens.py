@@ -604,3 +604,25 @@ def g_longcat_refine():
 
 if __name__ == "__main__" and "longcat_refine" in sys.argv[1:]:
     g_longcat_refine()
+
+
+def g_bsa_cdf():
+    """G14b: the reference's cdf / cdf+top-k block selection functions (bsa_interface.py:226-263), eager."""
+    sys.path.insert(0, "/root/reference/longcat_for_worldforge")
+    from longcat_video.block_sparse_attention import bsa_interface as B
+
+    g = torch.Generator().manual_seed(19)
+    out = {}
+    for name, (Hh, nq, nk, thr, sp) in {"cdf": (2, 6, 12, 0.6, None), "cdf_topk": (3, 5, 16, 0.3, 0.75)}.items():
+        qc = torch.randn(1, Hh, nq, 128, generator=g) * 2.0
+        kc = torch.randn(1, Hh, nk, 128, generator=g) * 2.0
+        idx, lens = B.get_select_indices(qc, kc, sp, thr)
+        out[f"{name}_qc"], out[f"{name}_kc"] = qc[0].numpy(), kc[0].numpy()
+        out[f"{name}_idx"], out[f"{name}_lens"] = idx[0].numpy(), lens[0].numpy()
+        out[f"{name}_cfg"] = np.array([thr, -1.0 if sp is None else sp])
+    np.savez_compressed(os.path.join(OUT, "g14b_bsa_cdf.npz"), **out)
+    print("g14b", {k: v.tolist() for k, v in out.items() if k.endswith("_lens")})
+
+
+if __name__ == "__main__" and "bsa_cdf" in sys.argv[1:]:
+    g_bsa_cdf()

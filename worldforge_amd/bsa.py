@@ -69,31 +69,48 @@ def select_topk(scores: torch.Tensor, sparsity: float) -> torch.Tensor:
     return torch.topk(scores, n)[1]
 
 
-def group_lists(block_indices: torch.Tensor, n_k: int):
+def select_cdf(scores: torch.Tensor, cdf_threshold: float, sparsity=None):
+    """BSA:226-263: softmax(score / sqrt(128)) block weights, descending; as many blocks as the cumulative weight needs to pass
+    cdf_threshold, at least the top-k count when `sparsity` is given.  Returns (sorted indices [heads, n_q, n_k], counts [heads, n_q])."""
+    w = torch.softmax(scores * (1 / 128 ** 0.5), dim=-1)
+    ws = torch.sort(w, dim=-1, descending=True)
+    cdf = torch.cumsum(ws.values, dim=-1)
+    thr = torch.full(cdf.shape[:-1] + (1,), cdf_threshold, dtype=cdf.dtype, device=cdf.device)
+    num = torch.searchsorted(cdf, thr, right=True).squeeze(-1)
+    if sparsity is not None:
+        num = num.clamp_min(int((1 - sparsity) * scores.shape[-1]))
+    return ws.indices, num.clamp_max(scores.shape[-1])
+
+
+def group_lists(block_indices: torch.Tensor, n_k: int, block_lens: torch.Tensor = None):
     """[heads, n_q, n_sel] selected key blocks per query block -> the per-workgroup lists `wf_attn_bsa_fwd` walks: one list per pair of
     consecutive query blocks (2 x 128 = the 256 query rows of a workgroup) holding the union of the pair's blocks in ascending order,
     entry = block * 4 + (selected by the first) + 2 * (selected by the second).  Returns (lists int32 [heads, n_groups, max_entries],
     counts int32 [heads, n_groups], max_entries); max_entries = min(2 * n_sel, n_k) is a shape-only bound: no host sync."""
     Hh, nq, nsel = block_indices.shape
     allow = torch.zeros((Hh, nq + (nq & 1), n_k), dtype=torch.bool, device=block_indices.device)
-    allow[:, :nq].scatter_(2, block_indices.long(), True)
+    if block_lens is None:
+        allow[:, :nq].scatter_(2, block_indices.long(), True)
+    else:  # variable-length selections (cdf threshold): the first block_lens entries of each row
+        use = torch.arange(nsel, device=block_indices.device).view(1, 1, -1) < block_lens.unsqueeze(-1)
+        allow[:, :nq].scatter_(2, block_indices.long(), use)
     a, b = allow[:, 0::2], allow[:, 1::2]
     union = a | b
     counts = union.sum(dim=-1).to(torch.int32)
     order = torch.sort((~union).to(torch.uint8), dim=-1, stable=True)[1]  # selected blocks first, ascending
-    max_entries = min(2 * nsel, n_k)
+    max_entries = min(2 * nsel, n_k)  # (variable-length lists come with nsel = n_k: the bound is n_k)
     order = order[..., :max_entries]
     entries = order * 4 + a.gather(2, order).long() + 2 * b.gather(2, order).long()
     return entries.to(torch.int32).contiguous(), counts.contiguous(), max_entries
 
 
 def sparse_attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, block_indices: torch.Tensor, scale: float,
-                     n_k_blocks: int):
+                     n_k_blocks: int, block_lens: torch.Tensor = None):
     """q [heads, Lq, 128], k [heads, Lkp, 128], vt [heads, Lkp/64, 128, 64] in block order; block_indices [heads, Lq/128, n_sel] over the
     first n_k_blocks key blocks -> out [Lq, ld] bf16 (block order)."""
     Hh, Lq, _ = q.shape
     Lkp = k.shape[1]
-    lists, counts, mx = group_lists(block_indices, n_k_blocks)
+    lists, counts, mx = group_lists(block_indices, n_k_blocks, block_lens)
     call("wf_attn_bsa_fwd", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), Hh, Lq, Lkp, out.stride(0), float(scale),
          lists.data_ptr(), counts.data_ptr(), mx, ops.stream())
     return out

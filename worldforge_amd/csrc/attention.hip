@@ -171,7 +171,15 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
   if constexpr (KIND == 2) {
     bsa = a.bsa_list + ((size_t)head * a.n_qblk + qblk) * a.bsa_max;
     ntiles = 2 * a.bsa_cnt[head * a.n_qblk + qblk];
-    if (ntiles == 0) return;  // nothing selected by either query block (cannot happen with top-k >= 1)
+    if (ntiles == 0) {
+      // nothing selected by either query block (a cdf-threshold selection may be empty: bsa_interface.py:239-240 with a dominant
+      // block): the reference's kernel then returns acc / l = 0 / 1 (flash_attn_bsa_varlen_mask.py:242-244) -> zeros
+      if (q_row < a.Lq) {
+        uint16_t* op = a.O + (size_t)q_row * a.ldo + head * D;
+        for (int d = hi * 64; d < hi * 64 + 64; d += 8) *reinterpret_cast<u32x4*>(op + d) = u32x4{0u, 0u, 0u, 0u};
+      }
+      return;
+    }
   }
   constexpr int PF = 4;  // fragment prefetch depth (LDS reads in flight ahead of the MFMA that consumes them)
   constexpr int NBUF = 4;
@@ -428,7 +436,8 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
 
   // ---- finish: combine the two half-wave partial sums, normalise, store ------------------------------------------------
   l_run += __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_run;
+  float inv = 1.0f / l_run;
+  if constexpr (KIND == 2) inv = l_run > 0.f ? inv : 0.f;  // a query block with an empty selection: zeros, as the reference (see above)
   if (q_row < a.Lq) {
     uint16_t* op = a.O + (size_t)q_row * a.ldo + head * D;
 #pragma unroll

@@ -135,8 +135,6 @@ class LongCatVideoTransformer3DModel:
         # sparsity, chunk_3d_shape_q, chunk_3d_shape_k (cdf_threshold is not built)
         self._bsa = bool(enable_bsa)
         self.bsa_params = dict(bsa_params) if bsa_params else dict(sparsity=0.875, chunk_3d_shape_q=[4, 4, 8], chunk_3d_shape_k=[4, 4, 8])  # bsa_interface.py:618-621 defaults
-        if self.bsa_params.get("cdf_threshold") is not None:
-            raise NotImplementedError("cdf-threshold block selection (bsa_interface.py:226-263) is not built; top-k only")
         self.last_bsa_indices = None
 
     def enable_bsa(self):
@@ -369,7 +367,16 @@ class LongCatVideoTransformer3DModel:
             pos_n = (pos[nc:] - nc).contiguous()
             vperm = _buf("vperm", (L, C), bf)
             aob = _buf("aob", (L, C), bf)
-            sparsity = float(self.bsa_params["sparsity"])
+            sparsity = self.bsa_params.get("sparsity")
+            cdf_thr = self.bsa_params.get("cdf_threshold")
+            if sparsity is None and cdf_thr is None:
+                raise ValueError("bsa_params needs sparsity and / or cdf_threshold (bsa_interface.py:265-274)")
+
+            def select(scores):  # bsa_interface.py:265-274 -> (block indices, per-row counts or None)
+                if cdf_thr is None:
+                    return bsa.select_topk(scores, float(sparsity)), None
+                return bsa.select_cdf(scores, float(cdf_thr), None if sparsity is None else float(sparsity))
+
             self.last_bsa_indices = []
 
         for i in range(cfg.depth):
@@ -392,12 +399,12 @@ class LongCatVideoTransformer3DModel:
                 kcmp = bsa.mean_pool(kh)
                 picked = []
                 if nc > 0:
-                    idx = bsa.select_topk(bsa.block_scores(bsa.mean_pool(qh_c), kcmp[:, :nc // 128]), sparsity)
-                    bsa.sparse_attention(qh_c, kh, vt, aob[:nc], idx, scale, nc // 128)
-                    picked.append(idx)
-                idx = bsa.select_topk(bsa.block_scores(bsa.mean_pool(qh_n), kcmp), sparsity)
-                bsa.sparse_attention(qh_n, kh, vt, aob[nc:], idx, scale, L // 128)
-                picked.append(idx)
+                    idx, lens = select(bsa.block_scores(bsa.mean_pool(qh_c), kcmp[:, :nc // 128]))
+                    bsa.sparse_attention(qh_c, kh, vt, aob[:nc], idx, scale, nc // 128, lens)
+                    picked.append(idx if lens is None else (idx, lens))
+                idx, lens = select(bsa.block_scores(bsa.mean_pool(qh_n), kcmp))
+                bsa.sparse_attention(qh_n, kh, vt, aob[nc:], idx, scale, L // 128, lens)
+                picked.append(idx if lens is None else (idx, lens))
                 self.last_bsa_indices.append(picked)
                 call("wf_gather_rows_bf16", aob.data_ptr(), aob.stride(0), pos.data_ptr(), ao.data_ptr(), ao.stride(0), L, C, ops.stream())
             else:
