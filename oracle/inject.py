@@ -4,7 +4,7 @@ Restates SCHED = utils/scheduling_unipc_multistep_clean.py and PIPE = utils/pipe
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Sequence
+from typing import Callable, List, Sequence
 
 import numpy as np
 import torch

@@ -6,7 +6,7 @@ Restates WanImageToVideoPipeline.prepare_latents (PIPE:301-362) and the loop of 
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Callable, List, Optional
+from typing import Callable, Optional
 
 import torch
 

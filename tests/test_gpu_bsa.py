@@ -1,7 +1,6 @@
 """GPU: block-sparse attention of the LongCat refine pass (worldforge_amd/bsa.py, wf_attn_bsa_fwd) against oracle/bsa.py.
 Tolerances: attention |err| <= 1e-2 * max|ref| (bf16 output, fp32 accumulation order); mean pooling <= 1 bf16 ulp; block scores
 <= 1 bf16 ulp of the fp32 product, and the selection must be identical wherever the oracle's top-k margin exceeds that."""
-import math
 
 import pytest
 import torch
@@ -128,10 +127,6 @@ def test_longcat_dit_with_block_sparse_attention(ncl):
     assert ((dense.cpu() - want).norm() / want.norm()).item() > rel + 4e-3  # (random weights: attention is a small part of the output)
     # the oracle's own selection (gating in bf16 as the reference's bf16 model) agrees with the product's on the first layer
     own = []
-
-    class _Rec(list):
-        pass
-
     import oracle.bsa as obsa
     orig = obsa.select_topk
     obsa.select_topk = lambda *a, **k: own.append(orig(*a, **k)) or own[-1]

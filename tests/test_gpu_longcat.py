@@ -4,7 +4,6 @@
 Tolerances (stated): the element-wise kernels reproduce the reference's bf16 rounding points, so they must match a torch
 restatement with the same casts to <= 1 bf16 ulp (2^-7 relative); whole model: relative L2 error <= 2e-2 against the fp32 oracle on
 identical bf16-valued weights and inputs (bf16 activations between layers, as the reference's bf16 model)."""
-import math
 import os
 
 import numpy as np
