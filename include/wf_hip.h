@@ -258,6 +258,15 @@ int wf_transpose_bf16(const void* in, int ld_in, void* out, int ld_out, int R, i
 int wf_ncthw_to_cl(const float* in, float* out_f32, void* out_bf16, int C, int Cpad, size_t N, void* stream);
 int wf_cl_to_ncthw(const float* in, float* out, int C, int ld, size_t N, float clamp, void* stream);
 
+/* ---- stage-1 forward warping (vggt/modules/utils_warp.py:863-945, warp_single_img without crack filling) ------------------------- */
+/* Depth-guided forward splat of one image to n_cameras new views: un-project (fp64) -> world -> each camera -> project -> nearest pixel,
+ * nearest source wins (z-buffer).  image f32 [H][W][3] in [0,1]; depth f32 [H][W] (NaN / <= 0 = invalid, i.e. already filtered by
+ * confidence); geometry = 30 doubles {K^-1 (9), K (9), R^T (9), -R^T t (3)} of the source camera; cameras = n x 12 doubles (rows of
+ * [R | t] of every new camera).  out_images u8 [n][H][W][3], out_masks u8 [n][H][W] (1 = written), out_depth f32 [n][H][W] (NaN =
+ * empty); zbuffer: n*H*W 8-byte words of scratch. */
+int wf_warp_splat(const float* image, const float* depth, const double* geometry, const double* cameras, void* out_images, void* out_masks,
+                  float* out_depth, void* zbuffer, int n_cameras, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

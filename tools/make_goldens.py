@@ -626,3 +626,42 @@ def g_bsa_cdf():
 
 if __name__ == "__main__" and "bsa_cdf" in sys.argv[1:]:
     g_bsa_cdf()
+
+
+# ------------------------------------------------------------------------------------------------------------
+def warp_case(seed=4, H=48, W=64):
+    g = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    depth = (2.0 + 0.6 * np.sin(xx / 9.0) + 0.4 * np.cos(yy / 7.0) + 0.05 * g.standard_normal((H, W))).astype(np.float32)
+    depth[(xx > 40) & (yy < 20)] = 1.1          # a near object: occlusions and disocclusions
+    depth[5:8, 5:9] = np.nan                     # invalid depth
+    image = g.random((H, W, 3)).astype(np.float32)
+    K = np.array([[55.0, 0, W / 2 - 0.5], [0, 55.0, H / 2 - 0.5], [0, 0, 1]])
+    th = 0.1
+    E = np.eye(4)
+    E[:3, :3] = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    E[:3, 3] = [0.05, -0.02, 0.1]
+    return image, depth, K, E
+
+
+def g_warp():
+    """G16: vggt/modules/utils_warp.py warp_single_img, unmodified, fill_cracks=False (the OpenCV-free part), two camera paths."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "refshim_cv2"))
+    sys.path.insert(0, "/root/reference/vggt")
+    from modules import utils_warp as UW
+
+    image, depth, K, E = warp_case()
+    out = dict(image=image, depth=depth, K=K, E=E)
+    for name, (direction, deg, fn) in {"right": ("right", 12.0, UW.get_look_right_camera_seq), "forward": ("forward", 30.0, UW.get_look_forward_camera_seq)}.items():
+        imgs, masks, infos = UW.warp_single_img(E[:3], K, torch.from_numpy(image).permute(2, 0, 1), torch.from_numpy(depth), depth_conf=None,
+                                                direction=direction, degree=deg, frame_num=5, fill_cracks=False)
+        mean_depth = np.nanmean(depth[~np.isnan(depth) & (depth > 0)])
+        cams = fn(E.copy(), deg, 5, mean_depth)
+        out[f"{name}_cams"] = np.stack(cams)
+        out[f"{name}_imgs"], out[f"{name}_masks"] = np.stack(imgs), np.stack(masks)
+        print("g16", name, out[f"{name}_imgs"].shape, float(np.stack(masks)[1:].mean()))
+    np.savez_compressed(os.path.join(OUT, "g16_warp.npz"), **out)
+
+
+if __name__ == "__main__" and "warp" in sys.argv[1:]:
+    g_warp()

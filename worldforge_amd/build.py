@@ -37,6 +37,7 @@ SOURCES = {
     "vae_ops.hip": [],
     "conv.hip": [],
     "comm.hip": [],
+    "warp.hip": ["-ffp-contract=off"],
 }
 
 
