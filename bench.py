@@ -159,6 +159,9 @@ def main_longcat(a):
     K, Wm = a.steps, a.warmup
     n_g = min(K, max(1, round(0.4 * K))) if K > 1 else 1
     guide = Wm + n_g
+    n_sched, cfg_scale = (16, 1.0) if a.distill else (50, 4.0)
+    if Wm + K > n_sched:
+        raise SystemExit(f"--warmup + --steps must fit the {n_sched}-step schedule")
     marks = {}
 
     class _Stop(Exception):
@@ -184,8 +187,9 @@ def main_longcat(a):
 
     try:
         pipe.generate_i2v(image=image, height=a.height, width=a.width, prompt_embeds=pe, prompt_attention_mask=pm, negative_prompt_embeds=ne,
-                          negative_prompt_attention_mask=nm, num_frames=frames, num_inference_steps=50, guidance_scale=4.0,
-                          generator=torch.manual_seed(42), output_type="latent", video_ref=ref, mask=mask, guided=True, resample_steps=3,
+                          negative_prompt_attention_mask=nm, num_frames=frames, num_inference_steps=n_sched, use_distill=a.distill,
+                          guidance_scale=cfg_scale, generator=torch.manual_seed(42), output_type="latent", video_ref=ref, mask=mask,
+                          guided=True, resample_steps=3,
                           guide_steps=guide, resample_round=guide, omega=1.8, omega_resample=1.0, use_pca_channel_selection=True,
                           static=True, step_hook=hook)
     except _Stop:
@@ -207,14 +211,19 @@ def main_longcat(a):
         out = {"metric": "denoising steps/sec (93f x 480p, LongCat-Video 13.6B)", "value": K / elapsed, "unit": "steps/s", "n_gpus": world,
                "steps": K, "warmup": Wm, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"LongCat-Video i2v, {frames}f {a.height}x{a.width}, 50-step schedule, IRR x3 + FLF + DSG + CFG-zero 4; timed "
-                                      f"steps {Wm}..{Wm + K - 1} = {len(gms)} guided + {len(pms)} plain",
+               "config": {"workload": f"LongCat-Video i2v, {frames}f {a.height}x{a.width}, "
+                                      + ("distilled 16-step schedule, IRR x3 + FLF + DSG, no CFG; timed " if a.distill else
+                                         "50-step schedule, IRR x3 + FLF + DSG + CFG-zero 4; timed ")
+                                      + f"steps {Wm}..{Wm + K - 1} = {len(gms)} guided + {len(pms)} plain",
                           "tokens": L, "dit_layers": cfg.depth, "dit_params_bytes": model.param_bytes(),
                           "parallelism": "single" if world == 1 else f"sp{world} (token-sharded DiT + row-sharded VAE, RCCL)"},
                "guided_step_ms": sum(gms) / len(gms) if gms else None, "plain_step_ms": sum(pms) / len(pms) if pms else None,
                "setup_s": t_setup}
         if gms and pms:
-            out["job50_steps_per_s"] = 50.0 / ((20 * out["guided_step_ms"] + 30 * out["plain_step_ms"]) / 1e3)
+            if a.distill:
+                out["job16_steps_per_s"] = 16.0 / ((6 * out["guided_step_ms"] + 10 * out["plain_step_ms"]) / 1e3)
+            else:
+                out["job50_steps_per_s"] = 50.0 / ((20 * out["guided_step_ms"] + 30 * out["plain_step_ms"]) / 1e3)
         if attn_ms and world == 1:
             avg = sum(attn_ms) / len(attn_ms)
             flop = 4.0 * (L - tpf) * L * 128 * cfg.num_heads
@@ -229,7 +238,8 @@ def main_longcat(a):
             C, Hd = cfg.hidden_size, cfg.ffn_hidden
             fwd = cfg.depth * (2.0 * L * C * (6 * C + 3 * Hd) + 4.0 * L * L * C)
             vae_flop = (5.19e6 + 8.70e6) * frames * a.height * a.width
-            t_cpu = (len(gms) * 6 + len(pms) * 2) * fwd / cb["dit_flops_per_s"] + len(gms) * vae_flop / cb["vae_flops_per_s"]
+            per = 1 if a.distill else 2  # DiT forwards per evaluation (CFG pair or not)
+            t_cpu = (len(gms) * 3 * per + len(pms) * per) * fwd / cb["dit_flops_per_s"] + len(gms) * vae_flop / cb["vae_flops_per_s"]
             out["cpu_baseline"] = {"value": K / t_cpu, "unit": "steps/s", "cores": cb["cores"], "kind": "port", "sample": cb["sample"]}
         print(json.dumps(out), flush=True)
     if comm is not None:
@@ -249,6 +259,9 @@ def main():
     ap.add_argument("--flow-backend", default="tdiff", choices=["tdiff", "farneback"],
                     help="FLF motion backend: tdiff = the branch the reference runs without cv2 (golden-pinned); farneback = the "
                          "GPU restatement of cv2.calcOpticalFlowFarneback (parity with cv2 unpinned)")
+    ap.add_argument("--distill", action="store_true",
+                    help="with --workload longcat: the distilled 16-step schedule without CFG (BASELINE config 4's first half; the "
+                         "cfg_step_lora is a weight fold and does not change the cost)")
     ap.add_argument("--workload", default="wan", choices=["wan", "longcat"],
                     help="wan = the BASELINE metric (default); longcat = the same contract on LongCat-Video 13.6B guided i2v (config 4's model)")
     a = ap.parse_args()
