@@ -665,3 +665,25 @@ def g_warp():
 
 if __name__ == "__main__" and "warp" in sys.argv[1:]:
     g_warp()
+
+
+def g_warp_cams():
+    """G16b: the reference's ten camera-path generators through warp_single_img's dispatch (utils_warp.py:818-839)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "refshim_cv2"))
+    sys.path.insert(0, "/root/reference/vggt")
+    from modules import utils_warp as UW
+
+    _, _, _, E = warp_case()
+    fns = {"up": (UW.get_look_up_camera_seq, 1), "down": (UW.get_look_up_camera_seq, -1), "right": (UW.get_look_right_camera_seq, 1),
+           "left": (UW.get_look_right_camera_seq, -1), "forward": (UW.get_look_forward_camera_seq, 1),
+           "backward": (UW.get_look_backward_camera_seq, 1), "up_pan": (UW.get_up_pan_camera_seq, 1), "down_pan": (UW.get_down_pan_camera_seq, 1),
+           "left_pan": (UW.get_left_pan_camera_seq, 1), "right_pan": (UW.get_right_pan_camera_seq, 1)}
+    out = {"E": E}
+    for name, (fn, sgn) in fns.items():
+        out[name] = np.stack(fn(E.copy(), sgn * 17.0, 6, 2.3))
+    np.savez_compressed(os.path.join(OUT, "g16b_warp_cams.npz"), **out)
+    print("g16b", len(out) - 1, "paths")
+
+
+if __name__ == "__main__" and "warp_cams" in sys.argv[1:]:
+    g_warp_cams()

@@ -40,3 +40,75 @@ def forward_splat(image: torch.Tensor, depth: torch.Tensor, intrinsic, extrinsic
     call("wf_warp_splat", img.data_ptr(), dep.data_ptr(), geom_d.data_ptr(), cams_d.data_ptr(), out_img.data_ptr(), out_mask.data_ptr(),
          out_depth.data_ptr(), zbuf.data_ptr(), n, H, W, ops.stream())
     return out_img, out_mask, out_depth
+
+
+# ---- camera paths (vggt/modules/utils_warp.py:64-383 + the dispatch of warp_single_img :818-839): 4x4 host math, float64 ------------
+def _rot(axis: str, rad: float) -> np.ndarray:
+    c, s = np.cos(rad), np.sin(rad)
+    if axis == "x":
+        return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+def _look_at(R0: np.ndarray, cam_pos: np.ndarray, target: np.ndarray, guarded: bool):
+    """Camera at cam_pos looking at target, up vector = the source camera's y axis made orthogonal to the view direction."""
+    z = target - cam_pos
+    n = np.linalg.norm(z)
+    if guarded and not n > 1e-6:
+        return None
+    z = z / n
+    y0 = R0.T @ np.array([0, 1, 0])
+    y = y0 - np.dot(y0, z) * z
+    yn = np.linalg.norm(y)
+    if guarded and not yn > 1e-6:
+        y = np.array([0, 1, 0]) if abs(z[1]) < 0.9 else np.array([1, 0, 0])
+        y = y - np.dot(y, z) * z
+        yn = np.linalg.norm(y)
+    y = y / yn
+    x = np.cross(y, z)
+    x = x / np.linalg.norm(x)
+    return np.column_stack([x, y, z]).T
+
+
+def camera_path(direction: str, extrinsic, degree: float, frame_num: int, look_at_depth: float):
+    """The reference's camera sequences: `up` / `down` / `left` / `right` orbit the point `look_at_depth` in front of the camera by up
+    to +-degree about the x / y axis and re-aim at it; `forward` / `backward` dolly along the view direction by degree % of that depth;
+    `*_pan` rotate in place.  Returns frame_num 4x4 world -> camera matrices, the first being the source camera."""
+    E = np.eye(4)
+    ext = np.asarray(extrinsic, dtype=np.float64)
+    E[:ext.shape[0], :] = ext
+    R, t = E[:3, :3], E[:3, 3]
+    cam_pos = -R.T @ t
+    d = direction.lower()
+    out = []
+    if d in ("up", "down", "left", "right"):
+        axis = "x" if d in ("up", "down") else "y"
+        sign = 1.0 if d in ("up", "right") else -1.0
+        look_at = cam_pos + R.T @ np.array([0, 0, look_at_depth])
+        for deg in np.linspace(0, sign * degree, frame_num):
+            new_pos = look_at - _rot(axis, np.deg2rad(deg)) @ (look_at - cam_pos)
+            nR = _look_at(R, new_pos, look_at, guarded=False)
+            out.append((nR, new_pos))
+    elif d in ("forward", "backward"):
+        centre = cam_pos + R.T @ np.array([0, 0, look_at_depth])
+        to_c = centre - cam_pos
+        radius = np.linalg.norm(to_c)
+        step = (to_c / radius) if d == "forward" else (-to_c / radius)
+        for prog in np.linspace(0, degree / 100.0, frame_num):
+            new_pos = cam_pos + step * (radius * prog)
+            nR = _look_at(R, new_pos, centre, guarded=True)
+            out.append((R.copy() if nR is None else nR, new_pos))
+    elif d in ("up_pan", "down_pan", "left_pan", "right_pan"):
+        axis = "x" if d in ("up_pan", "down_pan") else "y"
+        sign = 1.0 if d in ("up_pan", "right_pan") else -1.0
+        for deg in np.linspace(0, degree, frame_num):
+            out.append((R @ _rot(axis, np.deg2rad(sign * deg)), cam_pos))
+    else:
+        raise ValueError(f"Unsupported direction: {direction}")
+    cams = []
+    for nR, pos in out:
+        c = E.copy()
+        c[:3, :3] = nR
+        c[:3, 3] = -nR @ pos
+        cams.append(c)
+    return cams
