@@ -211,17 +211,18 @@ int wf_lc_swiglu(const void* in, int64_t ld, void* out, int L, int Hd, void* str
 int wf_refine_upsample_u8(const void* frames_u8, float* out, int F, int H0, int W0, int Fo, int H, int W, void* stream);
 
 /* ---- LongCat block-sparse attention of the 720p refine pass (longcat_video/block_sparse_attention/bsa_interface.py = BSA) --------- */
-/* mean_pooling_compression (BSA:169-179): in bf16 [H][L][128] -> out bf16 [H][L/128][128], mean of each 128-token block. */
-int wf_lc_mean_pool_blocks(const void* in, void* out, int H, int L, void* stream);
+/* mean_pooling_compression (BSA:169-179): in bf16 [H][L][128] -> out bf16 [H][L/block][128], mean of each block of 64 / 128 tokens. */
+int wf_lc_mean_pool_blocks(const void* in, void* out, int H, int L, int block, void* stream);
 /* out[i][:C] = in[index[i]][:C], bf16 rows: the token permutes of BSA:600-610 where they cannot ride on another kernel's store. */
 int wf_gather_rows_bf16(const void* in, int64_t ld_in, const int* index, void* out, int64_t ld_out, int n_rows, int C, void* stream);
 /* The sparse attention of BSA:538-560 (flash_attn_bsa_varlen_mask.py:174-285): Q [H][Lq][128], K [H][Lkp][128], Vt [H][Lkp/64][128][64]
- * in 3D-block token order, 128 tokens per block; every query block attends to its selected key blocks only.  The selection is given
- * per GROUP of two consecutive query blocks (the 256 query rows of one workgroup): group_lists [H][ceil(Lq/256)][max_entries] int32,
- * entry = key_block * 4 + flags (bit 0 / 1: selected by the first / second query block of the group), the union of both lists in any
- * order; group_counts [H][ceil(Lq/256)] entries used.  O [Lq][ldo] bf16 (block order), head h at columns h*128. */
+ * in 3D-block token order, `block` = 128 or 64 tokens per block; every query block attends to its selected key blocks only.  The
+ * selection is given per GROUP of g = 256 / block consecutive query blocks (the 256 query rows of one workgroup): group_lists
+ * [H][ceil(Lq/256)][max_entries] int32, entry = key_block * 2^g + flags (bit i: selected by the i-th query block of the group), the
+ * union of the group's lists in any order; group_counts [H][ceil(Lq/256)] entries used.  O [Lq][ldo] bf16 (block order), head h at
+ * columns h*128. */
 int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int ldo, float softmax_scale,
-                    const int* group_lists, const int* group_counts, int max_entries, void* stream);
+                    const int* group_lists, const int* group_counts, int max_entries, int block, void* stream);
 
 /* ---- 3D causal VAE (wan/modules/vae.py; the in-tree statement of diffusers' AutoencoderKLWan), channels-last ----------- */
 /* CausalConv3d / Conv2d as implicit GEMM on MFMA (vae.py:17-36, 76-96, 186-220).  in bf16 [Ti,Hi,Wi,Cin] (Cin % 32 == 0),

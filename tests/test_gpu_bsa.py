@@ -175,3 +175,42 @@ def test_cdf_threshold_selection_with_empty_and_variable_lists():
             assert (lens == 0).any()  # the empty-selection path is exercised
             empty = (lens.cpu() == 0).repeat_interleave(128, dim=1)
             assert got[empty].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("Hh,Sq,Sk,nsel", [(2, 256, 512, 3), (3, 448, 1024, 4), (1, 64, 64, 1), (4, 1088, 2048, 9)])
+def test_sparse_attention_kernel_64_token_blocks(Hh, Sq, Sk, nsel):
+    """chunk_3d_shape 4 x 4 x 4: four query blocks per workgroup, one 64-key tile per list entry."""
+    from worldforge_amd import bsa
+    q, k, v = _rand((Hh, Sq, 128), 1).to(BF), _rand((Hh, Sk, 128), 2).to(BF), _rand((Hh, Sk, 128), 3).to(BF)
+    nq, nk = Sq // 64, Sk // 64
+    g = torch.Generator().manual_seed(4)
+    idx = torch.stack([torch.stack([torch.randperm(nk, generator=g)[:nsel] for _ in range(nq)]) for _ in range(Hh)])
+    want = obsa.sparse_attention(q.float(), k.float(), v.float(), idx, 64, 64, 128 ** -0.5)
+    kd, vt = _layouts(k, v)
+    out = torch.full((Sq, Hh * 128), float("nan"), dtype=BF, device=DEV)
+    bsa.sparse_attention(q.to(DEV).contiguous(), kd, vt, out, idx.to(DEV), 128 ** -0.5, nk, block=64)
+    got = out.float().cpu().view(Sq, Hh, 128).permute(1, 0, 2)
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max().item() <= 1e-2 * want.abs().max().item()
+    qc = bsa.mean_pool(q.to(DEV).contiguous(), 64)
+    wq = obsa.mean_pool(q, 64)
+    assert (qc.float().cpu() - wq.float()).abs().max() <= 2.0 ** -8 * wq.float().abs().max()
+
+
+def test_longcat_dit_with_64_token_blocks():
+    from oracle import longcat_dit as olc
+    from worldforge_amd.longcat_dit import LongCatConfig, LongCatVideoTransformer3DModel
+    kw = dict(hidden_size=256, depth=2, num_heads=2, caption_channels=64, adaln_tembed_dim=64)
+    ocfg = olc.LongCatConfig(**kw)
+    W = olc.random_weights(ocfg, seed=6)
+    bsa_params = dict(sparsity=0.5, chunk_3d_shape_q=[4, 4, 4], chunk_3d_shape_k=[4, 4, 4])
+    m = LongCatVideoTransformer3DModel(LongCatConfig(**kw), DEV, enable_bsa=True, bsa_params=bsa_params).load_state_dict(W)
+    T, h, w, ncl = 8, 16, 24, 4   # token grid 8 x 8 x 12 -> 12 blocks of 64
+    x = _rand((16, T, h, w), 11).to(BF)
+    cap = _rand((20, 64), 12).to(BF)
+    ts = [0.0] * ncl + [400.0] * (T - ncl)
+    got = m.forward_tokens(x.to(DEV), ts, cap.to(DEV), None, ncl)
+    picked = [[i.cpu() for i in layer] for layer in m.last_bsa_indices]
+    want = olc.forward(W, ocfg, x.float(), torch.tensor(ts), cap.float(), None, num_cond_latents=ncl, bsa=bsa_params, bsa_indices=picked)
+    rel = ((got.cpu() - want).norm() / want.norm()).item()
+    assert torch.isfinite(got).all() and rel <= 2e-2, rel

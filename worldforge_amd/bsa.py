@@ -17,7 +17,7 @@ from . import ops
 from ._ffi import call
 from .dit import EPI_BF16, gemm
 
-BLOCK = 128
+BLOCK = 128  # default block; 64 (chunk 4 x 4 x 4) is the other size the kernels take
 _PERM: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
 
 
@@ -26,8 +26,8 @@ def block_permutation(T: int, H: int, W: int, chunk: Sequence[int], device) -> T
     t, h, w = chunk
     if T % t or H % h or W % w:
         raise ValueError(f"latent grid {(T, H, W)} is not a whole number of {tuple(chunk)} blocks")
-    if t * h * w != BLOCK:
-        raise NotImplementedError("the sparse attention kernel is built for 128-token blocks (4 x 4 x 8)")
+    if t * h * w not in (64, 128):
+        raise NotImplementedError("the sparse attention kernel takes 128- or 64-token blocks (e.g. 4 x 4 x 8, 4 x 4 x 4)")
     key = (T, H, W, t, h, w, str(device))
     if key not in _PERM:
         idx = torch.arange(T * H * W).view(T // t, t, H // h, h, W // w, w).permute(0, 2, 4, 1, 3, 5).reshape(-1)
@@ -37,12 +37,12 @@ def block_permutation(T: int, H: int, W: int, chunk: Sequence[int], device) -> T
     return _PERM[key]
 
 
-def mean_pool(x: torch.Tensor) -> torch.Tensor:
-    """BSA:169-179: [heads, L, 128] bf16 -> [heads, L / 128, 128] bf16."""
+def mean_pool(x: torch.Tensor, block: int = BLOCK) -> torch.Tensor:
+    """BSA:169-179: [heads, L, 128] bf16 -> [heads, L / block, 128] bf16."""
     Hh, L, D = x.shape
     assert D == 128 and x.dtype == torch.bfloat16 and x.is_contiguous()
-    out = torch.empty((Hh, L // BLOCK, D), dtype=torch.bfloat16, device=x.device)
-    call("wf_lc_mean_pool_blocks", x.data_ptr(), out.data_ptr(), Hh, L, ops.stream())
+    out = torch.empty((Hh, L // block, D), dtype=torch.bfloat16, device=x.device)
+    call("wf_lc_mean_pool_blocks", x.data_ptr(), out.data_ptr(), Hh, L, block, ops.stream())
     return out
 
 
@@ -82,35 +82,40 @@ def select_cdf(scores: torch.Tensor, cdf_threshold: float, sparsity=None):
     return ws.indices, num.clamp_max(scores.shape[-1])
 
 
-def group_lists(block_indices: torch.Tensor, n_k: int, block_lens: torch.Tensor = None):
-    """[heads, n_q, n_sel] selected key blocks per query block -> the per-workgroup lists `wf_attn_bsa_fwd` walks: one list per pair of
-    consecutive query blocks (2 x 128 = the 256 query rows of a workgroup) holding the union of the pair's blocks in ascending order,
-    entry = block * 4 + (selected by the first) + 2 * (selected by the second).  Returns (lists int32 [heads, n_groups, max_entries],
-    counts int32 [heads, n_groups], max_entries); max_entries = min(2 * n_sel, n_k) is a shape-only bound: no host sync."""
+def group_lists(block_indices: torch.Tensor, n_k: int, block_lens: torch.Tensor = None, block: int = BLOCK):
+    """[heads, n_q, n_sel] selected key blocks per query block -> the per-workgroup lists `wf_attn_bsa_fwd` walks: one list per group of
+    g = 256 / block consecutive query blocks (the 256 query rows of a workgroup) holding the union of the group's blocks in ascending
+    order, entry = key_block * 2^g + sum_i 2^i * (selected by the i-th query block).  Returns (lists int32 [heads, n_groups,
+    max_entries], counts int32 [heads, n_groups], max_entries); max_entries = min(g * n_sel, n_k) is a shape-only bound: no host sync."""
     Hh, nq, nsel = block_indices.shape
-    allow = torch.zeros((Hh, nq + (nq & 1), n_k), dtype=torch.bool, device=block_indices.device)
+    gs = 256 // block
+    allow = torch.zeros((Hh, (nq + gs - 1) // gs * gs, n_k), dtype=torch.bool, device=block_indices.device)
     if block_lens is None:
         allow[:, :nq].scatter_(2, block_indices.long(), True)
     else:  # variable-length selections (cdf threshold): the first block_lens entries of each row
         use = torch.arange(nsel, device=block_indices.device).view(1, 1, -1) < block_lens.unsqueeze(-1)
         allow[:, :nq].scatter_(2, block_indices.long(), use)
-    a, b = allow[:, 0::2], allow[:, 1::2]
-    union = a | b
+    parts = [allow[:, i::gs] for i in range(gs)]
+    union = parts[0]
+    for pt in parts[1:]:
+        union = union | pt
     counts = union.sum(dim=-1).to(torch.int32)
     order = torch.sort((~union).to(torch.uint8), dim=-1, stable=True)[1]  # selected blocks first, ascending
-    max_entries = min(2 * nsel, n_k)  # (variable-length lists come with nsel = n_k: the bound is n_k)
+    max_entries = min(gs * nsel, n_k)  # (variable-length lists come with nsel = n_k: the bound is n_k)
     order = order[..., :max_entries]
-    entries = order * 4 + a.gather(2, order).long() + 2 * b.gather(2, order).long()
+    entries = order * (1 << gs)
+    for i, pt in enumerate(parts):
+        entries = entries + (pt.gather(2, order).long() << i)
     return entries.to(torch.int32).contiguous(), counts.contiguous(), max_entries
 
 
 def sparse_attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, block_indices: torch.Tensor, scale: float,
-                     n_k_blocks: int, block_lens: torch.Tensor = None):
+                     n_k_blocks: int, block_lens: torch.Tensor = None, block: int = BLOCK):
     """q [heads, Lq, 128], k [heads, Lkp, 128], vt [heads, Lkp/64, 128, 64] in block order; block_indices [heads, Lq/128, n_sel] over the
     first n_k_blocks key blocks -> out [Lq, ld] bf16 (block order)."""
     Hh, Lq, _ = q.shape
     Lkp = k.shape[1]
-    lists, counts, mx = group_lists(block_indices, n_k_blocks, block_lens)
+    lists, counts, mx = group_lists(block_indices, n_k_blocks, block_lens, block)
     call("wf_attn_bsa_fwd", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), Hh, Lq, Lkp, out.stride(0), float(scale),
-         lists.data_ptr(), counts.data_ptr(), mx, ops.stream())
+         lists.data_ptr(), counts.data_ptr(), mx, block, ops.stream())
     return out

@@ -72,6 +72,7 @@ struct AttnArgs {
   const int* bsa_list;  // [H][n_qblk][bsa_max]
   const int* bsa_cnt;   // [H][n_qblk]
   int bsa_max;
+  int bsa_shift;        // flag bits per entry = query blocks per workgroup: 2 (128-token blocks, 2 tiles per entry) or 4 (64-token, 1 tile)
 };
 
 #ifdef WF_ATTN_TIMING
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
   int ntiles = (a.kv_len + KB - 1) / KB;
   if constexpr (KIND == 2) {
     bsa = a.bsa_list + ((size_t)head * a.n_qblk + qblk) * a.bsa_max;
-    ntiles = 2 * a.bsa_cnt[head * a.n_qblk + qblk];
+    ntiles = (a.bsa_shift == 2 ? 2 : 1) * a.bsa_cnt[head * a.n_qblk + qblk];
     if (ntiles == 0) {
       // nothing selected by either query block (a cdf-threshold selection may be empty: bsa_interface.py:239-240 with a dominant
       // block): the reference's kernel then returns acc / l = 0 / 1 (flash_attn_bsa_varlen_mask.py:242-244) -> zeros
@@ -188,7 +189,12 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
   const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_offset(smem));
   auto stage = [&](int t) {
     int kt = t;  // KV tile held by ring slot t
-    if constexpr (KIND == 2) kt = (__builtin_amdgcn_readfirstlane(bsa[t >> 1]) >> 2) * 2 + (t & 1);
+    if constexpr (KIND == 2) {
+      if (a.bsa_shift == 2)
+        kt = (__builtin_amdgcn_readfirstlane(bsa[t >> 1]) >> 2) * 2 + (t & 1);
+      else
+        kt = __builtin_amdgcn_readfirstlane(bsa[t]) >> 4;
+    }
     const int seg = kt / tiles_per_seg;
     const size_t tile_off = ((size_t)(seg * a.H + head) * tiles_per_seg + (kt - seg * tiles_per_seg)) * (KB * D);
     const uint32_t base = smem_base + (t % NBUF) * BUF_BYTES + wu * 2048;
@@ -239,8 +245,9 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
   };
   auto phase_softmax = [&](int t) {  // online softmax of the 64 scores per query row held by the lane pair (l, l^32)
     if constexpr (KIND == 2) {
-      const int flags = __builtin_amdgcn_readfirstlane(bsa[t >> 1]) & 3;
-      if (!((flags >> (wu >> 2)) & 1)) {  // this key block is not in the list of this wave's query block
+      const int e = __builtin_amdgcn_readfirstlane(bsa[a.bsa_shift == 2 ? (t >> 1) : t]);
+      const int mine = a.bsa_shift == 2 ? (wu >> 2) : (wu >> 1);  // this wave's query block within the workgroup (128 / 64 rows each)
+      if (!((e >> mine) & 1)) {  // this key block is not in the list of this wave's query block
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -1008,6 +1015,7 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
   a.bsa_list = nullptr;
   a.bsa_cnt = nullptr;
   a.bsa_max = 0;
+  a.bsa_shift = 2;
   const int hslots = (H + 7) / 8;
   const int grid = hslots * a.n_qblk * 8;
   const size_t lds = 4 * (K_TILE_BYTES + V_TILE_BYTES);
@@ -1050,10 +1058,11 @@ extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O
 }
 
 extern "C" int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int ldo, float softmax_scale,
-                               const int* group_lists, const int* group_counts, int max_entries, void* stream) {
+                               const int* group_lists, const int* group_counts, int max_entries, int block, void* stream) {
   WF_CHECK_ARG(Q && K && Vt && O && group_lists && group_counts, "wf_attn_bsa_fwd: null pointer");
   WF_CHECK_ARG(H > 0 && Lq > 0 && Lkp > 0 && max_entries > 0, "wf_attn_bsa_fwd: empty problem");
-  WF_CHECK_ARG(Lq % 128 == 0 && Lkp % 128 == 0, "wf_attn_bsa_fwd: Lq (%d) and Lkp (%d) must be whole 128-token blocks", Lq, Lkp);
+  WF_CHECK_ARG(block == 128 || block == 64, "wf_attn_bsa_fwd: block must be 128 or 64 tokens, got %d", block);
+  WF_CHECK_ARG(Lq % block == 0 && Lkp % block == 0, "wf_attn_bsa_fwd: Lq (%d) and Lkp (%d) must be whole %d-token blocks", Lq, Lkp, block);
   WF_CHECK_ARG(ldo % 4 == 0 && ldo >= H * D, "wf_attn_bsa_fwd: bad ldo %d", ldo);
   WF_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O) & 15) == 0, "wf_attn_bsa_fwd: 16-byte alignment");
   AttnArgs a;
@@ -1078,6 +1087,7 @@ extern "C" int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, voi
   a.bsa_list = group_lists;
   a.bsa_cnt = group_counts;
   a.bsa_max = max_entries;
+  a.bsa_shift = block == 128 ? 2 : 4;
   const int grid = ((H + 7) / 8) * a.n_qblk * 8;
   hipLaunchKernelGGL(k_attn<2>, dim3(grid), dim3(NT), 4 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream, a);
   WF_LAUNCH_CHECK("wf_attn_bsa_fwd");

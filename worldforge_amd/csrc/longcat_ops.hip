@@ -169,14 +169,13 @@ __global__ void k_lc_swiglu(const uint16_t* __restrict__ in, long ld, uint16_t* 
 
 // in bf16 [H][L][128] -> out bf16 [H][L / 128][128]: mean over each block of 128 consecutive rows, fp32 accumulation, one rounding
 // (torch's mean on a bf16 tensor; bsa_interface.py:169-179).  grid (L / 128, H), 256 threads = 16 row groups x 16 column chunks.
-__global__ __launch_bounds__(256) void k_lc_mean_pool(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int L) {
+__global__ __launch_bounds__(256) void k_lc_mean_pool(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int L, int block) {
   __shared__ float sm[16][128];
   const int blk = blockIdx.x, head = blockIdx.y;
   const int ch = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  const uint16_t* base = in + ((size_t)head * L + (size_t)blk * 128) * 128 + ch * 8;
+  const uint16_t* base = in + ((size_t)head * L + (size_t)blk * block) * 128 + ch * 8;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < block / 16; ++i) {
     float v[8];
     unpack8(*reinterpret_cast<const u32x4*>(base + (size_t)(grp + 16 * i) * 128), v);
 #pragma unroll
@@ -189,7 +188,7 @@ __global__ __launch_bounds__(256) void k_lc_mean_pool(const uint16_t* __restrict
     float t = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) t += sm[g][threadIdx.x];
-    out[((size_t)head * (L / 128) + blk) * 128 + threadIdx.x] = f32_to_bf16(t * (1.0f / 128.0f));
+    out[((size_t)head * (L / block) + blk) * 128 + threadIdx.x] = f32_to_bf16(t / (float)block);
   }
 }
 
@@ -206,10 +205,11 @@ __global__ void k_gather_rows(const uint16_t* __restrict__ in, int64_t ld_in, co
 
 }  // namespace
 
-extern "C" int wf_lc_mean_pool_blocks(const void* in, void* out, int H, int L, void* stream) {
+extern "C" int wf_lc_mean_pool_blocks(const void* in, void* out, int H, int L, int block, void* stream) {
   WF_CHECK_ARG(in && out, "wf_lc_mean_pool_blocks: null pointer");
-  WF_CHECK_ARG(H > 0 && L > 0 && L % 128 == 0, "wf_lc_mean_pool_blocks: L (%d) must be whole 128-token blocks", L);
-  hipLaunchKernelGGL(k_lc_mean_pool, dim3(L / 128, H), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in, (uint16_t*)out, L);
+  WF_CHECK_ARG(block == 128 || block == 64, "wf_lc_mean_pool_blocks: block must be 128 or 64");
+  WF_CHECK_ARG(H > 0 && L > 0 && L % block == 0, "wf_lc_mean_pool_blocks: L (%d) must be whole %d-token blocks", L, block);
+  hipLaunchKernelGGL(k_lc_mean_pool, dim3(L / block, H), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in, (uint16_t*)out, L, block);
   WF_LAUNCH_CHECK("wf_lc_mean_pool_blocks");
   return WF_OK;
 }

@@ -364,6 +364,7 @@ class LongCatVideoTransformer3DModel:
                 raise ValueError(f"block-sparse attention needs the condition ({ncl}) and noise ({T - ncl}) latent frames to be "
                                  f"multiples of {cq[0]} (the reference pads them: pipeline_longcat_video.py:1417-1419)")
             perm, pos = bsa.block_permutation(T, h2, w2, cq, dev)   # the first nc rows of the block order are the condition tokens
+            blk = cq[0] * cq[1] * cq[2]
             pos_n = (pos[nc:] - nc).contiguous()
             vperm = _buf("vperm", (L, C), bf)
             aob = _buf("aob", (L, C), bf)
@@ -396,14 +397,14 @@ class LongCatVideoTransformer3DModel:
                 call("wf_gather_rows_bf16", vsrc.data_ptr(), qkv.stride(0), perm.data_ptr(), vperm.data_ptr(), vperm.stride(0), L, C,
                      ops.stream())
                 self._vt(vperm, 0, vt, L)
-                kcmp = bsa.mean_pool(kh)
+                kcmp = bsa.mean_pool(kh, blk)
                 picked = []
                 if nc > 0:
-                    idx, lens = select(bsa.block_scores(bsa.mean_pool(qh_c), kcmp[:, :nc // 128]))
-                    bsa.sparse_attention(qh_c, kh, vt, aob[:nc], idx, scale, nc // 128, lens)
+                    idx, lens = select(bsa.block_scores(bsa.mean_pool(qh_c, blk), kcmp[:, :nc // blk]))
+                    bsa.sparse_attention(qh_c, kh, vt, aob[:nc], idx, scale, nc // blk, lens, blk)
                     picked.append(idx if lens is None else (idx, lens))
-                idx, lens = select(bsa.block_scores(bsa.mean_pool(qh_n), kcmp))
-                bsa.sparse_attention(qh_n, kh, vt, aob[nc:], idx, scale, L // 128, lens)
+                idx, lens = select(bsa.block_scores(bsa.mean_pool(qh_n, blk), kcmp))
+                bsa.sparse_attention(qh_n, kh, vt, aob[nc:], idx, scale, L // blk, lens, blk)
                 picked.append(idx if lens is None else (idx, lens))
                 self.last_bsa_indices.append(picked)
                 call("wf_gather_rows_bf16", aob.data_ptr(), aob.stride(0), pos.data_ptr(), ao.data_ptr(), ao.stride(0), L, C, ops.stream())
