@@ -338,7 +338,7 @@ class LongCatVideoTransformer3DModel:
         hbuf = _buf("h", (L, C), bf)
         qkv = _buf("qkv", (L, 3 * C), bf)
         qh_c = _buf("qh_c", (H, max(nc, 1), 128), bf)
-        qh_n = _buf("qh_n", (H, max(L - nc, 1), 128), bf)[:, :L - nc] if L - nc == 0 else _buf("qh_n", (H, L - nc, 128), bf)
+        qh_n = _buf("qh_n", (H, max(L - nc, 1), 128), bf)  # (a rank of a sequence-parallel job may hold condition rows only)
         kh = _buf("kh", (H, Sp, 128), bf, zero=True)
         vt = _buf("vt", (H, Sp // 64, 128, 64), bf)
         if comm is not None:
