@@ -184,16 +184,17 @@ int wf_act(const void* a, int dt_a, const void* b, int dt_b, void* out, int dt_o
 /* ---- LongCat-Video DiT companions (longcat_for_worldforge/longcat_video/modules; LCD = longcat_video_dit.py, LCA = attention.py,
  *      LCB = blocks.py, LCR = rope_3d.py).  The LongCat residual stream is bf16 and its AdaLN parameters are per latent frame. ---- */
 /* LayerNorm_FP32 (LCB:55-68) fused with y = ln * (plus_one + mul[g][c]) + add[g][c], g = (row0 + row) / rows_per_group (0: one group;
- * row0 = global index of the first row when x is one rank's token shard):
+ * row0 = global index of the first row when x is one rank's token shard; group_index (int32 per GLOBAL row, may be NULL) replaces the
+ * division when the rows are not in frame order -- the 3D-block token order of the refine pass):
  *   modulate_fp32 with per-frame shift / scale (LCB:133-141 as called at LCD:91, 114 and LCB:165): mul = scale, add = shift,
  *   mod_ld = floats between consecutive frames, rows_per_group = tokens per frame, plus_one = 1;
  *   affine pre_crs_attn_norm (LCD:111): mul = weight, add = bias, rows_per_group = 0, plus_one = 0.   x, out bf16 [L, C]. */
-int wf_lc_ln_modulate(const void* x, const float* mul, const float* add, int64_t mod_ld, int rows_per_group, int64_t row0, int plus_one,
-                      void* out, int L, int C, float eps, void* stream);
+int wf_lc_ln_modulate(const void* x, const float* mul, const float* add, int64_t mod_ld, int rows_per_group, int64_t row0,
+                      const int* group_index, int plus_one, void* out, int L, int C, float eps, void* stream);
 /* x = bf16(x + gate[(row0 + row) / rows_per_group][c] * y) (LCD:102-104, 117-120); gate NULL: x = bf16(x + y) (LCD:111).
  * x bf16 [L, C] in place; y bf16 [L, ldy]; gate f32 rows gate_ld floats apart. */
-int wf_lc_gate_residual(void* x, const void* y, int64_t ldy, const float* gate, int64_t gate_ld, int rows_per_group, int64_t row0, int L,
-                        int C, void* stream);
+int wf_lc_gate_residual(void* x, const void* y, int64_t ldy, const float* gate, int64_t gate_ld, int rows_per_group, int64_t row0,
+                        const int* group_index, int L, int C, void* stream);
 /* RMSNorm_FP32 over each head's 128 channels (LCB:40-52 as used at LCA:111 and LCA:231) + optional interleaved 3D RoPE
  * (LCR:32-36, 101-120; cos/sin tables [L][64] f32 per rotation pair, NULL -> none), written head-major for wf_attn_fwd:
  * in bf16 [L, ld] (head h at columns h*128) -> out bf16 [H][Lout][128] (rows L..Lout untouched); weight f32 [128].
@@ -219,10 +220,10 @@ int wf_gather_rows_bf16(const void* in, int64_t ld_in, const int* index, void* o
  * in 3D-block token order, `block` = 128 or 64 tokens per block; every query block attends to its selected key blocks only.  The
  * selection is given per GROUP of g = 256 / block consecutive query blocks (the 256 query rows of one workgroup): group_lists
  * [H][ceil(Lq/256)][max_entries] int32, entry = key_block * 2^g + flags (bit i: selected by the i-th query block of the group), the
- * union of the group's lists in any order; group_counts [H][ceil(Lq/256)] entries used.  O [Lq][ldo] bf16 (block order), head h at
- * columns h*128. */
-int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int ldo, float softmax_scale,
-                    const int* group_lists, const int* group_counts, int max_entries, int block, void* stream);
+ * union of the group's lists in any order; group_counts [H][ceil(Lq/256)] entries used.  seg_len = Lkp, or the per-rank shard length
+ * when K / Vt are all-gathered shards [P][H][seg_len][128] (as wf_attn_fwd).  O [Lq][ldo] bf16 (block order), head h at columns h*128. */
+int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int seg_len, int ldo,
+                    float softmax_scale, const int* group_lists, const int* group_counts, int max_entries, int block, void* stream);
 
 /* ---- 3D causal VAE (wan/modules/vae.py; the in-tree statement of diffusers' AutoencoderKLWan), channels-last ----------- */
 /* CausalConv3d / Conv2d as implicit GEMM on MFMA (vae.py:17-36, 76-96, 186-220).  in bf16 [Ti,Hi,Wi,Cin] (Cin % 32 == 0),

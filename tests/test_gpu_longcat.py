@@ -45,12 +45,12 @@ def test_ln_modulate(L, C, tpf, affine):
     xd = x.to(DEV)
     if affine:
         w, b = (_rand((C,), 2, 0.1) + 1).to(DEV), _rand((C,), 3, 0.1).to(DEV)
-        call("wf_lc_ln_modulate", xd.data_ptr(), w.data_ptr(), b.data_ptr(), 0, 0, 0, 0, out.data_ptr(), L, C, 1e-6, ops.stream())
+        call("wf_lc_ln_modulate", xd.data_ptr(), w.data_ptr(), b.data_ptr(), 0, 0, 0, None, 0, out.data_ptr(), L, C, 1e-6, ops.stream())
         want = olc.layer_norm(x, w.cpu(), b.cpu())
     else:
         mod = _rand((T, 3 * C), 4, 0.3).to(DEV)  # [shift | scale | unused] rows 3C apart
         shift, scale = mod[:, :C], mod[:, C:2 * C]
-        call("wf_lc_ln_modulate", xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mod.stride(0), tpf, 0, 1, out.data_ptr(), L, C, 1e-6,
+        call("wf_lc_ln_modulate", xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mod.stride(0), tpf, 0, None, 1, out.data_ptr(), L, C, 1e-6,
              ops.stream())
         want = olc.modulate(x, shift.cpu(), scale.cpu(), tpf)
     assert torch.isfinite(out.float()).all()
@@ -66,7 +66,7 @@ def test_gate_residual(L, C, tpf, gated):
     xd, yd = x.to(DEV), y.to(DEV)
     yv = yd[:, C:]
     call("wf_lc_gate_residual", xd.data_ptr(), yv.data_ptr(), yd.stride(0), gate[:, C:].data_ptr() if gated else None, gate.stride(0),
-         tpf if gated else 0, 0, L, C, ops.stream())
+         tpf if gated else 0, 0, None, L, C, ops.stream())
     g = gate[:, C:].cpu().repeat_interleave(tpf, dim=0) if gated else 1.0
     want = (x.float() + g * y[:, C:].float()).to(BF)
     assert torch.equal(xd.cpu(), want)
@@ -214,11 +214,34 @@ def test_row_offset_of_a_token_shard():
     full = torch.empty((L, C), dtype=BF, device=DEV)
     part = torch.empty((L - lo, C), dtype=BF, device=DEV)
     xd = x.to(DEV)
-    call("wf_lc_ln_modulate", xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mod.stride(0), tpf, 0, 1, full.data_ptr(), L, C, 1e-6, ops.stream())
-    call("wf_lc_ln_modulate", xd[lo:].data_ptr(), scale.data_ptr(), shift.data_ptr(), mod.stride(0), tpf, lo, 1, part.data_ptr(), L - lo, C, 1e-6,
+    call("wf_lc_ln_modulate", xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mod.stride(0), tpf, 0, None, 1, full.data_ptr(), L, C, 1e-6, ops.stream())
+    call("wf_lc_ln_modulate", xd[lo:].data_ptr(), scale.data_ptr(), shift.data_ptr(), mod.stride(0), tpf, lo, None, 1, part.data_ptr(), L - lo, C, 1e-6,
          ops.stream())
     assert torch.equal(full[lo:], part)
     xa, xb, yd = x.to(DEV).clone(), x.to(DEV).clone(), y.to(DEV)
-    call("wf_lc_gate_residual", xa.data_ptr(), yd.data_ptr(), yd.stride(0), gate.data_ptr(), mod.stride(0), tpf, 0, L, C, ops.stream())
-    call("wf_lc_gate_residual", xb[lo:].data_ptr(), yd[lo:].data_ptr(), yd.stride(0), gate.data_ptr(), mod.stride(0), tpf, lo, L - lo, C, ops.stream())
+    call("wf_lc_gate_residual", xa.data_ptr(), yd.data_ptr(), yd.stride(0), gate.data_ptr(), mod.stride(0), tpf, 0, None, L, C, ops.stream())
+    call("wf_lc_gate_residual", xb[lo:].data_ptr(), yd[lo:].data_ptr(), yd.stride(0), gate.data_ptr(), mod.stride(0), tpf, lo, None, L - lo, C, ops.stream())
     assert torch.equal(xa[lo:], xb[lo:])
+
+
+def test_group_index_replaces_the_frame_division():
+    """group_index: rows in an arbitrary (here shuffled) order pick their frame's parameters through a per-row index."""
+    from worldforge_amd._ffi import call
+    from worldforge_amd import ops
+    L, C, tpf = 48, 256, 8
+    g = torch.Generator().manual_seed(5)
+    perm = torch.randperm(L, generator=g)
+    x, y = _rand((L, C), 1, 2.0).to(BF), _rand((L, C), 2).to(BF)
+    mod = _rand((L // tpf, 3 * C), 4, 0.3).to(DEV)
+    shift, scale, gate = mod[:, :C], mod[:, C:2 * C], mod[:, 2 * C:]
+    gi = (perm // tpf).to(torch.int32).to(DEV)
+    a = torch.empty((L, C), dtype=BF, device=DEV)
+    b = torch.empty((L, C), dtype=BF, device=DEV)
+    xd, xp = x.to(DEV), x[perm].to(DEV).contiguous()
+    call("wf_lc_ln_modulate", xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mod.stride(0), tpf, 0, None, 1, a.data_ptr(), L, C, 1e-6, ops.stream())
+    call("wf_lc_ln_modulate", xp.data_ptr(), scale.data_ptr(), shift.data_ptr(), mod.stride(0), 0, 0, gi.data_ptr(), 1, b.data_ptr(), L, C, 1e-6, ops.stream())
+    assert torch.equal(a[perm.to(DEV)], b)
+    xa, xb, yd, yp = xd.clone(), xp.clone(), y.to(DEV), y[perm].to(DEV).contiguous()
+    call("wf_lc_gate_residual", xa.data_ptr(), yd.data_ptr(), yd.stride(0), gate.data_ptr(), mod.stride(0), tpf, 0, None, L, C, ops.stream())
+    call("wf_lc_gate_residual", xb.data_ptr(), yp.data_ptr(), yp.stride(0), gate.data_ptr(), mod.stride(0), 0, 0, gi.data_ptr(), L, C, ops.stream())
+    assert torch.equal(xa[perm.to(DEV)], xb)

@@ -194,3 +194,28 @@ def test_longcat_guided_sampler_on_sharded_dit_and_vae_equals_single(P):
     assert torch.isfinite(want).all()
     for r, got in enumerate(_run_ranks(P, run)):
         assert torch.equal(got, want), (r, (got - want).abs().max())
+
+
+@pytest.mark.parametrize("P,ncl,T", [(2, 4, 8), (4, 4, 8), (3, 0, 12)])
+def test_token_sharded_longcat_dit_with_block_sparse_attention_equals_single(P, ncl, T):
+    """The refine-pass DiT (block-sparse self-attention, network resident in 3D-block token order), sequence parallel over whole
+    256-row query groups: pooled key blocks and K / V^T shards are all-gathered, every rank selects for its own query blocks."""
+    from oracle import longcat_dit as olc
+    from worldforge_amd.longcat_dit import LongCatConfig, LongCatVideoTransformer3DModel
+    kw = dict(hidden_size=256, depth=2, num_heads=2, caption_channels=64, adaln_tembed_dim=64)
+    W = olc.random_weights(olc.LongCatConfig(**kw), seed=5)
+    bsa_params = dict(sparsity=0.5, chunk_3d_shape_q=[4, 4, 8], chunk_3d_shape_k=[4, 4, 8])
+    Hh, Ww = 16, 32   # 128 tokens per frame: 8 / 12 blocks of 128
+    x = _rand((16, T, Hh, Ww), 60).to(BF).to(DEV)
+    cap = _rand((30, 64), 61).to(BF).to(DEV)
+    ts = [0.0] * ncl + [500.0] * (T - ncl)
+    m0 = LongCatVideoTransformer3DModel(LongCatConfig(**kw), DEV, enable_bsa=True, bsa_params=bsa_params).load_state_dict(W)
+    ref = m0.forward_tokens(x, ts, cap, None, ncl).clone()
+
+    def rank_fn(comm):
+        m = LongCatVideoTransformer3DModel(LongCatConfig(**kw), DEV, enable_bsa=True, bsa_params=bsa_params, comm=comm)
+        m.w = m0.w
+        return m.forward_tokens(x, ts, cap, None, ncl).clone()
+
+    for r, got in enumerate(_run_ranks(P, rank_fn)):
+        assert torch.equal(got, ref), (r, (got - ref).abs().max())

@@ -41,8 +41,8 @@ if __name__ == "__main__":
         ms_all = timeit(lambda: bsa.sparse_attention(q, k, vt, out, idx, scale, nb))
         from worldforge_amd._ffi import call
         from worldforge_amd import ops
-        ms_k = timeit(lambda: call("wf_attn_bsa_fwd", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, L, L, out.stride(0), scale,
-                                   lists.data_ptr(), counts.data_ptr(), mx, ops.stream()))
+        ms_k = timeit(lambda: call("wf_attn_bsa_fwd", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, L, L, L, out.stride(0), scale,
+                                   lists.data_ptr(), counts.data_ptr(), mx, 128, ops.stream()))
         print(f"{name}: union {counts.float().mean().item():.1f} blocks per 2 query blocks; kernel {ms_k:.2f} ms = {flop / ms_k / 1e9:.0f} TFLOP/s of "
               f"selected work ({flop / ms_k / 1e9 * counts.float().mean().item() / nsel:.0f} walked); with list building {ms_all:.2f} ms")
     d = timeit(lambda: dit.attention(q, k, vt, out, L, scale), it=1)

@@ -122,7 +122,7 @@ if __name__ == "__main__":
             e0.record()
             r = orig(*aa, **kk)
             e1.record()
-            ev.append((e0, e1, aa[0].shape[1], kk.get("n_k_blocks", aa[-1] if isinstance(aa[-1], int) else 0)))
+            ev.append((e0, e1, aa[0].shape[1], kk.get("n_k_blocks", aa[6] if len(aa) > 6 else 0)))
             return r
 
         wbsa.sparse_attention = timed

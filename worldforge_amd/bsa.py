@@ -111,11 +111,15 @@ def group_lists(block_indices: torch.Tensor, n_k: int, block_lens: torch.Tensor 
 
 def sparse_attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, block_indices: torch.Tensor, scale: float,
                      n_k_blocks: int, block_lens: torch.Tensor = None, block: int = BLOCK):
-    """q [heads, Lq, 128], k [heads, Lkp, 128], vt [heads, Lkp/64, 128, 64] in block order; block_indices [heads, Lq/128, n_sel] over the
+    """q [heads, Lq, 128], k [heads, Lkp, 128] and vt [heads, Lkp/64, 128, 64] in block order -- or their all-gathered per-rank shards
+    k [P, heads, S, 128], vt [P, heads, S/64, 128, 64] (keys in shard-major order); block_indices [heads, Lq/block, n_sel] over the
     first n_k_blocks key blocks -> out [Lq, ld] bf16 (block order)."""
     Hh, Lq, _ = q.shape
-    Lkp = k.shape[1]
+    if k.dim() == 4:
+        Lkp, seg = k.shape[0] * k.shape[2], k.shape[2]
+    else:
+        Lkp = seg = k.shape[1]
     lists, counts, mx = group_lists(block_indices, n_k_blocks, block_lens, block)
-    call("wf_attn_bsa_fwd", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), Hh, Lq, Lkp, out.stride(0), float(scale),
+    call("wf_attn_bsa_fwd", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), Hh, Lq, Lkp, seg, out.stride(0), float(scale),
          lists.data_ptr(), counts.data_ptr(), mx, block, ops.stream())
     return out

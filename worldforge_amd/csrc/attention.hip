@@ -1057,12 +1057,15 @@ extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O
   return attn_launch(Q, K, Vt, O, H, Lq, Lkp, kv_len, seg_len, ldo, softmax_scale, accumulate, 1, nullptr, stream, "wf_attn_fwd");
 }
 
-extern "C" int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int ldo, float softmax_scale,
-                               const int* group_lists, const int* group_counts, int max_entries, int block, void* stream) {
+extern "C" int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int seg_len, int ldo,
+                               float softmax_scale, const int* group_lists, const int* group_counts, int max_entries, int block,
+                               void* stream) {
   WF_CHECK_ARG(Q && K && Vt && O && group_lists && group_counts, "wf_attn_bsa_fwd: null pointer");
   WF_CHECK_ARG(H > 0 && Lq > 0 && Lkp > 0 && max_entries > 0, "wf_attn_bsa_fwd: empty problem");
   WF_CHECK_ARG(block == 128 || block == 64, "wf_attn_bsa_fwd: block must be 128 or 64 tokens, got %d", block);
   WF_CHECK_ARG(Lq % block == 0 && Lkp % block == 0, "wf_attn_bsa_fwd: Lq (%d) and Lkp (%d) must be whole %d-token blocks", Lq, Lkp, block);
+  WF_CHECK_ARG(seg_len > 0 && seg_len % block == 0 && Lkp % seg_len == 0, "wf_attn_bsa_fwd: seg_len (%d) must be whole blocks dividing Lkp",
+               seg_len);
   WF_CHECK_ARG(ldo % 4 == 0 && ldo >= H * D, "wf_attn_bsa_fwd: bad ldo %d", ldo);
   WF_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O) & 15) == 0, "wf_attn_bsa_fwd: 16-byte alignment");
   AttnArgs a;
@@ -1074,7 +1077,7 @@ extern "C" int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, voi
   a.Lq = Lq;
   a.Lkp = Lkp;
   a.kv_len = Lkp;
-  a.seg_len = Lkp;
+  a.seg_len = seg_len;
   a.ldo = ldo;
   a.n_qblk = ceil_div(Lq, QB);
   a.scale_log2 = softmax_scale * 1.4426950408889634f;

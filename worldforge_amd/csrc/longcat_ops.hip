@@ -40,7 +40,8 @@ __device__ __forceinline__ u32x4 pack8(const float* y) {
 template <int VPT>  // chunks of 8 channels per thread: C <= 2048 * VPT
 __global__ __launch_bounds__(256) void k_lc_ln(const uint16_t* __restrict__ x, const float* __restrict__ mul,
                                                const float* __restrict__ add, long mod_ld, int rows_per_group, long row0,
-                                               float plus_one, uint16_t* __restrict__ out, int C, float eps) {
+                                               const int* __restrict__ gidx, float plus_one, uint16_t* __restrict__ out, int C,
+                                               float eps) {
   __shared__ float sm[4];
   const size_t row = blockIdx.x;
   const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * C);
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void k_lc_ln(const uint16_t* __restrict__ x, c
     }
   }
   const float rstd = rsqrtf(block_sum_4(q, sm) / (float)C + eps);
-  const size_t g = rows_per_group > 0 ? (row0 + row) / rows_per_group : 0;
+  const size_t g = gidx ? (size_t)gidx[row0 + row] : (rows_per_group > 0 ? (row0 + row) / rows_per_group : 0);
   const float* mg = mul ? mul + g * mod_ld : nullptr;
   const float* ag = add ? add + g * mod_ld : nullptr;
 #pragma unroll
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void k_lc_ln(const uint16_t* __restrict__ x, c
 
 // x[r][c] = bf16(x[r][c] + gate[r / rows_per_group][c] * y[r][c]);  n8 = L * C / 8 chunks
 __global__ void k_lc_gate_resid(uint16_t* __restrict__ x, const uint16_t* __restrict__ y, long ldy, const float* __restrict__ gate,
-                                long gate_ld, int rows_per_group, long row0, int C, size_t n8) {
+                                long gate_ld, int rows_per_group, long row0, const int* __restrict__ gidx, int C, size_t n8) {
   const int cpr = C >> 3;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
     const size_t row = i / cpr;
@@ -105,7 +106,8 @@ __global__ void k_lc_gate_resid(uint16_t* __restrict__ x, const uint16_t* __rest
     unpack8(*xp, xv);
     unpack8(reinterpret_cast<const u32x4*>(y + row * ldy)[ch], yv);
     if (gate) {
-      const float* gp = gate + ((row0 + row) / rows_per_group) * gate_ld + ch * 8;
+      const size_t grp = gidx ? (size_t)gidx[row0 + row] : (row0 + row) / rows_per_group;
+      const float* gp = gate + grp * gate_ld + ch * 8;
       const float4 g0 = reinterpret_cast<const float4*>(gp)[0], g1 = reinterpret_cast<const float4*>(gp)[1];
       g[0] = g0.x, g[1] = g0.y, g[2] = g0.z, g[3] = g0.w, g[4] = g1.x, g[5] = g1.y, g[6] = g1.z, g[7] = g1.w;
     }
@@ -228,7 +230,7 @@ extern "C" int wf_gather_rows_bf16(const void* in, int64_t ld_in, const int* ind
 }
 
 extern "C" int wf_lc_ln_modulate(const void* x, const float* mul, const float* add, int64_t mod_ld, int rows_per_group, int64_t row0,
-                                 int plus_one, void* out, int L, int C, float eps, void* stream) {
+                                 const int* group_index, int plus_one, void* out, int L, int C, float eps, void* stream) {
   WF_CHECK_ARG(x && out, "wf_lc_ln_modulate: null pointer");
   WF_CHECK_ARG(C % 8 == 0 && C > 0 && C <= 8192, "wf_lc_ln_modulate: C=%d must be a multiple of 8 and <= 8192", C);
   WF_CHECK_ARG(rows_per_group >= 0 && mod_ld % 4 == 0 && row0 >= 0, "wf_lc_ln_modulate: rows_per_group >= 0, mod_ld %% 4 == 0, row0 >= 0");
@@ -239,25 +241,25 @@ extern "C" int wf_lc_ln_modulate(const void* x, const float* mul, const float* a
   const uint16_t* xi = (const uint16_t*)x;
   uint16_t* oo = (uint16_t*)out;
   if (C <= 2048)
-    hipLaunchKernelGGL(k_lc_ln<1>, dim3(L), dim3(256), 0, s, xi, mul, add, mod_ld, rows_per_group, row0, p1, oo, C, eps);
+    hipLaunchKernelGGL(k_lc_ln<1>, dim3(L), dim3(256), 0, s, xi, mul, add, mod_ld, rows_per_group, row0, group_index, p1, oo, C, eps);
   else if (C <= 4096)
-    hipLaunchKernelGGL(k_lc_ln<2>, dim3(L), dim3(256), 0, s, xi, mul, add, mod_ld, rows_per_group, row0, p1, oo, C, eps);
+    hipLaunchKernelGGL(k_lc_ln<2>, dim3(L), dim3(256), 0, s, xi, mul, add, mod_ld, rows_per_group, row0, group_index, p1, oo, C, eps);
   else
-    hipLaunchKernelGGL(k_lc_ln<4>, dim3(L), dim3(256), 0, s, xi, mul, add, mod_ld, rows_per_group, row0, p1, oo, C, eps);
+    hipLaunchKernelGGL(k_lc_ln<4>, dim3(L), dim3(256), 0, s, xi, mul, add, mod_ld, rows_per_group, row0, group_index, p1, oo, C, eps);
   WF_LAUNCH_CHECK("wf_lc_ln_modulate");
   return WF_OK;
 }
 
 extern "C" int wf_lc_gate_residual(void* x, const void* y, int64_t ldy, const float* gate, int64_t gate_ld, int rows_per_group,
-                                   int64_t row0, int L, int C, void* stream) {
+                                   int64_t row0, const int* group_index, int L, int C, void* stream) {
   WF_CHECK_ARG(x && y, "wf_lc_gate_residual: null pointer");
   WF_CHECK_ARG(C % 8 == 0 && ldy % 8 == 0 && gate_ld % 4 == 0, "wf_lc_gate_residual: C, ldy %% 8, gate_ld %% 4");
-  WF_CHECK_ARG(!gate || rows_per_group > 0, "wf_lc_gate_residual: rows_per_group must be positive with a gate");
+  WF_CHECK_ARG(!gate || rows_per_group > 0 || group_index, "wf_lc_gate_residual: a gate needs rows_per_group > 0 or a group index");
   WF_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gate) & 15) == 0, "wf_lc_gate_residual: 16-byte alignment");
   const size_t n8 = (size_t)L * (C / 8);
   if (n8 == 0) return WF_OK;
   hipLaunchKernelGGL(k_lc_gate_resid, dim3(grid_for(n8, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)x,
-                     (const uint16_t*)y, ldy, gate, gate_ld, rows_per_group > 0 ? rows_per_group : 1, row0, C, n8);
+                     (const uint16_t*)y, ldy, gate, gate_ld, rows_per_group > 0 ? rows_per_group : 1, row0, group_index, C, n8);
   WF_LAUNCH_CHECK("wf_lc_gate_residual");
   return WF_OK;
 }

@@ -238,19 +238,19 @@ class LongCatVideoTransformer3DModel:
         gemm(lo, w, None, out, EPI_F32_ACC)
         return out
 
-    def _ln(self, x, mul, add, mod_ld, rows_per_group, plus_one, out, row0=0):
+    def _ln(self, x, mul, add, mod_ld, rows_per_group, plus_one, out, row0=0, gidx=None):
         L, C = x.shape
         if L == 0:
             return
-        call("wf_lc_ln_modulate", x.data_ptr(), mul.data_ptr(), add.data_ptr(), mod_ld, rows_per_group, row0, 1 if plus_one else 0,
-             out.data_ptr(), L, C, float(self.cfg.eps), ops.stream())
+        call("wf_lc_ln_modulate", x.data_ptr(), mul.data_ptr(), add.data_ptr(), mod_ld, rows_per_group, row0,
+             gidx.data_ptr() if gidx is not None else None, 1 if plus_one else 0, out.data_ptr(), L, C, float(self.cfg.eps), ops.stream())
 
-    def _resid(self, x, y, gate, gate_ld, rows_per_group, row0=0):
+    def _resid(self, x, y, gate, gate_ld, rows_per_group, row0=0, gidx=None):
         L, C = x.shape
         if L == 0:
             return
         call("wf_lc_gate_residual", x.data_ptr(), y.data_ptr(), y.stride(0), gate.data_ptr() if gate is not None else None, gate_ld,
-             rows_per_group, row0, L, C, ops.stream())
+             rows_per_group, row0, gidx.data_ptr() if gidx is not None and gate is not None else None, L, C, ops.stream())
 
     def _heads(self, src, col0, weight, cos, sin, out, r0, r1, row_map=None):
         """Rows [r0, r1) of columns [col0, col0 + C) of src -> out [H, Lout, 128] rows [0, r1 - r0)."""
@@ -290,16 +290,41 @@ class LongCatVideoTransformer3DModel:
         cos, sin = self._rope_tables(T, h2, w2)
         _buf = self._buf
         comm = self.comm
+        use_bsa = self._bsa and T > 1  # LCA:57: "bsa will not be used in image training / sampling"
+        gidx = perm = pos = None
+        blk = 64
+        if use_bsa:
+            # The refine pass keeps the WHOLE network in 3D-block token order (bsa_interface.py:600-604): every row-wise op is order
+            # agnostic once the per-frame AdaLN kernels take a per-row frame index, the RoPE tables are permuted once, and the
+            # velocity rows are put back in (T, H, W) order at the end -- no per-layer permutes, and contiguous runs of blocks are the
+            # shards of the sequence-parallel job.  The first nc rows of the block order are the condition tokens.
+            from . import bsa
+            cq, ck = self.bsa_params["chunk_3d_shape_q"], self.bsa_params["chunk_3d_shape_k"]
+            if list(cq) != list(ck):
+                raise NotImplementedError("different query / key block shapes")
+            ncl = int(num_cond_latents or 0)
+            if ncl % cq[0] or (T - ncl) % cq[0]:
+                raise ValueError(f"block-sparse attention needs the condition ({ncl}) and noise ({T - ncl}) latent frames to be "
+                                 f"multiples of {cq[0]} (the reference pads them: pipeline_longcat_video.py:1417-1419)")
+            perm, pos = bsa.block_permutation(T, h2, w2, cq, dev)
+            blk = cq[0] * cq[1] * cq[2]
+            key = ("blk", T, h2, w2, tuple(cq))
+            if key not in self._rope:
+                pl = perm.long()
+                self._rope[key] = (cos[pl].contiguous(), sin[pl].contiguous(), (perm // tpf).to(torch.int32).contiguous())
+            cos, sin, gidx = self._rope[key]
         if comm is not None:
-            from .parallel import gather_rows, shard_plan
-            plan = shard_plan(L, comm.world)
+            from .parallel import ShardPlan, gather_rows, shard_plan
+            if use_bsa:  # whole 256-row query groups (two 128-token / four 64-token blocks) per rank
+                per = (L + comm.world - 1) // comm.world
+                plan = ShardPlan(L=L, P=comm.world, shard_len=(per + 255) // 256 * 256)
+            else:
+                plan = shard_plan(L, comm.world)
             lo, hi = plan.bounds(comm.rank)
             Lr, Sp = hi - lo, plan.shard_len
             if Lr <= 0:
                 raise ValueError(f"sequence-parallel plan leaves rank {comm.rank} of {comm.world} without tokens ({L} tokens in shards "
                                  f"of {Sp}); use fewer ranks for this size")
-            if self._bsa and T > 1:
-                raise NotImplementedError("block-sparse attention is single-GPU for now")
         else:
             plan, lo, Lr, Sp = None, 0, L, Lp
         ncr = min(max(nc - lo, 0), Lr)  # this rank's condition rows
@@ -308,6 +333,11 @@ class LongCatVideoTransformer3DModel:
         # ---- embeddings ----
         tok = _buf("tok", (L, Cin * 4), bf)
         call("wf_patchify", x_in.data_ptr(), tok.data_ptr(), Cin, T, Hh, Ww, ops.stream())
+        if use_bsa:
+            tokb = _buf("tokb", (L, Cin * 4), bf)
+            call("wf_gather_rows_bf16", tok.data_ptr(), tok.stride(0), perm.data_ptr(), tokb.data_ptr(), tokb.stride(0), L, Cin * 4,
+                 ops.stream())
+            tok = tokb
         tok = tok[lo:lo + Lr]
         L_all, nc_all = L, nc
         L, nc = Lr, ncr  # from here on L / nc are this rank's row counts; L_all / nc_all the key counts
@@ -353,21 +383,7 @@ class LongCatVideoTransformer3DModel:
         ffh = _buf("ffh", (L, 2 * Hd), bf)
         ffg = _buf("ffg", (L, Hd), bf)
         ald = ada.stride(0)
-        use_bsa = self._bsa and T > 1  # LCA:57: "bsa will not be used in image training / sampling"
         if use_bsa:
-            from . import bsa
-            cq, ck = self.bsa_params["chunk_3d_shape_q"], self.bsa_params["chunk_3d_shape_k"]
-            if list(cq) != list(ck):
-                raise NotImplementedError("different query / key block shapes")
-            ncl = int(num_cond_latents or 0)
-            if ncl % cq[0] or (T - ncl) % cq[0]:
-                raise ValueError(f"block-sparse attention needs the condition ({ncl}) and noise ({T - ncl}) latent frames to be "
-                                 f"multiples of {cq[0]} (the reference pads them: pipeline_longcat_video.py:1417-1419)")
-            perm, pos = bsa.block_permutation(T, h2, w2, cq, dev)   # the first nc rows of the block order are the condition tokens
-            blk = cq[0] * cq[1] * cq[2]
-            pos_n = (pos[nc:] - nc).contiguous()
-            vperm = _buf("vperm", (L, C), bf)
-            aob = _buf("aob", (L, C), bf)
             sparsity = self.bsa_params.get("sparsity")
             cdf_thr = self.bsa_params.get("cdf_threshold")
             if sparsity is None and cdf_thr is None:
@@ -385,29 +401,37 @@ class LongCatVideoTransformer3DModel:
             m = ada[:, i * 6 * C:(i + 1) * 6 * C]
             shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = (m[:, j * C:(j + 1) * C] for j in range(6))
             # ---- self-attention (LCD:91-104, LCA:105-145) ----
-            self._ln(x, scale_msa, shift_msa, ald, tpf, True, hbuf, row0=lo)
+            self._ln(x, scale_msa, shift_msa, ald, tpf, True, hbuf, row0=lo, gidx=gidx)
             gemm(hbuf, W[p + "attn.qkv.w"], W[p + "attn.qkv.b"], qkv, EPI_BF16)
             if use_bsa:
-                # LCA:57-66 + bsa_interface.py:612-659.  q / k are written straight into 3D-block token order (row_map), V is gathered
-                # into it, the output is gathered back; gating = mean-pooled q / k blocks -> bf16 block scores -> top-k per query block
-                self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_c, 0, nc, row_map=pos)
-                self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_n, nc, L, row_map=pos_n)
-                self._heads(qkv, C, W[p + "attn.k_norm"], cos, sin, kh, 0, L, row_map=pos)
-                vsrc = qkv[:, 2 * C:]
-                call("wf_gather_rows_bf16", vsrc.data_ptr(), qkv.stride(0), perm.data_ptr(), vperm.data_ptr(), vperm.stride(0), L, C,
-                     ops.stream())
-                self._vt(vperm, 0, vt, L)
-                kcmp = bsa.mean_pool(kh, blk)
+                # LCA:57-66 + bsa_interface.py:612-659 on rows that already are in block order: gating = mean-pooled q / k blocks ->
+                # bf16 block scores -> top-k / cdf selection per query block -> sparse attention over the selected key blocks
+                self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_c, 0, nc)
+                self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_n, nc, L)
+                self._heads(qkv, C, W[p + "attn.k_norm"], cos, sin, kh, 0, L)
+                self._vt(qkv, 2 * C, vt, L)
+                kcmp = bsa.mean_pool(kh, blk)  # this rank's key blocks (zero rows past the last token pool to zero blocks)
+                kk, vv = kh, vt
+                if comm is not None:
+                    evs = (comm.all_gather_async(kh_all, kh), comm.all_gather_async(vt_all, vt))
+                    kc_all = torch.empty((comm.world,) + tuple(kcmp.shape), dtype=bf, device=dev)
+                    comm.all_gather(kc_all, kcmp)
+                    kcmp = kc_all.permute(1, 0, 2, 3).reshape(H, -1, 128)
+                    for ev in evs:
+                        if ev is not None:
+                            torch.cuda.current_stream().wait_event(ev)
+                    kk, vv = kh_all, vt_all
+                kcmp = kcmp[:, :L_all // blk].contiguous()
                 picked = []
                 if nc > 0:
-                    idx, lens = select(bsa.block_scores(bsa.mean_pool(qh_c, blk), kcmp[:, :nc // blk]))
-                    bsa.sparse_attention(qh_c, kh, vt, aob[:nc], idx, scale, nc // blk, lens, blk)
+                    idx, lens = select(bsa.block_scores(bsa.mean_pool(qh_c, blk), kcmp[:, :nc_all // blk].contiguous()))
+                    bsa.sparse_attention(qh_c, kk, vv, ao[:nc], idx, scale, nc_all // blk, lens, blk)
                     picked.append(idx if lens is None else (idx, lens))
-                idx, lens = select(bsa.block_scores(bsa.mean_pool(qh_n, blk), kcmp))
-                bsa.sparse_attention(qh_n, kh, vt, aob[nc:], idx, scale, L // blk, lens, blk)
-                picked.append(idx if lens is None else (idx, lens))
+                if L - nc > 0:
+                    idx, lens = select(bsa.block_scores(bsa.mean_pool(qh_n, blk), kcmp))
+                    bsa.sparse_attention(qh_n, kk, vv, ao[nc:], idx, scale, L_all // blk, lens, blk)
+                    picked.append(idx if lens is None else (idx, lens))
                 self.last_bsa_indices.append(picked)
-                call("wf_gather_rows_bf16", aob.data_ptr(), aob.stride(0), pos.data_ptr(), ao.data_ptr(), ao.stride(0), L, C, ops.stream())
             else:
                 self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_c, 0, nc)
                 self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_n, nc, L)
@@ -425,7 +449,7 @@ class LongCatVideoTransformer3DModel:
                 if L - nc > 0:
                     attention(qh_n, kk, vv, ao[nc:], L_all, scale, profile=True)  # noise tokens see everything (LCA:133-134)
             gemm(ao, W[p + "attn.proj.w"], W[p + "attn.proj.b"], ys, EPI_BF16)
-            self._resid(x, ys, gate_msa, ald, tpf, row0=lo)
+            self._resid(x, ys, gate_msa, ald, tpf, row0=lo, gidx=gidx)
             # ---- cross-attention on the noise tokens (LCD:108-111, LCA:218-276) ----
             if L - nc > 0:
                 self._ln(x[nc:], W[p + "norm.w"], W[p + "norm.b"], 0, 0, False, hbuf[nc:])
@@ -438,18 +462,23 @@ class LongCatVideoTransformer3DModel:
                 gemm(ao[nc:], W[p + "cross_attn.proj.w"], W[p + "cross_attn.proj.b"], ys[nc:], EPI_BF16)
                 self._resid(x[nc:], ys[nc:], None, 0, 0)
             # ---- SwiGLU FFN (LCD:113-120, LCB:36-37) ----
-            self._ln(x, scale_mlp, shift_mlp, ald, tpf, True, hbuf, row0=lo)
+            self._ln(x, scale_mlp, shift_mlp, ald, tpf, True, hbuf, row0=lo, gidx=gidx)
             gemm(hbuf, W[p + "ffn.w13"], None, ffh, EPI_BF16)
             call("wf_lc_swiglu", ffh.data_ptr(), ffh.stride(0), ffg.data_ptr(), L, Hd, ops.stream())
             gemm(ffg, W[p + "ffn.w2"], None, ys, EPI_BF16)
-            self._resid(x, ys, gate_mlp, ald, tpf, row0=lo)
+            self._resid(x, ys, gate_mlp, ald, tpf, row0=lo, gidx=gidx)
 
         # ---- final layer (LCB:159-168) + unpatchify (LCD:371-392) ----
-        self._ln(x, fmod[:, C:], fmod[:, :C], fmod.stride(0), tpf, True, hbuf, row0=lo)
+        self._ln(x, fmod[:, C:], fmod[:, :C], fmod.stride(0), tpf, True, hbuf, row0=lo, gidx=gidx)
         yo = _buf("yo", (L, 4 * cfg.out_channels), f32)
         gemm(hbuf, W["final_layer.linear.w"], W["final_layer.linear.b"], yo, EPI_F32)
         if comm is not None:
             yo = gather_rows(comm, yo, plan).contiguous()
+        if use_bsa:  # velocity rows back to (T, H, W) order: bsa_interface.py:606-610 (fp32 rows moved as 16-byte chunks)
+            yt = torch.empty_like(yo)
+            call("wf_gather_rows_bf16", yo.data_ptr(), 2 * yo.stride(0), pos.data_ptr(), yt.data_ptr(), 2 * yt.stride(0), L_all,
+                 2 * yo.shape[1], ops.stream())
+            yo = yt
         out = torch.empty((cfg.out_channels, T, Hh, Ww), dtype=f32, device=dev)
         call("wf_unpatchify", yo.data_ptr(), out.data_ptr(), cfg.out_channels, T, Hh, Ww, ops.stream())
         return out
