@@ -197,11 +197,9 @@ int wf_lc_gate_residual(void* x, const void* y, int64_t ldy, const float* gate, 
                         const int* group_index, int L, int C, void* stream);
 /* RMSNorm_FP32 over each head's 128 channels (LCB:40-52 as used at LCA:111 and LCA:231) + optional interleaved 3D RoPE
  * (LCR:32-36, 101-120; cos/sin tables [L][64] f32 per rotation pair, NULL -> none), written head-major for wf_attn_fwd:
- * in bf16 [L, ld] (head h at columns h*128) -> out bf16 [H][Lout][128] (rows L..Lout untouched); weight f32 [128].
- * row_map (int32 [L], may be NULL): input row r is written to output row row_map[r] -- the (T,H,W) -> 3D-block token order of the
- * block-sparse refine attention (block_sparse_attention/bsa_interface.py:600-604) applied for free on the way out. */
+ * in bf16 [L, ld] (head h at columns h*128) -> out bf16 [H][Lout][128] (rows L..Lout untouched); weight f32 [128]. */
 int wf_lc_norm_heads(const void* in, int64_t ld, const float* weight, const float* cos_tab, const float* sin_tab, void* out, int L,
-                     int Lout, int H, float eps, const int* row_map, void* stream);
+                     int Lout, int H, float eps, void* stream);
 /* FeedForwardSwiGLU gate (LCB:36-37): in bf16 [L, ld] with w1 x in columns [0, Hd) and w3 x in [Hd, 2 Hd) ->
  * out bf16 [L, Hd] = silu(w1 x) * w3 x. */
 int wf_lc_swiglu(const void* in, int64_t ld, void* out, int L, int Hd, void* stream);
@@ -214,7 +212,8 @@ int wf_refine_upsample_u8(const void* frames_u8, float* out, int F, int H0, int 
 /* ---- LongCat block-sparse attention of the 720p refine pass (longcat_video/block_sparse_attention/bsa_interface.py = BSA) --------- */
 /* mean_pooling_compression (BSA:169-179): in bf16 [H][L][128] -> out bf16 [H][L/block][128], mean of each block of 64 / 128 tokens. */
 int wf_lc_mean_pool_blocks(const void* in, void* out, int H, int L, int block, void* stream);
-/* out[i][:C] = in[index[i]][:C], bf16 rows: the token permutes of BSA:600-610 where they cannot ride on another kernel's store. */
+/* out[i][:C] = in[index[i]][:C], bf16 rows (16-byte chunks): the two token permutes of BSA:600-610 the refine pass needs per forward
+ * (patch tokens into 3D-block order, velocity rows back). */
 int wf_gather_rows_bf16(const void* in, int64_t ld_in, const int* index, void* out, int64_t ld_out, int n_rows, int C, void* stream);
 /* The sparse attention of BSA:538-560 (flash_attn_bsa_varlen_mask.py:174-285): Q [H][Lq][128], K [H][Lkp][128], Vt [H][Lkp/64][128][64]
  * in 3D-block token order, `block` = 128 or 64 tokens per block; every query block attends to its selected key blocks only.  The

@@ -88,7 +88,7 @@ def test_norm_heads(L, H, rope):
     view = sd[:Lr, C:2 * C]
     wd_, cd, sn = w.to(DEV), cos.to(DEV), sin.to(DEV)  # held: a temporary would be freed before the kernel reads it
     call("wf_lc_norm_heads", view.data_ptr(), sd.stride(0), wd_.data_ptr(), cd.data_ptr() if rope else None,
-         sn.data_ptr() if rope else None, out.data_ptr(), Lr, Lr + 3, H, 1e-6, None, ops.stream())
+         sn.data_ptr() if rope else None, out.data_ptr(), Lr, Lr + 3, H, 1e-6, ops.stream())
     q = src[:Lr, C:2 * C].view(Lr, H, 128).permute(1, 0, 2)  # [H, L, D] bf16
     want = olc.rms_norm_head(q, w.to(BF))
     if rope:

@@ -252,15 +252,14 @@ class LongCatVideoTransformer3DModel:
         call("wf_lc_gate_residual", x.data_ptr(), y.data_ptr(), y.stride(0), gate.data_ptr() if gate is not None else None, gate_ld,
              rows_per_group, row0, gidx.data_ptr() if gidx is not None and gate is not None else None, L, C, ops.stream())
 
-    def _heads(self, src, col0, weight, cos, sin, out, r0, r1, row_map=None):
+    def _heads(self, src, col0, weight, cos, sin, out, r0, r1):
         """Rows [r0, r1) of columns [col0, col0 + C) of src -> out [H, Lout, 128] rows [0, r1 - r0)."""
         if r1 <= r0:
             return
         view = src[r0:r1, col0:col0 + self.cfg.hidden_size]
         call("wf_lc_norm_heads", view.data_ptr(), src.stride(0), weight.data_ptr(),
              cos[r0:r1].data_ptr() if cos is not None else None, sin[r0:r1].data_ptr() if sin is not None else None,
-             out.data_ptr(), r1 - r0, out.shape[1], self.cfg.num_heads, float(self.cfg.eps),
-             row_map.data_ptr() if row_map is not None else None, ops.stream())
+             out.data_ptr(), r1 - r0, out.shape[1], self.cfg.num_heads, float(self.cfg.eps), ops.stream())
 
     def _vt(self, src, col0, out, L):
         view = src[:, col0:col0 + self.cfg.hidden_size]
