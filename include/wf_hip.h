@@ -218,8 +218,9 @@ int wf_gather_rows_bf16(const void* in, int64_t ld_in, const int* index, void* o
 /* The sparse attention of BSA:538-560 (flash_attn_bsa_varlen_mask.py:174-285): Q [H][Lq][128], K [H][Lkp][128], Vt [H][Lkp/64][128][64]
  * in 3D-block token order, `block` = 128 or 64 tokens per block; every query block attends to its selected key blocks only.  The
  * selection is given per GROUP of g = 256 / block consecutive query blocks (the 256 query rows of one workgroup): group_lists
- * [H][ceil(Lq/256)][max_entries] int32, entry = key_block * 2^g + flags (bit i: selected by the i-th query block of the group), the
- * union of the group's lists in any order; group_counts [H][ceil(Lq/256)] entries used.  seg_len = Lkp, or the per-rank shard length
+ * [H][ceil(Lq/256)][max_entries] int32, entry = physical_block * 2^g + flags (bit i: selected by the i-th query block of the group;
+ * physical_block = position of the key block in the K / Vt buffers counted in blocks: ((segment * H + head) * seg_len + offset) / block),
+ * the union of the group's lists in any order; group_counts [H][ceil(Lq/256)] entries used.  seg_len = Lkp, or the per-rank shard length
  * when K / Vt are all-gathered shards [P][H][seg_len][128] (as wf_attn_fwd).  O [Lq][ldo] bf16 (block order), head h at columns h*128. */
 int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int seg_len, int ldo,
                     float softmax_scale, const int* group_lists, const int* group_counts, int max_entries, int block, void* stream);

@@ -87,6 +87,10 @@ def test_group_lists_encoding():
     l = lists.cpu()[0]
     assert l[0, :3].tolist() == [0 * 4 + 1, 3 * 4 + 3, 5 * 4 + 2]
     assert l[1, :2].tolist() == [1 * 4 + 1, 2 * 4 + 1]
+    # physical block index: head 1 of two, two segments of 3 blocks -> block b sits at (b // 3) * 6 + 3 + b % 3
+    two = torch.tensor([[[0, 3]], [[4, 5]]], device=DEV)
+    l2, c2, _ = bsa.group_lists(two, 6, blocks_per_segment=3)
+    assert l2.cpu()[1, 0, :2].tolist() == [(6 + 3 + 1) * 4 + 1, (6 + 3 + 2) * 4 + 1] and l2.cpu()[0, 0, :2].tolist() == [0 * 4 + 1, 6 * 4 + 1]
 
 
 def test_block_permutation_matches_oracle():

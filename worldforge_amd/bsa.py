@@ -82,11 +82,14 @@ def select_cdf(scores: torch.Tensor, cdf_threshold: float, sparsity=None):
     return ws.indices, num.clamp_max(scores.shape[-1])
 
 
-def group_lists(block_indices: torch.Tensor, n_k: int, block_lens: torch.Tensor = None, block: int = BLOCK):
+def group_lists(block_indices: torch.Tensor, n_k: int, block_lens: torch.Tensor = None, block: int = BLOCK, blocks_per_segment: int = None):
     """[heads, n_q, n_sel] selected key blocks per query block -> the per-workgroup lists `wf_attn_bsa_fwd` walks: one list per group of
     g = 256 / block consecutive query blocks (the 256 query rows of a workgroup) holding the union of the group's blocks in ascending
-    order, entry = key_block * 2^g + sum_i 2^i * (selected by the i-th query block).  Returns (lists int32 [heads, n_groups,
-    max_entries], counts int32 [heads, n_groups], max_entries); max_entries = min(g * n_sel, n_k) is a shape-only bound: no host sync."""
+    order, entry = physical_block * 2^g + sum_i 2^i * (selected by the i-th query block), where physical_block is the block's position
+    in the K / V^T buffers ([P][heads][S][128] with S = blocks_per_segment * block keys per rank shard; one segment = the whole sequence
+    on one GPU): (b // bps) * heads * bps + head * bps + b % bps -- head and segment are folded in here so that the kernel does no index
+    arithmetic.  Returns (lists int32 [heads, n_groups, max_entries], counts int32 [heads, n_groups], max_entries); max_entries =
+    min(g * n_sel, n_k) is a shape-only bound: no host sync."""
     Hh, nq, nsel = block_indices.shape
     gs = 256 // block
     allow = torch.zeros((Hh, (nq + gs - 1) // gs * gs, n_k), dtype=torch.bool, device=block_indices.device)
@@ -103,7 +106,10 @@ def group_lists(block_indices: torch.Tensor, n_k: int, block_lens: torch.Tensor 
     order = torch.sort((~union).to(torch.uint8), dim=-1, stable=True)[1]  # selected blocks first, ascending
     max_entries = min(gs * nsel, n_k)  # (variable-length lists come with nsel = n_k: the bound is n_k)
     order = order[..., :max_entries]
-    entries = order * (1 << gs)
+    bps = blocks_per_segment or n_k
+    head = torch.arange(Hh, device=order.device).view(Hh, 1, 1)
+    phys = (order // bps) * (Hh * bps) + head * bps + order % bps
+    entries = phys * (1 << gs)
     for i, pt in enumerate(parts):
         entries = entries + (pt.gather(2, order).long() << i)
     return entries.to(torch.int32).contiguous(), counts.contiguous(), max_entries
@@ -119,7 +125,7 @@ def sparse_attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: to
         Lkp, seg = k.shape[0] * k.shape[2], k.shape[2]
     else:
         Lkp = seg = k.shape[1]
-    lists, counts, mx = group_lists(block_indices, n_k_blocks, block_lens, block)
+    lists, counts, mx = group_lists(block_indices, n_k_blocks, block_lens, block, seg // block)
     call("wf_attn_bsa_fwd", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), Hh, Lq, Lkp, seg, out.stride(0), float(scale),
          lists.data_ptr(), counts.data_ptr(), mx, block, ops.stream())
     return out

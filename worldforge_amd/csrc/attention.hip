@@ -189,14 +189,16 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
   const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_offset(smem));
   auto stage = [&](int t) {
     int kt = t;  // KV tile held by ring slot t
-    if constexpr (KIND == 2) {
+    size_t tile_off;
+    if constexpr (KIND == 2) {  // the list holds PHYSICAL block indices (head and segment already folded in by the host side)
       if (a.bsa_shift == 2)
-        kt = (__builtin_amdgcn_readfirstlane(bsa[t >> 1]) >> 2) * 2 + (t & 1);
+        tile_off = ((size_t)(__builtin_amdgcn_readfirstlane(bsa[t >> 1]) >> 2) * 2 + (t & 1)) * (KB * D);
       else
-        kt = __builtin_amdgcn_readfirstlane(bsa[t]) >> 4;
+        tile_off = (size_t)(__builtin_amdgcn_readfirstlane(bsa[t]) >> 4) * (KB * D);
+    } else {
+      const int seg = kt / tiles_per_seg;
+      tile_off = ((size_t)(seg * a.H + head) * tiles_per_seg + (kt - seg * tiles_per_seg)) * (KB * D);
     }
-    const int seg = kt / tiles_per_seg;
-    const size_t tile_off = ((size_t)(seg * a.H + head) * tiles_per_seg + (kt - seg * tiles_per_seg)) * (KB * D);
     const uint32_t base = smem_base + (t % NBUF) * BUF_BYTES + wu * 2048;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -542,7 +544,8 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
   f32x16 o[2][4];
   f32x16 sb[2][2][2];  // [buffer][q-block][key block]
   bf16x8 pf[2][4];
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f}, mcq[2] = {0.f, 0.f};
+  // KIND 3 (block-sparse, see k_attn<2>): the running max starts finite so that leading masked blocks cannot give inf - inf
+  float m_run[2] = {KIND == 3 ? -1e30f : -INFINITY, KIND == 3 ? -1e30f : -INFINITY}, l_run[2] = {0.f, 0.f}, mcq[2] = {0.f, 0.f};
 #pragma unroll
   for (int x = 0; x < 2; ++x) {
 #pragma unroll
@@ -558,8 +561,27 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
   const int ntiles_all = (a.kv_len + KB - 1) / KB;
   const int split = blockIdx.y;
   const int t_begin = split * a.tiles_per_split;                         // first KV tile of this split (absolute)
-  const int ntiles = min(a.tiles_per_split, ntiles_all - t_begin);       // tiles of this split (>= 1 by construction of the grid)
-  const bool ragged = (a.kv_len & (KB - 1)) != 0;
+  int ntiles_ = min(a.tiles_per_split, ntiles_all - t_begin);            // tiles of this split (>= 1 by construction of the grid)
+  // block-sparse variant: per-workgroup list of PHYSICAL key blocks (entry = block * 2^g + flags, g = bsa_shift query blocks per
+  // workgroup = 2 waves each for 128-token blocks / 1 wave each for 64-token blocks), tpe tiles per entry
+  const int* bsa = nullptr;
+  const int tpe = (KIND == 3 && a.bsa_shift == 2) ? 2 : 1;
+  const int mine = a.bsa_shift == 2 ? (wu >> 1) : wu;  // this wave's query block within the workgroup
+  if constexpr (KIND == 3) {
+    bsa = a.bsa_list + ((size_t)head * a.n_qblk + qblk) * a.bsa_max;
+    ntiles_ = tpe * a.bsa_cnt[head * a.n_qblk + qblk];
+    if (ntiles_ == 0) {  // empty selection for every query block of the group: zeros (flash_attn_bsa_varlen_mask.py:242-244)
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+        if (q_row[x] < a.Lq) {
+          uint16_t* op = a.O + (size_t)q_row[x] * a.ldo + head * D;
+          for (int d = hi * 64; d < hi * 64 + 64; d += 8) *reinterpret_cast<u32x4*>(op + d) = u32x4{0u, 0u, 0u, 0u};
+        }
+      return;
+    }
+  }
+  const int ntiles = ntiles_;
+  const bool ragged = KIND != 3 && (a.kv_len & (KB - 1)) != 0;
 
   // Element offset / LDS slot of the tile being staged (wave-uniform), advanced one tile at a time: a handful of scalar
   // instructions, no division.  Past the last tile the pieces are still issued (no branch in the MFMA stream): they re-read the last
@@ -570,9 +592,22 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
   size_t st_off = ((size_t)(seg0 * a.H + head) * tiles_per_seg + in0) * tile_bytes;  // byte offset of the staged tile in K and in V^T
   int st_tile = 0, st_left = tiles_per_seg - in0;  // tile number (in the split), tiles left in its segment
   uint32_t st_base = wu * 4096;                    // LDS byte offset of this wave's pieces in the ring slot of the staged tile
+  int e_stage = 0, e_mask = 0;                     // KIND 3: list entry of the tile being staged / of the tile whose scores come next
+  if constexpr (KIND == 3) {
+    e_stage = __builtin_amdgcn_readfirstlane(bsa[0]);
+    st_off = (size_t)(e_stage >> a.bsa_shift) * tpe * tile_bytes;
+  }
   auto stage_next = [&]() {  // select tile st_tile + 1
     ++st_tile;
     const bool live = st_tile < ntiles;
+    if constexpr (KIND == 3) {
+      if (live) {
+        if ((st_tile & (tpe - 1)) == 0) e_stage = __builtin_amdgcn_readfirstlane(bsa[tpe == 2 ? (st_tile >> 1) : st_tile]);
+        st_off = ((size_t)(e_stage >> a.bsa_shift) * tpe + (st_tile & (tpe - 1))) * tile_bytes;
+      }
+      st_base = st_base + BUF_BYTES >= (uint32_t)(NBUF * BUF_BYTES) ? st_base + BUF_BYTES - NBUF * BUF_BYTES : st_base + BUF_BYTES;
+      return;
+    }
     const bool wrap = --st_left == 0;
     st_off += live ? (wrap ? tile_bytes + seg_jump : tile_bytes) : 0;
     st_left = wrap ? tiles_per_seg : st_left;
@@ -665,6 +700,18 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
           int key = (t_begin + t) * KB + 32 * kb + 16 * (r >> 3) + 8 * hi + (r & 7);
           if (key >= a.kv_len) sb[B][x][kb][r] = -INFINITY;
         }
+  };
+
+  auto mask_unselected = [&](auto BC, int entry) {  // KIND 3: the key block of these scores is not in this wave's query block's list
+    constexpr int B = decltype(BC)::value;
+    if (!((entry >> mine) & 1)) {
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sb[B][x][kb][r] = -INFINITY;
+    }
   };
 
   // ---- one KV tile t (scores of tile t in buffer B, produced earlier): 64 MFMA gaps -------------------------------------------------
@@ -813,12 +860,19 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
       if constexpr (g == 31) W4MARK(0);
       if constexpr (g == 63) W4MARK(1);
 #endif
-      if constexpr (g == 0) stage_next();  // tile t + 3 (or trash): scalar bookkeeping, in the shadow of the first MFMA
+      if constexpr (g == 0) {
+        stage_next();  // tile t + 3 (or trash): scalar bookkeeping, in the shadow of the first MFMA
+        if constexpr (KIND == 3) {  // the entry of tile t + 1 (its scores are produced in this tile and masked at gap 51)
+          const int tn = t + 1 < ntiles ? t + 1 : t;
+          e_mask = __builtin_amdgcn_readfirstlane(bsa[tpe == 2 ? (tn >> 1) : tn]);
+        }
+      }
       if constexpr (g >= 2 && g < 32 && (g & 3) == 2) stage_piece((g - 2) >> 2);
       if constexpr (g == 51) {
         // the new scores were written by asm MFMAs (last one at gap 31): XDL write -> VALU read hazard is long covered; the ragged
         // mask of the last tile must be in place before its row max
         if (ragged && t_begin + t + 1 == ntiles_all - 1) mask_ragged(std::integral_constant<int, 1 - B>{}, t + 1);
+        if constexpr (KIND == 3) mask_unselected(std::integral_constant<int, 1 - B>{}, e_mask);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -864,6 +918,7 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
     }
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
     if (ragged && t_begin == ntiles_all - 1) mask_ragged(B0{}, 0);
+    if constexpr (KIND == 3) mask_unselected(B0{}, __builtin_amdgcn_readfirstlane(bsa[0]));
     const float m0 = rowmax_now(B0{}, std::integral_constant<int, 0>{});
     const float m1 = rowmax_now(B0{}, std::integral_constant<int, 1>{});
     commit(std::integral_constant<int, 0>{}, m0);
@@ -893,7 +948,8 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
   for (int x = 0; x < 2; ++x) {
     float l = l_run[x];
     l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
+    float inv = 1.0f / l;
+    if constexpr (KIND == 3) inv = l > 0.f ? inv : 0.f;  // empty selection of this query block: zeros
     if (a.nsplit > 1) {  // un-normalised partial result of this KV split: O (f32), reference max, row sum -> k_attn_merge
       if (q_row[x] < a.Lq) {
         float* op = a.o_part + ((size_t)split * a.Lq + q_row[x]) * (size_t)(a.H * D) + head * D;
@@ -1091,8 +1147,17 @@ extern "C" int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, voi
   a.bsa_cnt = group_counts;
   a.bsa_max = max_entries;
   a.bsa_shift = block == 128 ? 2 : 4;
+  a.tiles_per_split = 0;
   const int grid = ((H + 7) / 8) * a.n_qblk * 8;
-  hipLaunchKernelGGL(k_attn<2>, dim3(grid), dim3(NT), 4 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream, a);
+  // default: the one-wave-per-SIMD kernel (k_attn_w4<3>); WF_ATTN_KERNEL=w8 selects the two-waves-per-SIMD form (k_attn<2>)
+  static const int use_w4 = [] {
+    const char* e = getenv("WF_ATTN_KERNEL");
+    return e && e[0] == 'w' && e[1] == '8' ? 0 : 1;
+  }();
+  if (use_w4)
+    hipLaunchKernelGGL(k_attn_w4<3>, dim3(grid, 1), dim3(NT4), 5 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(k_attn<2>, dim3(grid), dim3(NT), 4 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream, a);
   WF_LAUNCH_CHECK("wf_attn_bsa_fwd");
   return WF_OK;
 }
