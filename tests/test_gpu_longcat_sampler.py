@@ -153,3 +153,21 @@ def test_refine_pass_matches_reference(name):
         np.testing.assert_allclose(l, G[f"step{j}"], rtol=0, atol=3e-2)
     np.testing.assert_allclose(out, want.numpy(), rtol=0, atol=2e-3)
     np.testing.assert_allclose(out, G["frames"], rtol=0, atol=3e-2)
+
+
+def test_reference_video_of_the_wrong_size_is_ignored_like_the_reference_does():
+    """SCHED:1136-1145: fuse_latents raises on a size mismatch inside its own try block, logs, and returns the prediction unchanged --
+    the job goes on without injection.  Mirrored: no exception, the VAE is decoded once per guided round but never re-encodes."""
+    from worldforge_amd.longcat_pipeline import LongCatVideoPipeline
+    from worldforge_amd.longcat_scheduler import FlowMatchEulerDiscreteScheduler
+    c = CASES["irr_flf"]
+    image, ref, mask, pe, pm, ne, nm = case_inputs(c)
+    dit, vae = FakeLongCatDiT(), FakeVAE()
+    pipe = LongCatVideoPipeline(vae, FlowMatchEulerDiscreteScheduler(shift=1.0), dit, device=DEV)
+    bad_ref = ref[:, :, :, :16]  # half the height
+    frames = pipe.generate_i2v(image=image, height=c["H"], width=c["W"], prompt_embeds=pe, prompt_attention_mask=pm,
+                               negative_prompt_embeds=ne, negative_prompt_attention_mask=nm, num_frames=c["F"], num_inference_steps=4,
+                               guidance_scale=4.0, generator=torch.manual_seed(1), video_ref=bad_ref, mask=mask, guided=True,
+                               resample_steps=2, guide_steps=2, resample_round=2, use_pca_channel_selection=True, static=True)
+    assert np.isfinite(frames).all()
+    assert vae.n_enc == 1 and vae.n_dec == 2 + 1   # prepare_latents' encode; one decode per guided step + the final one
