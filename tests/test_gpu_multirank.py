@@ -219,3 +219,39 @@ def test_token_sharded_longcat_dit_with_block_sparse_attention_equals_single(P, 
 
     for r, got in enumerate(_run_ranks(P, rank_fn)):
         assert torch.equal(got, ref), (r, (got - ref).abs().max())
+
+
+def test_longcat_refine_pass_on_two_ranks_equals_single():
+    """generate_refine end to end with the block-sparse DiT sequence-parallel (shards of whole query groups in block order) and the VAE
+    row-sharded: both ranks must reproduce the single-rank frames."""
+    from oracle import longcat_dit as olc
+    from worldforge_amd.longcat_dit import LongCatConfig, LongCatVideoTransformer3DModel
+    from worldforge_amd.longcat_pipeline import LongCatVideoPipeline
+    from worldforge_amd.longcat_scheduler import FlowMatchEulerDiscreteScheduler
+    from worldforge_amd.vae import AutoencoderKLWan
+    kw = dict(hidden_size=256, depth=2, num_heads=2, caption_channels=64, adaln_tembed_dim=64)
+    W = olc.random_weights(olc.LongCatConfig(**kw), seed=5)
+    bsa_params = dict(sparsity=0.5, chunk_3d_shape_q=[4, 4, 8], chunk_3d_shape_k=[4, 4, 8])
+    g = torch.Generator().manual_seed(3)
+    frames = (torch.rand(5, 48, 64, 3, generator=g) * 255).to(torch.uint8)
+    image = torch.rand(3, 128, 128, generator=g)
+    pe = _rand((1, 1, 20, 64), 7).to(BF)
+    pm = torch.ones(1, 20, dtype=torch.int64)
+    m0 = LongCatVideoTransformer3DModel(LongCatConfig(**kw), DEV, enable_bsa=True, bsa_params=bsa_params).load_state_dict(W)
+    v0 = AutoencoderKLWan(DEV).init_random(seed=1)
+
+    def run(comm):
+        m = LongCatVideoTransformer3DModel(LongCatConfig(**kw), DEV, enable_bsa=True, bsa_params=bsa_params, comm=comm)
+        m.w = m0.w
+        v = AutoencoderKLWan(DEV, comm=comm)
+        v.w = v0.w
+        pipe = LongCatVideoPipeline(v, FlowMatchEulerDiscreteScheduler(shift=3.0), m, device=DEV)
+        out = pipe.generate_refine(stage1_video=frames, height=128, width=128, prompt_embeds=pe, prompt_attention_mask=pm, image=image,
+                                   num_cond_frames=1, num_inference_steps=6, generator=torch.Generator().manual_seed(42), t_thresh=0.5,
+                                   spatial_refine_only=True)
+        return torch.from_numpy(out).clone()
+
+    want = run(None)
+    assert torch.isfinite(want).all()
+    for r, got in enumerate(_run_ranks(2, run)):
+        assert torch.equal(got, want), (r, (got - want).abs().max())
