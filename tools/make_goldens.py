@@ -1,6 +1,11 @@
 """Record golden vectors from the UNMODIFIED reference (runs only in the build container, where /root/reference exists).
 
-  python tools/make_goldens.py            # writes tests/golden/*.npz
+  python tools/make_goldens.py            # g1, g4, g6, g10 (Wan sampler state machine, FLF metric, harness)
+  python tools/make_goldens.py dit | vae   # g7, g8 (in-tree Wan DiT / VAE twins)
+  python tools/make_goldens.py longcat | longcat_pipe | longcat_lora | longcat_refine      # g11, g12, g13, g15 (LongCat DiT, guided
+                                           # i2v trajectories, run-time LoRA, refine-pass trajectories)
+  TORCHDYNAMO_DISABLE=1 python tools/make_goldens.py bsa | bsa_cdf                          # g14, g14b (block-sparse gating helpers)
+  python tools/make_goldens.py warp | warp_cams                                             # g16, g16b (stage-1 forward warp, cameras)
 
 The reference is imported through tools/refshim (a stub `diffusers` with base classes only); its DiT / VAE / encoders
 are replaced by the deterministic fakes of tests/fakes.py, so the recorded trajectories pin the *sampler state machine*
