@@ -125,11 +125,7 @@ def main_longcat(a):
     """`--workload longcat`: BASELINE config 4's model on the same contract -- LongCat-Video (13.6 B) guided i2v, 93 frames x 480 x 832,
     50-step schedule, IRR (3 rounds) + FLF + DSG + CFG-zero for the first 20 steps.  The timed window holds guided and plain steps in the
     job's 20 : 30 proportion."""
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if os.environ.get("WF_SHARE_GPU"):
-        local_rank = 0
+    rank, local_rank, world = rank_env(a)
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     from worldforge_amd import dit as wdit
@@ -246,7 +242,66 @@ def main_longcat(a):
         comm.barrier()
 
 
-def main():
+def launch_ranks(n: int, argv, script: str = None) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, RCCL rendezvous on 127.0.0.1) and
+    wait for them.  This parent never touches the GPU (no torch.cuda call that initialises HIP, no libwf_hip.so) and never
+    re-execs: the ranks are children, their stdout / stderr are inherited (rank 0 prints the JSON line), and the exit code is
+    non-zero if any rank fails.  (The reference's own multi-GPU entry has the same shape: run_upscale.py:71-77 reads
+    RANK / LOCAL_RANK from a launcher.)"""
+    import socket
+    import subprocess
+
+    share = bool(os.environ.get("WF_SHARE_GPU"))
+    have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if not share and have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible (WF_SHARE_GPU=1 WF_COMM_BACKEND=gloo runs all ranks on one GPU "
+              "as a debug configuration)", file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                r = p.poll()
+                if r is None:
+                    continue
+                pending.remove(p)
+                if r != 0 and rc == 0:
+                    rc = r if r > 0 else 1
+                    for q in pending:  # a rank died: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def rank_env(a):
+    """(rank, local_rank, world) from the launcher's environment; --gpus must agree with WORLD_SIZE."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch one rank per GPU (or run `python bench.py --gpus N` "
+                         "without a launcher: it starts the ranks itself)")
+    if os.environ.get("WF_SHARE_GPU"):  # debug: all ranks on one GPU (with WF_COMM_BACKEND=gloo) to exercise the N > 1 path
+        local_rank = 0
+    return rank, local_rank, world
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -256,26 +311,23 @@ def main():
     ap.add_argument("--width", type=int, default=832)
     ap.add_argument("--layers", type=int, default=40, help="DiT depth (40 = Wan2.1-14B; smaller only for debugging -> flagged)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--flow-backend", default="tdiff", choices=["tdiff", "farneback"],
-                    help="FLF motion backend: tdiff = the branch the reference runs without cv2 (golden-pinned); farneback = the "
-                         "GPU restatement of cv2.calcOpticalFlowFarneback (parity with cv2 unpinned)")
+    ap.add_argument("--flow-backend", default="farneback", choices=["tdiff", "farneback"],
+                    help="FLF motion backend: farneback (default) = what the installed reference executes, as the GPU restatement of "
+                         "cv2.calcOpticalFlowFarneback (parity with a real cv2 unpinned); tdiff = the branch the reference runs only "
+                         "when `import cv2` fails (golden-pinned)")
     ap.add_argument("--distill", action="store_true",
                     help="with --workload longcat: the distilled 16-step schedule without CFG (BASELINE config 4's first half; the "
                          "cfg_step_lora is a weight fold and does not change the cost)")
     ap.add_argument("--workload", default="wan", choices=["wan", "longcat"],
                     help="wan = the BASELINE metric (default); longcat = the same contract on LongCat-Video 13.6B guided i2v (config 4's model)")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become the launcher.  Nothing above or in here initialises the GPU in this process.
+        sys.exit(launch_ranks(a.gpus, argv))
     if a.workload == "longcat":
         return main_longcat(a)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    if os.environ.get("WF_SHARE_GPU"):  # debug: all ranks on one GPU (with WF_COMM_BACKEND=gloo) to exercise the N > 1 path
-        local_rank = 0
+    rank, local_rank, world = rank_env(a)
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
 
@@ -317,6 +369,7 @@ def main():
             barrier()
             marks["t0"] = time.perf_counter()
             wdit.PROFILE_ATTN = []
+            wdit.PROFILE_COMM = [] if comm is not None else None
         if phase == "begin":
             torch.cuda.synchronize()
             marks[("b", i)] = time.perf_counter()
@@ -343,10 +396,23 @@ def main():
     wdit.PROFILE_ATTN = None
     torch.cuda.synchronize()
     attn_ms = [s.elapsed_time(e) for s, e in prof]
+    cprof = wdit.PROFILE_COMM or []
+    wdit.PROFILE_COMM = None
+    comm_ms = [s.elapsed_time(e) for s, e in cprof]
     T = (a.frames - 1) // 4 + 1
     L = T * (a.height // 16) * (a.width // 16)
     Lq = model.local_tokens(L)
     attn_flop = 4.0 * Lq * L * 128 * cfg.num_heads
+    per_rank = None
+    if comm is not None:
+        # every rank's own figures: self-attention rate of its token shard, and how long its compute stream stalled per layer waiting
+        # for the K / V^T exchange (= the communication NOT hidden under the other CFG branch's layer)
+        mine = torch.tensor([sum(attn_ms) / max(len(attn_ms), 1), attn_flop, sum(comm_ms) / max(len(comm_ms), 1), float(len(comm_ms))],
+                            dtype=torch.float64, device=device)
+        allr = torch.empty((world, 4), dtype=torch.float64, device=device)
+        comm.all_gather(allr, mine)
+        per_rank = [{"rank": r, "attn_avg_ms": v[0], "attn_tflops": (v[1] / (v[0] * 1e-3) / 1e12) if v[0] > 0 else None,
+                     "comm_exposed_ms_per_layer": v[2], "layers_timed": int(v[3])} for r, v in enumerate(allr.cpu().tolist())]
     guided_ms = [1e3 * (marks[("e", i)] - marks[("b", i)]) for i in range(start + Wm, start + Wm + K) if i < guide]
     plain_ms = [1e3 * (marks[("e", i)] - marks[("b", i)]) for i in range(start + Wm, start + Wm + K) if i >= guide]
 
@@ -378,6 +444,8 @@ def main():
         if guided_ms and plain_ms:
             g, p = out["guided_step_ms"], out["plain_step_ms"]
             out["job50_steps_per_s"] = 50.0 / ((15 * g + 35 * p) / 1e3)
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if attn_ms:
             avg = sum(attn_ms) / len(attn_ms)
             ach = attn_flop / (avg * 1e-3) / 1e12

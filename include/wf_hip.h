@@ -255,6 +255,17 @@ int wf_rms_silu_cl(const float* x, const float* gamma, void* out_bf16, float* ou
 int wf_softmax_rows(const float* S, int lds, void* P, int ldp, int M, int N, float scale, void* stream);
 /* bf16 in [R, ld_in] (first C columns) -> out [C, ld_out], columns R..ld_out zero. */
 int wf_transpose_bf16(const void* in, int ld_in, void* out, int ld_out, int R, int C, void* stream);
+/* fp32-class VAE (the reference loads the VAE with torch_dtype=torch.float32, infer_worldforge.py:185-189; every conv / linear of
+ * vae.py then contracts fp32 operands).  The matrix cores take bf16, so an fp32 operand x is carried as hi = bf16(x), lo = bf16(x - hi)
+ * and a contraction as hi.hi + lo.hi + hi.lo in fp32 accumulators (dropped: lo.lo <= 2^-16 relative, tails <= 2^-17): src f32
+ * [rows, C] (row stride ld_src) -> dst bf16 [rows, 3C] (row stride ld_dst); side 0 (activation) = [hi | lo | hi], side 1 (weight) =
+ * [hi | hi | lo]: the unchanged conv / GEMM kernels then run on 3C "channels". */
+int wf_split_bf16x3(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, size_t rows, int C, int side, void* stream);
+/* wf_rms_silu_cl with the side-0 three-term output ([npix, 3C] bf16) written directly. */
+int wf_rms_silu_cl_x3(const float* x, const float* gamma, void* out_x3, size_t npix, int C, int silu, void* stream);
+/* wf_softmax_rows with f32 probabilities (vae.py:252-256 in fp32) / wf_transpose_bf16 on f32. */
+int wf_softmax_rows_f32(const float* S, int lds, float* P, int ldp, int M, int N, float scale, void* stream);
+int wf_transpose_f32(const float* in, int ld_in, float* out, int ld_out, int R, int C, void* stream);
 /* [C, N] f32 -> [N, Cpad] (f32 and/or bf16; channels C..Cpad zero, so thin inputs fill an MFMA K slice);
  * [N, ld] f32 (first C channels) -> [C, N] f32 with optional clamp (autoencoder_kl_wan.py:1222).  N = T*H*W. */
 int wf_ncthw_to_cl(const float* in, float* out_f32, void* out_bf16, int C, int Cpad, size_t N, void* stream);

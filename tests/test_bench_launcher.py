@@ -1,0 +1,79 @@
+"""`python bench.py --gpus N` must start the ranks itself: fresh child processes, rendezvous env, rc propagation,
+and no GPU call in the parent.  CPU-only: the children here are probe scripts, not the bench."""
+import json
+import os
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _probe(tmp_path, body):
+    p = tmp_path / "probe.py"
+    p.write_text(textwrap.dedent(body))
+    return str(p)
+
+
+def test_launcher_spawns_ranks_with_rendezvous_env(tmp_path, monkeypatch):
+    monkeypatch.setenv("WF_SHARE_GPU", "1")  # no GPUs in this container: skip the device-count check
+    out = tmp_path / "out"
+    out.mkdir()
+    script = _probe(tmp_path, f"""
+        import json, os, sys
+        keys = ["RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"]
+        json.dump({{k: os.environ.get(k) for k in keys}} | {{"argv": sys.argv[1:]}}, open(os.path.join({str(out)!r}, os.environ["RANK"]), "w"))
+    """)
+    rc = bench.launch_ranks(3, ["--gpus", "3", "--steps", "2"], script=script)
+    assert rc == 0
+    recs = [json.load(open(out / str(r))) for r in range(3)]
+    assert [r["RANK"] for r in recs] == ["0", "1", "2"] and [r["LOCAL_RANK"] for r in recs] == ["0", "1", "2"]
+    assert all(r["WORLD_SIZE"] == "3" and r["MASTER_ADDR"] == "127.0.0.1" for r in recs)
+    assert len({r["MASTER_PORT"] for r in recs}) == 1 and all(r["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for r in recs)
+    assert all(r["argv"] == ["--gpus", "3", "--steps", "2"] for r in recs)
+
+
+def test_launcher_propagates_failure_and_stops_the_other_ranks(tmp_path, monkeypatch):
+    monkeypatch.setenv("WF_SHARE_GPU", "1")
+    script = _probe(tmp_path, """
+        import os, sys, time
+        if os.environ["RANK"] == "1":
+            sys.exit(7)
+        time.sleep(60)  # a surviving rank would wait in a collective for ever
+    """)
+    import time
+    t0 = time.time()
+    rc = bench.launch_ranks(2, [], script=script)
+    assert rc == 7 and time.time() - t0 < 30
+
+
+def test_launcher_refuses_more_ranks_than_gpus(monkeypatch):
+    monkeypatch.delenv("WF_SHARE_GPU", raising=False)
+    assert bench.launch_ranks(64, []) == 2
+
+
+def test_main_becomes_launcher_before_any_gpu_call(monkeypatch):
+    import torch
+
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    seen = {}
+    monkeypatch.setattr(bench, "launch_ranks", lambda n, argv, script=None: seen.update(n=n, argv=list(argv)) or 0)
+
+    def boom(*a, **k):
+        raise AssertionError("the launcher parent touched the GPU")
+
+    monkeypatch.setattr(torch.cuda, "set_device", boom)
+    monkeypatch.setattr(torch.cuda, "init", boom)
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "2", "--steps", "2", "--layers", "2"])
+    assert e.value.code == 0 and seen == {"n": 2, "argv": ["--gpus", "2", "--steps", "2", "--layers", "2"]}
+
+
+def test_world_size_must_match_gpus(monkeypatch):
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    ns = type("A", (), {"gpus": 2})
+    with pytest.raises(SystemExit):
+        bench.rank_env(ns)

@@ -180,7 +180,7 @@ def test_flf_selector_end_to_end_golden(golden_dir):
     from worldforge_amd.flf import VideoMotionPCASelector
     g = np.load(os.path.join(golden_dir, "g4_flf.npz"))
     pred, enc = torch.from_numpy(g["e2e_pred"]).to(DEV), torch.from_numpy(g["e2e_enc"]).to(DEV)
-    sel = VideoMotionPCASelector()
+    sel = VideoMotionPCASelector(flow_backend="tdiff")  # g4 was recorded without cv2: the temporal-difference branch
     np.testing.assert_allclose(sel.channel_similarities(pred, enc), g["e2e_sims"], atol=2e-6)
     for step in (0, 1, 3, 8, 12):
         want = g[f"e2e_step{step}"].tolist() if f"e2e_step{step}" in g else []

@@ -238,3 +238,66 @@ def test_row_sharded_vae_equals_unsharded(P, H, model):
     for r in range(P):
         assert torch.equal(res[r][0], ref_mu), (r, (res[r][0] - ref_mu).abs().max())
         assert torch.equal(res[r][1], ref_dec), (r, (res[r][1] - ref_dec).abs().max())
+
+
+# ---- precision="fp32": three-term split operands (the reference runs the VAE in fp32, INFER:185-189) -----------------------------
+@pytest.fixture(scope="module")
+def model_fp32():
+    from worldforge_amd.vae import AutoencoderKLWan
+    return AutoencoderKLWan(DEV, precision="fp32").load_state_dict(ovae.random_weights(seed=5))
+
+
+@pytest.mark.parametrize("side", [0, 1])
+def test_split_bf16x3_reconstructs_fp32(side):
+    """hi + lo reproduces x to 2^-16 relative; layouts [hi | lo | hi] (activation) / [hi | hi | lo] (weight); strided source rows."""
+    from worldforge_amd import _ffi, ops
+    g = torch.Generator().manual_seed(11)
+    rows, C, ld = 37, 96, 128
+    src = (torch.randn(rows, ld, generator=g) * torch.logspace(-3, 3, rows).unsqueeze(1)).to(DEV)
+    dst = torch.empty(rows, 3 * C, dtype=BF, device=DEV)
+    _ffi.call("wf_split_bf16x3", src.data_ptr(), ld, dst.data_ptr(), 3 * C, rows, C, side, ops.stream())
+    x = src[:, :C]
+    hi = x.to(BF)
+    lo = (x - hi.float()).to(BF)
+    want = torch.cat([hi, lo, hi] if side == 0 else [hi, hi, lo], dim=1)
+    assert torch.equal(dst, want)
+    assert ((hi.float() + lo.float()) - x).abs().max().item() <= 2.0 ** -16 * x.abs().max().item()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fp32_mode_encode_decode_vs_twin_goldens(name, model_fp32, golden_dir):
+    """The fp32-class VAE against the fp32 twin goldens.  Tolerance (stated): 2e-4 relative L2, 1e-3 max abs on pixels in [-1, 1]
+    (75x tighter than the bf16-operand mode): what is left is the dropped lo.lo term, fp32 accumulation order and __expf-class
+    transcendental error."""
+    g = np.load(os.path.join(golden_dir, "g8_vae.npz"))
+    x, z = torch.from_numpy(g[f"{name}_x"]), torch.from_numpy(g[f"{name}_z"])
+    mu = model_fp32.encode(x.to(DEV)).latent_dist.mode().cpu()
+    dec = model_fp32.decode(z.to(DEV), return_dict=False)[0].cpu()
+    mu_ref, dec_ref = torch.from_numpy(g[f"{name}_mu"]), torch.from_numpy(g[f"{name}_dec"])
+    e_mu, e_dec = _rel(mu, mu_ref), _rel(dec, dec_ref)
+    print(f"[fp32 {name}] rel L2: mu {e_mu:.3e} dec {e_dec:.3e}; max abs: mu {(mu - mu_ref).abs().max():.3e} "
+          f"dec {(dec - dec_ref).abs().max():.3e}")
+    assert e_mu <= 2e-4 and e_dec <= 2e-4
+    assert (dec - dec_ref).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_fp32_mode_row_sharded_equals_unsharded(P, model_fp32):
+    """The row-slab (multi-GPU) VAE in the fp32-class mode: P simulated ranks == one rank, bit for bit."""
+    from tests.test_gpu_multirank import _run_ranks
+    from worldforge_amd.vae import AutoencoderKLWan
+    g = torch.Generator().manual_seed(21)
+    x = (torch.rand(1, 3, 9, 64, 96, generator=g) * 2 - 1).to(DEV)
+    z = torch.randn(1, 16, 3, 8, 12, generator=g).to(DEV)
+    mu0 = model_fp32.encode(x).latent_dist.mode().clone()
+    dec0 = model_fp32.decode(z, return_dict=False)[0].clone()
+
+    def run(comm):
+        v = AutoencoderKLWan(DEV, comm=comm, precision="fp32")
+        v.w = model_fp32.w
+        assert v.can_shard(8)
+        return v.encode(x).latent_dist.mode().clone(), v.decode(z, return_dict=False)[0].clone()
+
+    for r, (mu, dec) in enumerate(_run_ranks(P, run)):
+        assert torch.equal(mu, mu0), (r, (mu - mu0).abs().max())
+        assert torch.equal(dec, dec0), (r, (dec - dec0).abs().max())

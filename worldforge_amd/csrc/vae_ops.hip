@@ -14,7 +14,8 @@ namespace {
 // (G = 8 / 16 / 32 / 64 for C <= 128 / 256 / 512 / 1024: three or four float4 per lane), i.e. 64 / G pixels per wave: with one wave per
 // pixel only 24 of 64 lanes worked at C = 96 and the kernel ran at 2.4 TB/s.  The sum of squares is reduced inside the group by
 // xor-shuffles (fixed order: bit-identical wherever the pixel sits).
-template <int G>
+// SPLIT: the bf16 output is the three-term fp32-class operand [hi | lo | hi] (3C channels per pixel), see k_split3.
+template <int G, bool SPLIT = false>
 __global__ __launch_bounds__(256) void k_rms_silu(const float* __restrict__ x, const float* __restrict__ gamma,
                                                   uint16_t* __restrict__ out_bf16, float* __restrict__ out_f32, int C,
                                                   float scale, int silu, size_t npix) {
@@ -56,9 +57,19 @@ __global__ __launch_bounds__(256) void k_rms_silu(const float* __restrict__ x, c
         float y[4] = {v[i].x * inv * g.x, v[i].y * inv * g.y, v[i].z * inv * g.z, v[i].w * inv * g.w};
         if (silu) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) y[k] = y[k] / (1.0f + __expf(-y[k]));
+          for (int k = 0; k < 4; ++k) y[k] = y[k] / (1.0f + (SPLIT ? expf(-y[k]) : __expf(-y[k])));
         }
-        if (out_bf16) {
+        if constexpr (SPLIT) {
+          float r[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) r[k] = y[k] - rbf(y[k]);
+          const u32x2 hi = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+          const u32x2 lo = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+          uint16_t* o = out_bf16 + p * (size_t)(3 * C);
+          reinterpret_cast<u32x2*>(o)[id] = hi;
+          reinterpret_cast<u32x2*>(o + C)[id] = lo;
+          reinterpret_cast<u32x2*>(o + 2 * C)[id] = hi;
+        } else if (out_bf16) {
           u32x2 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
           reinterpret_cast<u32x2*>(out_bf16 + p * C)[id] = pk;
         }
@@ -92,14 +103,62 @@ __global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ 
   for (int i = threadIdx.x; i < ldp; i += 256) p[i] = i < N ? f32_to_bf16(__expf((s[i] - mx) * scale) * inv) : (uint16_t)0;
 }
 
-// in [R, ld_in] (first C columns) bf16 -> out [C, ld_out] bf16, columns R..ld_out zero-filled.  32x32 tiles through LDS.
-__global__ void k_transpose(const uint16_t* __restrict__ in, int ld_in, uint16_t* __restrict__ out, int ld_out, int R, int C) {
-  __shared__ uint16_t tile[32][34];
+// fp32-class operands for the bf16 matrix cores: x = hi + lo, hi = bf16(x), lo = bf16(x - hi) (x - hi is exact in fp32; the
+// dropped tail is <= 2^-17 |x|).  src f32 [rows, C] -> dst bf16 [rows, 3C]: side 0 (activation) [hi | lo | hi], side 1 (weight)
+// [hi | hi | lo], so that one K-concatenated bf16 MFMA contraction of a side-0 row with a side-1 row is hi.hi + lo.hi + hi.lo.
+__global__ __launch_bounds__(256) void k_split3(const float* __restrict__ src, long ld_src, uint16_t* __restrict__ dst, long ld_dst,
+                                                size_t rows, int C, int side) {
+  const int nvec = C >> 2;
+  const size_t n = rows * (size_t)nvec;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / nvec;
+    const int id = (int)(i % nvec);
+    const float4 v = reinterpret_cast<const float4*>(src + r * ld_src)[id];
+    const float y[4] = {v.x, v.y, v.z, v.w};
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = y[k] - rbf(y[k]);
+    const u32x2 hi = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+    const u32x2 lo = {pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3])};
+    uint16_t* o = dst + r * ld_dst;
+    reinterpret_cast<u32x2*>(o)[id] = hi;
+    reinterpret_cast<u32x2*>(o + C)[id] = side ? hi : lo;
+    reinterpret_cast<u32x2*>(o + 2 * C)[id] = side ? lo : hi;
+  }
+}
+
+// softmax over each row of S [M, N] f32 * scale -> P f32 [M, ldp] (columns N..ldp zero): the fp32-class VAE keeps P in f32 and splits it
+__global__ __launch_bounds__(256) void k_softmax_rows_f32(const float* __restrict__ S, int lds, float* __restrict__ P, int ldp, int N,
+                                                          float scale) {
+  __shared__ float sm[8];
+  const size_t row = blockIdx.x;
+  const float* s = S + row * lds;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < N; i += 256) mx = fmaxf(mx, s[i]);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) sum += expf((s[i] - mx) * scale);
+  sum = wave_sum(sum);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[4 + (threadIdx.x >> 6)] = sum;
+  __syncthreads();
+  sum = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+  float* p = P + row * ldp;
+  for (int i = threadIdx.x; i < ldp; i += 256) p[i] = i < N ? expf((s[i] - mx) * scale) / sum : 0.f;
+}
+
+// in [R, ld_in] (first C columns) -> out [C, ld_out], columns R..ld_out zero-filled.  32x32 tiles through LDS.
+template <typename E>
+__global__ void k_transpose(const E* __restrict__ in, int ld_in, E* __restrict__ out, int ld_out, int R, int C) {
+  __shared__ E tile[32][33 + (sizeof(E) == 2)];
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
   for (int k = ty; k < 32; k += 8) {
     int r = r0 + k, c = c0 + tx;
-    tile[k][tx] = (r < R && c < C) ? in[(size_t)r * ld_in + c] : (uint16_t)0;
+    tile[k][tx] = (r < R && c < C) ? in[(size_t)r * ld_in + c] : (E)0;
   }
   __syncthreads();
   for (int k = ty; k < 32; k += 8) {
@@ -168,9 +227,62 @@ extern "C" int wf_transpose_bf16(const void* in, int ld_in, void* out, int ld_ou
   WF_CHECK_ARG(in && out, "wf_transpose_bf16: null pointer");
   WF_CHECK_ARG(ld_out >= R && ld_in >= C, "wf_transpose_bf16: bad leading dimensions");
   if (R == 0 || C == 0) return WF_OK;
-  hipLaunchKernelGGL(k_transpose, dim3((C + 31) / 32, (ld_out + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_transpose<uint16_t>, dim3((C + 31) / 32, (ld_out + 31) / 32), dim3(256), 0, (hipStream_t)stream,
                      (const uint16_t*)in, ld_in, (uint16_t*)out, ld_out, R, C);
   WF_LAUNCH_CHECK("wf_transpose_bf16");
+  return WF_OK;
+}
+
+extern "C" int wf_transpose_f32(const float* in, int ld_in, float* out, int ld_out, int R, int C, void* stream) {
+  WF_CHECK_ARG(in && out, "wf_transpose_f32: null pointer");
+  WF_CHECK_ARG(ld_out >= R && ld_in >= C, "wf_transpose_f32: bad leading dimensions");
+  if (R == 0 || C == 0) return WF_OK;
+  hipLaunchKernelGGL(k_transpose<float>, dim3((C + 31) / 32, (ld_out + 31) / 32), dim3(256), 0, (hipStream_t)stream, in, ld_in, out,
+                     ld_out, R, C);
+  WF_LAUNCH_CHECK("wf_transpose_f32");
+  return WF_OK;
+}
+
+extern "C" int wf_softmax_rows_f32(const float* S, int lds, float* P, int ldp, int M, int N, float scale, void* stream) {
+  WF_CHECK_ARG(S && P, "wf_softmax_rows_f32: null pointer");
+  WF_CHECK_ARG(N > 0 && ldp >= N && lds >= N, "wf_softmax_rows_f32: bad sizes");
+  if (M == 0) return WF_OK;
+  hipLaunchKernelGGL(k_softmax_rows_f32, dim3(M), dim3(256), 0, (hipStream_t)stream, S, lds, P, ldp, N, scale);
+  WF_LAUNCH_CHECK("wf_softmax_rows_f32");
+  return WF_OK;
+}
+
+extern "C" int wf_split_bf16x3(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, size_t rows, int C, int side, void* stream) {
+  WF_CHECK_ARG(src && dst, "wf_split_bf16x3: null pointer");
+  WF_CHECK_ARG(C > 0 && C % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && ld_src >= C && ld_dst >= 3L * C,
+               "wf_split_bf16x3: C=%d ld_src=%ld ld_dst=%ld (C, strides multiples of 4; ld_dst >= 3C)", C, (long)ld_src, (long)ld_dst);
+  WF_CHECK_ARG(side == 0 || side == 1, "wf_split_bf16x3: side must be 0 (activation) or 1 (weight)");
+  if (rows == 0) return WF_OK;
+  hipLaunchKernelGGL(k_split3, dim3(grid_for(rows * (size_t)(C / 4), 256, 16384)), dim3(256), 0, (hipStream_t)stream, src, ld_src,
+                     (uint16_t*)dst, ld_dst, rows, C, side);
+  WF_LAUNCH_CHECK("wf_split_bf16x3");
+  return WF_OK;
+}
+
+extern "C" int wf_rms_silu_cl_x3(const float* x, const float* gamma, void* out_x3, size_t npix, int C, int silu, void* stream) {
+  WF_CHECK_ARG(x && gamma && out_x3, "wf_rms_silu_cl_x3: null pointer");
+  WF_CHECK_ARG(C % 4 == 0 && C > 0 && C <= 1024, "wf_rms_silu_cl_x3: C=%d must be a multiple of 4 and <= 1024", C);
+  if (npix == 0) return WF_OK;
+  const int G = C <= 128 ? 8 : (C <= 256 ? 16 : (C <= 512 ? 32 : 64));
+  size_t blocks = (npix + (size_t)(4 * (64 / G)) - 1) / (size_t)(4 * (64 / G));
+  if (blocks > 16384) blocks = 16384;
+  const float sc = sqrtf((float)C);
+  hipStream_t st = (hipStream_t)stream;
+  uint16_t* o = (uint16_t*)out_x3;
+  if (G == 8)
+    hipLaunchKernelGGL((k_rms_silu<8, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix);
+  else if (G == 16)
+    hipLaunchKernelGGL((k_rms_silu<16, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix);
+  else if (G == 32)
+    hipLaunchKernelGGL((k_rms_silu<32, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix);
+  else
+    hipLaunchKernelGGL((k_rms_silu<64, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix);
+  WF_LAUNCH_CHECK("wf_rms_silu_cl_x3");
   return WF_OK;
 }
 

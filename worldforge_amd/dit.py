@@ -68,6 +68,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
 
 
 PROFILE_ATTN = None  # bench.py sets this to a list: (start, end) HIP events around every self-attention launch
+PROFILE_COMM = None  # bench.py (N > 1) sets this to a list: (start, end) HIP events around the compute stream's wait for a layer's K / V^T exchange
 
 
 def kv_splits(H: int, Lq: int, kv_len: int, n_cu: int = 256) -> int:
@@ -515,9 +516,16 @@ class WanTransformer3DModel:
                 yield i
                 gemm(hbuf, W[p + "qkv.w"][:d], W[p + "qkv.b"][:d], qkv[:, :d], EPI_BF16)
                 self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L)
+                cprof = PROFILE_COMM
+                if cprof is not None:  # exposed communication = how long the compute stream stalls here
+                    cw0, cw1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    cw0.record()
                 for ev in (ev_k, ev_v):
                     if ev is not None:
                         torch.cuda.current_stream().wait_event(ev)
+                if cprof is not None:
+                    cw1.record()
+                    cprof.append((cw0, cw1))
                 attention(qh, kh_all, vt_all, ao, Lfull, scale, profile=True)
             gemm(ao, W[p + "self_attn.o.w"], W[p + "self_attn.o.b"], x, EPI_RESID, gate=emod[2])
             # ---- cross-attention (model.py:310, 202-229) ----

@@ -6,13 +6,15 @@ GPU for all 16 channels in two launches; the 16 similarities come back in ONE de
 D2H copies and 16 `.item()` syncs per call), and the threshold logic (16 scalars) stays on the host as in the reference.
 
 flow_backend:
-  "tdiff"     -- temporal difference motion (SCHED:391-392 / 478-479): the branch the reference executes whenever
-                 `import cv2` fails (SCHED:159-161 -> except at :390), and the one pinned by golden vectors.
-  "farneback" -- what the reference computes when OpenCV is installed (SCHED:156-248, cv2.calcOpticalFlowFarneback with the
-                 parameters of :220-224) as a batched GPU implementation (csrc/flow.hip): all 2 x 16 x (T-1) frame pairs in
-                 ~30 small launches, nothing copied to the host.  OpenCV is a third-party dependency absent from
-                 /root/reference and from this image, so this backend is checked against oracle/farneback.py (a restatement
-                 of the published algorithm) only: PARITY WITH A REAL cv2 IS UNPINNED.  It must be chosen explicitly.
+  "farneback" -- DEFAULT: what the reference computes as deployed (requirements.txt:8 installs opencv-python and
+                 use_optical_flow defaults to True): SCHED:156-248, cv2.calcOpticalFlowFarneback with the parameters of
+                 :220-224, as a batched GPU implementation (csrc/flow.hip): all 2 x 16 x (T-1) frame pairs in ~30 small
+                 launches, nothing copied to the host.  OpenCV is a third-party dependency absent from /root/reference and
+                 from this image, so this backend is checked against oracle/farneback.py (a restatement of the published
+                 algorithm) only: PARITY WITH A REAL cv2 IS UNPINNED.
+  "tdiff"     -- temporal difference motion (SCHED:391-392 / 478-479): the branch the reference executes only when
+                 `import cv2` fails (SCHED:159-161 -> except at :390); it is the branch the golden trajectories were
+                 recorded on (no cv2 in the build container), so the golden tests select it explicitly.
 """
 from __future__ import annotations
 
@@ -25,7 +27,7 @@ from . import ops
 
 
 class VideoMotionPCASelector:
-    def __init__(self, flow_backend: str = "tdiff"):
+    def __init__(self, flow_backend: str = "farneback"):
         if flow_backend not in ("tdiff", "farneback"):
             raise ValueError(f"unknown flow_backend {flow_backend!r}")
         self.flow_backend = flow_backend

@@ -42,7 +42,7 @@ class UniPCMultistepScheduler:
     def __init__(self, num_train_timesteps: int = 1000, solver_order: int = 2, prediction_type: str = "flow_prediction",
                  predict_x0: bool = True, solver_type: str = "bh2", lower_order_final: bool = True,
                  disable_corrector: Optional[List[int]] = None, use_flow_sigmas: bool = True, flow_shift: float = 3.0,
-                 final_sigmas_type: str = "zero", flow_backend: str = "tdiff"):
+                 final_sigmas_type: str = "zero", flow_backend: str = "farneback"):
         if prediction_type != "flow_prediction" or not use_flow_sigmas or not predict_x0 or solver_type != "bh2":
             raise NotImplementedError("only the Wan2.1 configuration (flow_prediction, flow sigmas, bh2, predict_x0) is built")
         if solver_order != 2 or final_sigmas_type != "zero":
@@ -65,6 +65,7 @@ class UniPCMultistepScheduler:
         self.this_order = None
         self.last_this_order = None
         self._pca_selector = None
+        self.flf_log = None  # set to a list to record every FLF gate decision (tools/vae_precision_study.py, tracing)
         self.flow_backend = flow_backend
         self.resample_sigmas = None
         self.resample_timesteps = None
@@ -252,6 +253,9 @@ class UniPCMultistepScheduler:
                 current_step=kwargs.get("current_step", 0), total_steps=kwargs.get("total_steps", 50),
                 use_optical_flow=kwargs.get("use_optical_flow", True), static=static)
             ops.channel_swap_(enc, x0, channels)
+            if self.flf_log is not None:  # trace: (outer step, swapped channels, the 16 similarities)
+                self.flf_log.append((int(kwargs.get("current_step", 0)), list(channels),
+                                     None if self._pca_selector.last_similarities is None else self._pca_selector.last_similarities.copy()))
         return ops.cast(enc, x0.dtype)
 
     # ---- SCHED:1423-1536 ---------------------------------------------------------------------------------

@@ -11,7 +11,13 @@ trivial against 288 GB) and every layer is ONE launch over all frames with causa
 the same function (oracle/vae.py proves it against the chunked twin).  Convolutions with MFMA-sized channel counts run as
 implicit GEMM (csrc/conv.hip); RMS-norm + SiLU is a fused one-pass kernel producing the bf16 conv operand; the nearest
 2x upsample and the stride-2 / zero-pad of Resample are folded into the convolution's gather; the mid-block attention is
-two MFMA GEMMs around a row softmax.  fp32 residual stream, bf16 MFMA operands, fp32 accumulation.
+two MFMA GEMMs around a row softmax.  fp32 residual stream, fp32 accumulation.
+
+precision (the reference loads the VAE with torch_dtype=torch.float32, INFER:185-189):
+  "bf16"  -- every matrix-core operand (activation and weight) rounded to bf16: 2^-9 relative per operand.
+  "fp32"  -- fp32-class contractions on the bf16 matrix cores: every operand x is carried as hi = bf16(x), lo = bf16(x - hi) and every
+             contraction as hi.hi + lo.hi + hi.lo in fp32 accumulators (wf_split_bf16x3: activations [hi | lo | hi], weights
+             [hi | hi | lo] on 3x the channels, the SAME conv / GEMM kernels; dropped terms <= 2^-16 relative).  3x the MFMA work.
 """
 from __future__ import annotations
 
@@ -102,7 +108,11 @@ class _LatentDist:
 class AutoencoderKLWan:
     dtype = torch.float32
 
-    def __init__(self, device="cuda:0", comm=None):
+    def __init__(self, device="cuda:0", comm=None, precision: str = "bf16"):
+        if precision not in ("bf16", "fp32"):
+            raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
+        self.precision = precision
+        self.x3 = precision == "fp32"  # three-term split operands
         self.device = torch.device(device)
         self.comm = comm  # row-slab sharding of the high-resolution stages over the ranks of `comm` (parallel.Comm or a stand-in)
         self.config = SimpleNamespace(z_dim=Z_DIM, latents_mean=LATENTS_MEAN, latents_std=LATENTS_STD)
@@ -116,13 +126,22 @@ class AutoencoderKLWan:
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         dev = self.device
         W: Dict[str, torch.Tensor] = {}
+        x3 = self.x3
+
+        def operand(w):  # f32 [..., Cin] (host) -> the matrix-core weight operand on the device
+            w = w.to(F32)
+            if not x3:
+                return w.to(device=dev, dtype=BF).contiguous()
+            hi = w.to(BF)
+            lo = (w - hi.to(F32)).to(BF)
+            return torch.cat([hi, hi, lo], dim=-1).to(dev).contiguous()  # weight side of wf_split_bf16x3
 
         def mfma_conv(p):  # [Cout,Cin,kt,kh,kw] -> bf16 [Cout, taps, Cin]
             w = sd[p + ".weight"]
             if w.dim() == 4:
                 w = w.unsqueeze(2)
             co, ci = w.shape[:2]
-            W[p + ".w"] = w.permute(0, 2, 3, 4, 1).reshape(co, -1, ci).to(device=dev, dtype=BF).contiguous()
+            W[p + ".w"] = operand(w.permute(0, 2, 3, 4, 1).reshape(co, -1, ci))
             W[p + ".b"] = sd[p + ".bias"].to(device=dev, dtype=F32).contiguous()
 
         def mfma_conv_padded(p, cin_pad=None, cout_pad=None):
@@ -136,7 +155,7 @@ class AutoencoderKLWan:
             wp[:co, :ci] = w
             bp = torch.zeros(cop, dtype=F32)
             bp[:co] = b
-            W[p + ".w"] = wp.permute(0, 2, 3, 4, 1).reshape(cop, -1, cip).to(device=dev, dtype=BF).contiguous()
+            W[p + ".w"] = operand(wp.permute(0, 2, 3, 4, 1).reshape(cop, -1, cip))
             W[p + ".b"] = bp.to(dev)
 
         def small_conv(p, cout_pad=None):  # -> f32 [taps, Cin, Cout]
@@ -153,7 +172,7 @@ class AutoencoderKLWan:
 
         def lin(p):  # 1x1(x1) conv as GEMM weight bf16 [Cout, Cin]
             w = sd[p + ".weight"]
-            W[p + ".w"] = w.reshape(w.shape[0], w.shape[1]).to(device=dev, dtype=BF).contiguous()
+            W[p + ".w"] = operand(w.reshape(w.shape[0], w.shape[1]))
             W[p + ".b"] = sd[p + ".bias"].to(device=dev, dtype=F32).contiguous()
 
         def gamma(p):
@@ -283,9 +302,35 @@ class AutoencoderKLWan:
 
     def _rms(self, x, gamma, silu=True):
         C = x.shape[-1]
+        if self.x3:
+            out = torch.empty(tuple(x.shape[:-1]) + (3 * C,), dtype=BF, device=x.device)
+            call("wf_rms_silu_cl_x3", x.data_ptr(), gamma.data_ptr(), out.data_ptr(), x.numel() // C, C, 1 if silu else 0, ops.stream())
+            return out
         out = torch.empty(x.shape, dtype=BF, device=x.device)
         call("wf_rms_silu_cl", x.data_ptr(), gamma.data_ptr(), out.data_ptr(), None, x.numel() // C, C, 1 if silu else 0,
              ops.stream())
+        return out
+
+    def _operand(self, x, side=0, out=None):
+        """f32 [..., C] -> the matrix-core operand: bf16 [..., C], or the three-term split [..., 3C] (precision="fp32"; side 0 =
+        activation, 1 = weight-side layout).  `out`: a contiguous destination of the operand's shape."""
+        if not self.x3:
+            y = ops.cast(x, BF)
+            if out is not None:
+                out.copy_(y)
+                return out
+            return y
+        assert x.dtype == F32 and x.stride(-1) == 1
+        C = x.shape[-1]
+        if x.dim() > 2:
+            assert x.is_contiguous()
+            x2 = x.view(-1, C)
+        else:
+            x2 = x
+        if out is None:
+            out = torch.empty(tuple(x.shape[:-1]) + (3 * C,), dtype=BF, device=x.device)
+        assert out.is_contiguous() and out.numel() == 3 * x2.shape[0] * C
+        call("wf_split_bf16x3", x2.data_ptr(), x2.stride(0), out.data_ptr(), 3 * C, x2.shape[0], C, side, ops.stream())
         return out
 
     def _res(self, x, p, cin, cout):
@@ -298,10 +343,10 @@ class AutoencoderKLWan:
         a2 = self._rms(y, W[p + ".residual.3.gamma"])
         del y
         if cin != cout:
-            xb = ops.cast(x, BF)
+            xb = self._operand(x)
             h = torch.empty((T, H, Wd, cout), dtype=F32, device=x.device)
-            gemm(xb.view(-1, cin), W[p + ".shortcut.w"], W[p + ".shortcut.b"], h.view(-1, cout), EPI_F32)
-            self.flops_last += 2 * T * H * Wd * cin * cout
+            gemm(xb.view(-1, xb.shape[-1]), W[p + ".shortcut.w"], W[p + ".shortcut.b"], h.view(-1, cout), EPI_F32)
+            self.flops_last += 2 * T * H * Wd * xb.shape[-1] * cout
             del xb
         else:
             h = x
@@ -315,6 +360,8 @@ class AutoencoderKLWan:
         hwp = (hw + 7) // 8 * 8  # K / N padding for the MFMA GEMMs; padded score columns are never read by the softmax
         W = self.w
         a = self._rms(x, W[p + ".norm.gamma"], silu=False)
+        if self.x3:
+            return self._attn_x3(x, p, a)
         qkv = torch.empty((T * hw + 8, 3 * C), dtype=BF, device=x.device)  # +8 rows: the padded K rows stay in-bounds
         qkv[T * hw:].zero_()
         gemm(a.view(-1, C), W[p + ".to_qkv.w"], W[p + ".to_qkv.b"], qkv[:T * hw], EPI_BF16)
@@ -334,38 +381,55 @@ class AutoencoderKLWan:
         self.flops_last += T * (4 * hw * hw * C) + 2 * T * hw * C * 4 * C
         return x
 
+    def _attn_x3(self, x, p, a):
+        """_attn with fp32-class contractions: q / k / v, the scores and the probabilities stay f32 and are split per use."""
+        T, H, Wd, C = x.shape
+        hw = H * Wd
+        hwp = (hw + 7) // 8 * 8
+        W = self.w
+        qkv = torch.zeros((T * hw + 8, 3 * C), dtype=F32, device=x.device)
+        gemm(a.view(-1, 3 * C), W[p + ".to_qkv.w"], W[p + ".to_qkv.b"], qkv[:T * hw], EPI_F32)
+        del a
+        S = torch.empty((hw, hwp), dtype=F32, device=x.device)
+        P = torch.empty((hw, hwp), dtype=F32, device=x.device)
+        Vt = torch.empty((C, hwp), dtype=F32, device=x.device)
+        Of = torch.empty((T * hw, C), dtype=F32, device=x.device)
+        scale = 1.0 / math.sqrt(C)
+        for t in range(T):
+            blk = qkv[t * hw:t * hw + hwp]
+            gemm(self._operand(blk[:hw, 0:C], 0), self._operand(blk[:, C:2 * C], 1), None, S, EPI_F32)
+            call("wf_softmax_rows_f32", S.data_ptr(), hwp, P.data_ptr(), hwp, hw, hw, float(scale), ops.stream())
+            call("wf_transpose_f32", blk[:, 2 * C:].data_ptr(), 3 * C, Vt.data_ptr(), hwp, hw, C, ops.stream())
+            gemm(self._operand(P, 0), self._operand(Vt, 1), None, Of[t * hw:(t + 1) * hw], EPI_F32)
+        gemm(self._operand(Of), W[p + ".proj.w"], W[p + ".proj.b"], x.view(-1, C), EPI_F32_ACC)
+        self.flops_last += 3 * (T * (4 * hw * hw * C) + 2 * T * hw * C * 4 * C)
+        return x
+
     def _down(self, x, p, C, temporal):
         """vae.py:87-96, 139-159."""
         T, H, Wd, _ = x.shape
         Ho, Wo = H // 2, Wd // 2
-        xb = ops.cast(x, BF)
+        xb = self._operand(x)
         if not temporal or T == 1:
             y, _ = self._conv(xb, p + ".resample.1", T, Ho, Wo, C, (1, 3, 3), ss=2, ps=0)
             return y
-        y, yb = self._conv(xb, p + ".resample.1", T, Ho, Wo, C, (1, 3, 3), ss=2, ps=0, out_f32=True, out_bf16=True)
+        y, yb = self._conv(xb, p + ".resample.1", T, Ho, Wo, C, (1, 3, 3), ss=2, ps=0, out_f32=True, out_bf16=not self.x3)
         del xb
+        if self.x3:
+            yb = self._operand(y)
         To = (T - 1) // 2
         out = torch.empty((1 + To, Ho, Wo, C), dtype=F32, device=x.device)
         out[0].copy_(y[0])  # frame 0 by-passes time_conv (vae.py:146-148)
         W = self.w
         call("wf_conv3d_cl", yb.data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
-             out[1:].data_ptr(), None, T, Ho, Wo, C, To, Ho, Wo, C, 3, 1, 1, 2, 1, 0, 0, 0, 0, 0, None, ops.stream())
-        self.flops_last += 2 * To * Ho * Wo * C * 3 * C
+             out[1:].data_ptr(), None, T, Ho, Wo, yb.shape[-1], To, Ho, Wo, C, 3, 1, 1, 2, 1, 0, 0, 0, 0, 0, None, ops.stream())
+        self.flops_last += 2 * To * Ho * Wo * C * 3 * yb.shape[-1]
         return out
 
     def _up(self, x, p, C, temporal):
         """vae.py:76-86, 101-141."""
         T, H, Wd, _ = x.shape
-        xb = ops.cast(x, BF)
-        if temporal and T > 1:
-            T2 = 1 + 2 * (T - 1)
-            yb = torch.empty((T2, H, Wd, C), dtype=BF, device=x.device)
-            yb[0].copy_(xb[0])  # first latent frame by-passes time_conv ('Rep', vae.py:106-108)
-            W = self.w
-            call("wf_conv3d_cl", xb[1:].data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
-                 None, yb.data_ptr(), T - 1, H, Wd, C, T - 1, H, Wd, 2 * C, 3, 1, 1, 1, 1, 2, 0, 0, 0, 1, None, ops.stream())
-            self.flops_last += 2 * (T - 1) * H * Wd * 2 * C * 3 * C
-            xb = yb
+        xb = self._time_up(self._operand(x), p, C) if temporal else self._operand(x)
         Tn = xb.shape[0]
         out, _ = self._conv(xb, p + ".resample.1", Tn, 2 * H, 2 * Wd, C // 2, (1, 3, 3), ps=1, up2=True)
         return out
@@ -439,9 +503,9 @@ class AutoencoderKLWan:
         a2 = self._halo_pad(self._rms(y, W[p + ".residual.3.gamma"]))
         del y
         if cin != cout:
-            xb = ops.cast(x, BF)
+            xb = self._operand(x)
             h = torch.empty((T, Hs, Wd, cout), dtype=F32, device=x.device)
-            gemm(xb.view(-1, cin), W[p + ".shortcut.w"], W[p + ".shortcut.b"], h.view(-1, cout), EPI_F32)
+            gemm(xb.view(-1, xb.shape[-1]), W[p + ".shortcut.w"], W[p + ".shortcut.b"], h.view(-1, cout), EPI_F32)
             del xb
         else:
             h = x
@@ -449,13 +513,24 @@ class AutoencoderKLWan:
         return out
 
     def _time_up(self, xb, p, C):
-        """'upsample3d' temporal part on a bf16 tensor (pointwise in space): [T,..] -> [1+2(T-1),..]."""
-        T, H, Wd, _ = xb.shape
+        """'upsample3d' temporal part (pointwise in space) on the conv operand xb of x: [T,..] -> [1+2(T-1),..] as an operand again.
+        The first latent frame by-passes time_conv ('Rep', vae.py:106-108): its operand is carried over as it is.  precision="fp32":
+        the interleaved frames are produced in f32 and split."""
+        T, H, Wd, Cop = xb.shape
         if T == 1:
             return xb
+        W = self.w
+        self.flops_last += 2 * (T - 1) * H * Wd * 2 * C * 3 * Cop
+        if self.x3:
+            yf = torch.empty((1 + 2 * (T - 1), H, Wd, C), dtype=F32, device=xb.device)  # frame 0 is not written (tsplit: 1 + 2t + h)
+            call("wf_conv3d_cl", xb[1:].data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
+                 yf.data_ptr(), None, T - 1, H, Wd, Cop, T - 1, H, Wd, 2 * C, 3, 1, 1, 1, 1, 2, 0, 0, 0, 1, None, ops.stream())
+            yb = torch.empty((1 + 2 * (T - 1), H, Wd, Cop), dtype=BF, device=xb.device)
+            yb[0].copy_(xb[0])
+            self._operand(yf[1:], out=yb[1:])
+            return yb
         yb = torch.empty((1 + 2 * (T - 1), H, Wd, C), dtype=BF, device=xb.device)
         yb[0].copy_(xb[0])
-        W = self.w
         call("wf_conv3d_cl", xb[1:].data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
              None, yb.data_ptr(), T - 1, H, Wd, C, T - 1, H, Wd, 2 * C, 3, 1, 1, 1, 1, 2, 0, 0, 0, 1, None, ops.stream())
         return yb
@@ -478,18 +553,20 @@ class AutoencoderKLWan:
     def _down_slab(self, x, p, C, temporal):
         """fp32 slab [T,Hs,W,C] -> [T',Hs/2,W/2,C]  (ZeroPad2d((0,1,0,1)) + stride-2 conv: bottom halo row only)."""
         T, Hs, Wd, _ = x.shape
-        xpad = self._halo_pad(ops.cast(x, BF))
+        xpad = self._halo_pad(self._operand(x))
         Ho, Wo = Hs // 2, Wd // 2
         if not temporal or T == 1:
             y, _ = self._conv(xpad, p + ".resample.1", T, Ho, Wo, C, (1, 3, 3), ss=2, ps=0, ph=-1)
             return y
-        y, yb = self._conv(xpad, p + ".resample.1", T, Ho, Wo, C, (1, 3, 3), ss=2, ps=0, ph=-1, out_f32=True, out_bf16=True)
+        y, yb = self._conv(xpad, p + ".resample.1", T, Ho, Wo, C, (1, 3, 3), ss=2, ps=0, ph=-1, out_f32=True, out_bf16=not self.x3)
+        if self.x3:
+            yb = self._operand(y)
         To = (T - 1) // 2
         out = torch.empty((1 + To, Ho, Wo, C), dtype=F32, device=x.device)
         out[0].copy_(y[0])
         W = self.w
         call("wf_conv3d_cl", yb.data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
-             out[1:].data_ptr(), None, T, Ho, Wo, C, To, Ho, Wo, C, 3, 1, 1, 2, 1, 0, 0, 0, 0, 0, None, ops.stream())
+             out[1:].data_ptr(), None, T, Ho, Wo, yb.shape[-1], To, Ho, Wo, C, 3, 1, 1, 2, 1, 0, 0, 0, 0, 0, None, ops.stream())
         return out
 
     def can_shard(self, H_lat: int) -> bool:
@@ -505,7 +582,7 @@ class AutoencoderKLWan:
         C, T, h, w = z.shape
         x = torch.empty((T, h, w, Z_DIM), dtype=F32, device=self.device)
         call("wf_ncthw_to_cl", z.data_ptr(), x.data_ptr(), None, Z_DIM, Z_DIM, T * h * w, ops.stream())
-        x = self._small_conv(x, "conv2", T, h, w, 32, (1, 1, 1), out_dtype=BF)
+        x = self._latent_in(x, T, h, w)
         plan = decoder_plan()
         first_up = next(i for i, e in enumerate(plan) if e[0] in ("up2d", "up3d"))
         x = self._run(x, plan[:first_up])                      # stage 0 replicated: [T,h,w,384] fp32
@@ -513,7 +590,7 @@ class AutoencoderKLWan:
         Hs = 2 * h // P                                        # my rows at the next resolution
         y0 = rank * Hs
         s0, s1 = (y0 - 1) >> 1, ((y0 + Hs) >> 1) + 1               # source rows incl. halo (s0 = -1 -> zero row)
-        src = self._rows_from_full(ops.cast(x, BF), s0, s1)
+        src = self._rows_from_full(self._operand(x), s0, s1)
         x = self._up_slab(src, p, cin, kind == "up3d", s0, y0, Hs, h)
         h_cur = 2 * h                                          # full image height at the current resolution
         row0 = y0                                              # global first row of my slab at the current resolution
@@ -522,7 +599,7 @@ class AutoencoderKLWan:
                 x = self._res_slab(x, p, cin, cout)
             elif kind in ("up2d", "up3d"):
                 Hcur = x.shape[1]
-                x = self._up_slab(self._halo_pad(ops.cast(x, BF)), p, cin, kind == "up3d", row0 - 1, 2 * row0, 2 * Hcur, h_cur)
+                x = self._up_slab(self._halo_pad(self._operand(x)), p, cin, kind == "up3d", row0 - 1, 2 * row0, 2 * Hcur, h_cur)
                 row0 *= 2
                 h_cur *= 2
             elif kind == "head":
@@ -539,8 +616,7 @@ class AutoencoderKLWan:
         comm = self.comm
         P, rank = comm.world, comm.rank
         C, Fr, H, Wd = video.shape
-        xfull = torch.empty((Fr, H, Wd, 32), dtype=BF, device=self.device)
-        call("wf_ncthw_to_cl", video.data_ptr(), None, xfull.data_ptr(), 3, 32, Fr * H * Wd, ops.stream())
+        xfull = self._video_in(video)
         plan = encoder_plan()
         Hs = H // P
         y0 = rank * Hs
@@ -563,6 +639,23 @@ class AutoencoderKLWan:
         call("wf_cl_to_ncthw", q.data_ptr(), out.data_ptr(), 2 * Z_DIM, 2 * Z_DIM, T * h * w, 0.0, ops.stream())
         return out  # [mean | logvar]
 
+    def _video_in(self, video):
+        """[3,F,H,W] f32 -> channels-last conv operand [F,H,W,32 (x3)]: 3 channels zero-padded to one MFMA K slice."""
+        C, Fr, H, Wd = video.shape
+        if self.x3:
+            xf = torch.empty((Fr, H, Wd, 32), dtype=F32, device=self.device)
+            call("wf_ncthw_to_cl", video.data_ptr(), xf.data_ptr(), None, 3, 32, Fr * H * Wd, ops.stream())
+            return self._operand(xf)
+        x = torch.empty((Fr, H, Wd, 32), dtype=BF, device=self.device)
+        call("wf_ncthw_to_cl", video.data_ptr(), None, x.data_ptr(), 3, 32, Fr * H * Wd, ops.stream())
+        return x
+
+    def _latent_in(self, x, T, h, w):
+        """post-quant conv2 (vae.py:558) on the channels-last latent -> conv operand [T,h,w,32 (x3)] (16 channels + 16 zero channels)."""
+        if self.x3:
+            return self._operand(self._small_conv(x, "conv2", T, h, w, 32, (1, 1, 1), out_dtype=F32))
+        return self._small_conv(x, "conv2", T, h, w, 32, (1, 1, 1), out_dtype=BF)
+
     # ------------------------------------------------------------------------------------------------------------
     # diffusers protocol
     # ------------------------------------------------------------------------------------------------------------
@@ -576,8 +669,7 @@ class AutoencoderKLWan:
         self.flops_last = 0
         if self.can_shard(H // 8):
             return self._encode_one_sharded(video)
-        x = torch.empty((Fr, H, Wd, 32), dtype=BF, device=self.device)  # 3 channels zero-padded to one MFMA K slice
-        call("wf_ncthw_to_cl", video.data_ptr(), None, x.data_ptr(), 3, 32, Fr * H * Wd, ops.stream())
+        x = self._video_in(video)
         y = self._run(x, encoder_plan())
         T, h, w, _ = y.shape
         q = self._small_conv(y, "conv1", T, h, w, 2 * Z_DIM, (1, 1, 1))
@@ -593,7 +685,7 @@ class AutoencoderKLWan:
             return self._decode_one_sharded(z)
         x = torch.empty((T, h, w, Z_DIM), dtype=F32, device=self.device)
         call("wf_ncthw_to_cl", z.data_ptr(), x.data_ptr(), None, Z_DIM, Z_DIM, T * h * w, ops.stream())
-        x = self._small_conv(x, "conv2", T, h, w, 32, (1, 1, 1), out_dtype=BF)  # 16 channels + 16 zero channels
+        x = self._latent_in(x, T, h, w)  # 16 channels + 16 zero channels
         y = self._run(x, decoder_plan())
         Fo, Ho, Wo, Cy = y.shape
         out = torch.empty((3, Fo, Ho, Wo), dtype=F32, device=self.device)
