@@ -301,3 +301,31 @@ def test_fp32_mode_row_sharded_equals_unsharded(P, model_fp32):
     for r, (mu, dec) in enumerate(_run_ranks(P, run)):
         assert torch.equal(mu, mu0), (r, (mu - mu0).abs().max())
         assert torch.equal(dec, dec0), (r, (dec - dec0).abs().max())
+
+
+@pytest.mark.parametrize("name", ["f9_32x32", "f5_48x40"])
+def test_diffusers_layout_checkpoint_loads_and_matches_executed_class(name, golden_dir, tmp_path):
+    """A diffusers-layout checkpoint on disk (vae/diffusion_pytorch_model.safetensors with the names + shapes of the class the reference
+    executes, recorded in g8b) -> AutoencoderKLWan.from_pretrained -> encode / decode against that class's recorded outputs."""
+    from safetensors.torch import save_file
+    from worldforge_amd.vae import AutoencoderKLWan, diffusers_key_map
+    b = np.load(os.path.join(golden_dir, "g8b_vae_akw.npz"))
+    g = np.load(os.path.join(golden_dir, "g8_vae.npz"))
+    shapes = {str(n): tuple(int(v) for v in str(s).split(",")) for n, s in zip(b["param_names"], b["param_shapes"])}
+    W = ovae.random_weights(seed=5)
+    inv = {v: k for k, v in diffusers_key_map().items()}
+    sd = {}
+    for k, v in W.items():
+        base, _, leaf = k.rpartition(".")
+        dk = f"{inv[base]}.{leaf}"
+        sd[dk] = v.reshape(shapes[dk]).contiguous()
+    assert set(sd) == set(shapes)
+    os.makedirs(tmp_path / "vae")
+    save_file(sd, str(tmp_path / "vae" / "diffusion_pytorch_model.safetensors"))
+    for precision, tol_rel, tol_abs in (("bf16", 1.5e-2, 6e-2), ("fp32", 2e-4, 1e-3)):
+        m = AutoencoderKLWan.from_pretrained(str(tmp_path), device=DEV, precision=precision)
+        mu = m.encode(torch.from_numpy(g[f"{name}_x"]).to(DEV)).latent_dist.mode().cpu()
+        dec = m.decode(torch.from_numpy(g[f"{name}_z"]).to(DEV), return_dict=False)[0].cpu()
+        mu_ref, dec_ref = torch.from_numpy(b[f"{name}_mu"]), torch.from_numpy(b[f"{name}_dec"])
+        assert _rel(mu, mu_ref) <= tol_rel and _rel(dec, dec_ref) <= tol_rel, (precision, _rel(mu, mu_ref), _rel(dec, dec_ref))
+        assert (dec - dec_ref).abs().max().item() <= tol_abs

@@ -31,3 +31,15 @@ def test_plans_and_shapes():
     sh = ovae.param_shapes()
     assert sum(int(np.prod(s)) for s in sh.values()) == 126_892_531  # the 127 M-parameter real config
     assert [k for k, *_ in ovae.decoder_plan()].count("up3d") == 2 and [k for k, *_ in ovae.encoder_plan()].count("down3d") == 2
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_encode_decode_match_executed_diffusers_class(name, weights, golden_dir):
+    """g8b: recorded from diffusers' AutoencoderKLWan (the class the reference executes, INFER:185-189; vendored copy
+    longcat_video/modules/autoencoder_kl_wan.py) with the same weights loaded through the diffusers key map: chunked _encode
+    (:1145-1170), decode with the clamp (:1222)."""
+    g, b = np.load(os.path.join(golden_dir, "g8_vae.npz")), np.load(os.path.join(golden_dir, "g8b_vae_akw.npz"))
+    mu = ovae.encode_mode(weights, torch.from_numpy(g[f"{name}_x"]))
+    dec = ovae.decode(weights, torch.from_numpy(g[f"{name}_z"]))
+    assert np.abs(mu.numpy() - b[f"{name}_mu"]).max() <= 2e-5 and np.abs(dec.numpy() - b[f"{name}_dec"]).max() <= 2e-5
+    assert np.abs(b[f"{name}_dec"]).max() <= 1.0

@@ -2,6 +2,7 @@
 
   python tools/make_goldens.py            # g1, g4, g6, g10 (Wan sampler state machine, FLF metric, harness)
   python tools/make_goldens.py dit | vae   # g7, g8 (in-tree Wan DiT / VAE twins)
+  python tools/make_goldens.py vae_akw     # g8b (the executed class: diffusers' AutoencoderKLWan as vendored under longcat_video/modules)
   python tools/make_goldens.py longcat | longcat_pipe | longcat_lora | longcat_refine      # g11, g12, g13, g15 (LongCat DiT, guided
                                            # i2v trajectories, run-time LoRA, refine-pass trajectories)
   TORCHDYNAMO_DISABLE=1 python tools/make_goldens.py bsa | bsa_cdf                          # g14, g14b (block-sparse gating helpers)
@@ -31,6 +32,15 @@ OUT = os.path.join(ROOT, "tests", "golden")
 from tests.fakes import FakeDiT, FakeVAE, synthetic_ref_and_mask  # noqa: E402
 
 
+def _longcat_paths():
+    """LongCat generators only: the reference package + the plain-softmax stand-in for the third-party `flash_attn` package its
+    attention module imports.  (Not on sys.path for the Wan generators: the Wan twin's attention.py would take
+    FLASH_ATTN_2_AVAILABLE = True from it and route fp32 tensors into flash_attention()'s half-dtype assert, attention.py:53.)"""
+    for p in ("/root/reference/longcat_for_worldforge", os.path.join(ROOT, "tools", "refshim_flash")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
 def t2n(t):
     if t.dtype == torch.bfloat16:
         return t.float().numpy()
@@ -38,7 +48,7 @@ def t2n(t):
 
 
 # ------------------------------------------------------------------------------------------------------------
-def g_schedules():
+def g_schedules(out_dir=OUT):
     from utils.scheduling_unipc_multistep_clean import UniPCMultistepScheduler
 
     out = {}
@@ -51,7 +61,7 @@ def g_schedules():
             out[k + "_sigmas"] = s.sigmas.numpy()
             out[k + "_rsig"] = s.resample_sigmas.numpy()
             out[k + "_rts"] = s.resample_timesteps.numpy()
-    np.savez_compressed(os.path.join(OUT, "g1_schedules.npz"), **out)
+    np.savez_compressed(os.path.join(out_dir, "g1_schedules.npz"), **out)
     print("g1_schedules", len(out))
 
 
@@ -260,7 +270,7 @@ def _load_wan_module(name):
 
 
 # ------------------------------------------------------------------------------------------------------------
-def g_dit():
+def g_dit(out_dir=OUT):
     """G7: tiny WanModel (in-tree twin, fp32, SDPA fallback for flash_attention) with the oracle's synthetic weights."""
     wattn = _load_wan_module("attention")
     wmodel = _load_wan_module("model")
@@ -294,7 +304,7 @@ def g_dit():
         out[f"{name}_clip"] = clip[0].numpy()
         out[f"{name}_out"] = o.numpy()
         out[f"{name}_cfg"] = np.array([dim, heads, ffn, layers, T, h, w])
-    np.savez_compressed(os.path.join(OUT, "g7_dit.npz"), **out)
+    np.savez_compressed(os.path.join(out_dir, "g7_dit.npz"), **out)
     print("g7_dit", {k: v.shape for k, v in out.items() if k.endswith("_out")})
 
 
@@ -337,14 +347,62 @@ if __name__ == "__main__" and "vae" in sys.argv[1:]:
     g_vae()
 
 
+def _load_akw():
+    """diffusers' AutoencoderKLWan as vendored at longcat_video/modules/autoencoder_kl_wan.py (imports diffusers base classes only ->
+    tools/refshim) -- the class the Wan path executes (INFER:185-189) and LongCat loads."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "akw_ref", "/root/reference/longcat_for_worldforge/longcat_video/modules/autoencoder_kl_wan.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def g_vae_akw(out_dir=OUT):
+    """G8b: the executed class.  The oracle's synthetic weights (twin names) are loaded into the unmodified diffusers-layout class
+    through the inverse of worldforge_amd.vae.diffusers_key_map; encode(x).latent_dist.mode() / decode(z).sample (clamped, :1222;
+    chunked _encode :1145-1170) on the g8 inputs.  Also records the class's parameter names + shapes (the key-map contract)."""
+    akw = _load_akw()
+    from oracle import vae as ovae
+    from worldforge_amd.vae import diffusers_key_map
+
+    m = akw.AutoencoderKLWan()
+    m.eval()
+    sd = m.state_dict()
+    W = ovae.random_weights(seed=5)
+    inv = {v: k for k, v in diffusers_key_map().items()}
+    new = {}
+    for k, v in W.items():
+        base, _, leaf = k.rpartition(".")
+        dk = f"{inv[base]}.{leaf}"
+        new[dk] = v.reshape(sd[dk].shape)
+    assert set(new) == set(sd), set(new) ^ set(sd)
+    m.load_state_dict(new, strict=True)
+    g8 = np.load(os.path.join(OUT, "g8_vae.npz"))
+    out = {"param_names": np.array(sorted(sd)), "param_shapes": np.array([",".join(map(str, sd[k].shape)) for k in sorted(sd)])}
+    with torch.no_grad():
+        for name in ("f9_32x32", "f5_48x40", "f1_32x32", "f17_16x24"):
+            x, z = torch.from_numpy(g8[f"{name}_x"]), torch.from_numpy(g8[f"{name}_z"])
+            mu = m.encode(x).latent_dist.mode()
+            dec = m.decode(z, return_dict=False)[0]
+            out[f"{name}_mu"], out[f"{name}_dec"] = mu.numpy(), dec.numpy()
+            print("g8b", name, float((mu - torch.from_numpy(g8[f"{name}_mu"])).abs().max()),
+                  float((dec - torch.from_numpy(g8[f"{name}_dec"])).abs().max()))
+    np.savez_compressed(os.path.join(out_dir, "g8b_vae_akw.npz"), **out)
+
+
+if __name__ == "__main__" and "vae_akw" in sys.argv[1:]:
+    g_vae_akw()
+
+
 # ------------------------------------------------------------------------------------------------------------
 def g_longcat_dit():
-    """G11: the unmodified LongCatVideoTransformer3DModel (fp32, CPU; its flash-attn calls served by tools/refshim/flash_attn) with
+    """G11: the unmodified LongCatVideoTransformer3DModel (fp32, CPU; its flash-attn calls served by tools/refshim_flash/flash_attn) with
     the oracle's synthetic weights, called the way generate_i2v calls it (pipeline_longcat_video.py:857-873: cond + uncond batch,
     per-frame timesteps with frame 0 at t = 0, num_cond_latents = 1, caption masks), plus one call without condition frames."""
     import warnings
 
-    sys.path.insert(0, "/root/reference/longcat_for_worldforge")
+    _longcat_paths()
     from longcat_video.modules.longcat_video_dit import LongCatVideoTransformer3DModel
     from oracle import longcat_dit as olc
 
@@ -419,7 +477,7 @@ def g_longcat_pipe():
     the VAE and the text encoder (encode_prompt) and a fixed target size instead of the resolution-bucket lookup."""
     from tests.fakes import FakeLongCatDiT
 
-    sys.path.insert(0, "/root/reference/longcat_for_worldforge")
+    _longcat_paths()
     from longcat_video.modules.scheduling_flow_match_euler_discrete import FlowMatchEulerDiscreteScheduler
     from longcat_video.pipeline_longcat_video import LongCatVideoPipeline
 
@@ -474,7 +532,7 @@ def g_longcat_lora():
     """G13: the reference DiT with a LoRA network enabled the reference's way (create_lora_network + enable_loras, LCD:189-247)."""
     import warnings
 
-    sys.path.insert(0, "/root/reference/longcat_for_worldforge")
+    _longcat_paths()
     from longcat_video.modules.longcat_video_dit import LongCatVideoTransformer3DModel
     from longcat_video.modules.lora_utils import create_lora_network
     from oracle import longcat_dit as olc
@@ -515,7 +573,7 @@ if __name__ == "__main__" and "longcat_lora" in sys.argv[1:]:
 # ------------------------------------------------------------------------------------------------------------
 def g_bsa():
     """G14: the reference's own BSA helper functions (permutes, mean pooling, top-k block selection; eager: TORCHDYNAMO_DISABLE=1)."""
-    sys.path.insert(0, "/root/reference/longcat_for_worldforge")
+    _longcat_paths()
     from longcat_video.block_sparse_attention import bsa_interface as B
 
     g = torch.Generator().manual_seed(9)
@@ -563,7 +621,7 @@ def g_longcat_refine():
     """G15: LongCatVideoPipeline.generate_refine, unmodified, with the deterministic DiT / VAE / text-encoder stand-ins."""
     from tests.fakes import FakeLongCatDiT
 
-    sys.path.insert(0, "/root/reference/longcat_for_worldforge")
+    _longcat_paths()
     from longcat_video.modules.scheduling_flow_match_euler_discrete import FlowMatchEulerDiscreteScheduler
     import longcat_video.pipeline_longcat_video as lcp
     from longcat_video.pipeline_longcat_video import LongCatVideoPipeline
@@ -613,7 +671,7 @@ if __name__ == "__main__" and "longcat_refine" in sys.argv[1:]:
 
 def g_bsa_cdf():
     """G14b: the reference's cdf / cdf+top-k block selection functions (bsa_interface.py:226-263), eager."""
-    sys.path.insert(0, "/root/reference/longcat_for_worldforge")
+    _longcat_paths()
     from longcat_video.block_sparse_attention import bsa_interface as B
 
     g = torch.Generator().manual_seed(19)

@@ -85,6 +85,72 @@ def decoder_plan() -> List[Tuple]:
     return plan
 
 
+def diffusers_key_map() -> Dict[str, str]:
+    """diffusers `AutoencoderKLWan` module name -> in-tree twin (`WanVAE_`) module name, for the Wan 2.1 configuration
+    (is_residual=False).  The diffusers class is what the reference executes (INFER:185-189 `AutoencoderKLWan.from_pretrained`; a
+    vendored copy is longcat_video/modules/autoencoder_kl_wan.py: encoder :505-584, decoder :783-872, mid block :430-451, up block
+    :714-753, residual block :311-340, top level :1029-1052).  Leaves (.weight / .bias / .gamma) are appended by the caller."""
+    m = {"encoder.conv_in": "encoder.conv1", "encoder.norm_out": "encoder.head.0", "encoder.conv_out": "encoder.head.2",
+         "decoder.conv_in": "decoder.conv1", "decoder.norm_out": "decoder.head.0", "decoder.conv_out": "decoder.head.2",
+         "quant_conv": "conv1", "post_quant_conv": "conv2"}
+    res = {"norm1": "residual.0", "conv1": "residual.2", "norm2": "residual.3", "conv2": "residual.6", "conv_shortcut": "shortcut"}
+    for side in ("encoder", "decoder"):
+        for j, name in ((0, "resnets.0"), (1, "attentions.0"), (2, "resnets.1")):
+            d, t = f"{side}.mid_block.{name}", f"{side}.middle.{j}"
+            if j == 1:
+                for leaf in ("norm", "to_qkv", "proj"):
+                    m[f"{d}.{leaf}"] = f"{t}.{leaf}"
+            else:
+                for a, b in res.items():
+                    m[f"{d}.{a}"] = f"{t}.{b}"
+    # encoder: down_blocks is the same flat list as the twin's downsamples
+    for kind, p, cin, cout in encoder_plan():
+        if not p.startswith("encoder.downsamples."):
+            continue
+        d = p.replace("encoder.downsamples.", "encoder.down_blocks.")
+        if kind == "res":
+            for a, b in res.items():
+                if a != "conv_shortcut" or cin != cout:
+                    m[f"{d}.{a}"] = f"{p}.{b}"
+        else:
+            m[f"{d}.resample.1"] = f"{p}.resample.1"
+            if kind.endswith("3d"):
+                m[f"{d}.time_conv"] = f"{p}.time_conv"
+    # decoder: up_blocks[i] = {resnets[0..2], upsamplers[0]} against the twin's flat upsamples list
+    blk, j = 0, 0
+    for kind, p, cin, cout in decoder_plan():
+        if not p.startswith("decoder.upsamples."):
+            continue
+        if kind == "res":
+            d = f"decoder.up_blocks.{blk}.resnets.{j}"
+            for a, b in res.items():
+                if a != "conv_shortcut" or cin != cout:
+                    m[f"{d}.{a}"] = f"{p}.{b}"
+            j += 1
+            if j == NUM_RES + 1 and blk == len(DIM_MULT) - 1:
+                blk, j = blk + 1, 0
+        else:
+            d = f"decoder.up_blocks.{blk}.upsamplers.0"
+            m[f"{d}.resample.1"] = f"{p}.resample.1"
+            if kind.endswith("3d"):
+                m[f"{d}.time_conv"] = f"{p}.time_conv"
+            blk, j = blk + 1, 0
+    return m
+
+
+def diffusers_to_twin_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Rename a diffusers-layout AutoencoderKLWan state dict to the twin's names (tensors are shared, shapes are the same up to the
+    trailing singleton dims of the RMS-norm gammas, which the loader flattens).  Unknown or missing parameters raise KeyError."""
+    km = diffusers_key_map()
+    out = {}
+    for k, v in sd.items():
+        base, _, leaf = k.rpartition(".")
+        if base not in km:
+            raise KeyError(f"unmapped diffusers AutoencoderKLWan parameter {k!r}")
+        out[f"{km[base]}.{leaf}"] = v
+    return out
+
+
 class _LatentDist:
     """diffusers' DiagonalGaussianDistribution surface the samplers use: mode() (Wan path, PIPE retrieve_latents "argmax") and
     sample(generator) (LongCat prepare_latents, pipeline_longcat_video.py:278: mean + std * randn, logvar clamped to [-30, 20])."""
@@ -204,6 +270,18 @@ class AutoencoderKLWan:
         small_conv("conv2", cout_pad=32)  # decoder input, zero-padded to one 32-channel MFMA K slice
         self.w = W
         return self
+
+    def load_diffusers_state_dict(self, sd: Dict[str, torch.Tensor]):
+        """State dict in the layout of the class the reference executes (diffusers AutoencoderKLWan, INFER:185-189)."""
+        return self.load_state_dict(diffusers_to_twin_state_dict(sd))
+
+    @classmethod
+    def from_pretrained(cls, path: str, device="cuda:0", comm=None, precision: str = "bf16", subfolder: str = "vae"):
+        """`AutoencoderKLWan.from_pretrained(model_id, subfolder="vae", torch_dtype=torch.float32)` (INFER:185-189) from a local
+        diffusers checkpoint directory: reads `<path>/<subfolder>/*.safetensors` (sharded or not) with checkpoint.load_dir."""
+        from . import checkpoint
+        folder = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
+        return cls(device, comm=comm, precision=precision).load_diffusers_state_dict(checkpoint.load_dir(folder))
 
     def init_random(self, seed: int = 0):
         """Synthetic weights of the real shapes, generated on the host in twin layout (127 M parameters)."""
