@@ -345,3 +345,46 @@ def test_context_kv_cache_is_transparent():
     ref_c = m.forward_tokens(x, 500.0, ca, clip)
     assert not torch.equal(ref_c, ref_a)
     assert torch.equal(got_c, ref_c)
+
+
+def test_diffusers_layout_transformer_checkpoint_loads(tmp_path):
+    """A sharded diffusers-layout `transformer/` directory (config.json + 2 safetensors shards + index; names through the inverse of
+    dit.diffusers_key_map, per-block / final scale_shift_table) -> WanTransformer3DModel.from_pretrained -> the same forward as the
+    twin-keyed loader, bit for bit."""
+    import json
+    from safetensors.torch import save_file
+    from worldforge_amd import dit
+    cfg = dit.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    ocfg = odit.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    W = odit.random_weights(ocfg, seed=9)
+    inv = {v: k for k, v in dit.diffusers_key_map(cfg.num_layers).items()}
+    sd = {}
+    for k, v in W.items():
+        if k == "head.modulation":
+            sd["scale_shift_table"] = v
+        elif k.endswith(".modulation"):
+            sd[k.replace(".modulation", ".scale_shift_table")] = v
+        else:
+            base, _, leaf = k.rpartition(".")
+            sd[f"{inv[base]}.{leaf}"] = v
+    sd = {k: v.to(BF).contiguous() for k, v in sd.items()}  # released checkpoints are bf16
+    folder = tmp_path / "transformer"
+    os.makedirs(folder)
+    names = sorted(sd)
+    half = len(names) // 2
+    wm = {}
+    for fn, ns in (("diffusion_pytorch_model-00001-of-00002.safetensors", names[:half]),
+                   ("diffusion_pytorch_model-00002-of-00002.safetensors", names[half:])):
+        save_file({n: sd[n] for n in ns}, str(folder / fn))
+        wm.update({n: fn for n in ns})
+    (folder / "diffusion_pytorch_model.safetensors.index.json").write_text(json.dumps({"metadata": {}, "weight_map": wm}))
+    (folder / "config.json").write_text(json.dumps({"_class_name": "WanTransformer3DModel", "num_attention_heads": 2, "attention_head_dim": 128,
+                                                     "ffn_dim": 512, "num_layers": 2, "in_channels": 36, "out_channels": 16, "text_dim": 64,
+                                                     "freq_dim": 256, "image_dim": 1280, "patch_size": [1, 2, 2], "eps": 1e-6}))
+    m1 = dit.WanTransformer3DModel.from_pretrained(str(tmp_path), device=DEV)
+    m0 = dit.WanTransformer3DModel(cfg, DEV).load_state_dict({k: v.to(BF) for k, v in W.items()})
+    assert m1.cfg == cfg
+    x = _rand((36, 2, 8, 12), 60).to(BF).to(DEV)
+    ctx, clip = _rand((30, 64), 61).to(BF).to(DEV), _rand((257, 1280), 62).to(BF).to(DEV)
+    a, b = m0.forward_tokens(x, 500.0, ctx, clip).clone(), m1.forward_tokens(x, 500.0, ctx, clip).clone()
+    assert torch.isfinite(a).all() and torch.equal(a, b)

@@ -251,6 +251,29 @@ class WanTransformer3DModel:
             out[f"{km[base]}.{leaf}"] = v
         return self.load_state_dict(out)
 
+    @classmethod
+    def from_pretrained(cls, path: str, device="cuda:0", comm=None, subfolder: str = "transformer"):
+        """The `transformer/` component of a local diffusers Wan2.1-I2V checkpoint directory (what
+        `WanImageToVideoPipeline.from_pretrained(model_id, ...)` loads at INFER:191-197): `config.json` (diffusers field names:
+        num_attention_heads x attention_head_dim, ffn_dim, num_layers, in_channels, out_channels, text_dim, freq_dim, image_dim,
+        eps -- recalled from diffusers 0.35, not verifiable offline; missing fields keep the Wan2.1-I2V-14B values of
+        wan/configs/wan_i2v_14B.py:27-36) + safetensors shards through checkpoint.load_dir and the diffusers key map."""
+        import json as _json
+        from . import checkpoint
+        folder = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
+        cfg = DiTConfig.wan_i2v_14b()
+        cj = os.path.join(folder, "config.json")
+        if os.path.exists(cj):
+            with open(cj) as f:
+                c = _json.load(f)
+            heads = int(c.get("num_attention_heads", cfg.num_heads))
+            cfg = DiTConfig(dim=heads * int(c.get("attention_head_dim", 128)), ffn_dim=int(c.get("ffn_dim", cfg.ffn_dim)), num_heads=heads,
+                            num_layers=int(c.get("num_layers", cfg.num_layers)), in_dim=int(c.get("in_channels", cfg.in_dim)),
+                            out_dim=int(c.get("out_channels", cfg.out_dim)), freq_dim=int(c.get("freq_dim", cfg.freq_dim)),
+                            text_dim=int(c.get("text_dim", cfg.text_dim)), img_dim=int(c.get("image_dim") or cfg.img_dim),
+                            patch_size=tuple(c.get("patch_size", cfg.patch_size)), eps=float(c.get("eps", cfg.eps)))
+        return cls(cfg, device, comm=comm).load_diffusers_state_dict(checkpoint.load_dir(folder))
+
     def init_random(self, seed: int = 0):
         """Synthetic weights of the right shapes, generated directly on the device: there are no checkpoints
         offline.  Scaled so activations stay O(1) through 40 layers."""

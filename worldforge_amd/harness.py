@@ -72,15 +72,17 @@ def target_size(image_height: int, image_width: int, max_area: int, mod_value: i
 
 
 def prepare_inputs(directory: str, model: str = "480p", num_frames: int = None, soften: bool = True,
-                   transition_distance: int = 15, decay_type: str = "sine", device=None):
+                   transition_distance: int = 15, decay_type: str = "sine", device=None, max_area: int = None):
     """INFER:153-254 -> (image PIL, video_ref [1,3,F,H,W] f32 in [0,1], mask [1,1,F,H,W], height, width).
     `num_frames` (not in the reference) truncates the warped sequence: the reference requires #reference frames == the
-    (4k+1) frame count it decodes, otherwise SCHED:1326 raises.  With `device` (a GPU) the mask softening runs there
+    (4k+1) frame count it decodes, otherwise SCHED:1326 raises.  `max_area` (not in the reference) overrides the model's pixel budget
+    (INFER:217: 480*832 or 720*1280) so that the same size rule can be exercised at test sizes.  With `device` (a GPU) the mask softening runs there
     (wf_soften_mask: exact windowed EDT) and video_ref / mask are returned on that device."""
     frames, masks, first = read_frames_from_directory(directory)
     if num_frames is not None:
         frames, masks = frames[:num_frames], masks[:num_frames]
-    max_area = 480 * 832 if model == "480p" else 720 * 1280
+    if max_area is None:
+        max_area = 480 * 832 if model == "480p" else 720 * 1280
     h, w = target_size(first.height, first.width, max_area)
     image = first.resize((w, h))
     video = torch.stack([torch.tensor(np.array(f.resize((w, h)))).permute(2, 0, 1).float() / 255.0 for f in frames])
