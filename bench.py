@@ -52,43 +52,61 @@ def synthetic_inputs(F, H, W, device, seed=42):
     return image, ref.to(device), mask.to(device), text.to(bf).to(device), neg.to(bf).to(device), img_emb.to(bf).to(device)
 
 
-def cpu_baseline(budget_s=25.0):
-    """Oracle (CPU port of the reference arithmetic, fp32) timed on this host: one full-width DiT block and one VAE
-    decode+encode on a bounded sample; converted to steps/s of the timed step mix by the algorithmic FLOP counts."""
+def _median3(fn):
+    """median of 3 runs after 1 warm-up."""
+    fn()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[1]
+
+
+def cpu_baseline(L, frames, height, width):
+    """BASELINE.md section 3 on a bounded sample (~15-25 s on the GPU box's host): the oracle (CPU port of the reference arithmetic,
+    fp32, all host threads), median of 3 after a warm-up of
+      (i)   one full-width DiT block (d = 5120, 40 heads, FFN 13824, text+image cross-attention) at the C1 token count L1 = 4524, and its
+            self-attention core alone at L1 -- everything in a block except that core is linear in L;
+      (ii)  the self-attention core with the config's TRUE key length: L1 query rows x L keys on 4 of the 40 heads (the core is linear
+            in query rows and in heads, so this prices the L^2 term at the real L without the 40 x L x L score tensor);
+      (iii) VAE encode + decode of a 5 x 96 x 96 clip (linear in pixel-frames);
+    returns per-unit CPU seconds at the config's true sizes: one DiT forward (40 blocks) and one VAE decode + encode."""
     from oracle import dit as odit
     from oracle import vae as ovae
 
     torch.manual_seed(0)
     cores = torch.get_num_threads()
     cfg = odit.DiTConfig(num_layers=1)
-    Ls = 1024
+    L1 = 4524  # BASELINE config 1: 9 frames of 464 x 832
     W = odit.random_weights(cfg, seed=1)
-    f, h, w = 1, 32, 32
-    tok = torch.randn(Ls, cfg.dim)
+    f, h, w = 3, 29, 52
+    tok = torch.randn(L1, cfg.dim)
     e0 = torch.randn(6, cfg.dim) * 0.1
     ctx = torch.randn(769, cfg.dim)
     ang = odit.rope_tables(128, f, h, w)
+    nh, hd = cfg.num_heads, cfg.dim // cfg.num_heads
+    q1, k1, v1 = (torch.randn(L1, nh, hd) for _ in range(3))
+    hs = 4
+    qL, kL, vL = torch.randn(L1, hs, hd), torch.randn(L, hs, hd), torch.randn(L, hs, hd)
     with torch.no_grad():
-        odit.block(tok[:64], e0, ctx, W, 0, cfg, ang[:64])  # warm-up
-        t0 = time.time()
-        odit.block(tok, e0, ctx, W, 0, cfg, ang)
-        t_blk = time.time() - t0
-    d, ff = cfg.dim, cfg.ffn_dim
-    flop_blk = Ls * (12 * d * d + 4 * d * ff) + 4 * 769 * d * d + 4 * Ls * Ls * d + 4 * Ls * 769 * d
-    dit_rate = flop_blk / t_blk
+        t_blk = _median3(lambda: odit.block(tok, e0, ctx, W, 0, cfg, ang))
+        t_core1 = _median3(lambda: odit.attention(q1, k1, v1))
+        t_coreL = _median3(lambda: odit.attention(qL, kL, vL))
     del W
+    t_block_true = (t_blk - t_core1) * (L / L1) + t_coreL * (nh / hs) * (L / L1)
     Wv = ovae.random_weights(seed=2)
-    Fs, Hs, Ws = 5, 64, 64
+    Fs, Hs, Ws = 5, 96, 96
+    xs = torch.rand(1, 3, Fs, Hs, Ws) * 2 - 1
     with torch.no_grad():
-        t0 = time.time()
-        z = ovae.encode_mode(Wv, torch.rand(1, 3, Fs, Hs, Ws) * 2 - 1)
-        ovae.decode(Wv, z)
-        t_vae = time.time() - t0
-    flop_vae = (5.19e6 + 8.70e6) * Fs * Hs * Ws  # BASELINE.md section 2
-    vae_rate = flop_vae / t_vae
-    return dict(cores=cores, dit_flops_per_s=dit_rate, vae_flops_per_s=vae_rate, t_block_s=t_blk, t_vae_s=t_vae,
-                sample=f"oracle fp32: 1 DiT block (d=5120, 40 heads, FFN 13824) at L={Ls} tokens in {t_blk:.2f}s + VAE "
-                       f"encode+decode of {Fs}x{Hs}x{Ws} in {t_vae:.2f}s; extrapolated by algorithmic FLOPs to the timed step mix")
+        t_vae = _median3(lambda: ovae.decode(Wv, ovae.encode_mode(Wv, xs)))
+    t_vae_true = t_vae * (frames * height * width) / (Fs * Hs * Ws)
+    return dict(cores=cores, t_dit_forward_s=40 * t_block_true, t_vae_roundtrip_s=t_vae_true,
+                sample=f"oracle fp32, {cores} threads, median of 3 after warm-up: DiT block (d=5120, 40 heads, FFN 13824) at L1={L1}: {t_blk:.2f}s "
+                       f"(its self-attention core {t_core1:.2f}s); core with the true key length {L1} q x {L} k on {hs}/40 heads: {t_coreL:.2f}s; "
+                       f"VAE encode+decode {Fs}x{Hs}x{Ws}: {t_vae:.2f}s; block@L = (block - core)*L/L1 + core_L*(40/{hs})*L/L1 = "
+                       f"{t_block_true:.1f}s, x40 blocks per forward; VAE scaled by pixel-frames to {frames}x{height}x{width}: {t_vae_true:.0f}s; "
+                       "steps/s = steps / sum(count x unit time) over the timed step mix (extrapolation)")
 
 
 def cpu_baseline_longcat():
@@ -315,6 +333,9 @@ def main(argv=None):
                     help="FLF motion backend: farneback (default) = what the installed reference executes, as the GPU restatement of "
                          "cv2.calcOpticalFlowFarneback (parity with a real cv2 unpinned); tdiff = the branch the reference runs only "
                          "when `import cv2` fails (golden-pinned)")
+    ap.add_argument("--vae-precision", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 (default): fp32-class VAE contractions as the reference's fp32 VAE (INFER:185-189) -- three-term split bf16 "
+                         "operands on the matrix cores, 3x the VAE MFMA work; bf16: every VAE operand rounded to bf16 (faster, 2^-9 per operand)")
     ap.add_argument("--distill", action="store_true",
                     help="with --workload longcat: the distilled 16-step schedule without CFG (BASELINE config 4's first half; the "
                          "cfg_step_lora is a weight fold and does not change the cost)")
@@ -343,7 +364,7 @@ def main(argv=None):
     cfg.num_layers = a.layers
     t0 = time.time()
     model = wdit.WanTransformer3DModel(cfg, device, comm=comm).init_random(seed=0)
-    vae = AutoencoderKLWan(device, comm=comm).init_random(seed=1)  # high-resolution stages row-sharded over the ranks
+    vae = AutoencoderKLWan(device, comm=comm, precision=a.vae_precision).init_random(seed=1)  # high-resolution stages row-sharded over the ranks
     sch = UniPCMultistepScheduler(flow_shift=3.0, flow_backend=a.flow_backend)
     pipe = WanImageToVideoPipeline(model, vae, sch, device=device)
     image, ref, mask, text, neg, img_emb = synthetic_inputs(a.frames, a.height, a.width, device)
@@ -435,7 +456,7 @@ def main(argv=None):
                             f"timed steps {start + Wm}..{start + Wm + K - 1} = {len(guided_ms)} guided + {len(plain_ms)} plain",
                 "tokens": L, "dit_layers": cfg.num_layers, "dit_params_bytes": model.param_bytes(),
                 "parallelism": "single" if world == 1 else f"sp{world} (token-sharded DiT with K/V all-gather + row-sharded VAE with halo all-gather, RCCL)",
-                "flow_backend": a.flow_backend,
+                "flow_backend": a.flow_backend, "vae_precision": a.vae_precision,
             },
             "guided_step_ms": sum(guided_ms) / len(guided_ms) if guided_ms else None,
             "plain_step_ms": sum(plain_ms) / len(plain_ms) if plain_ms else None,
@@ -458,11 +479,9 @@ def main(argv=None):
         if a.layers != 40:
             out["invalid_reason"] = f"debug run with {a.layers} DiT layers (the named model has 40)"
         if not a.no_cpu_baseline and world == 1:
-            cb = cpu_baseline()
+            cb = cpu_baseline(L, a.frames, a.height, a.width)
             ng, npl = len(guided_ms), len(plain_ms)
-            dit_flop = 40 * (8 * L * 5120 ** 2 + 4 * L * 5120 ** 2 + 4 * 769 * 5120 ** 2 + 4 * L * 5120 * 13824 + 4 * L * L * 5120 + 4 * L * 769 * 5120)
-            vae_flop = (5.19e6 + 8.70e6) * a.frames * a.height * a.width
-            t_cpu = (ng * 4 + npl * 2) * dit_flop / cb["dit_flops_per_s"] + ng * 2 * vae_flop / cb["vae_flops_per_s"]
+            t_cpu = (ng * 4 + npl * 2) * cb["t_dit_forward_s"] + ng * 2 * cb["t_vae_roundtrip_s"]
             out["cpu_baseline"] = {"value": K / t_cpu, "unit": "steps/s", "cores": cb["cores"], "kind": "port", "sample": cb["sample"]}
         print(json.dumps(out), flush=True)
     if comm is not None:

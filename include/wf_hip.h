@@ -240,10 +240,14 @@ int wf_conv3d_cl(const void* in, const void* w, const float* bias, const float* 
  * an 8 x 64 pixel tile of one output frame x 96 output channels per workgroup, all 27 taps read the (3 x 10 x 66)-pixel patch of a
  * 16-channel slice from LDS.  Weights in the re-packed layout [27][Cin/16][Cout][16] produced by wf_conv3d_pack333 from
  * [Cout][27][Cin].  in [T,Hi,Wi,Cin] bf16 (Hi = Ho for ph = 1; row slabs carry their halo rows: Hi = Ho + 2, ph = 0),
- * out [T,Ho,Wi,Cout]; Cin % 32 == 0, Cout % 32 == 0; zero_page >= 64 bf16 zeros.  Same arithmetic as wf_conv3d_cl. */
+ * out [T,Ho,Wi,Cout]; Cin % 32 == 0, Cout % 32 == 0; zero_page >= 64 bf16 zeros.  Same arithmetic as wf_conv3d_cl.
+ * layout 0: in is pixel-major [T,Hi,Wi,Cin_stored]; layout 1: slice-major [T,Hi,Cin_stored/16,Wi,16] (what wf_rms_silu_cl_blocked
+ * writes: a patch row of a 16-channel slice is contiguous, so the LDS-DMA gather reads whole cache lines).  Cin_stored = Cin, or
+ * 2/3 Cin when the fp32-class three-term operand [hi | lo | hi] (wf_split_bf16x3 side 0) is stored as [hi | lo] and its hi half is
+ * read for both K thirds. */
 int wf_conv3d_pack333(const void* w, void* w_packed, int Cout, int Cin, void* stream);
 int wf_conv3d_333(const void* in, const void* w_packed, const float* bias, const float* resid, float* out_f32, void* out_bf16, int T,
-                  int Hi, int Wi, int Cin, int Ho, int Cout, int ph, const void* zero_page, void* stream);
+                  int Hi, int Wi, int Cin, int Ho, int Cout, int ph, const void* zero_page, int layout, int Cin_stored, void* stream);
 /* Direct convolution for the thin layers (3->96, 16->384, 96->3, 384->32, 1x1x1 quant convs; vae.py:288, 316, 392, 421, 505-506).
  * in f32 or bf16 channels-last, w f32 [taps][Cin][Cout]; clamp > 0 clamps the output (autoencoder_kl_wan.py:1222). */
 int wf_conv3d_small(const void* in, int in_dtype, const float* w, const float* bias, float* out_f32, void* out_bf16, int Ti, int Hi,
@@ -263,6 +267,9 @@ int wf_transpose_bf16(const void* in, int ld_in, void* out, int ld_out, int R, i
 int wf_split_bf16x3(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, size_t rows, int C, int side, void* stream);
 /* wf_rms_silu_cl with the side-0 three-term output ([npix, 3C] bf16) written directly. */
 int wf_rms_silu_cl_x3(const float* x, const float* gamma, void* out_x3, size_t npix, int C, int silu, void* stream);
+/* wf_rms_silu_cl writing the slice-major conv operand of wf_conv3d_333 (layout 1): x f32 [npix, C] (npix = whole rows of W pixels)
+ * -> bf16 [npix / W][C/16][W][16]; split != 0: the fp32-class operand stored as [hi | lo] slices, [npix / W][2C/16][W][16]. */
+int wf_rms_silu_cl_blocked(const float* x, const float* gamma, void* out, size_t npix, int C, int silu, int W, int split, void* stream);
 /* wf_softmax_rows with f32 probabilities (vae.py:252-256 in fp32) / wf_transpose_bf16 on f32. */
 int wf_softmax_rows_f32(const float* S, int lds, float* P, int ldp, int M, int N, float scale, void* stream);
 int wf_transpose_f32(const float* in, int ld_in, float* out, int ld_out, int R, int C, void* stream);

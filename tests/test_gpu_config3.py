@@ -90,7 +90,7 @@ def test_vae_c3_row_sharded_equals_unsharded():
     """81 x 720 x 1280: decode and encode on 4 simulated ranks (row slabs + halo all-gather) == unsharded, bit for bit."""
     from tests.fakes import SimComm
     from worldforge_amd.vae import AutoencoderKLWan
-    v0 = AutoencoderKLWan(DEV).init_random(seed=1)
+    v0 = AutoencoderKLWan(DEV, precision="bf16").init_random(seed=1)   # memory: the three-term operands of the fp32-class mode are 3x wider
     z = _dev_randn((1, 16, T3, h3, w3), 720, 1.0, F32)
     g = torch.Generator(device=DEV).manual_seed(721)
     video = torch.rand((1, 3, 81, 720, 1280), generator=g, device=DEV) * 2 - 1
@@ -99,13 +99,14 @@ def test_vae_c3_row_sharded_equals_unsharded():
     assert ref_dec.min().item() >= -1.0 and ref_dec.max().item() <= 1.0
     ref_mu = v0.encode(video).latent_dist.mode()
     assert ref_mu.shape == (1, 16, T3, h3, w3) and torch.isfinite(ref_mu).all()
+    torch.cuda.empty_cache()   # the unsharded pass peaks at ~100 GB of activations; hand the cached blocks back before the rank threads
     P = 4
     shared = {"slots": [None] * P, "bar": threading.Barrier(P)}
     ok, errs = [False] * P, []
 
     def worker(r):
         try:
-            m = AutoencoderKLWan(DEV, comm=SimComm(P, r, shared))
+            m = AutoencoderKLWan(DEV, comm=SimComm(P, r, shared), precision="bf16")
             m.w = v0.w
             assert m.can_shard(h3)
             d = m.decode(z, return_dict=False)[0]

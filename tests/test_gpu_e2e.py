@@ -1,6 +1,8 @@
 """GPU: the whole guided job (IRR + FLF + DSG sampler, DiT, real-config VAE) on the HIP path against the CPU oracle (fp32) run with
 identical weights, seeds and inputs -- SURVEY 8d's "PSNR vs reference on final frames" (target >= 40 dB).  Tolerance: the
-product computes GEMM / attention / conv operands in bf16 (as the reference does on a GPU), the oracle in fp32."""
+product computes the DiT's GEMM / attention operands in bf16 (as the reference does on a GPU) and the VAE in its fp32-class mode (the
+reference's VAE is fp32); the oracle computes everything in fp32.  Jobs this short never reach an FLF swap (current_step <= 5 -> no
+channel): the schedule-length behaviour, where the discrete gate decisions matter, is tests/test_gpu_schedule_length.py."""
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -10,6 +12,7 @@ pytestmark = pytest.mark.gpu
     dict(dim=256, ffn_dim=512, heads=2, layers=2, Fr=9, H=32, Wd=32, steps=3, guide=2),
     dict(dim=1024, ffn_dim=2048, heads=8, layers=4, Fr=13, H=64, Wd=96, steps=5, guide=3),
     dict(dim=5120, ffn_dim=13824, heads=40, layers=2, Fr=9, H=64, Wd=96, steps=4, guide=3),   # the 14B width, two layers
+    dict(dim=1024, ffn_dim=2048, heads=8, layers=4, Fr=13, H=64, Wd=96, steps=5, guide=3, vae_precision="bf16"),  # the opt-in fast VAE
 ])
 def test_guided_job_frames_psnr_vs_oracle(cfg):
     import __graft_entry__ as ge

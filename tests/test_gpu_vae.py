@@ -23,7 +23,7 @@ CASES = ["f9_32x32", "f5_48x40", "f1_32x32", "f17_16x24"]
 @pytest.fixture(scope="module")
 def model():
     from worldforge_amd.vae import AutoencoderKLWan
-    return AutoencoderKLWan(DEV).load_state_dict(ovae.random_weights(seed=5))
+    return AutoencoderKLWan(DEV, precision="bf16").load_state_dict(ovae.random_weights(seed=5))
 
 
 def _rel(a, b):
@@ -126,7 +126,7 @@ def test_conv3d_333_vs_torch(cfg):
     of = torch.full((T, Ho, W, cout), float("nan"), dtype=F32, device=DEV)
     ob = torch.empty((T, Ho, W, cout), dtype=BF, device=DEV)
     _ffi.call("wf_conv3d_333", xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), rd.data_ptr(), of.data_ptr(), ob.data_ptr(), T, H, W, cin, Ho,
-              cout, 0 if halo else 1, zp.data_ptr(), ops.stream())
+              cout, 0 if halo else 1, zp.data_ptr(), 0, cin, ops.stream())
     want = ref + resid
     err = (of.cpu() - want).abs().max().item()
     assert err <= 2e-3 * max(1.0, want.abs().max().item()), err
@@ -223,7 +223,7 @@ def test_row_sharded_vae_equals_unsharded(P, H, model):
 
     def worker(r):
         try:
-            m = AutoencoderKLWan(DEV, comm=_SimComm(P, r, shared))
+            m = AutoencoderKLWan(DEV, comm=_SimComm(P, r, shared), precision=model.precision)
             m.w = model.w
             assert m.can_shard(H // 8)
             res[r] = (m.encode(x).latent_dist.mode(), m.decode(z, return_dict=False)[0])

@@ -10,6 +10,6 @@ q = torch.randn(H, L, 128, device=dev).to(torch.bfloat16)
 k = torch.zeros(H, Lp, 128, device=dev, dtype=torch.bfloat16); k[:, :L] = torch.randn(H, L, 128, device=dev).to(torch.bfloat16)
 vt = torch.randn(H, Lp // 64, 128, 64, device=dev).to(torch.bfloat16)
 out = torch.empty(L, H * 128, device=dev, dtype=torch.bfloat16)
-for _ in range(3):
+for _ in range(int(os.environ.get("N", 3))):
     dit.attention(q, k, vt, out, L, 1 / math.sqrt(128))
 torch.cuda.synchronize()

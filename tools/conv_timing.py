@@ -6,8 +6,11 @@ from worldforge_amd import _ffi, ops
 lib = _ffi.lib()
 buf = (ctypes.c_ulonglong * 8)()
 sl = (ctypes.c_ulonglong * 32)()
+LAYOUT = int(os.environ.get("LAYOUT", 1))
 for (T, H, W, C) in ((81, 480, 832, 96), (41, 120, 208, 384)):
     x = torch.randn(T, H, W, C, device="cuda:0").to(torch.bfloat16)
+    if LAYOUT:
+        x = x.view(T, H, W, C // 16, 16).permute(0, 1, 3, 2, 4).contiguous()
     w = (torch.randn(C, 27, C, device="cuda:0") / math.sqrt(C * 27)).to(torch.bfloat16)
     out = torch.empty(T, H, W, C, device="cuda:0")
     zp = torch.zeros(1024, dtype=torch.bfloat16, device="cuda:0")
@@ -15,7 +18,7 @@ for (T, H, W, C) in ((81, 480, 832, 96), (41, 120, 208, 384)):
     _ffi.call("wf_conv3d_pack333", w.data_ptr(), wp.data_ptr(), C, C, ops.stream())
     def run():
         _ffi.call("wf_conv3d_333", x.data_ptr(), wp.data_ptr(), None, None, out.data_ptr(), None, T, H, W, C, H, C, 1, zp.data_ptr(),
-                  ops.stream())
+                  LAYOUT, C, ops.stream())
     run(); torch.cuda.synchronize(); lib.wf_debug_conv_cycles(buf, 1); lib.wf_debug_conv_slices(sl)
     run(); torch.cuda.synchronize(); lib.wf_debug_conv_cycles(buf, 1); lib.wf_debug_conv_slices(sl)
     nwg, nt = max(buf[5], 1), max(buf[6], 1)

@@ -14,7 +14,12 @@ and reports PSNR of the final frames pairwise, the per-step relative distance of
 FLF channel lists of every gate.  A vs B isolates the VAE's operand precision (everything else is bit-identical HIP arithmetic);
 B vs C is what the rest of the path (bf16 DiT activations) contributes.
 
-Usage:  python tools/vae_precision_study.py [--oracle] [--frames 17 --height 128 --width 128 --steps 20 --guide 15] [--out FILE]
+Because the FLF gate is a DISCRETE decision on 16 nearly tied similarities, two arithmetically close runs can swap different channels
+and then diverge (a swapped channel is a large change of x0).  The tool therefore reports both the free-running comparison (with the
+decision margin of every gate) and the comparison with the parity target's decisions replayed (scheduler.flf_replay).
+
+Usage:  python tools/vae_precision_study.py [--oracle [--save-fixture F.npz] | --fixture F.npz] [--frames 17 --height 128 --width 128
+                                             --steps 20 --guide 15] [--out FILE]
 """
 from __future__ import annotations
 
@@ -64,7 +69,7 @@ def make_inputs(Fr, H, Wd):
     return image, ref, mask, text, neg, img
 
 
-def run_hip(precision, Wd_, Wv, ocfg, inputs, Fr, H, Wd, steps, guide, flow_backend):
+def run_hip(precision, Wd_, Wv, ocfg, inputs, Fr, H, Wd, steps, guide, flow_backend, replay=None):
     from worldforge_amd import dit
     from worldforge_amd.pipeline import WanImageToVideoPipeline
     from worldforge_amd.scheduler import UniPCMultistepScheduler
@@ -77,6 +82,7 @@ def run_hip(precision, Wd_, Wv, ocfg, inputs, Fr, H, Wd, steps, guide, flow_back
     vae = AutoencoderKLWan(dev, precision=precision).load_state_dict(Wv)
     sch = UniPCMultistepScheduler(flow_shift=3.0, flow_backend=flow_backend)
     sch.flf_log = []
+    sch.flf_replay = dict(replay) if replay is not None else None
     lat = []
     pipe = WanImageToVideoPipeline(model, vae, sch, device=dev)
 
@@ -110,12 +116,22 @@ def run_oracle(Wd_, Wv, ocfg, inputs, Fr, H, Wd, steps, guide, flow_backend):
     log = []
     orig = oinject.select_motion_related_channels
 
+    sims_log = []
+    orig_sims = oinject.channel_similarities
+
+    def logged_sims(pred, enc_, flow_backend="tdiff"):
+        sm = orig_sims(pred, enc_, flow_backend)
+        sims_log.append([float(v) for v in sm])
+        return sm
+
     def logged(pred, enc_, current_step, flow_backend="tdiff"):
+        n = len(sims_log)
         ch = orig(pred, enc_, current_step, flow_backend=flow_backend)
-        log.append((int(current_step), list(ch)))
+        log.append((int(current_step), list(ch), sims_log[-1] if len(sims_log) > n else None))
         return ch
 
     oinject.select_motion_related_channels = logged
+    oinject.channel_similarities = logged_sims
 
     def tr(x, t, ctx, im):
         v = odit.forward(Wd_, ocfg, x[0].float(), t.reshape(-1)[0], ctx[0].float(), im[0].float())
@@ -130,12 +146,36 @@ def run_oracle(Wd_, Wv, ocfg, inputs, Fr, H, Wd, steps, guide, flow_backend):
             frames = osampler.decode_final(out, dec, ovae.MEAN, ovae.STD)[0]
     finally:
         oinject.select_motion_related_channels = orig
+        oinject.channel_similarities = orig_sims
     lats = [e[2].float() for e in trace if e[0] == "latents"]
-    return frames, lats, [(s, c) for s, c in log]
+    return frames, lats, [(s, c) for s, c, _ in log], [sm for _, _, sm in log]
+
+
+def decision_margin(sims, step):
+    """How far the FLF decision at this gate is from flipping, in similarity units.  Every rule of SCHED:408-437 selects a PREFIX of the
+    ascending-sorted similarities (the lowest 1; or all below mean - 0.625 std, clamped to 2..6): the decision changes when the order
+    across the prefix boundary changes (gap between the last selected and the first unselected) or, when the prefix length comes from
+    the threshold, when the threshold crosses a similarity."""
+    import numpy as np
+    if sims is None or step <= 5:
+        return None
+    c = np.sort(np.asarray(sims, dtype=np.float64))
+    if step <= 10:
+        return float(c[1] - c[0])
+    thr = c.mean() - 0.625 * c.std()
+    n = int((c < thr).sum())
+    k = min(max(n, 2), 6)
+    gap = float(c[k] - c[k - 1])
+    if 2 <= n <= 6:
+        gap = min(gap, float(min(abs(thr - c[n - 1]), abs(c[n] - thr))))
+    return gap
 
 
 def study(dim=1024, ffn_dim=2048, heads=8, layers=4, Fr=17, H=128, Wd=128, steps=20, guide=15, flow_backend="farneback",
-          with_oracle=False, verbose=True):
+          with_oracle=False, verbose=True, fixture=None, save_fixture=None, oracle_only=False):
+    """fixture: an .npz written by an earlier `--oracle --save-fixture` run (oracle frames / latents / gate decisions for exactly
+    this job) used instead of running the CPU oracle again."""
+    import numpy as np
     from oracle import dit as odit
     from oracle import vae as ovae
 
@@ -144,35 +184,65 @@ def study(dim=1024, ffn_dim=2048, heads=8, layers=4, Fr=17, H=128, Wd=128, steps
     Wd_ = {k: (v.to(torch.bfloat16).float() if v.dim() >= 2 else v) for k, v in Wd_.items()}
     Wv = ovae.random_weights(seed=4)
     inputs = make_inputs(Fr, H, Wd)
-    res = {"config": dict(dit=f"d{dim} x {layers} layers x {heads} heads", frames=Fr, height=H, width=Wd, steps=steps, guided_steps=guide,
-                          round_trips=2 * guide + 1, flow_backend=flow_backend)}
-    t0 = time.time()
-    fa, la, ca, sa = run_hip("bf16", Wd_, Wv, ocfg, inputs, Fr, H, Wd, steps, guide, flow_backend)
-    fb, lb, cb, sb = run_hip("fp32", Wd_, Wv, ocfg, inputs, Fr, H, Wd, steps, guide, flow_backend)
-    res["hip_s"] = time.time() - t0
-    res["psnr_bf16vae_vs_fp32vae_db"] = psnr(fa, fb)
-    res["flf_gates"] = len(ca)
-    res["flf_lists_bf16vae"] = ca
-    res["flf_lists_fp32vae"] = cb
-    res["flf_same_bf16_vs_fp32vae"] = ca == cb
-    res["flf_swapping_gates"] = sum(1 for _, c in cb if c)
-    # decision margin of every gate: how far the selection threshold is from the nearest similarity (fp32-class VAE run)
-    if la and lb:
-        res["latent_db_bf16_vs_fp32vae_per_step"] = [round(db(a, b), 1) for a, b in zip(la, lb)]
-    if with_oracle:
+    job = dict(dit=f"d{dim} x {layers} layers x {heads} heads", frames=Fr, height=H, width=Wd, steps=steps, guided_steps=guide,
+               round_trips=2 * guide + 1, flow_backend=flow_backend)
+    res = {"config": job}
+    args = (Wd_, Wv, ocfg, inputs, Fr, H, Wd, steps, guide, flow_backend)
+    if oracle_only:  # CPU only: record the oracle's result for this job (no GPU needed)
         t0 = time.time()
-        fc, lc, cc = run_oracle(Wd_, Wv, ocfg, inputs, Fr, H, Wd, steps, guide, flow_backend)
+        orc = run_oracle(*args)
+        np.savez_compressed(save_fixture, job=json.dumps(job), frames=orc[0].numpy().astype(np.float16),
+                            latents=np.stack([x.numpy() for x in orc[1]]), flf_lists=json.dumps(orc[2]), flf_sims=json.dumps(orc[3]))
+        print(f"oracle: {time.time() - t0:.0f} s -> {save_fixture}; gates {orc[2]}")
+        return res
+    t0 = time.time()
+    fa, la, ca, sa = run_hip("bf16", *args)
+    fb, lb, cb, sb = run_hip("fp32", *args)
+    res["hip_s"] = time.time() - t0
+    res["free_running"] = {
+        "psnr_bf16vae_vs_fp32vae_db": psnr(fa, fb), "flf_gates": len(ca), "flf_swapping_gates": sum(1 for _, c in cb if c),
+        "flf_lists_bf16vae": ca, "flf_lists_fp32vae": cb, "flf_same_bf16_vs_fp32vae": ca == cb,
+        "gate_margin_fp32vae": [(st, decision_margin(sm, st)) for (st, _), sm in zip(cb, sb)],
+        "gate_max_sim_delta_bf16_vs_fp32vae": [(st, None if x is None or y is None else float(np.abs(np.asarray(x) - np.asarray(y)).max()))
+                                               for (st, _), x, y in zip(cb, sa, sb)],
+        "latent_db_bf16_vs_fp32vae_per_step": [round(db(a, b), 1) for a, b in zip(la, lb)]}
+    orc = None
+    if fixture is not None:
+        z = np.load(fixture, allow_pickle=False)
+        assert json.loads(str(z["job"])) == json.loads(json.dumps(job)), "fixture was recorded for a different job"
+        lists = json.loads(str(z["flf_lists"]))
+        orc = (torch.from_numpy(z["frames"].astype(np.float32)), [torch.from_numpy(x) for x in z["latents"]],
+               [(int(st), list(c)) for st, c in lists], json.loads(str(z["flf_sims"])))
+    elif with_oracle:
+        t0 = time.time()
+        orc = run_oracle(*args)
         res["oracle_s"] = time.time() - t0
-        res["psnr_bf16vae_vs_oracle_db"] = psnr(fa, fc)
-        res["psnr_fp32vae_vs_oracle_db"] = psnr(fb, fc)
-        res["flf_lists_oracle"] = cc
-        res["flf_same_bf16vae_vs_oracle"] = ca == cc
-        res["flf_same_fp32vae_vs_oracle"] = cb == cc
-        if lc and la:
-            res["latent_db_bf16vae_vs_oracle_per_step"] = [round(db(a, c), 1) for a, c in zip(la, lc)]
-            res["latent_db_fp32vae_vs_oracle_per_step"] = [round(db(b, c), 1) for b, c in zip(lb, lc)]
+        if save_fixture:
+            np.savez_compressed(save_fixture, job=json.dumps(job), frames=orc[0].numpy().astype(np.float16),
+                                latents=np.stack([x.numpy() for x in orc[1]]), flf_lists=json.dumps(orc[2]), flf_sims=json.dumps(orc[3]))
+    if orc is not None:
+        fc, lc, cc, sc = orc
+        res["free_running"].update({
+            "psnr_bf16vae_vs_oracle_db": psnr(fa, fc), "psnr_fp32vae_vs_oracle_db": psnr(fb, fc), "flf_lists_oracle": cc,
+            "flf_same_bf16vae_vs_oracle": ca == cc, "flf_same_fp32vae_vs_oracle": cb == cc,
+            "gate_margin_oracle": [(st, decision_margin(sm, st)) for (st, _), sm in zip(cc, sc)],
+            "gate_max_sim_delta_fp32vae_vs_oracle": [(st, None if x is None or y is None else float(np.abs(np.asarray(x) - np.asarray(y)).max()))
+                                                     for (st, _), x, y in zip(cc, sb, sc)],
+            "latent_db_bf16vae_vs_oracle_per_step": [round(db(a, c), 1) for a, c in zip(la, lc)],
+            "latent_db_fp32vae_vs_oracle_per_step": [round(db(b, c), 1) for b, c in zip(lb, lc)]})
+    # the same job with the gate decisions of the parity target replayed: what the ARITHMETIC of the path contributes
+    target = dict(orc[2]) if orc is not None else dict(cb)
+    ra, lra, _, _ = run_hip("bf16", *args, replay=target)
+    rb, lrb, _, _ = run_hip("fp32", *args, replay=target)
+    rep = {"decisions_from": "oracle" if orc is not None else "fp32-class VAE run", "psnr_bf16vae_vs_fp32vae_db": psnr(ra, rb),
+           "latent_db_bf16_vs_fp32vae_per_step": [round(db(a, b), 1) for a, b in zip(lra, lrb)]}
+    if orc is not None:
+        rep.update({"psnr_bf16vae_vs_oracle_db": psnr(ra, orc[0]), "psnr_fp32vae_vs_oracle_db": psnr(rb, orc[0]),
+                    "latent_db_bf16vae_vs_oracle_per_step": [round(db(a, c), 1) for a, c in zip(lra, orc[1])],
+                    "latent_db_fp32vae_vs_oracle_per_step": [round(db(b, c), 1) for b, c in zip(lrb, orc[1])]})
+    res["decisions_replayed"] = rep
     if verbose:
-        print(json.dumps(res, indent=1, default=str))
+        print(json.dumps(res, indent=None, default=str))
     return res
 
 
@@ -188,9 +258,13 @@ if __name__ == "__main__":
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--flow-backend", default="farneback")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--save-fixture", default=None, help="with --oracle: write the oracle's frames / latents / gate decisions (.npz)")
+    ap.add_argument("--oracle-only", action="store_true", help="CPU only: run the oracle for this job and write --save-fixture")
+    ap.add_argument("--fixture", default=None, help="use a recorded oracle result instead of running the CPU oracle")
     a = ap.parse_args()
     r = study(dim=a.dim, ffn_dim=2 * a.dim, heads=a.dim // 128, layers=a.layers, Fr=a.frames, H=a.height, Wd=a.width, steps=a.steps,
-              guide=a.guide, flow_backend=a.flow_backend, with_oracle=a.oracle)
+              guide=a.guide, flow_backend=a.flow_backend, with_oracle=a.oracle, fixture=a.fixture, save_fixture=a.save_fixture,
+              oracle_only=a.oracle_only)
     if a.out:
         with open(a.out, "w") as f:
             json.dump(r, f, indent=1, default=str)

@@ -534,6 +534,15 @@ struct ConvW4Args {
   ConvArgs c;
   const uint16_t* zeros;
   int tiles_x, tiles_y;
+  // input addressing (elements): pixel (t, y, x), stored 16-channel slice s -> ((t * Hi + y) * row_stride + x * pix_stride + s * slice_stride)
+  //   pixel-major  [T][Hi][Wi][Cs]:        row_stride = Wi * Cs,        pix_stride = Cs, slice_stride = 16
+  //   slice-major  [T][Hi][Cs/16][Wi][16]: row_stride = (Cs/16)*Wi*16,  pix_stride = 16, slice_stride = Wi * 16
+  //     (a patch row of one slice is Wi * 32 contiguous bytes: every 1 KiB LDS-DMA piece reads 8 whole cache lines instead of 32
+  //      32-byte fragments of 32 different pixels)
+  // nsa = stored slices Cs / 16; K slice cs reads stored slice cs mod nsa: the fp32-class three-term operand [hi | lo | hi] is stored
+  // as [hi | lo] (Cs = 2/3 Cin) and its hi slices are read twice.
+  long row_stride, slice_stride;
+  int pix_stride, nsa;
 };
 
 __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
@@ -578,7 +587,7 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
       const int r = rem / PC, cc = rem - r * PC;
       const int tt = tt0 - 2 + f, yy = yy0 - a.ph + r, xx = xx0 - 1 + cc;
       const bool ok = p < PATCH_PX && tt >= 0 && yy >= 0 && yy < a.Hi && xx >= 0 && xx < a.Wi;
-      psrc[j] = ok ? a.in + (((size_t)tt * a.Hi + yy) * a.Wi + xx) * Cin + ch * 8 : pa.zeros;
+      psrc[j] = ok ? a.in + ((size_t)tt * a.Hi + yy) * pa.row_stride + (size_t)xx * pa.pix_stride + ch * 8 : pa.zeros;
       pvalid |= ok ? (1u << j) : 0u;
     }
   };
@@ -586,7 +595,8 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   compute_psrc(t, y0, x0);
   const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_offset(smem));
   auto dma_piece = [&](int cs, int j) {  // piece j of the patch of channel slice cs -> buffer cs & 1
-    const uint16_t* src = psrc[j] + (((pvalid >> j) & 1u) ? cs * 16 : 0);
+    const int acs = cs >= pa.nsa ? cs - pa.nsa : cs;
+    const uint16_t* src = psrc[j] + (((pvalid >> j) & 1u) ? (size_t)acs * pa.slice_stride : (size_t)0);
     // issued from inline asm: with the builtin hipcc drains vmcnt(0) in front of every later ds_read (it cannot prove that the DMA's
     // LDS destination does not alias it), i.e. every few MFMAs here.  Ordering is ours: vmcnt + barrier at the end of the slice.
     glds16_async(src, smem_base + (uint32_t)((cs & 1) * PATCH_BUF + (wid * 16 + j) * 1024));
@@ -893,9 +903,12 @@ extern "C" int wf_conv3d_pack333(const void* w, void* w_packed, int Cout, int Ci
 
 extern "C" int wf_conv3d_333(const void* in, const void* w_packed, const float* bias, const float* resid, float* out_f32,
                              void* out_bf16, int T, int Hi, int Wi, int Cin, int Ho, int Cout, int ph, const void* zero_page,
-                             void* stream) {
+                             int layout, int Cin_stored, void* stream) {
   WF_CHECK_ARG(in && w_packed && zero_page && (out_f32 || out_bf16), "wf_conv3d_333: null pointer");
   WF_CHECK_ARG(Cin % 32 == 0 && Cout % 32 == 0, "wf_conv3d_333: Cin (%d) and Cout (%d) must be multiples of 32", Cin, Cout);
+  WF_CHECK_ARG(layout == 0 || layout == 1, "wf_conv3d_333: layout must be 0 (pixel-major) or 1 (slice-major)");
+  WF_CHECK_ARG(Cin_stored == Cin || (Cin % 3 == 0 && Cin_stored == Cin / 3 * 2 && Cin_stored % 16 == 0),
+               "wf_conv3d_333: Cin_stored (%d) must be Cin (%d) or, for the three-term operand stored as [hi | lo], 2/3 of it", Cin_stored, Cin);
   WF_CHECK_ARG((long)27 * Cin * Cout * 2 < (1L << 31), "wf_conv3d_333: weight tensor too large");
   if ((long)T * Ho * Wi == 0) return WF_OK;
   ConvW4Args wa;
@@ -914,6 +927,12 @@ extern "C" int wf_conv3d_333(const void* in, const void* w_packed, const float* 
   wa.zeros = (const uint16_t*)zero_page;
   wa.tiles_x = (Wi + WX - 1) / WX;
   wa.tiles_y = (Ho + WY - 1) / WY;
+  wa.nsa = Cin_stored / 16;
+  if (layout == 0) {
+    wa.row_stride = (long)Wi * Cin_stored; wa.pix_stride = Cin_stored; wa.slice_stride = 16;
+  } else {
+    wa.row_stride = (long)wa.nsa * Wi * 16; wa.pix_stride = 16; wa.slice_stride = (long)Wi * 16;
+  }
   const int ny = (Cout + 95) / 96, ntile = wa.tiles_x * wa.tiles_y * T;
   const int gx = std::min(ntile, std::max(1, 256 / ny));  // one persistent workgroup per CU
   dim3 grid((unsigned)gx, (unsigned)ny);

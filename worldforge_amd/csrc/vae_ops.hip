@@ -18,7 +18,7 @@ namespace {
 template <int G, bool SPLIT = false>
 __global__ __launch_bounds__(256) void k_rms_silu(const float* __restrict__ x, const float* __restrict__ gamma,
                                                   uint16_t* __restrict__ out_bf16, float* __restrict__ out_f32, int C,
-                                                  float scale, int silu, size_t npix) {
+                                                  float scale, int silu, size_t npix, int Wrow = 0) {
   constexpr int PPW = 64 / G;  // pixels per wave
   const int lane = threadIdx.x & 63;
   const int sub = lane & (G - 1), q = lane / G;
@@ -59,7 +59,22 @@ __global__ __launch_bounds__(256) void k_rms_silu(const float* __restrict__ x, c
 #pragma unroll
           for (int k = 0; k < 4; ++k) y[k] = y[k] / (1.0f + (SPLIT ? expf(-y[k]) : __expf(-y[k])));
         }
-        if constexpr (SPLIT) {
+        if (Wrow > 0) {
+          // slice-major operand for wf_conv3d_333 (layout 1): [row = p / W][stored slice][x][16]; SPLIT stores [hi | lo] slices
+          const size_t row = p / (size_t)Wrow;
+          const int xx = (int)(p - row * (size_t)Wrow);
+          const int S = C >> 4, stot = SPLIT ? 2 * S : S;
+          uint16_t* o = out_bf16 + ((row * stot + (id >> 2)) * (size_t)Wrow + xx) * 16 + (id & 3) * 4;
+          const u32x2 hi = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+          *reinterpret_cast<u32x2*>(o) = hi;
+          if constexpr (SPLIT) {
+            float r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = y[k] - rbf(y[k]);
+            const u32x2 lo = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+            *reinterpret_cast<u32x2*>(o + (size_t)S * Wrow * 16) = lo;
+          }
+        } else if constexpr (SPLIT) {
           float r[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) r[k] = y[k] - rbf(y[k]);
@@ -203,13 +218,13 @@ extern "C" int wf_rms_silu_cl(const float* x, const float* gamma, void* out_bf16
   const float sc = sqrtf((float)C);
   hipStream_t st = (hipStream_t)stream;
   if (G == 8)
-    hipLaunchKernelGGL(k_rms_silu<8>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix);
+    hipLaunchKernelGGL(k_rms_silu<8>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix, 0);
   else if (G == 16)
-    hipLaunchKernelGGL(k_rms_silu<16>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix);
+    hipLaunchKernelGGL(k_rms_silu<16>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix, 0);
   else if (G == 32)
-    hipLaunchKernelGGL(k_rms_silu<32>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix);
+    hipLaunchKernelGGL(k_rms_silu<32>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix, 0);
   else
-    hipLaunchKernelGGL(k_rms_silu<64>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix);
+    hipLaunchKernelGGL(k_rms_silu<64>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix, 0);
   WF_LAUNCH_CHECK("wf_rms_silu_cl");
   return WF_OK;
 }
@@ -275,13 +290,13 @@ extern "C" int wf_rms_silu_cl_x3(const float* x, const float* gamma, void* out_x
   hipStream_t st = (hipStream_t)stream;
   uint16_t* o = (uint16_t*)out_x3;
   if (G == 8)
-    hipLaunchKernelGGL((k_rms_silu<8, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix);
+    hipLaunchKernelGGL((k_rms_silu<8, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix, 0);
   else if (G == 16)
-    hipLaunchKernelGGL((k_rms_silu<16, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix);
+    hipLaunchKernelGGL((k_rms_silu<16, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix, 0);
   else if (G == 32)
-    hipLaunchKernelGGL((k_rms_silu<32, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix);
+    hipLaunchKernelGGL((k_rms_silu<32, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix, 0);
   else
-    hipLaunchKernelGGL((k_rms_silu<64, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix);
+    hipLaunchKernelGGL((k_rms_silu<64, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix, 0);
   WF_LAUNCH_CHECK("wf_rms_silu_cl_x3");
   return WF_OK;
 }
@@ -302,5 +317,34 @@ extern "C" int wf_cl_to_ncthw(const float* in, float* out, int C, int ld, size_t
   if (N == 0) return WF_OK;
   hipLaunchKernelGGL(k_from_cl, dim3(grid_for(N * C, 256, 8192)), dim3(256), 0, (hipStream_t)stream, in, out, C, ld, N, clamp);
   WF_LAUNCH_CHECK("wf_cl_to_ncthw");
+  return WF_OK;
+}
+
+extern "C" int wf_rms_silu_cl_blocked(const float* x, const float* gamma, void* out, size_t npix, int C, int silu, int W, int split,
+                                      void* stream) {
+  WF_CHECK_ARG(x && gamma && out, "wf_rms_silu_cl_blocked: null pointer");
+  WF_CHECK_ARG(C % 16 == 0 && C > 0 && C <= 1024, "wf_rms_silu_cl_blocked: C=%d must be a multiple of 16 and <= 1024", C);
+  WF_CHECK_ARG(W > 0 && npix % (size_t)W == 0, "wf_rms_silu_cl_blocked: npix must be whole rows of W=%d pixels", W);
+  if (npix == 0) return WF_OK;
+  const int G = C <= 128 ? 8 : (C <= 256 ? 16 : (C <= 512 ? 32 : 64));
+  size_t blocks = (npix + (size_t)(4 * (64 / G)) - 1) / (size_t)(4 * (64 / G));
+  if (blocks > 16384) blocks = 16384;
+  const float sc = sqrtf((float)C);
+  hipStream_t st = (hipStream_t)stream;
+  uint16_t* o = (uint16_t*)out;
+  float* nof = nullptr;
+#define WF_RMS_BLOCKED(GG)                                                                                                          \
+  do {                                                                                                                              \
+    if (split)                                                                                                                      \
+      hipLaunchKernelGGL((k_rms_silu<GG, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, nof, C, sc, silu, npix, W);  \
+    else                                                                                                                            \
+      hipLaunchKernelGGL((k_rms_silu<GG, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, nof, C, sc, silu, npix, W); \
+  } while (0)
+  if (G == 8) WF_RMS_BLOCKED(8);
+  else if (G == 16) WF_RMS_BLOCKED(16);
+  else if (G == 32) WF_RMS_BLOCKED(32);
+  else WF_RMS_BLOCKED(64);
+#undef WF_RMS_BLOCKED
+  WF_LAUNCH_CHECK("wf_rms_silu_cl_blocked");
   return WF_OK;
 }

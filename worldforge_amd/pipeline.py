@@ -16,7 +16,7 @@ from typing import Any, Callable, Dict, List, Optional, Union
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, trace
 
 
 @dataclass
@@ -34,7 +34,8 @@ class WanImageToVideoPipeline:
         self.vae_scale_factor_temporal = 2 ** sum(tds)  # PIPE:162
         self.vae_scale_factor_spatial = 2 ** len(tds)   # PIPE:163
         self._guidance_scale = 1.0
-        self.timing: Dict[str, float] = {}
+        self.tracer = trace.Tracer.from_env()  # WF_TRACE=<file.json>: roctx ranges + per-phase GPU time log (trace.py)
+        self.timing: Dict[str, Dict[str, float]] = {}  # {phase: {count, total_ms, mean_ms}} of the last call when tracing is on
 
     @property
     def guidance_scale(self):
@@ -157,6 +158,8 @@ class WanImageToVideoPipeline:
         if not hasattr(sch, "derivative_history"):
             sch.derivative_history = []
 
+        tr = self.tracer
+        sch.tracer = tr
         if start_step:
             # bench window: enter the schedule at `start_step` (UniPC restarts at order 1 there, like step 0)
             sch._step_index = start_step
@@ -184,6 +187,8 @@ class WanImageToVideoPipeline:
                         sch.lower_order_nums -= 1
                     sch.this_order = sch.last_this_order
                 latent_model_input = self._model_input(latents, condition, transformer_dtype)
+                _rng = tr.range("dit_cfg", step=i, round=r)
+                _rng.__enter__()
                 pair = getattr(self.transformer, "forward_cfg_pair", None) if self.do_classifier_free_guidance else None
                 if pair is not None:
                     # same two calls as below, advanced in lock-step so that under sequence parallelism each branch's K / V
@@ -206,12 +211,14 @@ class WanImageToVideoPipeline:
                     noise_pred = ops.cfg_combine(noise_pred, noise_uncond, guidance_scale)
                     if r < 1:
                         sch.derivative_history.append(noise_pred)
-                scheduler_output = sch.step(noise_pred, t, latents, mask=mask,
-                                            guided=guided and i < guide_steps and r < resample_steps,
-                                            video_latents=video_ref, vae=self.vae, resampling=r > 0, return_dict=True,
-                                            current_step=i, resample_count=resample_steps,
-                                            is_resample_round=i < resample_round,
-                                            use_pca_channel_selection=use_pca_channel_selection, static=static)
+                _rng.__exit__(None, None, None)
+                with tr.range("scheduler_step", step=i, round=r):
+                    scheduler_output = sch.step(noise_pred, t, latents, mask=mask,
+                                                guided=guided and i < guide_steps and r < resample_steps,
+                                                video_latents=video_ref, vae=self.vae, resampling=r > 0, return_dict=True,
+                                                current_step=i, resample_count=resample_steps,
+                                                is_resample_round=i < resample_round,
+                                                use_pca_channel_selection=use_pca_channel_selection, static=static)
                 pred_original_sample = scheduler_output.pred_x0
                 if i >= resample_round:
                     break
@@ -220,14 +227,16 @@ class WanImageToVideoPipeline:
                         noise = torch.randn(pred_original_sample.shape, generator=generator).to(device=device)
                     else:
                         noise = torch.randn(pred_original_sample.shape, device=device)
-                    latents = sch.add_noise(pred_original_sample, noise, sch.get_resample_timestep(i), r,
-                                            use_resample_sigma=True)
+                    with tr.range("renoise", step=i, round=r):
+                        latents = sch.add_noise(pred_original_sample, noise, sch.get_resample_timestep(i), r,
+                                                use_resample_sigma=True)
             if len(sch.derivative_history) > 1:
                 noise_pred_good = sch.derivative_history[-1]
                 noise_pred_worse = sch.derivative_history[0]
                 if i >= guide_steps:
                     omega = omega_resample
-                noise_pred_better = ops.dsg(noise_pred_good, noise_pred_worse, omega)
+                with tr.range("dsg", step=i):
+                    noise_pred_better = ops.dsg(noise_pred_good, noise_pred_worse, omega)
                 sch._step_index -= 1
                 if sch.lower_order_nums > 0 and sch.last_lower_order_nums < sch.config.solver_order:
                     sch.lower_order_nums -= 1
@@ -254,10 +263,15 @@ class WanImageToVideoPipeline:
         else:
             z = ops.latent_denorm(ops.cast(latents, torch.float32), self.vae.config.latents_mean,
                                   self.vae.config.latents_std)
-            video = self.vae.decode(z, return_dict=False)[0]
-            video = torch.stack([ops.postprocess_video(v) for v in video])  # [B,F,H,W,C]
+            with tr.range("final_decode"):
+                video = self.vae.decode(z, return_dict=False)[0]
+                video = torch.stack([ops.postprocess_video(v) for v in video])  # [B,F,H,W,C]
             if output_type == "np":
                 video = video.cpu().numpy()
+        if tr.enabled:
+            self.timing = tr.summary()
+            if getattr(tr, "path", None):
+                tr.finish()
         if not return_dict:
             return (video,)
         return WanPipelineOutput(frames=video)

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import ops
+from . import trace
 from .flf import VideoMotionPCASelector
 
 
@@ -65,6 +66,8 @@ class UniPCMultistepScheduler:
         self.this_order = None
         self.last_this_order = None
         self._pca_selector = None
+        self.tracer = trace.NULL  # the pipeline installs its tracer (trace.py): roctx ranges + GPU time per injection phase
+        self.flf_replay = None  # {outer step: channel list} to force the FLF decisions of another run (analysis only)
         self.flf_log = None  # set to a list to record every FLF gate decision (tools/vae_precision_study.py, tracing)
         self.flow_backend = flow_backend
         self.resample_sigmas = None
@@ -240,18 +243,29 @@ class UniPCMultistepScheduler:
             return pred_original_sample
         x0 = pred_original_sample
         mean, std = vae.config.latents_mean, vae.config.latents_std
-        decoded = vae.decode(ops.latent_denorm(x0, mean, std), return_dict=False)[0]
-        ref, m = align_reference(video_latents, mask, decoded.shape)
-        fused = ops.blend_pixels(ref, m, decoded)
-        enc = vae.encode(fused).latent_dist.mode()
-        enc = ops.latent_norm(enc, mean, std, const_dtype=x0.dtype)
+        tr, step = self.tracer, kwargs.get("current_step", 0)
+        with tr.range("vae_decode", step=step):
+            decoded = vae.decode(ops.latent_denorm(x0, mean, std), return_dict=False)[0]
+        with tr.range("blend", step=step):
+            ref, m = align_reference(video_latents, mask, decoded.shape)
+            fused = ops.blend_pixels(ref, m, decoded)
+        with tr.range("vae_encode", step=step):
+            enc = vae.encode(fused).latent_dist.mode()
+            enc = ops.latent_norm(enc, mean, std, const_dtype=x0.dtype)
         if kwargs.get("use_pca_channel_selection") and not kwargs.get("resampling", False):
             if self._pca_selector is None:
                 self._pca_selector = VideoMotionPCASelector(flow_backend=self.flow_backend)
-            channels = self._pca_selector.select_motion_related_channels(
-                pred_original_sample=x0, video_latents=ops.cast(enc, x0.dtype), mask=None, keep_channels=12,
-                current_step=kwargs.get("current_step", 0), total_steps=kwargs.get("total_steps", 50),
-                use_optical_flow=kwargs.get("use_optical_flow", True), static=static)
+            with tr.range("flf_gate", step=step):
+                channels = self._pca_selector.select_motion_related_channels(
+                    pred_original_sample=x0, video_latents=ops.cast(enc, x0.dtype), mask=None, keep_channels=12,
+                    current_step=kwargs.get("current_step", 0), total_steps=kwargs.get("total_steps", 50),
+                    use_optical_flow=kwargs.get("use_optical_flow", True), static=static)
+            if self.flf_replay is not None:
+                # analysis only (tools/vae_precision_study.py): the gate is a discrete decision on 16 nearly tied similarities, so
+                # two arithmetically close runs can swap different channels; replaying one run's decisions in the other separates
+                # the arithmetic error of the path from the decision flips.  The gate above still ran (and is logged below).
+                free = channels
+                channels = list(self.flf_replay.get(int(kwargs.get("current_step", 0)), free))
             ops.channel_swap_(enc, x0, channels)
             if self.flf_log is not None:  # trace: (outer step, swapped channels, the 16 similarities)
                 self.flf_log.append((int(kwargs.get("current_step", 0)), list(channels),

@@ -14,8 +14,10 @@ implicit GEMM (csrc/conv.hip); RMS-norm + SiLU is a fused one-pass kernel produc
 two MFMA GEMMs around a row softmax.  fp32 residual stream, fp32 accumulation.
 
 precision (the reference loads the VAE with torch_dtype=torch.float32, INFER:185-189):
-  "bf16"  -- every matrix-core operand (activation and weight) rounded to bf16: 2^-9 relative per operand.
-  "fp32"  -- fp32-class contractions on the bf16 matrix cores: every operand x is carried as hi = bf16(x), lo = bf16(x - hi) and every
+  "bf16"  -- every matrix-core operand (activation and weight) rounded to bf16: 2^-9 relative per operand.  Opt-in fast mode: over a
+             guided job's 31 decode -> encode round trips this noise is enough to flip near-tied FLF gate decisions
+             (tools/vae_precision_study.py).
+  "fp32"  -- DEFAULT.  fp32-class contractions on the bf16 matrix cores: every operand x is carried as hi = bf16(x), lo = bf16(x - hi) and every
              contraction as hi.hi + lo.hi + hi.lo in fp32 accumulators (wf_split_bf16x3: activations [hi | lo | hi], weights
              [hi | hi | lo] on 3x the channels, the SAME conv / GEMM kernels; dropped terms <= 2^-16 relative).  3x the MFMA work.
 """
@@ -174,7 +176,7 @@ class _LatentDist:
 class AutoencoderKLWan:
     dtype = torch.float32
 
-    def __init__(self, device="cuda:0", comm=None, precision: str = "bf16"):
+    def __init__(self, device="cuda:0", comm=None, precision: str = "fp32"):
         if precision not in ("bf16", "fp32"):
             raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
         self.precision = precision
@@ -276,7 +278,7 @@ class AutoencoderKLWan:
         return self.load_state_dict(diffusers_to_twin_state_dict(sd))
 
     @classmethod
-    def from_pretrained(cls, path: str, device="cuda:0", comm=None, precision: str = "bf16", subfolder: str = "vae"):
+    def from_pretrained(cls, path: str, device="cuda:0", comm=None, precision: str = "fp32", subfolder: str = "vae"):
         """`AutoencoderKLWan.from_pretrained(model_id, subfolder="vae", torch_dtype=torch.float32)` (INFER:185-189) from a local
         diffusers checkpoint directory: reads `<path>/<subfolder>/*.safetensors` (sharded or not) with checkpoint.load_dir."""
         from . import checkpoint
@@ -327,8 +329,15 @@ class AutoencoderKLWan:
     # ------------------------------------------------------------------------------------------------------------
     def _conv(self, x, p, To, Ho, Wo, Cout, k, st=1, ss=1, pt=0, ps=0, up2=False, tsplit=False, resid=None, out_f32=True,
               out_bf16=False, out_shape=None, out_bf_tensor=None, ph=None):
-        """ps: symmetric spatial padding (top = left); ph overrides the top padding (row slabs with halo rows)."""
-        Ti, Hi, Wi, Cin = x.shape
+        """ps: symmetric spatial padding (top = left); ph overrides the top padding (row slabs with halo rows).  x: channels-last
+        [T,H,W,C], or the slice-major operand [T,H,C_stored/16,W,16] of _rms(blocked=True) (3x3x3 stride-1 layers only)."""
+        layout, Cst = 0, x.shape[-1]
+        if x.dim() == 5:
+            Ti, Hi, nsl, Wi, _ = x.shape
+            layout, Cst = 1, 16 * nsl
+            Cin = Cst * 3 // 2 if self.x3 else Cst  # fp32-class: [hi | lo] stored, K = [hi | lo | hi]
+        else:
+            Ti, Hi, Wi, Cin = x.shape
         assert x.dtype == BF and x.is_contiguous()
         shape = out_shape or (To, Ho, Wo, Cout)
         of = torch.empty(shape, dtype=F32, device=x.device) if out_f32 else None
@@ -341,8 +350,9 @@ class AutoencoderKLWan:
             call("wf_conv3d_333", x.data_ptr(), self._packed333(p, Cout, Cin).data_ptr(), W[p + ".b"].data_ptr(),
                  resid.data_ptr() if resid is not None else None, of.data_ptr() if of is not None else None,
                  ob.data_ptr() if ob is not None else None, Ti, Hi, Wi, Cin, Ho, Cout, ps if ph is None else ph,
-                 self._zero_page().data_ptr(), ops.stream())
+                 self._zero_page().data_ptr(), layout, Cst, ops.stream())
         else:
+            assert layout == 0, "slice-major operands are for the 3x3x3 stride-1 kernel only"
             call("wf_conv3d_cl", x.data_ptr(), W[p + ".w"].data_ptr(), W[p + ".b"].data_ptr(),
                  resid.data_ptr() if resid is not None else None, of.data_ptr() if of is not None else None,
                  ob.data_ptr() if ob is not None else None, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, k[0], k[1], k[2], st, ss, pt,
@@ -378,8 +388,16 @@ class AutoencoderKLWan:
         self.flops_last += 2 * To * Ho * Wo * Cout * k[0] * k[1] * k[2] * Cin
         return out
 
-    def _rms(self, x, gamma, silu=True):
+    def _rms(self, x, gamma, silu=True, blocked=False):
+        """RMS_norm (+ SiLU) of the f32 stream -> the next layer's matrix-core operand.  blocked: the slice-major operand of the 3x3x3
+        kernel, [T,H,C/16,W,16] (fp32-class mode: [hi | lo] slices, [T,H,2C/16,W,16])."""
         C = x.shape[-1]
+        if blocked and C % 32 == 0 and not os.environ.get("WF_CONV_NO_W4"):
+            T, H, Wd, _ = x.shape
+            out = torch.empty((T, H, (2 if self.x3 else 1) * C // 16, Wd, 16), dtype=BF, device=x.device)
+            call("wf_rms_silu_cl_blocked", x.data_ptr(), gamma.data_ptr(), out.data_ptr(), x.numel() // C, C, 1 if silu else 0, Wd,
+                 1 if self.x3 else 0, ops.stream())
+            return out
         if self.x3:
             out = torch.empty(tuple(x.shape[:-1]) + (3 * C,), dtype=BF, device=x.device)
             call("wf_rms_silu_cl_x3", x.data_ptr(), gamma.data_ptr(), out.data_ptr(), x.numel() // C, C, 1 if silu else 0, ops.stream())
@@ -415,10 +433,10 @@ class AutoencoderKLWan:
         """vae.py:186-220."""
         T, H, Wd, _ = x.shape
         W = self.w
-        a = self._rms(x, W[p + ".residual.0.gamma"])
+        a = self._rms(x, W[p + ".residual.0.gamma"], blocked=True)
         y, _ = self._conv(a, p + ".residual.2", T, H, Wd, cout, (3, 3, 3), pt=2, ps=1)
         del a
-        a2 = self._rms(y, W[p + ".residual.3.gamma"])
+        a2 = self._rms(y, W[p + ".residual.3.gamma"], blocked=True)
         del y
         if cin != cout:
             xb = self._operand(x)
@@ -539,10 +557,11 @@ class AutoencoderKLWan:
     # Only all-gather is used.  Results are bit-identical to the unsharded path (same per-pixel accumulation order).
     # ------------------------------------------------------------------------------------------------------------
     def _halo_pad(self, a):
-        """a [T,Hs,W,C] bf16 -> [T,Hs+2,W,C] with the neighbours' boundary rows (zeros at the image boundary)."""
+        """a [T,Hs,W,C] (or slice-major [T,Hs,S,W,16]) bf16 -> [T,Hs+2,...] with the neighbours' boundary rows (zeros at the image
+        boundary)."""
         comm = self.comm
-        T, Hs, Wd, C = a.shape
-        out = torch.empty((T, Hs + 2, Wd, C), dtype=a.dtype, device=a.device)
+        T, Hs = a.shape[:2]
+        out = torch.empty((T, Hs + 2) + tuple(a.shape[2:]), dtype=a.dtype, device=a.device)
         out[:, 1:Hs + 1].copy_(a)
         mine = torch.stack([a[:, 0], a[:, Hs - 1]])  # [2,T,W,C]
         allb = torch.empty((comm.world,) + tuple(mine.shape), dtype=a.dtype, device=a.device)
@@ -575,10 +594,10 @@ class AutoencoderKLWan:
     def _res_slab(self, x, p, cin, cout):
         T, Hs, Wd, _ = x.shape
         W = self.w
-        a = self._halo_pad(self._rms(x, W[p + ".residual.0.gamma"]))
+        a = self._halo_pad(self._rms(x, W[p + ".residual.0.gamma"], blocked=True))
         y, _ = self._conv(a, p + ".residual.2", T, Hs, Wd, cout, (3, 3, 3), pt=2, ps=1, ph=0)
         del a
-        a2 = self._halo_pad(self._rms(y, W[p + ".residual.3.gamma"]))
+        a2 = self._halo_pad(self._rms(y, W[p + ".residual.3.gamma"], blocked=True))
         del y
         if cin != cout:
             xb = self._operand(x)
