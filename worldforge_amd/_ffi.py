@@ -18,7 +18,7 @@ import torch  # noqa: F401
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "wf_hip.h")
-LIB_PATH = os.path.join(HERE, "_lib", "libwf_hip.so")
+LIB_PATH = os.environ.get("WF_LIB") or os.path.join(HERE, "_lib", "libwf_hip.so")  # WF_LIB: an instrumented build (tools/*_timing.py)
 
 WF_F32, WF_BF16 = 0, 1
 
