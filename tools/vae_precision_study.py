@@ -36,6 +36,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+FIXTURE_FRAMES = [0, 4, 8, 12, 16]  # the recorded oracle result keeps these frames (fp16) + every step's latents (fp16)
+
+
 def psnr(a, b):
     mse = ((a.float() - b.float()) ** 2).mean().item()
     return 10 * math.log10(1.0 / max(mse, 1e-12))
@@ -191,8 +194,8 @@ def study(dim=1024, ffn_dim=2048, heads=8, layers=4, Fr=17, H=128, Wd=128, steps
     if oracle_only:  # CPU only: record the oracle's result for this job (no GPU needed)
         t0 = time.time()
         orc = run_oracle(*args)
-        np.savez_compressed(save_fixture, job=json.dumps(job), frames=orc[0].numpy().astype(np.float16),
-                            latents=np.stack([x.numpy() for x in orc[1]]), flf_lists=json.dumps(orc[2]), flf_sims=json.dumps(orc[3]))
+        np.savez_compressed(save_fixture, job=json.dumps(job), frames=orc[0].numpy().astype(np.float16)[FIXTURE_FRAMES], frame_idx=np.array(FIXTURE_FRAMES),
+                            latents=np.stack([x.numpy() for x in orc[1]]).astype(np.float16), flf_lists=json.dumps(orc[2]), flf_sims=json.dumps(orc[3]))
         print(f"oracle: {time.time() - t0:.0f} s -> {save_fixture}; gates {orc[2]}")
         return res
     t0 = time.time()
@@ -206,24 +209,26 @@ def study(dim=1024, ffn_dim=2048, heads=8, layers=4, Fr=17, H=128, Wd=128, steps
         "gate_max_sim_delta_bf16_vs_fp32vae": [(st, None if x is None or y is None else float(np.abs(np.asarray(x) - np.asarray(y)).max()))
                                                for (st, _), x, y in zip(cb, sa, sb)],
         "latent_db_bf16_vs_fp32vae_per_step": [round(db(a, b), 1) for a, b in zip(la, lb)]}
-    orc = None
+    orc, fidx = None, None
+    sel = lambda f: f if fidx is None else f[fidx]  # noqa: E731  (a recorded oracle result keeps a subset of the frames)
     if fixture is not None:
         z = np.load(fixture, allow_pickle=False)
         assert json.loads(str(z["job"])) == json.loads(json.dumps(job)), "fixture was recorded for a different job"
         lists = json.loads(str(z["flf_lists"]))
-        orc = (torch.from_numpy(z["frames"].astype(np.float32)), [torch.from_numpy(x) for x in z["latents"]],
+        fidx = [int(i) for i in z["frame_idx"]]
+        orc = (torch.from_numpy(z["frames"].astype(np.float32)), [torch.from_numpy(x.astype(np.float32)) for x in z["latents"]],
                [(int(st), list(c)) for st, c in lists], json.loads(str(z["flf_sims"])))
     elif with_oracle:
         t0 = time.time()
         orc = run_oracle(*args)
         res["oracle_s"] = time.time() - t0
         if save_fixture:
-            np.savez_compressed(save_fixture, job=json.dumps(job), frames=orc[0].numpy().astype(np.float16),
-                                latents=np.stack([x.numpy() for x in orc[1]]), flf_lists=json.dumps(orc[2]), flf_sims=json.dumps(orc[3]))
+            np.savez_compressed(save_fixture, job=json.dumps(job), frames=orc[0].numpy().astype(np.float16)[FIXTURE_FRAMES], frame_idx=np.array(FIXTURE_FRAMES),
+                                latents=np.stack([x.numpy() for x in orc[1]]).astype(np.float16), flf_lists=json.dumps(orc[2]), flf_sims=json.dumps(orc[3]))
     if orc is not None:
         fc, lc, cc, sc = orc
         res["free_running"].update({
-            "psnr_bf16vae_vs_oracle_db": psnr(fa, fc), "psnr_fp32vae_vs_oracle_db": psnr(fb, fc), "flf_lists_oracle": cc,
+            "psnr_bf16vae_vs_oracle_db": psnr(sel(fa), fc), "psnr_fp32vae_vs_oracle_db": psnr(sel(fb), fc), "flf_lists_oracle": cc,
             "flf_same_bf16vae_vs_oracle": ca == cc, "flf_same_fp32vae_vs_oracle": cb == cc,
             "gate_margin_oracle": [(st, decision_margin(sm, st)) for (st, _), sm in zip(cc, sc)],
             "gate_max_sim_delta_fp32vae_vs_oracle": [(st, None if x is None or y is None else float(np.abs(np.asarray(x) - np.asarray(y)).max()))
@@ -237,7 +242,7 @@ def study(dim=1024, ffn_dim=2048, heads=8, layers=4, Fr=17, H=128, Wd=128, steps
     rep = {"decisions_from": "oracle" if orc is not None else "fp32-class VAE run", "psnr_bf16vae_vs_fp32vae_db": psnr(ra, rb),
            "latent_db_bf16_vs_fp32vae_per_step": [round(db(a, b), 1) for a, b in zip(lra, lrb)]}
     if orc is not None:
-        rep.update({"psnr_bf16vae_vs_oracle_db": psnr(ra, orc[0]), "psnr_fp32vae_vs_oracle_db": psnr(rb, orc[0]),
+        rep.update({"psnr_bf16vae_vs_oracle_db": psnr(sel(ra), orc[0]), "psnr_fp32vae_vs_oracle_db": psnr(sel(rb), orc[0]),
                     "latent_db_bf16vae_vs_oracle_per_step": [round(db(a, c), 1) for a, c in zip(lra, orc[1])],
                     "latent_db_fp32vae_vs_oracle_per_step": [round(db(b, c), 1) for b, c in zip(lrb, orc[1])]})
     res["decisions_replayed"] = rep

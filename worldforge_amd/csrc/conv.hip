@@ -525,6 +525,7 @@ constexpr int WY = 8, WX = 64, W4T = 256;
 constexpr int PR = WY + 2, PC = WX + 2;
 constexpr int PATCH_PX = 3 * PR * PC;      // 1980 pixels of 32 B
 constexpr int PATCH_BUF = 64 * 1024;       // 64 pieces of 1 KiB (1980 * 32 B = 61.9 KiB, the tail of the last piece is padding)
+constexpr int W4_LDS = 2 * PATCH_BUF;
 
 #ifdef WF_CONV_TIMING
 __device__ unsigned long long g_conv_cycles[8];
@@ -545,6 +546,9 @@ struct ConvW4Args {
   int pix_stride, nsa;
 };
 
+// DBG (ablation builds only, -DWF_CONV_ABLATE + WF_CONV_DEBUG=<bits>; wrong results): bit 0 = no in-loop LDS-DMA, bit 1 = no in-loop weight
+// loads, bit 2 = no in-loop LDS fragment reads.  Compile-time, so that the production instantiation (DBG = 0) carries no branches.
+template <int DBG>
 __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const ConvArgs& a = pa.c;
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   decode(tile_begin, t, y0, x0);
   compute_psrc(t, y0, x0);
   const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_offset(smem));
-  auto dma_piece = [&](int cs, int j) {  // piece j of the patch of channel slice cs -> buffer cs & 1
+  auto dma_piece = [&](int cs, int j) {  // piece j of the patch of K slice cs -> buffer cs & 1 (stored slice cs mod nsa)
     const int acs = cs >= pa.nsa ? cs - pa.nsa : cs;
     const uint16_t* src = psrc[j] + (((pvalid >> j) & 1u) ? (size_t)acs * pa.slice_stride : (size_t)0);
     // issued from inline asm: with the builtin hipcc drains vmcnt(0) in front of every later ds_read (it cannot prove that the DMA's
@@ -603,7 +607,11 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   };
 
   // ---- fragment addressing ----
-  // B (pixels): wave rows 2w, 2w+1 of the tile, two 32-pixel column blocks; patch pixel (dt, row + dy, col + dx), 32 B per pixel
+  // B (pixels): wave rows 2w, 2w+1 of the tile, two 32-pixel column blocks; patch pixel (dt, row + dy, col + dx), 32 B per pixel.
+  // (All 16 lanes of a ds_read_b128 service group read the same channel half, i.e. only the even or the odd 16-byte slots: a 2-way bank
+  // conflict on every fragment read -- PMC: SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE.  Swapping the two halves of a pixel by bit
+  // 3 of its patch column (applied to the DMA source chunk, undone by one offset register per dx) removes them, and measured 3 % SLOWER
+  // on every VAE shape: the LDS array is ~20 % busy here, the extra address registers cost more than the conflicts.  Not kept.)
   uint32_t boff[4];
 #pragma unroll
   for (int pb = 0; pb < 4; ++pb) {
@@ -614,11 +622,18 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   const uint32_t aoff = (uint32_t)((l31 * 16 + 8 * hi) * 2);
   const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.w) + (size_t)n0 * 32;
   const size_t wslice = (size_t)a.Cout * 32;  // bytes per (tap, slice)
-  auto wload = [&](int cs, int tap, int cb) {
+  // Weight loads are issued from inline asm (saddr form: wave-uniform 64-bit base + the lane's constant 32-bit offset) and waited for by
+  // hand.  The LDS-DMA pieces are inline asm too, i.e. invisible to the compiler's s_waitcnt insertion: with compiler-managed weight
+  // loads it emitted vmcnt(N) for N outstanding loads IT knew of, while the hardware counter also held the younger DMA pieces -- every
+  // wait then drained loads issued barely one tap earlier and the MFMA stream stalled on L2 latency (43 instead of 32 cycles per MFMA).
+  auto wload = [&](u32x4& dst, int cs, int tap, int cb) {
     const int csc = cs < ns ? cs : 0;  // past the last slice: slice 0 of the next tile (same weights)
-    const unsigned char* sb = wbase + (size_t)(tap * ns + csc) * wslice + cb * 1024;
-    return *reinterpret_cast<const u32x4*>(sb + aoff);
+    const unsigned char* sb = wbase + (size_t)(tap * ns + csc) * wslice + cb * 1024;  // wave-uniform
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(aoff), "s"(sb) : "memory");
   };
+  // VMEM issue order per tap t of a slice: W(t+2) x 3 (gaps 4..6), then D x 2 (gaps 8, 10; taps 0..7 only).  Before the MFMAs of tap t
+  // its weights W(t) must have landed; younger than them are D(t-2), W(t+1), D(t-1): vmcnt = 3 + 2 [0 <= t-2 < 8] + 2 [0 <= t-1 < 8].
+  // (Loads return in order, so W(t) also waits for every older DMA piece -- those were issued >= 3 taps ~ 1200 cycles earlier.)
 
   f32x16 acc[4][3];
   auto mma = [&](f32x16& c, const u32x4& wv, const u32x4& xv) {
@@ -642,7 +657,7 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
 #pragma unroll
   for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
-    for (int cb = 0; cb < 3; ++cb) af[tp][cb] = wload(0, tp, cb);
+    for (int cb = 0; cb < 3; ++cb) wload(af[tp][cb], 0, tp, cb);
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // the 16 pieces landed (the 6 weight loads were issued after them)
   bar();
 #pragma unroll
@@ -682,17 +697,21 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
       constexpr int tap = decltype(TC)::value;
       constexpr int ntap = tap + 2 < 27 ? tap + 2 : tap + 2 - 27;
       const int ncs = tap + 2 < 27 ? cs : cs + 1;  // == ns on the last slice: wload wraps it to slice 0 of the next tile
+      if constexpr (!(DBG & 2)) {
+        constexpr int nd = (DBG & 1) ? 0 : 2;  // LDS-DMA pieces per tap over taps 0..7
+        constexpr int nwait = 3 + ((tap >= 2 && tap - 2 < 8) ? nd : 0) + ((tap >= 1 && tap - 1 < 8) ? nd : 0);
+        asm volatile("s_waitcnt vmcnt(%3)" : "+v"(af[tap % 3][0]), "+v"(af[tap % 3][1]), "+v"(af[tap % 3][2]) : "n"(nwait));
+      }
       for_const<12>([&](auto MC) {
         (void)&acc, (void)&af, (void)&bf;
         constexpr int m = decltype(MC)::value;
         constexpr int cb = m % 3, pb = m / 3;
         mma(acc[pb][cb], af[tap % 3][cb], bf[tap & 1][pb]);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (m < 4 && tap < 26) bf[(tap + 1) & 1][m] = bread(buf, tap + 1, m);  // next tap's pixel fragments
-        if constexpr (m >= 4 && m < 7) af[(tap + 2) % 3][m - 4] = wload(ncs, ntap, m - 4);  // weights two taps ahead
-        // next slice's patch, 2 pieces per tap over taps 0..7.  (Measured: the gather -- 32 B per pixel, 32-64 cache lines per piece --
-        // costs ~300 cycles of issue per piece, 30 % of the loop; weights 10 %; the LDS fragment reads nothing.)
-        if constexpr ((m == 8 || m == 10) && tap < 8) dma_piece(csn, 2 * tap + (m - 8) / 2);
+        if constexpr (m < 4 && tap < 26 && !(DBG & 4)) bf[(tap + 1) & 1][m] = bread(buf, tap + 1, m);  // next tap's pixel fragments
+        if constexpr (m >= 4 && m < 7 && !(DBG & 2)) wload(af[(tap + 2) % 3][m - 4], ncs, ntap, m - 4);  // weights two taps ahead
+        // the staged patch, 2 pieces per tap over taps 0..7
+        if constexpr ((m == 8 || m == 10) && tap < 8 && !(DBG & 1)) dma_piece(csn, 2 * tap + (m - 8) / 2);
         __builtin_amdgcn_sched_barrier(0);
       });
     });
@@ -704,6 +723,7 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
 #ifdef WF_CONV_TIMING
     t_wait += __builtin_readcyclecounter() - tw0;
     if (lane == 0 && wid == 0 && cs < 32) atomicAdd(&g_conv_slice[cs], __builtin_readcyclecounter() - ts0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the atomic is a VMEM op the hand-counted vmcnt waits of the next slice do not know
 #endif
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb) bf[0][pb] = bread(buf ^ 1, 0, pb);
@@ -928,6 +948,7 @@ extern "C" int wf_conv3d_333(const void* in, const void* w_packed, const float* 
   wa.tiles_x = (Wi + WX - 1) / WX;
   wa.tiles_y = (Ho + WY - 1) / WY;
   wa.nsa = Cin_stored / 16;
+
   if (layout == 0) {
     wa.row_stride = (long)Wi * Cin_stored; wa.pix_stride = Cin_stored; wa.slice_stride = 16;
   } else {
@@ -936,7 +957,19 @@ extern "C" int wf_conv3d_333(const void* in, const void* w_packed, const float* 
   const int ny = (Cout + 95) / 96, ntile = wa.tiles_x * wa.tiles_y * T;
   const int gx = std::min(ntile, std::max(1, 256 / ny));  // one persistent workgroup per CU
   dim3 grid((unsigned)gx, (unsigned)ny);
-  hipLaunchKernelGGL(k_conv_w4, grid, dim3(W4T), 2 * PATCH_BUF, (hipStream_t)stream, wa);
+#ifdef WF_CONV_ABLATE
+  {
+    const char* dbg = getenv("WF_CONV_DEBUG");
+    const int d = dbg ? atoi(dbg) : 0;
+    if (d == 1) hipLaunchKernelGGL(k_conv_w4<1>, grid, dim3(W4T), W4_LDS, (hipStream_t)stream, wa);
+    else if (d == 2) hipLaunchKernelGGL(k_conv_w4<2>, grid, dim3(W4T), W4_LDS, (hipStream_t)stream, wa);
+    else if (d == 3) hipLaunchKernelGGL(k_conv_w4<3>, grid, dim3(W4T), W4_LDS, (hipStream_t)stream, wa);
+    else if (d == 7) hipLaunchKernelGGL(k_conv_w4<7>, grid, dim3(W4T), W4_LDS, (hipStream_t)stream, wa);
+    else hipLaunchKernelGGL(k_conv_w4<0>, grid, dim3(W4T), W4_LDS, (hipStream_t)stream, wa);
+  }
+#else
+  hipLaunchKernelGGL(k_conv_w4<0>, grid, dim3(W4T), W4_LDS, (hipStream_t)stream, wa);
+#endif
   WF_LAUNCH_CHECK("wf_conv3d_333");
   return WF_OK;
 }
