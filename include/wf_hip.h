@@ -148,7 +148,9 @@ int wf_gemm_bf16(const void* X, const void* W, const float* bias, void* out, con
  * softmax(Q K^T * softmax_scale) V, no mask, head_dim 128.  Q [H][Lq][128], K [H][Lkp][128] (rows >= kv_len zero),
  * Vt [H][Lkp/64][128][64] (wf_v_transpose), O [Lq][ldo] bf16 with head h at columns h*128.  accumulate != 0: O += result.
  * seg_len: Lkp for one contiguous K/V; with sequence parallelism K/V are the all-gathered per-rank shards [P][H][seg_len][128]
- * (seg_len % 64 == 0, Lkp = P*seg_len) and key index = seg*seg_len + row. */
+ * (seg_len % 64 == 0, Lkp = P*seg_len) and key index = seg*seg_len + row.
+ * softmax_scale = 0: Q already carries softmax_scale * log2(e) (wf_rmsnorm_heads out_scale) -- the score accumulators then start
+ * from -m instead of 0 and hold s - m directly, which takes one VALU instruction per score out of the softmax. */
 int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len, int ldo,
                 float softmax_scale, int accumulate, void* stream);
 /* The same with the KV sweep split nsplit ways (each split leaves un-normalised partials in the workspace, a merge kernel combines
@@ -166,9 +168,11 @@ int wf_ln_modulate(const float* x, const float* mul, const float* add, void* out
                    int plus_one, void* stream);
 
 /* WanRMSNorm over all C channels (model.py:73-89, 142-143, 215-218) + optional 3-axis RoPE (model.py:43-70; cos/sin tables
- * [L][64] f32, NULL -> none), written head-major: in bf16 [L, ld] -> out bf16 [C/128][Lout][128] (rows L..Lout untouched). */
+ * [L][64] f32, NULL -> none), written head-major: in bf16 [L, ld] -> out bf16 [C/128][Lout][128] (rows L..Lout untouched).
+ * out_scale (1 = none) multiplies the f32 result in front of the one bf16 rounding: the self-attention Q is produced as
+ * q * head_dim^-1/2 * log2(e), and wf_attn_fwd is then called with softmax_scale = 0 ("Q is pre-scaled"). */
 int wf_rmsnorm_heads(const void* in, int ld, const float* weight, const float* cos_tab, const float* sin_tab, void* out, int L,
-                     int Lout, int C, float eps, void* stream);
+                     int Lout, int C, float eps, float out_scale, void* stream);
 
 /* V [L, ld] bf16 (head h at columns h*128) -> Vt [H][Lp/64][128][64] bf16, keys >= L zero-filled. */
 int wf_v_transpose(const void* V, int ld, void* Vt, int L, int Lp, int H, void* stream);

@@ -193,6 +193,62 @@ def test_attention_online_softmax_rescale_is_exercised():
     assert _rel(out, ref) <= 1e-2
 
 
+@pytest.mark.parametrize("H,Lq,Lk,nsplit", [(2, 300, 1000, 1), (1, 256, 4524, 1), (3, 77, 640, 1), (1, 128, 8192 + 37, 1), (2, 300, 1000, 2),
+                                            (1, 128, 8192 + 37, 8), (2, 64, 40, 1)])
+def test_attention_prescaled_q(H, Lq, Lk, nsplit):
+    """softmax_scale = 0 (k_attn_w4<4>): Q arrives multiplied by head_dim^-1/2 * log2(e), the score accumulators start from -m.  The
+    oracle gets the very same bf16 Q values divided by that factor, so the two compute the same function; late key spikes force the
+    rescale branch (running max grows by far more than 2^8) and re-base the already-computed scores of the next tile."""
+    from worldforge_amd import dit
+    scale = 1 / math.sqrt(128)
+    alpha = scale * 1.4426950408889634
+    q0 = _rand((H, Lq, 128), 40)
+    k = _rand((H, Lk, 128), 41)
+    if Lk > 600:
+        k[:, 300] = q0[:, 5] * 3.0
+        k[:, Lk - 70] = q0[:, 17 % Lq] * 5.0
+        k[:, Lk - 3] = q0[:, 9] * 7.0
+    k = k.to(BF)
+    qs = (q0 * alpha).to(BF)                       # what wf_rmsnorm_heads(out_scale = alpha) hands over
+    v = _rand((H, Lk, 128), 42).to(BF)
+    Lkp = (Lk + 63) // 64 * 64
+    kp = torch.zeros((H, Lkp, 128), dtype=BF)
+    kp[:, :Lk] = k
+    vp = torch.zeros((H, Lkp, 128), dtype=BF)
+    vp[:, :Lk] = v
+    vt = vp.view(H, Lkp // 64, 64, 128).transpose(2, 3).contiguous()
+    out = torch.full((Lq, H * 128), float("nan"), dtype=BF, device=DEV)
+    dit.attention(qs.to(DEV), kp.to(DEV), vt.to(DEV), out, Lk, 0.0, nsplit=nsplit)
+    ref = _attn_ref(qs.float() / alpha, k.float(), v.float(), scale)
+    assert torch.isfinite(out).all()
+    assert _rel(out, ref) <= 1e-2, _rel(out, ref)
+    # the in-kernel-scale path on the same operands is the same function (bf16 output rounding apart)
+    qf = (qs.float() / alpha)
+    if torch.equal(qf.to(BF).float(), qf):   # only comparable when the un-scaled Q is representable (it is not in general)
+        two = torch.empty_like(out)
+        dit.attention(qf.to(BF).to(DEV), kp.to(DEV), vt.to(DEV), two, Lk, scale, nsplit=nsplit)
+        assert _rel(out, two.float().cpu()) <= 6e-3
+    dit.attention(qs.to(DEV), kp.to(DEV), vt.to(DEV), out, Lk, 0.0, accumulate=True, nsplit=nsplit)
+    assert _rel(out, 2 * ref) <= 1.5e-2
+
+
+def test_rmsnorm_heads_out_scale_is_applied_before_the_rounding():
+    from worldforge_amd import _ffi, dit, ops
+    L, H, f, h, w = 40, 2, 2, 4, 5
+    C = H * 128
+    x = _rand((L, C), 50).to(BF).to(DEV)
+    wq = (1 + 0.1 * _rand((C,), 51)).to(DEV)
+    cos, sin = dit.rope_tables(128, f, h, w)
+    cd, sd = cos.to(DEV), sin.to(DEV)
+    a, b = torch.zeros((H, L, 128), dtype=BF, device=DEV), torch.zeros((H, L, 128), dtype=BF, device=DEV)
+    alpha = 1.4426950408889634 / math.sqrt(128)
+    _ffi.call("wf_rmsnorm_heads", x.data_ptr(), C, wq.data_ptr(), cd.data_ptr(), sd.data_ptr(), a.data_ptr(), L, L, C, 1e-6, 1.0, ops.stream())
+    _ffi.call("wf_rmsnorm_heads", x.data_ptr(), C, wq.data_ptr(), cd.data_ptr(), sd.data_ptr(), b.data_ptr(), L, L, C, 1e-6, alpha, ops.stream())
+    # b = bf16(y * alpha) with y the un-rounded result: within half a bf16 ulp of alpha * y, i.e. 2^-8 relative of bf16(y) * alpha
+    assert ((b.float() - a.float() * alpha).abs() <= 2.0 ** -7 * (a.float() * alpha).abs() + 1e-8).all()
+    assert not torch.equal(b.float(), (a.float() * alpha).to(BF).float())   # not the double rounding
+
+
 def test_ln_modulate_and_affine():
     from worldforge_amd import _ffi, ops
     for C in (256, 1280, 5120):
@@ -219,14 +275,14 @@ def test_rmsnorm_rope_heads_and_v_transpose():
     out = torch.zeros((H, 64, 128), dtype=BF, device=DEV)
     qd, wqd, cd, sd = qkv.to(DEV), wq.to(DEV), cos.to(DEV), sin.to(DEV)
     _ffi.call("wf_rmsnorm_heads", qd[:, C:2 * C].data_ptr(), 3 * C, wqd.data_ptr(), cd.data_ptr(),
-              sd.data_ptr(), out.data_ptr(), L, 64, C, 1e-6, ops.stream())
+              sd.data_ptr(), out.data_ptr(), L, 64, C, 1e-6, 1.0, ops.stream())
     kk = qkv[:, C:2 * C].float()
     ref = odit.rope_apply(odit.rms_norm(kk, wq, 1e-6).view(L, H, 128), odit.rope_tables(128, f, h, w))
     got = out[:, :L].permute(1, 0, 2).float().cpu()
     assert (got - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
     assert out[:, L:].abs().max().item() == 0
     # no-rope variant
-    _ffi.call("wf_rmsnorm_heads", qd.data_ptr(), 3 * C, wqd.data_ptr(), None, None, out.data_ptr(), L, 64, C, 1e-6,
+    _ffi.call("wf_rmsnorm_heads", qd.data_ptr(), 3 * C, wqd.data_ptr(), None, None, out.data_ptr(), L, 64, C, 1e-6, 1.0,
               ops.stream())
     ref2 = odit.rms_norm(qkv[:, :C].float(), wq, 1e-6).view(L, H, 128)
     assert (out[:, :L].permute(1, 0, 2).float().cpu() - ref2).abs().max().item() <= 2e-2 * ref2.abs().max().item()

@@ -11,5 +11,5 @@ k = torch.zeros(H, Lp, 128, device=dev, dtype=torch.bfloat16); k[:, :L] = torch.
 vt = torch.randn(H, Lp // 64, 128, 64, device=dev).to(torch.bfloat16)
 out = torch.empty(L, H * 128, device=dev, dtype=torch.bfloat16)
 for _ in range(int(os.environ.get("N", 3))):
-    dit.attention(q, k, vt, out, L, 1 / math.sqrt(128))
+    dit.attention(q, k, vt, out, L, 0.0 if os.environ.get("PRESCALED") else 1 / math.sqrt(128))
 torch.cuda.synchronize()

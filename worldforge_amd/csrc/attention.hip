@@ -546,6 +546,12 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
   bf16x8 pf[2][4];
   // KIND 3 (block-sparse, see k_attn<2>): the running max starts finite so that leading masked blocks cannot give inf - inf
   float m_run[2] = {KIND == 3 ? -1e30f : -INFINITY, KIND == 3 ? -1e30f : -INFINITY}, l_run[2] = {0.f, 0.f}, mcq[2] = {0.f, 0.f};
+  // KIND 4 ("prescaled"): Q arrives multiplied by softmax_scale * log2(e) (wf_rmsnorm_heads out_scale: applied before the producer's
+  // single bf16 rounding, so it costs no precision), i.e. the MFMA result is already in the exp2 domain, and the score accumulators are
+  // INITIALISED with -m (the C operand of each block's first MFMA is minit = 16 registers holding -m of the lane's query): the
+  // registers hold t = s - m directly and the 64 v_fma of softmax stage A disappear from every tile.  m moves only in the rare rescale.
+  constexpr bool PS = KIND == 4;
+  f32x16 minit[2];
 #pragma unroll
   for (int x = 0; x < 2; ++x) {
 #pragma unroll
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) pf[x][i] = as_bf16x8(u32x4{0u, 0u, 0u, 0u});
   }
-  const float c = a.scale_log2;
+  const float c = PS ? 1.0f : a.scale_log2;
   const int ntiles_all = (a.kv_len + KB - 1) / KB;
   const int split = blockIdx.y;
   const int t_begin = split * a.tiles_per_split;                         // first KV tile of this split (absolute)
@@ -636,8 +642,10 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
     const int db = i & 3, m4 = i >> 2;
     return *reinterpret_cast<const u32x4*>(sVb + vrow_off[db] + (((2 * m4 + hi) ^ vrow_sw[db]) << 4));
   };
-  auto mfma_s = [&](f32x16& acc, u32x4 kf, const bf16x8& q, bool first) {
-    if (first)
+  auto mfma_s = [&](f32x16& acc, u32x4 kf, const bf16x8& q, bool first, const f32x16* init = nullptr) {
+    if (first && init)
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(kf), "a"(q), "v"(*init));
+    else if (first)
       asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(kf), "a"(q));
     else
       asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(kf), "a"(q));
@@ -654,6 +662,38 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
   // commit of the running max of q-block X given the row max `mloc` of the next tile's scores (already exchanged between the lane
   // halves); rare path: some row max grew -> rescale O_X, l_X.  O_X lives in AGPRs and must never be a VALU operand in the hot
   // loop: the copies to VGPRs and back are pinned inside this block by the empty asm statements.
+  auto set_minit = [&](auto XC) {
+    constexpr int X = decltype(XC)::value;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) minit[X][r] = -m_run[X];
+    asm volatile("" : "+v"(minit[X]));
+  };
+  // KIND 4: `rel` = max(row max of the NEW scores relative to m_run, 0), already exchanged between the lane halves; `nb` = the score
+  // buffer that holds those new scores (they were computed against the old m and are re-based here)
+  auto commit_ps = [&](auto XC, auto NBC, float rel) {
+    constexpr int X = decltype(XC)::value, NB = decltype(NBC)::value;
+    if (__any(rel > 8.0f)) {
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
+      const float alpha = __builtin_amdgcn_exp2f(-rel);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        f32x16 tmp = o[X][db];
+        asm volatile("" : "+v"(tmp));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmp[r] *= alpha;
+        asm volatile("" : "+v"(tmp));
+        o[X][db] = tmp;
+        asm volatile("" : "+a"(o[X][db]));
+      }
+      l_run[X] *= alpha;
+      m_run[X] += rel;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sb[NB][X][kb][r] -= rel;
+      set_minit(XC);
+    }
+  };
   auto commit = [&](auto XC, float m_new) {
     constexpr int X = decltype(XC)::value;
     // Deferred rescale: the reference max m_run only has to bound the scores well enough for exp2 not to overflow; it is the SAME m
@@ -764,7 +804,7 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
       constexpr int q = g & 1;
       if constexpr (g < 32) {
         constexpr int i = g >> 1;  // K fragment i: key block i & 1, k-step i >> 1
-        mfma_s(sb_[1 - B][q][i & 1], ring_[i % PF4], qf[q][i >> 1], i < 2);
+        mfma_s(sb_[1 - B][q][i & 1], ring_[i % PF4], qf[q][i >> 1], i < 2, PS ? &minit[q] : nullptr);
         __builtin_amdgcn_sched_barrier(0);  // the gap's VALU must not be hoisted above its MFMA
         if constexpr (q == 1) {  // fragment i consumed by both q-blocks: refill its slot
           if constexpr (i + PF4 < 16)
@@ -790,7 +830,7 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
         (void)&sb_, (void)&pf_, (void)&tq__, (void)&pq_, (void)&ls_, (void)&pk_, (void)&mcq_;
         constexpr int k = decltype(KC)::value;
         constexpr int f = k >> 4, x = (k >> 3) & 1, e = 8 * f + (k & 7);
-        if constexpr ((50 * k) / 64 == g) {  // stage A
+        if constexpr (!PS && (50 * k) / 64 == g) {  // stage A (KIND 4: the score register already holds s - m)
           tq__[k] = c * sb_[B][x][e >> 4][e & 15] - mcq_[x];
           asm volatile("" : "+v"(tq__[k]));
         }
@@ -821,7 +861,12 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
         (void)&sb_, (void)&pf_, (void)&tq__, (void)&pq_, (void)&ls_, (void)&pk_, (void)&mcq_;
         constexpr int k = decltype(KC)::value;
         if constexpr ((50 * k) / 64 + 1 == g) {  // stage B
-          pq_[k] = __builtin_amdgcn_exp2f(tq__[k]);
+          if constexpr (PS) {
+            constexpr int f = k >> 4, x = (k >> 3) & 1, e = 8 * f + (k & 7);
+            pq_[k] = __builtin_amdgcn_exp2f(sb_[B][x][e >> 4][e & 15]);
+          } else {
+            pq_[k] = __builtin_amdgcn_exp2f(tq__[k]);
+          }
           asm volatile("" : "+v"(pq_[k]));
         }
       });
@@ -849,7 +894,12 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
         constexpr int x = g - 62;
         const unsigned mu = __float_as_uint(mn[x]);
         auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
-        asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(mn[x]) : "v"(__uint_as_float(sw[0])), "v"(__uint_as_float(sw[1])), "v"(m_run[x]));
+        if constexpr (PS) {
+          const float zero = 0.0f;
+          asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(mn[x]) : "v"(__uint_as_float(sw[0])), "v"(__uint_as_float(sw[1])), "v"(zero));
+        } else {
+          asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(mn[x]) : "v"(__uint_as_float(sw[0])), "v"(__uint_as_float(sw[1])), "v"(m_run[x]));
+        }
       }
       if constexpr (g == 54 || g == 56) {  // the row sums of this tile are complete (last pack at gap 51)
         constexpr int x = (g - 54) >> 1;
@@ -877,7 +927,12 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     });
     // one test for both q-blocks in the hot path; the (rare) commits re-test per q-block
-    if (t + 1 < ntiles && __any(c * fmaxf(mn[0] - m_run[0], mn[1] - m_run[1]) > 8.0f)) {
+    if constexpr (PS) {
+      if (t + 1 < ntiles && __any(fmaxf(mn[0], mn[1]) > 8.0f)) {
+        commit_ps(std::integral_constant<int, 0>{}, std::integral_constant<int, 1 - B>{}, mn[0]);
+        commit_ps(std::integral_constant<int, 1>{}, std::integral_constant<int, 1 - B>{}, mn[1]);
+      }
+    } else if (t + 1 < ntiles && __any(c * fmaxf(mn[0] - m_run[0], mn[1] - m_run[1]) > 8.0f)) {
       commit(std::integral_constant<int, 0>{}, mn[0]);
       commit(std::integral_constant<int, 1>{}, mn[1]);
     }
@@ -921,8 +976,21 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
     if constexpr (KIND == 3) mask_unselected(B0{}, __builtin_amdgcn_readfirstlane(bsa[0]));
     const float m0 = rowmax_now(B0{}, std::integral_constant<int, 0>{});
     const float m1 = rowmax_now(B0{}, std::integral_constant<int, 1>{});
-    commit(std::integral_constant<int, 0>{}, m0);
-    commit(std::integral_constant<int, 1>{}, m1);
+    if constexpr (PS) {  // O = l = 0: nothing to rescale; the scores of tile 0 were accumulated from 0 and are re-based to the first max
+      m_run[0] = m0;
+      m_run[1] = m1;
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sb[0][x][kb][r] -= m_run[x];
+      set_minit(std::integral_constant<int, 0>{});
+      set_minit(std::integral_constant<int, 1>{});
+    } else {
+      commit(std::integral_constant<int, 0>{}, m0);
+      commit(std::integral_constant<int, 1>{}, m1);
+    }
     const unsigned char* sK1 = smem + (ntiles > 1 ? 1 : 0) * BUF_BYTES;
 #pragma unroll
     for (int i = 0; i < PF4; ++i) ring[i] = kread(sK1, i);
@@ -1057,7 +1125,8 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
   a.seg_len = seg_len;
   a.ldo = ldo;
   a.n_qblk = ceil_div(Lq, QB);
-  a.scale_log2 = softmax_scale * 1.4426950408889634f;
+  const bool prescaled = softmax_scale == 0.0f;  // Q already carries softmax_scale * log2(e) (wf_rmsnorm_heads out_scale)
+  a.scale_log2 = prescaled ? 1.0f : softmax_scale * 1.4426950408889634f;
   a.accumulate = accumulate;
   {
     const char* e = getenv("WF_ATTN_PRIO");
@@ -1091,8 +1160,11 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
     a.o_part = (float*)workspace;
     a.ml_part = a.o_part + (size_t)ns * Lq * H * D;
   }
+  WF_CHECK_ARG(!prescaled || use_w4, "%s: softmax_scale = 0 (pre-scaled Q) needs the k_attn_w4 kernel", who);
   if (use_w4) {
-    if (Lkp > 1024)
+    if (prescaled)
+      hipLaunchKernelGGL(k_attn_w4<4>, dim3(grid, a.nsplit), dim3(NT4), lds_w4, (hipStream_t)stream, a);
+    else if (Lkp > 1024)
       hipLaunchKernelGGL(k_attn_w4<0>, dim3(grid, a.nsplit), dim3(NT4), lds_w4, (hipStream_t)stream, a);
     else
       hipLaunchKernelGGL(k_attn_w4<1>, dim3(grid, a.nsplit), dim3(NT4), lds_w4, (hipStream_t)stream, a);

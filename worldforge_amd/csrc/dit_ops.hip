@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_ln_mod(const float* __restrict__ x, con
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void k_rms_heads(const uint16_t* __restrict__ in, int ld, const float* __restrict__ w,
                                                    const float* __restrict__ cs, const float* __restrict__ sn,
-                                                   uint16_t* __restrict__ out, int L, int Lout, int C, float eps) {
+                                                   uint16_t* __restrict__ out, int L, int Lout, int C, float eps, float out_scale) {
   __shared__ float sm[4];
   const int row = blockIdx.x;
   const uint16_t* xr = in + (size_t)row * ld;
@@ -135,6 +135,10 @@ __global__ __launch_bounds__(128) void k_rms_heads(const uint16_t* __restrict__ 
           y[2 * k] = re;
           y[2 * k + 1] = im;
         }
+      }
+      if (out_scale != 1.0f) {  // softmax_scale * log2(e) folded into Q in front of the one bf16 rounding (wf_attn_fwd, softmax_scale = 0)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] *= out_scale;
       }
       u32x4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
       *reinterpret_cast<u32x4*>(out + ((size_t)head * Lout + row) * 128 + within * 8) = pk;
@@ -236,14 +240,15 @@ extern "C" int wf_ln_modulate(const float* x, const float* mul, const float* add
 }
 
 extern "C" int wf_rmsnorm_heads(const void* in, int ld, const float* weight, const float* cos_tab, const float* sin_tab,
-                                void* out, int L, int Lout, int C, float eps, void* stream) {
+                                void* out, int L, int Lout, int C, float eps, float out_scale, void* stream) {
   WF_CHECK_ARG(in && weight && out, "wf_rmsnorm_heads: null pointer");
+  WF_CHECK_ARG(out_scale > 0.0f, "wf_rmsnorm_heads: out_scale must be positive (1 = none)");
   WF_CHECK_ARG(C % 128 == 0 && C <= 8192 && ld % 8 == 0, "wf_rmsnorm_heads: C=%d must be a multiple of 128 (<= 8192), ld %% 8", C);
   WF_CHECK_ARG(Lout >= L, "wf_rmsnorm_heads: Lout < L");
   WF_CHECK_ARG((cos_tab == nullptr) == (sin_tab == nullptr), "wf_rmsnorm_heads: cos/sin must both be given or both null");
   if (L == 0) return WF_OK;
   hipLaunchKernelGGL(k_rms_heads, dim3(L), dim3(128), 0, (hipStream_t)stream, (const uint16_t*)in, ld, weight, cos_tab,
-                     sin_tab, (uint16_t*)out, L, Lout, C, eps);
+                     sin_tab, (uint16_t*)out, L, Lout, C, eps, out_scale);
   WF_LAUNCH_CHECK("wf_rmsnorm_heads");
   return WF_OK;
 }

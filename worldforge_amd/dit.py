@@ -415,12 +415,13 @@ class WanTransformer3DModel:
              L, C, float(eps), 1 if plus_one else 0, ops.stream())
         return out
 
-    def _heads(self, src, col0, weight, cos, sin, out, L):
-        """RMSNorm(+RoPE) of columns [col0, col0+dim) of src [L, ld] -> out [H, Lout, 128]."""
+    def _heads(self, src, col0, weight, cos, sin, out, L, out_scale: float = 1.0):
+        """RMSNorm(+RoPE) of columns [col0, col0+dim) of src [L, ld] -> out [H, Lout, 128]; out_scale: see wf_rmsnorm_heads."""
         C = self.cfg.dim
         view = src[:, col0:col0 + C]
         call("wf_rmsnorm_heads", view.data_ptr(), src.stride(0), weight.data_ptr(), cos.data_ptr() if cos is not None else None,
-             sin.data_ptr() if sin is not None else None, out.data_ptr(), L, out.shape[1], C, float(self.cfg.eps), ops.stream())
+             sin.data_ptr() if sin is not None else None, out.data_ptr(), L, out.shape[1], C, float(self.cfg.eps), float(out_scale),
+             ops.stream())
 
     def _vt(self, src, col0, out, L):
         view = src[:, col0:col0 + self.cfg.dim]
@@ -471,6 +472,11 @@ class WanTransformer3DModel:
         Lfull = f * h2 * w2
         d, H = cfg.dim, cfg.num_heads
         scale = 1.0 / math.sqrt(128.0)
+        # self-attention: softmax_scale * log2(e) is folded into Q by its producer (in front of the one bf16 rounding) and the attention
+        # kernel is told so with softmax_scale = 0 (k_attn_w4<4>: score accumulators start from -m); WF_ATTN_PRESCALE=0 keeps the scale
+        # inside the kernel (A/B), as does the two-wave kernel
+        prescale = os.environ.get("WF_ATTN_PRESCALE", "1") != "0" and os.environ.get("WF_ATTN_KERNEL", "") != "w8"
+        q_scale, sa_scale = (scale * 1.4426950408889634, 0.0) if prescale else (1.0, scale)
         cos, sin = self._rope_tables(f, h2, w2)
         e, e0, ctx_t, ctx_i = self._embed_condition(t_value, text, img, tag)
         n_img = ctx_i.shape[0]
@@ -525,10 +531,10 @@ class WanTransformer3DModel:
             self._ln(x, emod[1], emod[0], hbuf, cfg.eps, plus_one=True)
             if comm is None:
                 gemm(hbuf, W[p + "qkv.w"], W[p + "qkv.b"], qkv, EPI_BF16)
-                self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L)
+                self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L, out_scale=q_scale)
                 self._heads(qkv, d, W[p + "self_attn.norm_k"], cos, sin, kh, L)
                 self._vt(qkv, 2 * d, vt, L)
-                attention(qh, kh, vt, ao, L, scale, profile=True)
+                attention(qh, kh, vt, ao, L, sa_scale, profile=True)
             else:
                 # K and V first, their all-gather runs on the communication stream under the Q projection
                 gemm(hbuf, W[p + "qkv.w"][d:], W[p + "qkv.b"][d:], qkv[:, d:], EPI_BF16)
@@ -538,7 +544,7 @@ class WanTransformer3DModel:
                 ev_v = comm.all_gather_async(vt_all, vt)
                 yield i
                 gemm(hbuf, W[p + "qkv.w"][:d], W[p + "qkv.b"][:d], qkv[:, :d], EPI_BF16)
-                self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L)
+                self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L, out_scale=q_scale)
                 cprof = PROFILE_COMM
                 if cprof is not None:  # exposed communication = how long the compute stream stalls here
                     cw0, cw1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -549,7 +555,7 @@ class WanTransformer3DModel:
                 if cprof is not None:
                     cw1.record()
                     cprof.append((cw0, cw1))
-                attention(qh, kh_all, vt_all, ao, Lfull, scale, profile=True)
+                attention(qh, kh_all, vt_all, ao, Lfull, sa_scale, profile=True)
             gemm(ao, W[p + "self_attn.o.w"], W[p + "self_attn.o.b"], x, EPI_RESID, gate=emod[2])
             # ---- cross-attention (model.py:310, 202-229) ----
             self._ln(x, W[p + "norm3.w"], W[p + "norm3.b"], hbuf, cfg.eps, plus_one=False)
