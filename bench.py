@@ -471,7 +471,8 @@ def main(argv=None):
         if attn_ms:
             avg = sum(attn_ms) / len(attn_ms)
             ach = attn_flop / (avg * 1e-3) / 1e12
-            out["roofline"] = {"kernel": ("k_attn<0>" if os.environ.get("WF_ATTN_KERNEL") == "w8" else "k_attn_w4<0>") + " (DiT self-attention, model.py:149-154)",
+            out["roofline"] = {"kernel": ("k_attn<0>" if os.environ.get("WF_ATTN_KERNEL") == "w8" else ("k_attn_w4<0>" if os.environ.get("WF_ATTN_PRESCALE", "1") == "0" else "k_attn_w4<4> (pre-scaled Q)"))
+                                         + " (DiT self-attention, model.py:149-154)",
                                "bound": "mfma", "achieved": ach,
                                "peak": MFMA_PEAK_TFLOPS_BF16, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS_BF16,
                                "traffic": ATTN_TRAFFIC_BYTES_C2 if (L == 32760 and world == 1 and cfg.num_heads == 40 and os.environ.get("WF_ATTN_KERNEL") != "w8") else None,

@@ -152,13 +152,21 @@ int wf_gemm_bf16(const void* X, const void* W, const float* bias, void* out, con
  * softmax_scale = 0: Q already carries softmax_scale * log2(e) (wf_rmsnorm_heads out_scale) -- the score accumulators then start
  * from -m instead of 0 and hold s - m directly, which takes one VALU instruction per score out of the softmax. */
 int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len, int ldo,
-                float softmax_scale, int accumulate, void* stream);
+                float softmax_scale, int accumulate, const float* kmax2, int kmax_n, const float* qmax2, int qmax_n, void* stream);
+/* Per-head max over the rows of |x|^2: X bf16 [H][Lp][128] (rows >= L ignored) -> out f32 [H], which the caller zeroes first.
+ * Computed for K and for the pre-scaled Q and handed to wf_attn_fwd (softmax_scale = 0 only) as kmax2 / qmax2 -- kmax_n / qmax_n such
+ * vectors each, one per shard when the tensor is all-gathered -- it lets the kernel prove by Cauchy-Schwarz that no score of the head
+ * can overflow: B = max|q| max|k| bounds |s|, a row's reference max is >= -B, so s - m <= 2B; with 2B <= 100 (exp2 domain) the
+ * workgroup runs WITHOUT the running-max tracking of the online softmax (exact: the same m is used for P and the row sum).  The tracked
+ * path remains the fallback (larger norms, NaNs) and the only path when either pointer is NULL. */
+int wf_head_max_norm2(const void* X, int H, int L, int Lp, float* out, void* stream);
 /* The same with the KV sweep split nsplit ways (each split leaves un-normalised partials in the workspace, a merge kernel combines
  * them exactly): fills the chip when Lq is short, e.g. one rank's token shard of the sequence-parallel DiT (Lq = 4096 at 8 ranks:
  * 640 workgroups on 256 CUs).  workspace: wf_attn_split_workspace_bytes(H, Lq, nsplit) bytes, 16-byte aligned. */
 size_t wf_attn_split_workspace_bytes(int H, int Lq, int nsplit);
 int wf_attn_fwd_split(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len, int ldo,
-                      float softmax_scale, int accumulate, int nsplit, void* workspace, void* stream);
+                      float softmax_scale, int accumulate, int nsplit, void* workspace, const float* kmax2, int kmax_n, const float* qmax2,
+                      int qmax_n, void* stream);
 
 /* WanLayerNorm (model.py:92-102; eps, no affine) fused with y = ln * (plus_one + mul[c]) + add[c]:
  *   AdaLN modulate (model.py:303, 311, 346): mul = scale e[1]/e[4], add = shift e[0]/e[3], plus_one = 1;

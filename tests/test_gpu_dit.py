@@ -232,6 +232,51 @@ def test_attention_prescaled_q(H, Lq, Lk, nsplit):
     assert _rel(out, 2 * ref) <= 1.5e-2
 
 
+@pytest.mark.parametrize("H,Lq,Lk,nsplit,kscale", [(2, 300, 1000, 1, 1.0), (1, 256, 4524, 1, 1.0), (1, 128, 8192 + 37, 8, 1.0), (2, 300, 1000, 1, 40.0),
+                                                   (2, 64, 40, 1, 1.0)])
+def test_attention_prescaled_q_with_key_norm_bound(H, Lq, Lk, nsplit, kscale):
+    """kmax2 / qmax2 given: heads whose Cauchy-Schwarz bound B = max|q| max|k| is <= 50 (exp2 domain) run without running-max tracking --
+    the same function, within tolerance; keys scaled by 40 push B past 50 so that the tracked fallback runs (late spikes included in both;
+    with the unit-scale spikes B is ~ 30-45 here, so the un-tracked path does see scores far above its first-tile reference max)."""
+    from worldforge_amd import dit
+    scale = 1 / math.sqrt(128)
+    alpha = scale * 1.4426950408889634
+    q0 = _rand((H, Lq, 128), 60)
+    k = _rand((H, Lk, 128), 61) * kscale
+    if Lk > 600:
+        k[:, 300] = q0[:, 5] * 3.0
+        k[:, Lk - 3] = q0[:, 9] * 7.0
+    k = k.to(BF)
+    qs = (q0 * alpha).to(BF)
+    v = _rand((H, Lk, 128), 62).to(BF)
+    Lkp = (Lk + 63) // 64 * 64
+    kp = torch.zeros((H, Lkp, 128), dtype=BF)
+    kp[:, :Lk] = k
+    vp = torch.zeros((H, Lkp, 128), dtype=BF)
+    vp[:, :Lk] = v
+    vt = vp.view(H, Lkp // 64, 64, 128).transpose(2, 3).contiguous()
+    kd = kp.to(DEV)
+    km = dit.head_max_norm2(kd, Lk, torch.empty(H, device=DEV))
+    qm = dit.head_max_norm2(qs.to(DEV), Lq, torch.empty(H, device=DEV))
+    want_km = (k.float() ** 2).sum(-1).max(dim=1).values
+    assert torch.allclose(km.cpu(), want_km, rtol=1e-5)
+    assert torch.allclose(qm.cpu(), (qs.float() ** 2).sum(-1).max(dim=1).values, rtol=1e-5)
+    print("B per head", (km * qm).sqrt().cpu().tolist())
+    out = torch.full((Lq, H * 128), float("nan"), dtype=BF, device=DEV)
+    dit.attention(qs.to(DEV), kd, vt.to(DEV), out, Lk, 0.0, nsplit=nsplit, kmax2=km, qmax2=qm)
+    ref = _attn_ref(qs.float() / alpha, k.float(), v.float(), scale)
+    assert torch.isfinite(out).all()
+    assert _rel(out, ref) <= 1e-2, _rel(out, ref)
+    trk = torch.empty_like(out)
+    dit.attention(qs.to(DEV), kd, vt.to(DEV), trk, Lk, 0.0, nsplit=nsplit)
+    assert _rel(out, trk.float().cpu()) <= 6e-3
+    # two shard vectors (all-gathered K): the kernel takes the max over them
+    km2 = torch.stack([km * 0.25, km]).contiguous()
+    out2 = torch.empty_like(out)
+    dit.attention(qs.to(DEV), kd, vt.to(DEV), out2, Lk, 0.0, nsplit=nsplit, kmax2=km2, qmax2=qm)
+    assert torch.equal(out2, out)
+
+
 def test_rmsnorm_heads_out_scale_is_applied_before_the_rounding():
     from worldforge_amd import _ffi, dit, ops
     L, H, f, h, w = 40, 2, 2, 4, 5

@@ -73,6 +73,11 @@ struct AttnArgs {
   const int* bsa_cnt;   // [H][n_qblk]
   int bsa_max;
   int bsa_shift;        // flag bits per entry = query blocks per workgroup: 2 (128-token blocks, 2 tiles per entry) or 4 (64-token, 1 tile)
+  // KIND 4: per-head max over the rows of |k|^2 and of |q|^2 (wf_head_max_norm2; Q pre-scaled), kmax_n / qmax_n vectors of H floats each
+  // (one per rank shard of an all-gathered K), or NULL
+  const float* kmax2;
+  const float* qmax2;
+  int kmax_n, qmax_n;
 };
 
 #ifdef WF_ATTN_TIMING
@@ -484,8 +489,10 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
 // ======================================================================================================================================
 constexpr int NT4 = 256;
 
-template <int KIND>
-__global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
+// NOMAX (KIND 4 only, chosen per workgroup by the kernel below): no running-max tracking after tile 0 -- the reference max of every row
+// stays the first tile's for the whole sweep.
+template <int KIND, bool NOMAX>
+__device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BUF_BYTES = K_TILE_BYTES + V_TILE_BYTES;
   constexpr int NBUF = 5;  // ring of 5 tile buffers = the whole 160 KiB: lets the workgroup barrier run every SECOND tile
@@ -872,7 +879,7 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
       });
       // ---- row max of the new scores: 2 q-blocks x 4 chains x 4 v_max3 steps in gaps 52..59 (4 steps per gap); tree, lane-half
       // exchange and running max in gaps 60..63, so that only the (rare) rescale decision is left after the last MFMA ----
-      if constexpr (g >= 52 && g < 60) {
+      if constexpr (!NOMAX && g >= 52 && g < 60) {
         for_const<4>([&](auto JC) {
           (void)&sb_, (void)&mx_;
           constexpr int k = 4 * (g - 52) + decltype(JC)::value;  // 0..31
@@ -885,12 +892,12 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
           }
         });
       }
-      if constexpr (g == 60 || g == 61) {
+      if constexpr (!NOMAX && (g == 60 || g == 61)) {
         constexpr int x = g - 60;
         asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(mn[x]) : "v"(mx_[x][0]), "v"(mx_[x][1]), "v"(mx_[x][2]));
         asm volatile("v_max_f32 %0, %0, %1" : "+v"(mn[x]) : "v"(mx_[x][3]));
       }
-      if constexpr (g == 62 || g == 63) {
+      if constexpr (!NOMAX && (g == 62 || g == 63)) {
         constexpr int x = g - 62;
         const unsigned mu = __float_as_uint(mn[x]);
         auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
@@ -927,7 +934,8 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     });
     // one test for both q-blocks in the hot path; the (rare) commits re-test per q-block
-    if constexpr (PS) {
+    if constexpr (NOMAX) {
+    } else if constexpr (PS) {
       if (t + 1 < ntiles && __any(fmaxf(mn[0], mn[1]) > 8.0f)) {
         commit_ps(std::integral_constant<int, 0>{}, std::integral_constant<int, 1 - B>{}, mn[0]);
         commit_ps(std::integral_constant<int, 1>{}, std::integral_constant<int, 1 - B>{}, mn[1]);
@@ -1065,6 +1073,34 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
   }
 }
 
+// KIND 4 with kmax2 / qmax2: Cauchy-Schwarz bounds every score of the head by B = max|q| max|k| (Q is pre-scaled: exp2 units), and the
+// reference max a row takes from its first tile is >= -B, so s - m <= 2 B for every later score.  With 2 B <= 100 nothing can overflow
+// exp2(s - m) or the fp32 row sums (P <= 2^100, l <= 2^117) and, the SAME m being used for P and l, the result is exact for that m: the
+// workgroup runs the body WITHOUT running-max tracking (38 VALU + the rescale test per tile).  Otherwise (no bounds given, large norms,
+// NaNs) it runs the tracked body.  The choice is made once, before anything else, and is uniform over the workgroup.
+template <int KIND>
+__global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
+  if constexpr (KIND == 4) {
+    bool fast = false;
+    if (a.kmax2 && a.qmax2) {
+      const int b = blockIdx.x;
+      const int head = ((b >> 3) / a.n_qblk) * 8 + (b & 7);
+      if (head < a.H) {
+        float kn2 = 0.f, qn2 = 0.f;
+        for (int i = 0; i < a.kmax_n; ++i) kn2 = fmaxf(kn2, a.kmax2[i * a.H + head]);
+        for (int i = 0; i < a.qmax_n; ++i) qn2 = fmaxf(qn2, a.qmax2[i * a.H + head]);
+        fast = qn2 * kn2 <= 2500.0f;  // B <= 50; false for NaN
+      }
+    }
+    if (__builtin_amdgcn_readfirstlane((int)fast))
+      attn_w4_body<4, true>(a);
+    else
+      attn_w4_body<4, false>(a);
+  } else {
+    attn_w4_body<KIND, false>(a);
+  }
+}
+
 // Merge of the KV splits of k_attn_w4:  O = sum_s O_s 2^(c (m_s - M)) / sum_s l_s 2^(c (m_s - M)),  M = max_s m_s  (exact flash combine).
 // One thread per (row, head, 4 consecutive head-dim values).
 __global__ void k_attn_merge(AttnArgs a) {
@@ -1105,8 +1141,10 @@ __global__ void k_attn_merge(AttnArgs a) {
 }  // namespace
 
 static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len, int ldo,
-                       float softmax_scale, int accumulate, int nsplit, void* workspace, void* stream, const char* who) {
+                       float softmax_scale, int accumulate, int nsplit, void* workspace, const float* kmax2, int kmax_n, const float* qmax2,
+                       int qmax_n, void* stream, const char* who) {
   WF_CHECK_ARG(Q && K && Vt && O, "%s: null pointer", who);
+  WF_CHECK_ARG((!kmax2 || (kmax_n >= 1 && kmax_n <= 64)) && (!qmax2 || (qmax_n >= 1 && qmax_n <= 64)), "%s: kmax_n / qmax_n must be 1..64", who);
   WF_CHECK_ARG(H > 0 && Lq > 0 && kv_len > 0, "%s: empty problem", who);
   WF_CHECK_ARG(Lkp % KB == 0 && kv_len <= Lkp, "%s: Lkp (%d) must be a multiple of 64 and >= kv_len (%d)", who, Lkp, kv_len);
   WF_CHECK_ARG(seg_len > 0 && seg_len % KB == 0 && Lkp % seg_len == 0, "%s: seg_len (%d) must be a multiple of 64 dividing Lkp", who,
@@ -1141,6 +1179,10 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
   a.bsa_cnt = nullptr;
   a.bsa_max = 0;
   a.bsa_shift = 2;
+  a.kmax2 = kmax2;
+  a.qmax2 = qmax2;
+  a.kmax_n = kmax2 ? kmax_n : 0;
+  a.qmax_n = qmax2 ? qmax_n : 0;
   const int hslots = (H + 7) / 8;
   const int grid = hslots * a.n_qblk * 8;
   const size_t lds = 4 * (K_TILE_BYTES + V_TILE_BYTES);
@@ -1181,8 +1223,45 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
 }
 
 extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len,
-                           int ldo, float softmax_scale, int accumulate, void* stream) {
-  return attn_launch(Q, K, Vt, O, H, Lq, Lkp, kv_len, seg_len, ldo, softmax_scale, accumulate, 1, nullptr, stream, "wf_attn_fwd");
+                           int ldo, float softmax_scale, int accumulate, const float* kmax2, int kmax_n, const float* qmax2, int qmax_n,
+                           void* stream) {
+  return attn_launch(Q, K, Vt, O, H, Lq, Lkp, kv_len, seg_len, ldo, softmax_scale, accumulate, 1, nullptr, kmax2, kmax_n, qmax2, qmax_n,
+                     stream, "wf_attn_fwd");
+}
+
+// max over the rows of each head of |x|^2 (X bf16 [H][Lp][128], rows >= L ignored) -> out[h] (atomic max on the float bits: norms are
+// >= 0, so the unsigned order is the float order; out must be zeroed by the caller)
+namespace {
+__global__ __launch_bounds__(256) void k_head_max_norm2(const uint16_t* __restrict__ X, int L, int Lp, int rows_per_block, float* __restrict__ out) {
+  const int head = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(L, r0 + rows_per_block);
+  const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;  // 16 lanes x 16 bytes = one 256-byte row
+  float best = 0.f;
+  for (int r = r0 + grp; r < r1; r += 16) {
+    const u32x4 w4 = *reinterpret_cast<const u32x4*>(X + ((size_t)head * Lp + r) * D + sub * 8);
+    float sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = __uint_as_float(w4[e] << 16), hi = __uint_as_float(w4[e] & 0xffff0000u);
+      sq += lo * lo + hi * hi;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    best = fmaxf(best, sq);
+  }
+  best = wave_max(best);
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out + head), __float_as_uint(best));
+}
+}  // namespace
+
+extern "C" int wf_head_max_norm2(const void* X, int H, int L, int Lp, float* out, void* stream) {
+  WF_CHECK_ARG(X && out, "wf_head_max_norm2: null pointer");
+  WF_CHECK_ARG(H > 0 && L > 0 && Lp >= L, "wf_head_max_norm2: bad sizes H=%d L=%d Lp=%d", H, L, Lp);
+  const int rows_per_block = 512;
+  hipLaunchKernelGGL(k_head_max_norm2, dim3((L + rows_per_block - 1) / rows_per_block, H), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)X, L, Lp, rows_per_block, out);
+  WF_LAUNCH_CHECK("wf_head_max_norm2");
+  return WF_OK;
 }
 
 extern "C" int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int seg_len, int ldo,
@@ -1220,6 +1299,8 @@ extern "C" int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, voi
   a.bsa_max = max_entries;
   a.bsa_shift = block == 128 ? 2 : 4;
   a.tiles_per_split = 0;
+  a.kmax2 = a.qmax2 = nullptr;
+  a.kmax_n = a.qmax_n = 0;
   const int grid = ((H + 7) / 8) * a.n_qblk * 8;
   // default: the one-wave-per-SIMD kernel (k_attn_w4<3>); WF_ATTN_KERNEL=w8 selects the two-waves-per-SIMD form (k_attn<2>)
   static const int use_w4 = [] {
@@ -1240,10 +1321,11 @@ extern "C" size_t wf_attn_split_workspace_bytes(int H, int Lq, int nsplit) {
 }
 
 extern "C" int wf_attn_fwd_split(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len,
-                                 int ldo, float softmax_scale, int accumulate, int nsplit, void* workspace, void* stream) {
+                                 int ldo, float softmax_scale, int accumulate, int nsplit, void* workspace, const float* kmax2, int kmax_n,
+                                 const float* qmax2, int qmax_n, void* stream) {
   WF_CHECK_ARG(nsplit >= 1 && nsplit <= 8, "wf_attn_fwd_split: nsplit %d out of range 1..8", nsplit);
-  return attn_launch(Q, K, Vt, O, H, Lq, Lkp, kv_len, seg_len, ldo, softmax_scale, accumulate, nsplit, workspace, stream,
-                     "wf_attn_fwd_split");
+  return attn_launch(Q, K, Vt, O, H, Lq, Lkp, kv_len, seg_len, ldo, softmax_scale, accumulate, nsplit, workspace, kmax2, kmax_n, qmax2,
+                     qmax_n, stream, "wf_attn_fwd_split");
 }
 
 #ifdef WF_ATTN_TIMING

@@ -548,7 +548,9 @@ struct ConvW4Args {
 
 // DBG (ablation builds only, -DWF_CONV_ABLATE + WF_CONV_DEBUG=<bits>; wrong results): bit 0 = no in-loop LDS-DMA, bit 1 = no in-loop weight
 // loads, bit 2 = no in-loop LDS fragment reads.  Compile-time, so that the production instantiation (DBG = 0) carries no branches.
-template <int DBG>
+// NCB = 32-channel output blocks per workgroup: 3 (96 output channels, the ResidualBlock layers) or 1 (the 96 -> 3 decoder head and the
+// 384 -> 32 encoder head, zero-padded to 32 output channels: a third of the MFMAs of the 96-wide tile they used to be computed with).
+template <int DBG, int NCB = 3>
 __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const ConvArgs& a = pa.c;
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   // The first patch of the NEXT tile is staged during the last channel slice of the current one, so that only the very first tile
   // of a workgroup pays the cold-start DMA latency, and the epilogue stores run under that flight.
   const int ntile = pa.tiles_x * pa.tiles_y * a.To;
-  const int n0 = blockIdx.y * 96;
+  const int n0 = blockIdx.y * (32 * NCB);
   const int Cin = a.Cin;
   const int ns = Cin / 16;  // even (Cin % 32 == 0): a tile starts in LDS buffer 0 and ends in buffer 1
   int t, y0, x0;
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   // its weights W(t) must have landed; younger than them are D(t-2), W(t+1), D(t-1): vmcnt = 3 + 2 [0 <= t-2 < 8] + 2 [0 <= t-1 < 8].
   // (Loads return in order, so W(t) also waits for every older DMA piece -- those were issued >= 3 taps ~ 1200 cycles earlier.)
 
-  f32x16 acc[4][3];
+  f32x16 acc[4][NCB];
   auto mma = [&](f32x16& c, const u32x4& wv, const u32x4& xv) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(wv), "v"(xv));
   };
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
     __builtin_amdgcn_s_barrier();
   };
   u32x4 bf[2][4];  // pixel fragments: tap parity (27 taps: tap 26 and the next slice's tap 0 share slot 0, refilled behind the barrier)
-  u32x4 af[3][3];  // weight fragments: ring over taps, 2 ahead (27 = 9 x 3: the slot of a tap is tap % 3 in every slice)
+  u32x4 af[3][NCB];  // weight fragments: ring over taps, 2 ahead (27 = 9 x 3: the slot of a tap is tap % 3 in every slice)
   auto bread = [&](int buf, int tap, int pb) {
     const int dt = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
     const unsigned char* base = smem + buf * PATCH_BUF + ((dt * PR + dy) * PC + dx) * 32;
@@ -657,8 +659,8 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
 #pragma unroll
   for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
-    for (int cb = 0; cb < 3; ++cb) wload(af[tp][cb], 0, tp, cb);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // the 16 pieces landed (the 6 weight loads were issued after them)
+    for (int cb = 0; cb < NCB; ++cb) wload(af[tp][cb], 0, tp, cb);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCB) : "memory");  // the 16 pieces landed (the 2 NCB weight loads were issued after them)
   bar();
 #pragma unroll
   for (int pb = 0; pb < 4; ++pb) bf[0][pb] = bread(0, 0, pb);
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
 #pragma unroll
   for (int pb = 0; pb < 4; ++pb)
 #pragma unroll
-    for (int cb = 0; cb < 3; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[pb][cb][r] = 0.f;
       asm volatile("" : "+a"(acc[pb][cb]));
@@ -699,26 +701,32 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
       const int ncs = tap + 2 < 27 ? cs : cs + 1;  // == ns on the last slice: wload wraps it to slice 0 of the next tile
       if constexpr (!(DBG & 2)) {
         constexpr int nd = (DBG & 1) ? 0 : 2;  // LDS-DMA pieces per tap over taps 0..7
-        constexpr int nwait = 3 + ((tap >= 2 && tap - 2 < 8) ? nd : 0) + ((tap >= 1 && tap - 1 < 8) ? nd : 0);
-        asm volatile("s_waitcnt vmcnt(%3)" : "+v"(af[tap % 3][0]), "+v"(af[tap % 3][1]), "+v"(af[tap % 3][2]) : "n"(nwait));
+        constexpr int nwait = NCB + ((tap >= 2 && tap - 2 < 8) ? nd : 0) + ((tap >= 1 && tap - 1 < 8) ? nd : 0);
+        if constexpr (NCB == 3)
+          asm volatile("s_waitcnt vmcnt(%3)" : "+v"(af[tap % 3][0]), "+v"(af[tap % 3][1]), "+v"(af[tap % 3][2]) : "n"(nwait));
+        else
+          asm volatile("s_waitcnt vmcnt(%1)" : "+v"(af[tap % 3][0]) : "n"(nwait));
       }
-      for_const<12>([&](auto MC) {
+      // gap m of the tap: MFMA (pixel block m / NCB, output block m % NCB); in its shadow: gaps 0..3 the next tap's 4 pixel fragments, then
+      // the NCB weight fragments two taps ahead (VMEM), then the 2 LDS-DMA pieces of the next slice's patch (VMEM, taps 0..7) -- the VMEM
+      // issue ORDER (weights before pieces within a tap) is what the hand-counted waits above assume
+      constexpr int M = 4 * NCB, WL0 = NCB == 3 ? 4 : 1, D0 = NCB == 3 ? 8 : 2, D1 = NCB == 3 ? 10 : 3;
+      for_const<M>([&](auto MC) {
         (void)&acc, (void)&af, (void)&bf;
         constexpr int m = decltype(MC)::value;
-        constexpr int cb = m % 3, pb = m / 3;
+        constexpr int cb = m % NCB, pb = m / NCB;
         mma(acc[pb][cb], af[tap % 3][cb], bf[tap & 1][pb]);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (m < 4 && tap < 26 && !(DBG & 4)) bf[(tap + 1) & 1][m] = bread(buf, tap + 1, m);  // next tap's pixel fragments
-        if constexpr (m >= 4 && m < 7 && !(DBG & 2)) wload(af[(tap + 2) % 3][m - 4], ncs, ntap, m - 4);  // weights two taps ahead
-        // the staged patch, 2 pieces per tap over taps 0..7
-        if constexpr ((m == 8 || m == 10) && tap < 8 && !(DBG & 1)) dma_piece(csn, 2 * tap + (m - 8) / 2);
+        if constexpr (m >= WL0 && m < WL0 + NCB && !(DBG & 2)) wload(af[(tap + 2) % 3][m - WL0], ncs, ntap, m - WL0);  // weights two taps ahead
+        if constexpr ((m == D0 || m == D1) && tap < 8 && !(DBG & 1)) dma_piece(csn, 2 * tap + (m == D1 ? 1 : 0));
         __builtin_amdgcn_sched_barrier(0);
       });
     });
 #ifdef WF_CONV_TIMING
     const unsigned long long tw0 = __builtin_readcyclecounter();
 #endif
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // patch of slice cs+1 landed (only the 6 prefetched weight loads are younger)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCB) : "memory");  // patch of slice cs+1 landed (only the 2 NCB prefetched weight loads are younger)
     bar();
 #ifdef WF_CONV_TIMING
     t_wait += __builtin_readcyclecounter() - tw0;
@@ -740,7 +748,7 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
     const bool inb = y < a.Ho && x < a.Wo;
     const size_t m = ((size_t)t * a.Ho + y) * a.Wo + x;
 #pragma unroll
-    for (int cb = 0; cb < 3; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
       f32x16 av = acc[pb][cb];
       asm volatile("" : "+v"(av));
       if (!inb) continue;
@@ -954,7 +962,8 @@ extern "C" int wf_conv3d_333(const void* in, const void* w_packed, const float* 
   } else {
     wa.row_stride = (long)wa.nsa * Wi * 16; wa.pix_stride = 16; wa.slice_stride = (long)Wi * 16;
   }
-  const int ny = (Cout + 95) / 96, ntile = wa.tiles_x * wa.tiles_y * T;
+  const bool thin = Cout <= 32;  // one 32-channel output block per workgroup (the VAE heads)
+  const int ny = thin ? 1 : (Cout + 95) / 96, ntile = wa.tiles_x * wa.tiles_y * T;
   const int gx = std::min(ntile, std::max(1, 256 / ny));  // one persistent workgroup per CU
   dim3 grid((unsigned)gx, (unsigned)ny);
 #ifdef WF_CONV_ABLATE
@@ -968,7 +977,10 @@ extern "C" int wf_conv3d_333(const void* in, const void* w_packed, const float* 
     else hipLaunchKernelGGL(k_conv_w4<0>, grid, dim3(W4T), W4_LDS, (hipStream_t)stream, wa);
   }
 #else
-  hipLaunchKernelGGL(k_conv_w4<0>, grid, dim3(W4T), W4_LDS, (hipStream_t)stream, wa);
+  if (thin)
+    hipLaunchKernelGGL((k_conv_w4<0, 1>), grid, dim3(W4T), W4_LDS, (hipStream_t)stream, wa);
+  else
+    hipLaunchKernelGGL((k_conv_w4<0, 3>), grid, dim3(W4T), W4_LDS, (hipStream_t)stream, wa);
 #endif
   WF_LAUNCH_CHECK("wf_conv3d_333");
   return WF_OK;

@@ -82,8 +82,17 @@ def kv_splits(H: int, Lq: int, kv_len: int, n_cu: int = 256) -> int:
     return 2 if eff(2) > eff(1) + 0.08 else 1
 
 
+def head_max_norm2(k: torch.Tensor, L: int, out: torch.Tensor) -> torch.Tensor:
+    """k [H, Lp, 128] bf16 -> out [H] f32 = max over the first L rows of |k|^2 per head (see wf_head_max_norm2)."""
+    H, Lp, _ = k.shape
+    out.zero_()
+    call("wf_head_max_norm2", k.data_ptr(), H, L, Lp, out.data_ptr(), ops.stream())
+    return out
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, kv_len: int, scale: float,
-              accumulate: bool = False, profile: bool = False, nsplit: Optional[int] = None):
+              accumulate: bool = False, profile: bool = False, nsplit: Optional[int] = None, kmax2: Optional[torch.Tensor] = None,
+              qmax2: Optional[torch.Tensor] = None):
     """q [H,Lq,128]; k [H,Lkp,128] and vt [H,Lkp/64,128,64], or their all-gathered per-rank shards k [P,H,S,128],
     vt [P,H,S/64,128,64] (S = shard length, keys in shard-major order) -> out [Lq, H*128] bf16."""
     H, Lq, D = q.shape
@@ -98,16 +107,21 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
     prof = PROFILE_ATTN if profile else None
     if nsplit is None:
         nsplit = kv_splits(H, Lq, kv_len)
+    kmp, kmn, qmp, qmn = None, 0, None, 0
+    if kmax2 is not None and qmax2 is not None:  # [H] or [P, H] f32 each (one vector per gathered shard); only with scale == 0 (pre-scaled Q)
+        for t in (kmax2, qmax2):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.shape[-1] == H
+        kmp, kmn, qmp, qmn = kmax2.data_ptr(), kmax2.numel() // H, qmax2.data_ptr(), qmax2.numel() // H
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     if nsplit > 1:
         ws = ops._workspace("attn_split", (_ffi.lib().wf_attn_split_workspace_bytes(H, Lq, nsplit) + 3) // 4, q.device)
         call("wf_attn_fwd_split", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Lq, Lkp, kv_len, seg, out.stride(0),
-             float(scale), 1 if accumulate else 0, nsplit, ws.data_ptr(), ops.stream())
+             float(scale), 1 if accumulate else 0, nsplit, ws.data_ptr(), kmp, kmn, qmp, qmn, ops.stream())
     else:
         call("wf_attn_fwd", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Lq, Lkp, kv_len, seg, out.stride(0),
-             float(scale), 1 if accumulate else 0, ops.stream())
+             float(scale), 1 if accumulate else 0, kmp, kmn, qmp, qmn, ops.stream())
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1))
@@ -506,9 +520,14 @@ class WanTransformer3DModel:
         qh = _buf("qh", (H, L, 128), bf)
         kh = _buf("kh", (H, Lp, 128), bf, zero=True)
         vt = _buf("vt", (H, Lp // 64, 128, 64), bf)
+        # per-head max |k|^2 lets the kernel drop its running-max tracking when no score can overflow (wf_head_max_norm2); WF_ATTN_TRACK_MAX=1
+        # keeps the tracking (A/B)
+        km = _buf("kmax2", (H,), f32) if prescale and os.environ.get("WF_ATTN_TRACK_MAX", "0") != "1" else None
+        qm = _buf("qmax2", (H,), f32) if km is not None else None
         if comm is not None:
             kh_all = _buf("kh_all", (comm.world, H, Lp, 128), bf)
             vt_all = _buf("vt_all", (comm.world, H, Lp // 64, 128, 64), bf)
+            km_all = _buf("kmax2_all", (comm.world, H), f32) if prescale else None
         ao = _buf("ao", (L, d), bf)
         qc = _buf("qc", (L, d), bf)
         ffh = _buf("ffh", (L, cfg.ffn_dim), bf)
@@ -534,7 +553,10 @@ class WanTransformer3DModel:
                 self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L, out_scale=q_scale)
                 self._heads(qkv, d, W[p + "self_attn.norm_k"], cos, sin, kh, L)
                 self._vt(qkv, 2 * d, vt, L)
-                attention(qh, kh, vt, ao, L, sa_scale, profile=True)
+                if km is not None:
+                    head_max_norm2(kh, L, km)
+                    head_max_norm2(qh, L, qm)
+                attention(qh, kh, vt, ao, L, sa_scale, profile=True, kmax2=km, qmax2=qm)
             else:
                 # K and V first, their all-gather runs on the communication stream under the Q projection
                 gemm(hbuf, W[p + "qkv.w"][d:], W[p + "qkv.b"][d:], qkv[:, d:], EPI_BF16)
@@ -542,6 +564,9 @@ class WanTransformer3DModel:
                 self._vt(qkv, 2 * d, vt, L)
                 ev_k = comm.all_gather_async(kh_all, kh)
                 ev_v = comm.all_gather_async(vt_all, vt)
+                if km is not None:  # every shard's per-head max |k|^2 travels with it (40 floats per rank)
+                    head_max_norm2(kh, L, km)
+                    ev_m = comm.all_gather_async(km_all, km)
                 yield i
                 gemm(hbuf, W[p + "qkv.w"][:d], W[p + "qkv.b"][:d], qkv[:, :d], EPI_BF16)
                 self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L, out_scale=q_scale)
@@ -549,13 +574,15 @@ class WanTransformer3DModel:
                 if cprof is not None:  # exposed communication = how long the compute stream stalls here
                     cw0, cw1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     cw0.record()
-                for ev in (ev_k, ev_v):
+                for ev in (ev_k, ev_v) + ((ev_m,) if km is not None else ()):
                     if ev is not None:
                         torch.cuda.current_stream().wait_event(ev)
                 if cprof is not None:
                     cw1.record()
                     cprof.append((cw0, cw1))
-                attention(qh, kh_all, vt_all, ao, Lfull, sa_scale, profile=True)
+                if km is not None:  # this rank's own queries only
+                    head_max_norm2(qh, L, qm)
+                attention(qh, kh_all, vt_all, ao, Lfull, sa_scale, profile=True, kmax2=km_all if km is not None else None, qmax2=qm)
             gemm(ao, W[p + "self_attn.o.w"], W[p + "self_attn.o.b"], x, EPI_RESID, gate=emod[2])
             # ---- cross-attention (model.py:310, 202-229) ----
             self._ln(x, W[p + "norm3.w"], W[p + "norm3.b"], hbuf, cfg.eps, plus_one=False)

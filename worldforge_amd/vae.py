@@ -267,7 +267,7 @@ class AutoencoderKLWan:
                         mfma_conv(p + ".time_conv")
                 elif kind == "head":
                     gamma(p + ".0.gamma")
-                    mfma_conv_padded(p + ".2", cout_pad=(cout + 3) // 4 * 4)
+                    mfma_conv_padded(p + ".2", cout_pad=(cout + 31) // 32 * 32)  # one 32-channel output block of the 3x3x3 kernel
         small_conv("conv1")
         small_conv("conv2", cout_pad=32)  # decoder input, zero-padded to one 32-channel MFMA K slice
         self.w = W
@@ -545,8 +545,8 @@ class AutoencoderKLWan:
             elif kind in ("up2d", "up3d"):
                 x = self._up(x, p, cin, kind == "up3d")
             elif kind == "head":
-                a = self._rms(x, W[p + ".0.gamma"])
-                x, _ = self._conv(a, p + ".2", T, H, Wd, (cout + 3) // 4 * 4, (3, 3, 3), pt=2, ps=1)
+                a = self._rms(x, W[p + ".0.gamma"], blocked=True)
+                x, _ = self._conv(a, p + ".2", T, H, Wd, (cout + 31) // 32 * 32, (3, 3, 3), pt=2, ps=1)
         return x
 
     # ------------------------------------------------------------------------------------------------------------
@@ -701,8 +701,8 @@ class AutoencoderKLWan:
                 h_cur *= 2
             elif kind == "head":
                 Tn, Hn, Wn, _ = x.shape
-                a = self._halo_pad(self._rms(x, self.w[p + ".0.gamma"]))
-                x, _ = self._conv(a, p + ".2", Tn, Hn, Wn, (cout + 3) // 4 * 4, (3, 3, 3), pt=2, ps=1, ph=0)
+                a = self._halo_pad(self._rms(x, self.w[p + ".0.gamma"], blocked=True))
+                x, _ = self._conv(a, p + ".2", Tn, Hn, Wn, (cout + 31) // 32 * 32, (3, 3, 3), pt=2, ps=1, ph=0)
         y = self._gather_rows(x)
         Fo, Ho, Wo, Cy = y.shape
         out = torch.empty((3, Fo, Ho, Wo), dtype=F32, device=self.device)
