@@ -143,6 +143,11 @@ int wf_farneback_flows(const void* x, int dt, float* flow, int C, int T, int h, 
  * X, W bf16 (row strides ldx, ldw); bias/gate f32; K % 8 == 0, N % 4 == 0, 16-byte aligned pointers. */
 int wf_gemm_bf16(const void* X, const void* W, const float* bias, void* out, const float* gate, int M, int N, int K, int ldx,
                  int ldw, int ldo, int epilogue, void* stream);
+/* `batch` independent small products in one launch: out_b = X_b . W_b^T with problem b at X + b*bsx, W + b*bsw, out + b*bso elements;
+ * epilogue WF_EPI_BF16 or WF_EPI_F32, no bias.  The per-head block-score products of the block-sparse gating
+ * (bsa_interface.py:181-185: one [n_q, 128] x [n_k, 128]^T per head) and the per-frame score / PV products of the VAE mid-block. */
+int wf_gemm_bf16_batched(const void* X, const void* W, void* out, int batch, int M, int N, int K, int ldx, int ldw, int ldo,
+                         int64_t bsx, int64_t bsw, int64_t bso, int epilogue, void* stream);
 
 /* flash_attention (attention.py:24-130) as used by model.py:149-154 (self) and :220-222 (cross): fused
  * softmax(Q K^T * softmax_scale) V, no mask, head_dim 128.  Q [H][Lq][128], K [H][Lkp][128] (rows >= kv_len zero),

@@ -15,7 +15,7 @@ import torch
 
 from . import ops
 from ._ffi import call
-from .dit import EPI_BF16, gemm
+from .dit import EPI_BF16
 
 BLOCK = 128  # default block; 64 (chunk 4 x 4 x 4) is the other size the kernels take
 _PERM: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -56,8 +56,9 @@ def block_scores(q_cmp: torch.Tensor, k_cmp: torch.Tensor) -> torch.Tensor:
         kp = torch.zeros((Hh, nkp, D), dtype=k_cmp.dtype, device=k_cmp.device)
         kp[:, :nk] = k_cmp
     sc = torch.empty((Hh, nq, nkp), dtype=torch.bfloat16, device=q_cmp.device)
-    for h in range(Hh):
-        gemm(q_cmp[h], kp[h], None, sc[h], EPI_BF16)
+    # one launch for all heads (round 1 issued one small GEMM per head: ~130 launches per layer)
+    call("wf_gemm_bf16_batched", q_cmp.data_ptr(), kp.data_ptr(), sc.data_ptr(), Hh, nq, nkp, D, D, D, nkp, nq * D, nkp * D, nq * nkp,
+         EPI_BF16, ops.stream())
     return sc[:, :, :nk]
 
 

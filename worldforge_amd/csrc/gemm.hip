@@ -39,6 +39,8 @@ struct GemmArgs {
   const float* gate;  // [N] f32 (EPI_RESID) or null
   int M, N, K, ldx, ldw, ldo;
   int mt, nt;  // tile counts
+  // batched launches of k_gemm (blockIdx.y = batch b): X, W, out of problem b start b * bsx / bsw / bso ELEMENTS further (0 = not batched)
+  long bsx, bsw, bso;
 };
 
 enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32 = 2, EPI_RESID = 3, EPI_F32_ACC = 4 };
@@ -89,8 +91,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_gemm(GemmArgs a) {
     int row = (tid >> 3) + 32 * i;
     int wr = min(n0 + row, a.N - 1);
     int xr = min(m0 + row, a.M - 1);
-    pW[i] = a.W + (size_t)wr * a.ldw + ck * 8;
-    pX[i] = a.X + (size_t)xr * a.ldx + ck * 8;
+    pW[i] = a.W + (size_t)blockIdx.y * a.bsw + (size_t)wr * a.ldw + ck * 8;
+    pX[i] = a.X + (size_t)blockIdx.y * a.bsx + (size_t)xr * a.ldx + ck * 8;
     ldsoff[i] = row * ROW_BYTES + swz(row, ck) * 16;
   }
   bool stage_ok = true;
@@ -189,17 +191,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_gemm(GemmArgs a) {
             for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
           }
           u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + o) = pk;
+          *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + (size_t)blockIdx.y * a.bso + o) = pk;
         } else if constexpr (EPI == EPI_F32) {
           f32x4 ov = {v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + o) = ov;
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)blockIdx.y * a.bso + o) = ov;
         } else if constexpr (EPI == EPI_F32_ACC) {
-          float* po = reinterpret_cast<float*>(a.out) + o;
+          float* po = reinterpret_cast<float*>(a.out) + (size_t)blockIdx.y * a.bso + o;
           f32x4 old = *reinterpret_cast<const f32x4*>(po);
           f32x4 ov = {old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
           *reinterpret_cast<f32x4*>(po) = ov;
         } else {  // EPI_RESID: x += (acc + bias) * gate   (model.py:306, 310, 313)
-          float* po = reinterpret_cast<float*>(a.out) + o;
+          float* po = reinterpret_cast<float*>(a.out) + (size_t)blockIdx.y * a.bso + o;
           f32x4 old = *reinterpret_cast<const f32x4*>(po);
           f32x4 gg = {1.f, 1.f, 1.f, 1.f};
           if (a.gate) gg = *reinterpret_cast<const f32x4*>(a.gate + n);
@@ -780,6 +782,7 @@ extern "C" int wf_gemm_bf16(const void* X, const void* W, const float* bias, voi
   a.ldo = ldo;
   a.mt = ceil_div(M, BM);
   a.nt = ceil_div(N, BN);
+  a.bsx = a.bsw = a.bso = 0;
   const int nsuper = ((a.mt + 7) / 8) * ((a.nt + 7) / 8);
   const int grid = ((nsuper + 7) / 8) * 8 * 64;
   const size_t lds = 4 * TILE_BYTES;
@@ -836,3 +839,34 @@ extern "C" int wf_debug_gemm_cycles(unsigned long long* out8, int reset) {
   return 0;
 }
 #endif
+
+// `batch` independent small GEMMs in ONE launch (blockIdx.y = problem): out_b[M,N] = X_b[M,K] . W_b[N,K]^T, problem b at X + b*bsx,
+// W + b*bsw, out + b*bso (elements).  The 128 x 128 register-staged kernel; epilogue EPI_BF16 or EPI_F32, no bias / gate.
+extern "C" int wf_gemm_bf16_batched(const void* X, const void* W, void* out, int batch, int M, int N, int K, int ldx, int ldw, int ldo,
+                                    int64_t bsx, int64_t bsw, int64_t bso, int epilogue, void* stream) {
+  WF_CHECK_ARG(X && W && out, "wf_gemm_bf16_batched: null pointer");
+  WF_CHECK_ARG(batch > 0 && batch <= 65535 && M > 0 && N > 0 && K > 0, "wf_gemm_bf16_batched: empty problem batch=%d M=%d N=%d K=%d", batch, M, N, K);
+  WF_CHECK_ARG(K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldw >= K && ldx >= K && bsx % 8 == 0 && bsw % 8 == 0,
+               "wf_gemm_bf16_batched: K, ldx, ldw, bsx, bsw must be multiples of 8 with ld >= K");
+  WF_CHECK_ARG(N % 4 == 0 && ldo % 4 == 0 && bso % 4 == 0, "wf_gemm_bf16_batched: N, ldo, bso must be multiples of 4");
+  WF_CHECK_ARG((((uintptr_t)X | (uintptr_t)W | (uintptr_t)out) & 15) == 0, "wf_gemm_bf16_batched: pointers must be 16-byte aligned");
+  WF_CHECK_ARG(epilogue == EPI_BF16 || epilogue == EPI_F32, "wf_gemm_bf16_batched: epilogue must be 0 (bf16) or 2 (f32)");
+  GemmArgs a;
+  a.X = (const uint16_t*)X;
+  a.W = (const uint16_t*)W;
+  a.bias = nullptr;
+  a.out = out;
+  a.gate = nullptr;
+  a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldo = ldo;
+  a.mt = ceil_div(M, BM);
+  a.nt = ceil_div(N, BN);
+  a.bsx = bsx; a.bsw = bsw; a.bso = bso;
+  const int nsuper = ((a.mt + 7) / 8) * ((a.nt + 7) / 8);
+  const int grid = ((nsuper + 7) / 8) * 8 * 64;
+  if (epilogue == EPI_BF16)
+    hipLaunchKernelGGL(k_gemm<EPI_BF16>, dim3(grid, batch), dim3(NTHREADS), 4 * TILE_BYTES, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(k_gemm<EPI_F32>, dim3(grid, batch), dim3(NTHREADS), 4 * TILE_BYTES, (hipStream_t)stream, a);
+  WF_LAUNCH_CHECK("wf_gemm_bf16_batched");
+  return WF_OK;
+}
