@@ -41,3 +41,17 @@ def test_read_frames_from_directory(tmp_path):
         ph.read_frames_from_directory(str(tmp_path / "missing"))
     img, ref, mask, h, w = ph.prepare_inputs(str(tmp_path), num_frames=1, soften=False)
     assert ref.shape == (1, 3, 1, h, w) and mask.shape == (1, 1, 1, h, w) and ref.dtype.is_floating_point
+
+
+def test_save_png_frames_round_trip(tmp_path):
+    """INFER:323-339: float frames are truncated to uint8 exactly as `(x * 255).clip(0, 255).astype(np.uint8)`, names frame_%04d.png."""
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    frames = rng.random((3, 6, 8, 3)).astype(np.float32)
+    frames[0, 0, 0] = [1.0, 0.0, 0.99999]
+    d = ph.save_png_frames(frames, str(tmp_path / "out" / "video.mp4"))
+    assert d.endswith("video_frames") and sorted(os.listdir(d)) == ["frame_0000.png", "frame_0001.png", "frame_0002.png"]
+    for i in range(3):
+        got = np.array(Image.open(os.path.join(d, f"frame_{i:04d}.png")))
+        np.testing.assert_array_equal(got, (frames[i] * 255).clip(0, 255).astype(np.uint8))
+    assert tuple(np.array(Image.open(os.path.join(d, "frame_0000.png")))[0, 0]) == (255, 0, 254)

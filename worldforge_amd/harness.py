@@ -98,3 +98,25 @@ def prepare_inputs(directory: str, model: str = "480p", num_frames: int = None, 
         marr = soften_mask(marr, transition_distance, decay_type)
     mask = torch.from_numpy(marr).unsqueeze(0).unsqueeze(0)
     return image, video_ref, mask, h, w
+
+
+def save_png_frames(frames, output_path: str) -> str:
+    """INFER:323-339 (`--save-png`): frames [F,H,W,3] (float in [0,1] or uint8, numpy / torch / a list of PIL images) -> PNG files
+    `<output stem>_frames/frame_0000.png ...`; float frames are quantised as the reference does, `(x * 255).clip(0, 255).astype(uint8)`
+    (truncation).  Returns the directory.  (The mp4 container itself -- diffusers' `export_to_video`, INFER:317 -- is an external encoder.)"""
+    from PIL import Image
+
+    png_dir = os.path.splitext(output_path)[0] + "_frames"
+    os.makedirs(png_dir, exist_ok=True)
+    if isinstance(frames, torch.Tensor):
+        frames = frames.detach().cpu().numpy()
+    for i, frame in enumerate(frames):
+        if isinstance(frame, Image.Image):
+            img = frame
+        else:
+            arr = np.array(frame)
+            if arr.dtype in (np.float32, np.float64):
+                arr = (arr * 255).clip(0, 255).astype(np.uint8)
+            img = Image.fromarray(arr)
+        img.save(os.path.join(png_dir, f"frame_{i:04d}.png"), format="PNG")
+    return png_dir
