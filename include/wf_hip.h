@@ -303,6 +303,16 @@ int wf_cl_to_ncthw(const float* in, float* out, int C, int ld, size_t N, float c
  * empty); zbuffer: n*H*W 8-byte words of scratch. */
 int wf_warp_splat(const float* image, const float* depth, const double* geometry, const double* cameras, void* out_images, void* out_masks,
                   float* out_depth, void* zbuffer, int n_cameras, int H, int W, void* stream);
+/* Depth-aware crack filling of the warped views (vggt/modules/utils_warp.py depth_aware_crack_filling :647-691 with segment_depth_map
+ * :506-536, fill_segment_cracks :567-634 (fast outlier test), fill_small_cracks step 1 :390-430, vectorized_depth_estimation :539-564,
+ * merge_depth_segments :637-676, as warp_single_img runs them per view :954-985): img u8 [n,H,W,3], mask u8 [n,H,W], depth f32 [n,H,W]
+ * (NaN = empty) -> filled image / mask / depth of the same shapes.  min_neighbors: outlier threshold (3 x 3 count incl. the centre);
+ * min_valid_neighbors: valid 8-neighbours a newly covered pixel needs; num_segments <= 5.  OpenCV's filter2D / morphologyEx are restated
+ * (BORDER_REFLECT_101 correlation; closing that ignores the border): parity with a real cv2 is unpinned.  workspace:
+ * wf_crack_fill_workspace_bytes(n, H, W) bytes. */
+size_t wf_crack_fill_workspace_bytes(int n, int H, int W);
+int wf_crack_fill(const void* img, const void* mask, const float* depth, void* out_img, void* out_mask, float* out_depth, int n, int H,
+                  int W, int min_neighbors, int min_valid_neighbors, int num_segments, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -75,7 +75,9 @@ def segment_depth_map(depth: np.ndarray, mask: np.ndarray, num_segments: int = 5
     lo, hi = np.nanmin(vd), np.nanmax(vd)
     if lo == hi:
         return [valid]
-    b = np.linspace(lo, hi, num_segments + 1)
+    # the reference pins numpy < 2 (requirements.txt:6): linspace of two float32 SCALARS is float64 there (value-based promotion), float32
+    # under NEP 50 -- spelled out so that this restatement follows the reference's environment on either numpy
+    b = np.linspace(np.float64(lo), np.float64(hi), num_segments + 1)
     segs = []
     for i in range(num_segments):
         if i == num_segments - 1:

@@ -52,3 +52,79 @@ def test_splat_at_video_size_matches_oracle():
         cams.append(c)
     imgs, masks, depths = warp.forward_splat(image, depth, K, np.eye(4), cams)
     _check(imgs, masks, depths, *owarp.splat(image, depth, K, np.eye(4), cams))
+
+
+DEV = "cuda:0"
+
+
+def _case(H=64, W=96):
+    """A slanted, textured plane with a nearer box in front of it, a few invalid depths; intrinsics / identity extrinsics."""
+    rng = np.random.default_rng(9)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    depth = (3.0 + 0.01 * xx + 0.004 * yy).astype(np.float32)
+    depth[H // 3:2 * H // 3, W // 3:W // 2] = 1.6
+    depth[rng.random((H, W)) < 0.01] = np.nan
+    image = rng.random((H, W, 3)).astype(np.float32)
+    K = np.array([[80.0, 0, W / 2 - 0.5], [0, 80.0, H / 2 - 0.5], [0, 0, 1]])
+    return image, depth, K, np.eye(4)
+
+
+def _cf_check(img_u8, mask, depth, params):
+    """wf_crack_fill vs oracle/crackfill.py on a stack of views: masks bit-exact, depths equal, colours within one grey level (the
+    8-neighbour sums are fp32 in a different order)."""
+    from oracle import crackfill as ocf
+    from worldforge_amd import warp
+    oi, om, od = warp.crack_fill(torch.from_numpy(img_u8).to(DEV), torch.from_numpy(mask).to(DEV), torch.from_numpy(depth).to(DEV),
+                                 min_neighbors=params["min_neighbors"], min_valid_neighbors=params["min_valid_neighbors"])
+    oi, om, od = oi.cpu().numpy(), om.cpu().numpy(), od.cpu().numpy()
+    filled = 0
+    for f in range(img_u8.shape[0]):
+        wi, wm, wd = ocf.warp_frame_fill(img_u8[f], mask[f], depth[f], params)
+        np.testing.assert_array_equal(om[f], wm)
+        assert np.array_equal(np.isnan(od[f]), np.isnan(wd))
+        np.testing.assert_allclose(od[f][~np.isnan(wd)], wd[~np.isnan(wd)], rtol=1e-6)
+        assert np.abs(oi[f].astype(np.int32) - wi.astype(np.int32)).max() <= 1
+        filled += int(((wm > 0) & (mask[f] == 0)).sum())
+    return filled
+
+
+def test_crack_fill_matches_oracle_on_constructed_scenes():
+    from oracle import crackfill as ocf
+    from tests.test_oracle_crackfill import _scene
+    img, mask, depth = _scene()
+    stack_i, stack_m, stack_d = [(img * 255).astype(np.uint8)], [mask], [depth]
+    # a second view: random holes + stray pixels over three depth layers, so that several segments have outliers and fills overlap
+    rng = np.random.default_rng(5)
+    H, W = img.shape[:2]
+    d2 = np.choose(rng.integers(0, 3, (H // 4, W // 4)).repeat(4, 0).repeat(4, 1), [1.0, 2.5, 6.0]).astype(np.float32) + rng.random((H, W)).astype(np.float32) * 0.2
+    m2 = (rng.random((H, W)) > 0.12).astype(np.uint8)
+    i2 = (rng.random((H, W, 3)) * 255).astype(np.uint8)
+    d2[m2 == 0] = np.nan
+    i2[m2 == 0] = 0
+    stack_i.append(i2), stack_m.append(m2), stack_d.append(d2)
+    # a third view: a single depth value (min == max: one segment), and a fourth: empty
+    d3 = np.full((H, W), 2.0, dtype=np.float32)
+    m3 = m2.copy()
+    d3[m3 == 0] = np.nan
+    stack_i.append(i2), stack_m.append(m3), stack_d.append(d3)
+    for p in (ocf.RUN_WARP_PARAMS, ocf.DEFAULT_PARAMS):
+        filled = _cf_check(np.stack(stack_i), np.stack(stack_m), np.stack(stack_d), p)
+        assert filled > 20
+
+
+def test_crack_fill_after_the_splat_of_a_camera_path():
+    """The stage-1 chain on the GPU: forward splat of 4 views of a slanted textured plane, then crack filling, against the oracle chain."""
+    from oracle import crackfill as ocf
+    from oracle import warp as owarp
+    from worldforge_amd import warp
+    image, depth, K, E = _case(H=64, W=96)
+    cams = warp.camera_path("right", E, 12.0, 5, float(np.nanmean(depth)))[1:]
+    gi, gm, gd = warp.forward_splat(torch.from_numpy(image), torch.from_numpy(depth), K, E, cams, device=DEV)
+    wi, wm, wd = owarp.splat(image, depth, K, E, cams)
+    np.testing.assert_array_equal(gm.cpu().numpy(), wm)
+    # crack filling is compared on the ORACLE's splat (colour ties of the splat aside), the full GPU chain must agree on the masks
+    filled = _cf_check(wi, wm, wd, ocf.RUN_WARP_PARAMS)
+    assert filled > 0
+    fi, fm, fd = warp.crack_fill(gi, gm, gd, min_valid_neighbors=2)
+    want_m = np.stack([ocf.warp_frame_fill(wi[f], wm[f], wd[f], ocf.RUN_WARP_PARAMS)[1] for f in range(len(cams))])
+    np.testing.assert_array_equal(fm.cpu().numpy(), want_m)

@@ -36,8 +36,8 @@ SOURCES = {
     "longcat_ops.hip": ["-ffp-contract=off"],
     "vae_ops.hip": [],
     "conv.hip": [],
-    "comm.hip": [],
     "warp.hip": ["-ffp-contract=off"],
+    "crackfill.hip": ["-ffp-contract=off"],
 }
 
 

@@ -1,8 +1,8 @@
-"""Stage-1 depth-guided forward warping on the GPU (vggt/modules/utils_warp.py warp_single_img :863-945, without crack filling).
+"""Stage-1 depth-guided forward warping on the GPU (vggt/modules/utils_warp.py warp_single_img :724-1001).
 
-`forward_splat` is the tensor-sized part of the stage-1 warper: one image + depth map -> n warped views with validity masks (the
-`warp_*` / `mask_*` frames the guided sampler consumes).  The camera paths (:64-383) are 4x4 host math and the confidence filter a
-percentile on the host: both stay with the caller, as does the OpenCV-based crack filling (:386-706, not built).
+`forward_splat` (:863-945) and `crack_fill` (:954-985 -> :386-706) are the tensor-sized parts of the stage-1 warper: one image + depth map
+-> n warped views with validity masks (the `warp_*` / `mask_*` frames the guided sampler consumes), cracks closed.  The camera paths
+(:64-383) are 4x4 host math (`camera_path`) and the confidence filter a percentile on the host: both stay with the caller.
 """
 from __future__ import annotations
 
@@ -112,3 +112,23 @@ def camera_path(direction: str, extrinsic, degree: float, frame_num: int, look_a
         c[:3, 3] = -nR @ pos
         cams.append(c)
     return cams
+
+
+def crack_fill(images: torch.Tensor, masks: torch.Tensor, depths: torch.Tensor, min_neighbors: int = 4, min_valid_neighbors: int = 3,
+               num_segments: int = 5):
+    """Depth-aware crack filling of splatted views (utils_warp.py depth_aware_crack_filling :647-691 as warp_single_img applies it per view,
+    :954-985): images u8 [n,H,W,3], masks u8 [n,H,W], depths f32 [n,H,W] (NaN = empty), as forward_splat returns them -> the same three,
+    filled.  Defaults = create_default_crack_params(None) (:694-704); run_warp.py passes min_valid_neighbors = 2 (:54, 294).  Views with
+    <= 100 splatted pixels take the reference's depth-confidence path (:973-981), which is not built: they are returned as they are."""
+    n, H, W, _ = images.shape
+    assert images.dtype == torch.uint8 and masks.dtype == torch.uint8 and depths.dtype == torch.float32
+    images, masks, depths = images.contiguous(), masks.contiguous(), depths.contiguous()
+    from ._ffi import lib
+    ws = torch.empty(int(lib().wf_crack_fill_workspace_bytes(n, H, W)), dtype=torch.uint8, device=images.device)
+    oi, om, od = torch.empty_like(images), torch.empty_like(masks), torch.empty_like(depths)
+    call("wf_crack_fill", images.data_ptr(), masks.data_ptr(), depths.data_ptr(), oi.data_ptr(), om.data_ptr(), od.data_ptr(), n, H, W,
+         int(min_neighbors), int(min_valid_neighbors), int(num_segments), ws.data_ptr(), ops.stream())
+    few = (~torch.isnan(depths)).flatten(1).sum(1) <= 100
+    if bool(few.any()):  # once per camera path, outside any loop
+        oi[few], om[few], od[few] = images[few], masks[few], depths[few]
+    return oi, om, od
