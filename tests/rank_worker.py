@@ -1,0 +1,66 @@
+"""Rank process of tests/test_gpu_rccl2.py: `python tests/rank_worker.py` with RANK / WORLD_SIZE / MASTER_* in the environment.
+WF_SHARE_GPU=1 + WF_COMM_BACKEND=gloo put every rank on GPU 0 (one-GPU boxes); otherwise rank r runs on GPU r over RCCL.
+Checks, on every rank: Comm.all_gather / all_gather_async (communication stream + event), the token-sharded DiT forward and the
+lock-step CFG pair, the row-sharded VAE -- each against the single-rank result computed locally.  Exit code 0 = all equal."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = 0 if os.environ.get("WF_SHARE_GPU") else rank
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    from worldforge_amd import dit, parallel
+    from worldforge_amd.vae import AutoencoderKLWan
+    comm = parallel.init(world, rank, local)
+    BF = torch.bfloat16
+
+    def rnd(shape, seed, scale=1.0):
+        return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+    # --- plumbing
+    mine = torch.full((3, 5), float(rank), device=dev)
+    out = torch.empty((world, 3, 5), device=dev)
+    comm.all_gather(out, mine)
+    assert all(float(out[r].min()) == float(out[r].max()) == r for r in range(world)), "all_gather"
+    out2 = torch.zeros_like(out)
+    ev = comm.all_gather_async(out2, mine * 2)
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+    assert all(float(out2[r].max()) == 2 * r for r in range(world)), "all_gather_async"
+
+    # --- token-sharded DiT == single rank (same seed -> same weights on every rank)
+    cfg = dit.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    x = rnd((36, 3, 16, 20), 60).to(BF).to(dev)
+    ctx, ctx_b, clip = rnd((30, 64), 61).to(BF).to(dev), rnd((17, 64), 63).to(BF).to(dev), rnd((257, 1280), 62).to(BF).to(dev)
+    m0 = dit.WanTransformer3DModel(cfg, dev).init_random(5)
+    ref, ref_b = m0.forward_tokens(x, 500.0, ctx, clip).clone(), m0.forward_tokens(x, 500.0, ctx_b, clip).clone()
+    m1 = dit.WanTransformer3DModel(cfg, dev, comm=comm)
+    m1.w = m0.w
+    got = m1.forward_tokens(x, 500.0, ctx, clip)
+    assert torch.equal(got, ref), f"sharded DiT forward differs: {(got - ref).abs().max().item()}"
+    for _ in range(2):
+        a, b = m1.forward_tokens_pair(x, 500.0, ctx, ctx_b, clip)
+        assert torch.equal(a, ref) and torch.equal(b, ref_b), "lock-step CFG pair differs"
+
+    # --- row-sharded VAE == single rank (fp32-class default)
+    v0 = AutoencoderKLWan(dev).init_random(seed=1)
+    v1 = AutoencoderKLWan(dev, comm=comm)
+    v1.w = v0.w
+    video = (torch.rand(1, 3, 5, 64, 96, generator=torch.Generator().manual_seed(7)) * 2 - 1).to(dev)
+    z = rnd((1, 16, 2, 8, 12), 8).to(dev)
+    assert v1.can_shard(8)
+    assert torch.equal(v1.encode(video).latent_dist.mode(), v0.encode(video).latent_dist.mode()), "sharded VAE encode differs"
+    assert torch.equal(v1.decode(z, return_dict=False)[0], v0.decode(z, return_dict=False)[0]), "sharded VAE decode differs"
+    comm.barrier()
+    torch.cuda.synchronize()
+    print(f"rank {rank}/{world} ok ({torch.distributed.get_backend()})", flush=True)
+
+
+if __name__ == "__main__":
+    main()
