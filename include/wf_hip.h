@@ -129,9 +129,12 @@ int wf_flow_metrics_variant(const float* ref_flow, const float* chan_flow, float
  * pair of every channel of a latent tensor, including the reference's preparation of its input: normalisation by the tensor's
  * global min / range (SCHED:376-388, 462-474), x255, truncation to uint8 (SCHED:175), RGB2GRAY of three equal channels.
  * x [C,T,h,w] (f32 / bf16) -> flow [C, T-1, 2, h, w] f32 (x then y displacement, the layout of SCHED:240-244).
- * OpenCV is a third-party dependency absent from the reference tree: parity with a real cv2 is UNPINNED. */
+ * OpenCV is a third-party dependency absent from the reference tree: parity with a real cv2 is UNPINNED.
+ * quant_mode selects the reference's uint8 preparation: 0 = Wan (above); 1 = LongCat-Video (LSCHED:105-121, 290-297): min / range per
+ * CHANNEL, normalised in the tensor's own dtype (bf16 arithmetic on a bf16 tensor), then uint8(clip((n + 1) * 127.5, 0, 255)); C <= 64. */
 size_t wf_farneback_workspace_bytes(int C, int T, int h, int w);
-int wf_farneback_flows(const void* x, int dt, float* flow, int C, int T, int h, int w, void* ws, void* stream);
+int wf_farneback_flows(const void* x, int dt, float* flow, int C, int T, int h, int w, int quant_mode, void* ws, void* stream);
+
 
 /* ---- DiT (wan/modules/model.py; the in-tree statement of diffusers' WanTransformer3DModel) --------------------------- */
 #define WF_EPI_BF16 0       /* out bf16 = acc + bias */

@@ -4,8 +4,10 @@ Restates, from /root/reference/longcat_for_worldforge/longcat_video:
   pipeline_longcat_video.py (PIPE)  : get_timesteps_sigmas :317-331, prepare_latents :214-286, optimized_scale :374-383,
                                       the loop of generate_i2v :823-994, the decode tail :998-1004
   modules/scheduling_flow_match_euler_discrete.py (SCHED): set_timesteps :610-716, step :740-912, add_noise :1041-1070,
-                                      fuse_latents :1072-1233, the channel selector :165-170, 172-243, 245-381 (temporal-difference
-                                      branch: the one the reference executes when `import cv2` fails, SCHED:45-51, 307-309)
+                                      fuse_latents :1072-1233, the channel selector :165-170, 172-243, 245-381: its temporal-difference
+                                      branch (executed when `import cv2` fails, SCHED:45-51, 307-309; the golden fixtures were
+                                      recorded through it) and its Farneback branch (:105-163, 290-300; cv2 restated by
+                                      oracle/farneback.py: PARITY UNPINNED for that branch)
 Pinned against trajectories recorded from the imported, unmodified reference pipeline + scheduler with deterministic stand-ins for
 the DiT / VAE / text encoder (tests/golden/g12_longcat_pipe_*.npz, tools/make_goldens.py longcat_pipe).
 """
@@ -35,6 +37,7 @@ class LongCatSamplerConfig:
     use_pca_channel_selection: bool = False
     max_replace_threshold: Optional[int] = None
     dit_dtype: torch.dtype = torch.bfloat16
+    flow_backend: str = "tdiff"      # "farneback" = the branch taken where cv2 imports (SCHED:45-51)
 
 
 # ---- schedule ---------------------------------------------------------------------------------------------------------------
@@ -107,10 +110,30 @@ def flow_similarity(ref_motion: torch.Tensor, cand_motion: torch.Tensor) -> floa
     return torch.clamp(1.0 - werr, 0.0, 1.0).item()
 
 
-def channel_similarities(pred: torch.Tensor, enc: torch.Tensor) -> List[float]:
-    """SCHED:281-316, temporal-difference branch (SCHED:165-170)."""
+def farneback_motion(channel: torch.Tensor) -> torch.Tensor:
+    """SCHED:290-292 + 105-158 for one channel [1, 1, T, h, w] -> [1, T-1, 2, h, w] fp32.  The three RGB planes are equal, so one is
+    carried; normalisation runs in the tensor's dtype (bf16 ops round after every step), the uint8 step in numpy float32."""
+    from . import farneback
+
+    n = (channel - channel.min()) / (channel.max() - channel.min() + 1e-8)
+    v = n.to(torch.float32)[0, 0].numpy()
+    if v.min() >= -1.1 and v.max() <= 1.1:  # always: n lies in [0, 1]
+        q = ((v + 1.0) * 127.5).clip(0, 255).astype(np.uint8)
+    else:
+        q = (v * 255).clip(0, 255).astype(np.uint8)
+    fl = [farneback.calc_optical_flow_farneback(q[t], q[t + 1]) for t in range(q.shape[0] - 1)]
+    return torch.from_numpy(np.stack(fl, axis=0).transpose(0, 3, 1, 2).astype(np.float32)).unsqueeze(0)
+
+
+def channel_similarities(pred: torch.Tensor, enc: torch.Tensor, flow_backend: str = "tdiff") -> List[float]:
+    """SCHED:281-316: temporal-difference branch (SCHED:165-170) or the Farneback branch (SCHED:286-300)."""
     enc = enc.to(pred.device, dtype=pred.dtype)
     sims = []
+    if flow_backend == "farneback":
+        for c in range(pred.shape[1]):
+            sims.append(flow_similarity(farneback_motion(enc[:, c:c + 1]), farneback_motion(pred[:, c:c + 1])))
+        return sims
+    assert flow_backend == "tdiff", flow_backend
     for c in range(pred.shape[1]):
         pm = inject.temporal_diff_motion(pred[:, c:c + 1].to(torch.float32))
         rm = inject.temporal_diff_motion(enc[:, c:c + 1].to(torch.float32))
@@ -143,7 +166,8 @@ def select_from_similarities(sims: Sequence[float], current_step: int, use_disti
 
 
 def fuse_latents(x0_full: torch.Tensor, ref: torch.Tensor, mask: torch.Tensor, *, decode: Callable, encode_mode: Callable, mean, std,
-                 use_flf: bool, current_step: int, use_distill: bool = False, max_replace_threshold: Optional[int] = None) -> torch.Tensor:
+                 use_flf: bool, current_step: int, use_distill: bool = False, max_replace_threshold: Optional[int] = None,
+                 flow_backend: str = "tdiff") -> torch.Tensor:
     """SCHED:1072-1233: de-normalise -> decode -> ref*mask + dec*(1-mask) at the exact decoded size (no alignment: a shape mismatch
     raises inside the reference's try block and returns the prediction unchanged) -> encode (mode) -> normalise -> FLF."""
     dec = decode(denormalize(x0_full, mean, std))
@@ -159,7 +183,7 @@ def fuse_latents(x0_full: torch.Tensor, ref: torch.Tensor, mask: torch.Tensor, *
         return x0_full
     enc = normalize(enc, mean, std)
     if use_flf:
-        for c in select_from_similarities(channel_similarities(x0_full, enc), current_step, use_distill, max_replace_threshold):
+        for c in select_from_similarities(channel_similarities(x0_full, enc, flow_backend), current_step, use_distill, max_replace_threshold):
             if 0 <= c < enc.shape[1]:
                 enc[:, c] = x0_full[:, c]
     return enc.to(x0_full.dtype)
@@ -216,7 +240,7 @@ def run(cfg: LongCatSamplerConfig, *, latents: torch.Tensor, dit: Callable, prom
                 def fuse(x0_full):
                     return fuse_latents(x0_full, video_ref, mask, decode=decode, encode_mode=encode_mode, mean=mean, std=std,
                                         use_flf=cfg.use_pca_channel_selection, current_step=i, use_distill=cfg.use_distill,
-                                        max_replace_threshold=cfg.max_replace_threshold)
+                                        max_replace_threshold=cfg.max_replace_threshold, flow_backend=cfg.flow_backend)
             prev, pred_x0 = euler(v[:, :, 1:], latents[:, :, 1:].to(torch.float32), fuse)
             if trace is not None:
                 trace.append(("step", i, r, prev.clone(), pred_x0.clone()))

@@ -24,7 +24,10 @@ def test_guided_job_frames_psnr_vs_oracle(cfg):
 @pytest.mark.parametrize("cfg", [
     dict(hidden=256, heads=2, depth=2, Fr=9, H=32, Wd=32, steps=4, guide=3),
     dict(hidden=1024, heads=8, depth=3, Fr=13, H=64, Wd=96, steps=5, guide=4, resample=3),
-    dict(hidden=4096, heads=32, depth=1, Fr=9, H=64, Wd=64, steps=4, guide=3),   # the released width, one block
+    # the released width, one block.  Temporal-difference FLF: on this 8 x 8 latent grid with random weights the Farneback similarities of
+    # the 16 channels lie within bf16 noise of each other, so the (discrete) channel choice of product and oracle differs -- the same
+    # chaos DESIGN.md section 4b documents for Wan; the Farneback gate itself is pinned in test_gpu_flow.py
+    dict(hidden=4096, heads=32, depth=1, Fr=9, H=64, Wd=64, steps=4, guide=3, flow_backend="tdiff"),
 ])
 def test_longcat_guided_job_frames_psnr_vs_oracle(cfg):
     """LongCat-Video config of SURVEY section 8f-1: Euler flow-match sampler + IRR / FLF / DSG / CFG-zero + LongCat DiT + VAE."""

@@ -71,3 +71,51 @@ def test_flf_gate_with_farneback_backend_matches_oracle(step):
     assert np.abs(sel.last_similarities - want_s).max() <= 2e-3
     want = oinject.select_from_similarities(sel.last_similarities, step)
     assert chans == want
+
+
+@pytest.mark.parametrize("C,T,h,w,dtype", [
+    (16, 4, 30, 52, torch.float32),     # the LongCat 480p latent grid
+    (3, 3, 90, 160, torch.bfloat16),    # 720p refine grid, two pyramid levels, normalisation in bf16
+    (2, 3, 4, 4, torch.bfloat16),
+    (16, 3, 8, 8, torch.float32),
+])
+def test_longcat_quantisation_mode_matches_oracle(C, T, h, w, dtype):
+    """quant_mode 1: a range per channel, normalisation in the tensor's dtype, uint8(clip((n + 1) * 127.5)) -- LongCat scheduler :105-121,
+    290-297 as restated by oracle.longcat_sampler.farneback_motion."""
+    from oracle import longcat_sampler as ols
+    from worldforge_amd import ops
+    x = _latents(C, T, h, w, seed=h * 5 + w).to(dtype)
+    x[0] = x[0] * 7 + 3                  # ranges differ per channel: a global range would give other grey levels
+    got = ops.farneback_flows(x.to(DEV), quant_mode=1).cpu().numpy()
+    for c in range(C):
+        want = ols.farneback_motion(x[None, c:c + 1])[0].numpy()
+        err = np.abs(got[c] - want).max()
+        scale = max(1.0, np.abs(want).max())
+        assert err <= 2e-3 * scale, (c, err, scale)
+    if h >= 24:
+        assert not np.array_equal(got, ops.farneback_flows(x.to(DEV), quant_mode=0).cpu().numpy())
+
+
+def test_longcat_constant_channel_is_all_zero_grey():
+    """max == min: the range is 1e-8, every value normalises to 0 -> grey 127 everywhere -> zero flow (no NaN)."""
+    from worldforge_amd import ops
+    x = _latents(2, 3, 16, 16, seed=3)
+    x[1] = 0.25
+    got = ops.farneback_flows(x.to(DEV), quant_mode=1)
+    assert torch.isfinite(got).all() and got[1].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("step,distill", [(3, False), (8, False), (8, True)])
+def test_longcat_flf_gate_with_farneback_backend_matches_oracle(step, distill):
+    from oracle import longcat_sampler as ols
+    from worldforge_amd.longcat_scheduler import VideoMotionChannelSelector
+    enc = _latents(16, 4, 24, 32, seed=21).unsqueeze(0)
+    pred = enc + 0.3 * _latents(16, 4, 24, 32, seed=22).unsqueeze(0)
+    sel = VideoMotionChannelSelector()
+    assert sel.flow_backend == "farneback" and sel.use_optical_flow
+    chans = sel.select_motion_related_channels(pred.to(DEV), enc.to(DEV), current_step=step, use_distill=distill)
+    want_s = np.array(ols.channel_similarities(pred, enc, flow_backend="farneback"))
+    assert np.abs(sel.last_similarities - want_s).max() <= 2e-3
+    assert chans == ols.select_from_similarities(sel.last_similarities, step, distill)
+    with pytest.raises(ValueError):
+        VideoMotionChannelSelector("cv2")

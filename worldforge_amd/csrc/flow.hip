@@ -50,10 +50,13 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 __device__ __forceinline__ int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
 
 // ---- global min / range of the tensor (SCHED:376-378, 462-464): exact whatever the reduction order --------------------------
+// blockIdx.y = group: the whole tensor (Wan: one global range) or one channel (LongCat: a range per channel); n elements per group
 __global__ void k_minmax_partial(TView x, size_t n, float* part) {
   float mn = INFINITY, mx = -INFINITY;
+  const size_t g0 = (size_t)blockIdx.y * n;
+  part += (size_t)blockIdx.y * 2 * gridDim.x;
   for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
-    const float v = tload(x, i);
+    const float v = tload(x, g0 + i);
     mn = fminf(mn, v);
     mx = fmaxf(mx, v);
   }
@@ -68,32 +71,51 @@ __global__ void k_minmax_partial(TView x, size_t n, float* part) {
     part[2 * blockIdx.x + 1] = mx;
   }
 }
-__global__ void k_minmax_final(const float* part, int nb, float* mm) {
+__global__ void k_minmax_final(const float* part, int nb, float* mm, int bf16_math) {
   float mn = INFINITY, mx = -INFINITY;
+  part += (size_t)blockIdx.x * 2 * nb;
+  mm += 2 * blockIdx.x;
   for (int i = threadIdx.x; i < nb; i += 64) mn = fminf(mn, part[2 * i]), mx = fmaxf(mx, part[2 * i + 1]);
   mn = wave_min(mn);
   mx = wave_max(mx);
   if (threadIdx.x == 0) {
     mm[0] = mn;
-    mm[1] = (mx - mn) + 1e-8f;  // video_global_range (fp32 tensor arithmetic)
+    // range + 1e-8 in the tensor's arithmetic: fp32 (Wan: the channel was promoted first), or bf16 ops on a bf16 tensor (LongCat)
+    mm[1] = bf16_math ? rbf(rbf(mx - mn) + 1e-8f) : (mx - mn) + 1e-8f;
   }
 }
 
 // ---- quantise to the uint8 grey level the reference hands to OpenCV, fused with the horizontal pass of the pre-blur -----------
+// mode 0 (Wan, SCHED:165-201): one global range, uint8(n * 255).  mode 1 (LongCat, LSCHED:105-121, 290-297): a range per channel,
+// normalised in the tensor's own dtype (bf16 ops round after every step), then -- the normalised value lies in [0, 1], inside the
+// reference's "[-1.1, 1.1]" test -- uint8(clip((n + 1) * 127.5, 0, 255)) in fp32.
+template <int MODE>
 __device__ __forceinline__ float grey(const TView& x, size_t i, float mn, float rg) {
-  const float nrm = (tload(x, i) - mn) / rg;       // (channel_rgb - min) / range            SCHED:388 / 474
-  const float s = nrm * 255.0f;                    // video_np * 255                         SCHED:175
-  return (float)(unsigned char)(int)s;             // .astype(np.uint8): truncation; RGB2GRAY of 3 equal channels is the identity
+  if constexpr (MODE == 0) {
+    const float nrm = (tload(x, i) - mn) / rg;       // (channel_rgb - min) / range            SCHED:388 / 474
+    const float s = nrm * 255.0f;                    // video_np * 255                         SCHED:175
+    return (float)(unsigned char)(int)s;             // .astype(np.uint8): truncation; RGB2GRAY of 3 equal channels is the identity
+  } else {
+    float nrm;
+    if (x.dt == WF_BF16)
+      nrm = rbf(rbf(tload(x, i) - mn) / rg);
+    else
+      nrm = (tload(x, i) - mn) / rg;
+    const float s = fminf(fmaxf((nrm + 1.0f) * 127.5f, 0.0f), 255.0f);
+    return (float)(unsigned char)(int)s;
+  }
 }
-__global__ void k_quant_blur_rows(TView x, const float* mm, float* out, int N, int h, int w, Blur b) {
+template <int MODE>
+__global__ void k_quant_blur_rows(TView x, const float* mm, float* out, int N, int h, int w, Blur b, int frames_per_group) {
   const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
   if (i >= (size_t)N * h * w) return;
   const int xx = (int)(i % w);
   const size_t row = i - xx;
-  const float mn = mm[0], rg = mm[1];
+  const size_t grp = MODE == 0 ? 0 : i / ((size_t)frames_per_group * h * w);
+  const float mn = mm[2 * grp], rg = mm[2 * grp + 1];
   const int r = b.ksize / 2;
   float acc = 0.f;
-  for (int j = 0; j < b.ksize; ++j) acc = acc + b.k[j] * grey(x, row + reflect101(xx + j - r, w), mn, rg);
+  for (int j = 0; j < b.ksize; ++j) acc = acc + b.k[j] * grey<MODE>(x, row + reflect101(xx + j - r, w), mn, rg);
   out[i] = acc;
 }
 __global__ void k_blur_cols(const float* __restrict__ in, float* __restrict__ out, int N, int h, int w, Blur b) {
@@ -402,7 +424,7 @@ inline unsigned blocks(size_t n) { return (unsigned)((n + NT - 1) / NT); }
 extern "C" size_t wf_farneback_workspace_bytes(int C, int T, int h, int w) {
   if (C <= 0 || T <= 1 || h <= 0 || w <= 0) return 0;
   const size_t N = (size_t)C * T, P = (size_t)C * (T - 1), hw = (size_t)h * w;
-  size_t b = 4096;                        // min / range + block partials
+  size_t b = 8192;                        // min / range per group + block partials
   b += 3 * al256(N * hw * 4);             // row-blurred, blurred, level image
   b += al256(N * hw * 3 * 4);             // vertical expansion pass
   b += al256(N * hw * 5 * 4);             // R
@@ -412,16 +434,17 @@ extern "C" size_t wf_farneback_workspace_bytes(int C, int T, int h, int w) {
   return b;
 }
 
-extern "C" int wf_farneback_flows(const void* x, int dt, float* flow, int C, int T, int h, int w, void* ws, void* stream) {
+extern "C" int wf_farneback_flows(const void* x, int dt, float* flow, int C, int T, int h, int w, int quant_mode, void* ws, void* stream) {
   WF_CHECK_ARG(x && flow && ws, "wf_farneback_flows: null pointer");
+  WF_CHECK_ARG(quant_mode == 0 || (quant_mode == 1 && C <= 64), "wf_farneback_flows: quant_mode must be 0 (Wan) or 1 (LongCat, C <= 64)");
   WF_CHECK_ARG(dt == WF_F32 || dt == WF_BF16, "wf_farneback_flows: dtype %d", dt);
   WF_CHECK_ARG(C > 0 && T > 1 && h > 0 && w > 0, "wf_farneback_flows: bad shape C=%d T=%d h=%d w=%d", C, T, h, w);
   hipStream_t st = (hipStream_t)stream;
   const size_t N = (size_t)C * T, P = (size_t)C * (T - 1), hw = (size_t)h * w;
   char* base = (char*)ws;
-  float* mm = (float*)base;             // [0] min, [1] range
-  float* part = mm + 8;                 // up to 480 block partials
-  base += 4096;
+  float* mm = (float*)base;             // per group: [0] min, [1] range (one group, or one per channel: <= 64)
+  float* part = mm + 128;               // per group up to 480 / groups block partials
+  base += 8192;
   auto take = [&](size_t bytes) {
     char* p = base;
     base += al256(bytes);
@@ -437,9 +460,11 @@ extern "C" int wf_farneback_flows(const void* x, int dt, float* flow, int C, int
   float* fl[2] = {(float*)take(P * hw * 2 * 4), (float*)take(P * hw * 2 * 4)};
 
   TView xv{const_cast<void*>(x), dt};
-  const int nb = (int)std::min<size_t>(480, (N * hw + NT - 1) / NT);
-  hipLaunchKernelGGL(k_minmax_partial, dim3(nb), dim3(NT), 0, st, xv, N * hw, part);
-  hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(64), 0, st, part, nb, mm);
+  const int groups = quant_mode == 1 ? C : 1;
+  const size_t per_group = N * hw / groups;
+  const int nb = (int)std::max<size_t>(1, std::min<size_t>(480 / groups, (per_group + NT - 1) / NT));
+  hipLaunchKernelGGL(k_minmax_partial, dim3(nb, groups), dim3(NT), 0, st, xv, per_group, part);
+  hipLaunchKernelGGL(k_minmax_final, dim3(groups), dim3(64), 0, st, part, nb, mm, quant_mode == 1 && dt == WF_BF16 ? 1 : 0);
 
   Level lv[MAX_LEVELS + 1];
   const int nl = plan_levels(h, w, lv);
@@ -452,7 +477,10 @@ extern "C" int wf_farneback_flows(const void* x, int dt, float* flow, int C, int
     const size_t lhw = (size_t)L.h * L.w;
     Blur b;
     gaussian_kernel(L.ksize, L.sigma, &b);
-    hipLaunchKernelGGL(k_quant_blur_rows, dim3(blocks(N * hw)), dim3(NT), 0, st, xv, mm, rowb, (int)N, h, w, b);
+    if (quant_mode == 1)
+      hipLaunchKernelGGL(k_quant_blur_rows<1>, dim3(blocks(N * hw)), dim3(NT), 0, st, xv, mm, rowb, (int)N, h, w, b, T);
+    else
+      hipLaunchKernelGGL(k_quant_blur_rows<0>, dim3(blocks(N * hw)), dim3(NT), 0, st, xv, mm, rowb, (int)N, h, w, b, T);
     hipLaunchKernelGGL(k_blur_cols, dim3(blocks(N * hw)), dim3(NT), 0, st, rowb, blur, (int)N, h, w, b);
     const float* img = blur;
     if (L.h != h || L.w != w) {

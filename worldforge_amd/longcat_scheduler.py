@@ -27,19 +27,32 @@ class FlowMatchEulerDiscreteSchedulerOutput:
 
 
 class VideoMotionChannelSelector:
-    """SCHED:35-381, temporal-difference motion (SCHED:165-170: the branch the reference executes when `import cv2` fails; OpenCV is
-    absent from /root/reference and from this image).  Motion extraction + the three-way metric for all 16 channels run in two
-    launches; the 16 similarities come back in ONE device->host copy; the threshold logic (16 scalars) stays on the host."""
+    """SCHED:35-381.  flow_backend "farneback" (default) = the branch the reference executes where `import cv2` succeeds, i.e. as
+    deployed (SCHED:45-51, 286-300: per-channel normalisation, uint8, dense Farneback flow: `wf_farneback_flows` quant_mode 1);
+    "tdiff" = temporal-difference motion (SCHED:165-170), the branch taken when the import fails -- OpenCV is absent from
+    /root/reference and from this image, so the golden fixtures were recorded through it.  Motion extraction + the three-way metric for
+    all 16 channels run in a handful of launches; the 16 similarities come back in ONE device->host copy; the threshold logic (16
+    scalars) stays on the host."""
 
-    def __init__(self):
+    def __init__(self, flow_backend: str = "farneback"):
+        if flow_backend not in ("farneback", "tdiff"):
+            raise ValueError(f"flow_backend must be 'farneback' or 'tdiff', got {flow_backend!r}")
+        self.flow_backend = flow_backend
+        self.use_optical_flow = flow_backend == "farneback"  # SCHED:45-51
         self.last_similarities = None
 
     def channel_similarities(self, pred_original_sample: torch.Tensor, encoded_video: torch.Tensor) -> np.ndarray:
         if pred_original_sample.shape[0] != 1:
             raise NotImplementedError("FLF: batch size 1 only")
-        ref_m = ops.temporal_diff(ops.cast(encoded_video, pred_original_sample.dtype)[0])  # [C, T-1, h, w] fp32
-        ch_m = ops.temporal_diff(pred_original_sample[0])
-        sim = ops.flow_metrics(ref_m.unsqueeze(2), ch_m.unsqueeze(2), variant=1)
+        enc = ops.cast(encoded_video, pred_original_sample.dtype)[0]
+        if self.use_optical_flow:
+            ref_m = ops.farneback_flows(enc, quant_mode=1)                     # [C, T-1, 2, h, w] fp32
+            ch_m = ops.farneback_flows(pred_original_sample[0], quant_mode=1)
+            sim = ops.flow_metrics(ref_m, ch_m, variant=1)
+        else:
+            ref_m = ops.temporal_diff(enc)                                      # [C, T-1, h, w] fp32
+            ch_m = ops.temporal_diff(pred_original_sample[0])
+            sim = ops.flow_metrics(ref_m.unsqueeze(2), ch_m.unsqueeze(2), variant=1)
         self.last_similarities = sim.cpu().numpy().astype(np.float64)  # the single sync of the FLF gate
         return self.last_similarities
 
@@ -83,7 +96,8 @@ class FlowMatchEulerDiscreteScheduler:
 
     def __init__(self, num_train_timesteps: int = 1000, shift: float = 1.0, use_dynamic_shifting: bool = False,
                  invert_sigmas: bool = False, shift_terminal: Optional[float] = None, use_karras_sigmas: bool = False,
-                 use_exponential_sigmas: bool = False, use_beta_sigmas: bool = False, stochastic_sampling: bool = False, **unused):
+                 use_exponential_sigmas: bool = False, use_beta_sigmas: bool = False, stochastic_sampling: bool = False, flow_backend: str = "farneback",
+                 **unused):
         if use_dynamic_shifting or invert_sigmas or shift_terminal or use_karras_sigmas or use_exponential_sigmas or use_beta_sigmas \
                 or stochastic_sampling:
             raise NotImplementedError("only the static-shift deterministic Euler configuration of the WorldForge path is built")
@@ -97,6 +111,7 @@ class FlowMatchEulerDiscreteScheduler:
         self.sigmas = sig
         self.sigma_min, self.sigma_max = self.sigmas[-1].item(), self.sigmas[0].item()
         self._shift = shift
+        self.flow_backend = flow_backend  # FLF motion extraction: see VideoMotionChannelSelector
         self._step_index = None
         self._begin_index = None
         self.num_inference_steps = None
@@ -236,7 +251,7 @@ class FlowMatchEulerDiscreteScheduler:
         enc = ops.latent_norm(enc, mean, std, const_dtype=x0.dtype)
         if use_pca_channel_selection:
             if self._channel_selector is None:
-                self._channel_selector = VideoMotionChannelSelector()
+                self._channel_selector = VideoMotionChannelSelector(self.flow_backend)
             channels = self._channel_selector.select_motion_related_channels(
                 pred_original_sample=x0, encoded_video=enc, current_step=current_step, total_steps=total_steps, static=static,
                 use_distill=use_distill, max_replace_threshold=max_replace_threshold)

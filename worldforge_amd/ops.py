@@ -236,14 +236,15 @@ def soften_mask(mask: torch.Tensor, transition_distance: int = 15, decay_type: s
     return out
 
 
-def farneback_flows(x: torch.Tensor) -> torch.Tensor:
-    """SCHED:156-248 for every channel at once: x [C,T,h,w] (f32 / bf16) -> flows [C,T-1,2,h,w] fp32 (device)."""
+def farneback_flows(x: torch.Tensor, quant_mode: int = 0) -> torch.Tensor:
+    """SCHED:156-248 for every channel at once: x [C,T,h,w] (f32 / bf16) -> flows [C,T-1,2,h,w] fp32 (device).
+    quant_mode 0 = the Wan scheduler's uint8 preparation (one global range), 1 = the LongCat scheduler's (a range per channel)."""
     x = _dev(x)
     C, T, h, w = x.shape
     nbytes = _ffi.lib().wf_farneback_workspace_bytes(C, T, h, w)
     ws = _workspace("farneback", (nbytes + 3) // 4, x.device)
     out = torch.empty((C, T - 1, 2, h, w), dtype=torch.float32, device=x.device)
-    call("wf_farneback_flows", x.data_ptr(), _dt(x), out.data_ptr(), C, T, h, w, ws.data_ptr(), stream())
+    call("wf_farneback_flows", x.data_ptr(), _dt(x), out.data_ptr(), C, T, h, w, quant_mode, ws.data_ptr(), stream())
     return out
 
 
