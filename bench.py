@@ -154,7 +154,8 @@ def main_longcat(a):
     from worldforge_amd.longcat_scheduler import FlowMatchEulerDiscreteScheduler
     from worldforge_amd.vae import AutoencoderKLWan
 
-    comm = parallel.init(world, rank, local_rank) if world > 1 else None
+    # WF_FORCE_COMM=1: a one-rank process group, so that a one-GPU box runs the sharded code path over RCCL itself (debug / CI aid)
+    comm = parallel.init(world, rank, local_rank) if (world > 1 or os.environ.get("WF_FORCE_COMM")) else None
     cfg = LongCatConfig(depth=a.layers if a.layers != 40 else 48)
     frames = a.frames if a.frames != 81 else 93
     t0 = time.time()
@@ -359,7 +360,8 @@ def main(argv=None):
     from worldforge_amd.scheduler import UniPCMultistepScheduler
     from worldforge_amd.vae import AutoencoderKLWan
 
-    comm = parallel.init(world, rank, local_rank) if world > 1 else None
+    # WF_FORCE_COMM=1: a one-rank process group, so that a one-GPU box runs the sharded code path over RCCL itself (debug / CI aid)
+    comm = parallel.init(world, rank, local_rank) if (world > 1 or os.environ.get("WF_FORCE_COMM")) else None
 
     cfg = wdit.DiTConfig.wan_i2v_14b()
     cfg.num_layers = a.layers

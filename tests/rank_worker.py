@@ -54,7 +54,7 @@ def main():
     v1.w = v0.w
     video = (torch.rand(1, 3, 5, 64, 96, generator=torch.Generator().manual_seed(7)) * 2 - 1).to(dev)
     z = rnd((1, 16, 2, 8, 12), 8).to(dev)
-    assert v1.can_shard(8)
+    assert v1.can_shard(8) == (world > 1)
     assert torch.equal(v1.encode(video).latent_dist.mode(), v0.encode(video).latent_dist.mode()), "sharded VAE encode differs"
     assert torch.equal(v1.decode(z, return_dict=False)[0], v0.decode(z, return_dict=False)[0]), "sharded VAE decode differs"
     comm.barrier()

@@ -48,6 +48,14 @@ def test_two_ranks_in_separate_processes():
         assert "gloo" in outs[0]
 
 
+def test_one_rank_over_rccl():
+    """A one-rank RCCL group on one GPU: the transport is trivial, but every call the N > 1 path makes (init_process_group("nccl",
+    device_id), all_gather_into_tensor of bf16 / fp32 views on the communication stream, events, barrier) goes through RCCL itself,
+    which the shared-GPU gloo run cannot show on a one-GPU box."""
+    outs = _run(1, {})
+    assert "nccl" in outs[0]
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 4, reason="needs 4 GPUs")
 def test_four_ranks_rccl():
     _run(4, {})
