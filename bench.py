@@ -257,7 +257,7 @@ def main_longcat(a):
             per = 1 if a.distill else 2  # DiT forwards per evaluation (CFG pair or not)
             t_cpu = (len(gms) * 3 * per + len(pms) * per) * fwd / cb["dit_flops_per_s"] + len(gms) * vae_flop / cb["vae_flops_per_s"]
             out["cpu_baseline"] = {"value": K / t_cpu, "unit": "steps/s", "cores": cb["cores"], "kind": "port", "sample": cb["sample"]}
-        print(json.dumps(out), flush=True)
+        emit_json(out)
     if comm is not None:
         comm.barrier()
 
@@ -307,6 +307,29 @@ def launch_ranks(n: int, argv, script: str = None) -> int:
     return rc
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout of every rank (seen with RCCL 2.26 on the
+    GPU box, flushed at exit, i.e. AFTER the line), and other libraries may chat there too: keep a private duplicate of fd 1 for the JSON
+    line and point fd 1 at stderr for everything else, in every rank, before anything is initialised."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_json(out: dict):
+    data = (json.dumps(out) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, data)
+
+
 def rank_env(a):
     """(rank, local_rank, world) from the launcher's environment; --gpus must agree with WORLD_SIZE."""
     rank = int(os.environ.get("RANK", "0"))
@@ -347,6 +370,7 @@ def main(argv=None):
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: become the launcher.  Nothing above or in here initialises the GPU in this process.
         sys.exit(launch_ranks(a.gpus, argv))
+    claim_stdout()
     if a.workload == "longcat":
         return main_longcat(a)
 
@@ -490,7 +514,7 @@ def main(argv=None):
             ng, npl = len(guided_ms), len(plain_ms)
             t_cpu = (ng * 4 + npl * 2) * cb["t_dit_forward_s"] + ng * 2 * cb["t_vae_roundtrip_s"]
             out["cpu_baseline"] = {"value": K / t_cpu, "unit": "steps/s", "cores": cb["cores"], "kind": "port", "sample": cb["sample"]}
-        print(json.dumps(out), flush=True)
+        emit_json(out)
     if comm is not None:
         comm.barrier()
 

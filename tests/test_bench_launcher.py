@@ -2,6 +2,7 @@
 and no GPU call in the parent.  CPU-only: the children here are probe scripts, not the bench."""
 import json
 import os
+import subprocess
 import sys
 import textwrap
 
@@ -77,3 +78,16 @@ def test_world_size_must_match_gpus(monkeypatch):
     ns = type("A", (), {"gpus": 2})
     with pytest.raises(SystemExit):
         bench.rank_env(ns)
+
+
+def test_stdout_carries_only_the_json_line():
+    """RCCL prints a version banner on the C-level stdout of a rank (flushed at exit, after the result line): bench.claim_stdout() keeps
+    fd 1 for the JSON line alone and sends every other writer -- Python prints, C stdio, child processes -- to stderr."""
+    code = ("import os, sys, ctypes; sys.path.insert(0, %r); import bench; bench.claim_stdout(); bench.claim_stdout();"
+            "print('python chatter'); libc = ctypes.CDLL(None); libc.puts(b'C stdio banner'); os.system('echo child chatter');"
+            "bench.emit_json({'metric': 'x', 'value': 1.5})") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == '{"metric": "x", "value": 1.5}\n'
+    for noise in ("python chatter", "C stdio banner", "child chatter"):
+        assert noise in r.stderr
