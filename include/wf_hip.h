@@ -232,6 +232,16 @@ int wf_refine_upsample_u8(const void* frames_u8, float* out, int F, int H0, int 
 /* ---- LongCat block-sparse attention of the 720p refine pass (longcat_video/block_sparse_attention/bsa_interface.py = BSA) --------- */
 /* mean_pooling_compression (BSA:169-179): in bf16 [H][L][128] -> out bf16 [H][L/block][128], mean of each block of 64 / 128 tokens. */
 int wf_lc_mean_pool_blocks(const void* in, void* out, int H, int L, int block, void* stream);
+/* Block selection (BSA:211-224, `torch.topk(score, int((1 - sparsity) * n_k))`) fused with the list building of the sparse kernel:
+ * scores bf16 [heads][n_q][ld] (n_k valid columns: the gating products of BSA:181-185) -> for every group of g = 256 / block consecutive
+ * query blocks the ascending union of their n_sel best key blocks, entry = physical_block * 2^g + sum_i 2^i [selected by the i-th query
+ * block of the group], physical_block = (b / blocks_per_segment) * heads * blocks_per_segment + head * blocks_per_segment + b %
+ * blocks_per_segment (the block's position in the all-gathered K / V^T buffers; one segment = the whole sequence on one GPU).
+ * lists int32 [heads][ceil(n_q / g)][max_entries], counts int32 [heads][ceil(n_q / g)]; max_entries >= min(g * n_sel, n_k).  Equal
+ * scores at the n_sel-th place are taken by ascending block index.  sel_mask (NULL or uint32 [heads][n_q][ceil(n_k / 32)]): bit b of a row
+ * = key block b selected by that query block (read back by tests).  n_k <= 2048. */
+int wf_bsa_topk_lists(const void* scores, int64_t ld, int heads, int n_q, int n_k, int n_sel, int block, int blocks_per_segment,
+                      int* lists, int* counts, int max_entries, uint32_t* sel_mask, void* stream);
 /* out[i][:C] = in[index[i]][:C], bf16 rows (16-byte chunks): the two token permutes of BSA:600-610 the refine pass needs per forward
  * (patch tokens into 3D-block order, velocity rows back). */
 int wf_gather_rows_bf16(const void* in, int64_t ld_in, const int* index, void* out, int64_t ld_out, int n_rows, int C, void* stream);

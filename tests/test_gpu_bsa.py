@@ -218,3 +218,72 @@ def test_longcat_dit_with_64_token_blocks():
     want = olc.forward(W, ocfg, x.float(), torch.tensor(ts), cap.float(), None, num_cond_latents=ncl, bsa=bsa_params, bsa_indices=picked)
     rel = ((got.cpu() - want).norm() / want.norm()).item()
     assert torch.isfinite(got).all() and rel <= 2e-2, rel
+
+
+@pytest.mark.parametrize("Hh,nq,nk,sparsity,block,bps", [
+    (3, 10, 40, 0.5, 128, None),       # even groups
+    (2, 7, 33, 0.875, 128, None),      # ragged last group, n_k not a multiple of 32, n_sel = 4
+    (4, 9, 70, 0.75, 64, None),        # four query blocks per workgroup, ragged
+    (2, 12, 64, 0.5, 128, 16),         # four all-gathered segments: head and segment folded into the physical block
+    (40, 770, 770, 0.875, 128, None),  # the 720p refine pass: 96 of 770
+    (2, 5, 1540, 0.875, 64, None),     # 64-token blocks at that length
+])
+def test_fused_topk_lists_equal_torch_topk_plus_group_lists(Hh, nq, nk, sparsity, block, bps):
+    """wf_bsa_topk_lists == group_lists(select_topk(scores)) (BSA:211-224 through torch.topk) on distinct scores: same lists, counts and
+    per-row selections.  The scores of a row are made distinct so that the n_sel-th place has no tie."""
+    from worldforge_amd import bsa
+    g = torch.Generator().manual_seed(nq * 31 + nk)
+    # distinct bf16 values per row: a random permutation of a grid that bf16 represents exactly (mixed signs, several binades)
+    grid = torch.cat([torch.arange(1, 129) / 128.0, torch.arange(129, 257) / 64.0, torch.arange(257, 385) / 16.0])
+    grid = torch.cat([grid, -grid, grid * 64, -grid * 64, grid / 256, torch.zeros(1)])
+    grid = torch.unique(grid.to(BF))
+    assert grid.numel() >= nk
+    sc = torch.stack([torch.stack([grid[torch.randperm(grid.numel(), generator=g)[:nk]] for _ in range(nq)]) for _ in range(Hh)])
+    nkp = (nk + 7) // 8 * 8
+    buf = torch.full((Hh, nq, nkp), float("inf"), dtype=BF, device=DEV)  # padding columns must never be looked at
+    buf[:, :, :nk] = sc.to(DEV)
+    view = buf[:, :, :nk]
+    lists, counts, mx, sel = bsa.topk_lists(view, sparsity, block, bps)
+    idx = bsa.select_topk(view, sparsity)
+    wl, wc, wmx = bsa.group_lists(idx, nk, None, block, bps)
+    assert mx == wmx and torch.equal(counts, wc)
+    live = torch.arange(mx, device=DEV).view(1, 1, -1) < counts.unsqueeze(-1)
+    assert torch.equal(torch.where(live, lists, 0), torch.where(live, wl, 0))
+    assert bool((torch.where(live, 0, lists) == 0).all())  # the tail is zero-filled
+    assert torch.equal(sel.cpu(), idx.sort(-1).values.cpu())
+
+
+def test_fused_topk_ties_take_the_lowest_block_indices():
+    """Equal scores at the n_sel-th place: the kernel's rule is ascending block index; the selection is still a valid top-k."""
+    from worldforge_amd import bsa
+    sc = torch.zeros((1, 2, 16), dtype=BF, device=DEV)
+    sc[0, 0, 5] = 2.0
+    sc[0, 0, 9] = 1.0
+    sc[0, 1] = -1.0
+    sc[0, 1, 15] = -0.5
+    lists, counts, mx, sel = bsa.topk_lists(sc, 0.75, 128)  # 4 of 16
+    idx = sel.cpu()
+    assert idx[0, 0].tolist() == [0, 1, 5, 9] and idx[0, 1].tolist() == [0, 1, 2, 15]
+    assert counts.item() == 6
+    ent = lists[0, 0, :6].cpu().tolist()
+    assert [e >> 2 for e in ent] == [0, 1, 2, 5, 9, 15] and [e & 3 for e in ent] == [3, 3, 2, 1, 1, 2]
+
+
+def test_longcat_dit_fused_selection_equals_torch_selection(monkeypatch):
+    """The DiT forward with the fused selection kernel == the same forward with torch.topk + group_lists (bitwise: same lists -> same kernel)."""
+    from oracle import longcat_dit as olc
+    from worldforge_amd.longcat_dit import LongCatConfig, LongCatVideoTransformer3DModel
+    kw = dict(hidden_size=256, depth=2, num_heads=2, caption_channels=64, adaln_tembed_dim=64)
+    W = olc.random_weights(olc.LongCatConfig(**kw), seed=6)
+    bsa_params = dict(sparsity=0.5, chunk_3d_shape_q=[4, 4, 8], chunk_3d_shape_k=[4, 4, 8])
+    m = LongCatVideoTransformer3DModel(LongCatConfig(**kw), DEV, enable_bsa=True, bsa_params=bsa_params).load_state_dict(W)
+    T, h, w, ncl = 8, 16, 32, 4
+    x, cap = _rand((16, T, h, w), 11).to(BF).to(DEV), _rand((20, 64), 12).to(BF).to(DEV)
+    ts = [0.0] * ncl + [400.0] * (T - ncl)
+    a = m.forward_tokens(x, ts, cap, None, ncl).clone()
+    pa = [[i.cpu() for i in layer] for layer in m.last_bsa_indices]
+    monkeypatch.setenv("WF_BSA_TORCH_SELECT", "1")
+    b = m.forward_tokens(x, ts, cap, None, ncl)
+    pb = [[i.cpu().sort(-1).values for i in layer] for layer in m.last_bsa_indices]
+    assert all(torch.equal(u, v) for la, lb in zip(pa, pb) for u, v in zip(la, lb))
+    assert torch.equal(a, b)

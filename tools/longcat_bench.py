@@ -126,6 +126,17 @@ if __name__ == "__main__":
             return r
 
         wbsa.sparse_attention = timed
+        orig_t = wbsa.sparse_attention_topk
+
+        def timed_topk(*aa, **kk):  # (fused selection + list building + the sparse kernel: both launches inside the events)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig_t(*aa, **kk)
+            e1.record()
+            ev.append((e0, e1, aa[0].shape[1], aa[4].shape[2]))
+            return r
+
+        wbsa.sparse_attention_topk = timed_topk
     m.forward_tokens(x, ts, cap, mask, ncl)
     torch.cuda.synchronize()
     dit.PROFILE_ATTN = []

@@ -3,9 +3,9 @@
 Mirror of longcat_video/block_sparse_attention/bsa_interface.py (BSA): `flash_attn_bsa_3d` :612-659 = 3D-block token permute (:600-610)
 -> mean-pool gating (:169-179) -> block scores (:181-185) -> top-k block selection (:211-224) -> sparse attention (:538-560, the Triton
 kernel of flash_attn_bsa_varlen_mask.py:174-285) -> inverse permute.  Token-sized work runs in libwf_hip.so (`wf_lc_mean_pool_blocks`,
-`wf_gemm_bf16` for the block scores, `wf_attn_bsa_fwd`, the permutes ride on `wf_lc_norm_heads` / `wf_gather_rows_bf16`); the
-selection itself -- a top-k over a [heads, n_q_blocks, n_k_blocks] score table and the index bookkeeping that turns it into
-per-workgroup block lists -- is a few small integer tensor ops left to torch on the device (no host sync).
+`wf_gemm_bf16_batched` for the block scores, `wf_attn_bsa_fwd`, the permutes ride on `wf_lc_norm_heads` / `wf_gather_rows_bf16`); the
+top-k selection and the index bookkeeping that turns it into per-workgroup block lists are one kernel too (`wf_bsa_topk_lists`, round
+2); the cdf-threshold rule (variable-length selections) keeps its small integer tensor ops in torch on the device (no host sync).
 """
 from __future__ import annotations
 
@@ -114,6 +114,60 @@ def group_lists(block_indices: torch.Tensor, n_k: int, block_lens: torch.Tensor 
     for i, pt in enumerate(parts):
         entries = entries + (pt.gather(2, order).long() << i)
     return entries.to(torch.int32).contiguous(), counts.contiguous(), max_entries
+
+
+TOPK_MAX_BLOCKS = 2048  # wf_bsa_topk_lists keeps a row of scores in LDS
+
+
+class SelectionMask:
+    """The selection wf_bsa_topk_lists made, as it left the kernel: bit b of mask[head, query block, b // 32] = key block b selected.
+    `.cpu()` gives what `torch.topk(...)[1]` would have given up to order: int64 [heads, n_q, n_sel], ascending (tests, oracle hand-over)."""
+
+    def __init__(self, mask: torch.Tensor, n_k: int, n_sel: int):
+        self.mask, self.n_k, self.n_sel = mask, n_k, n_sel
+
+    def indices(self) -> torch.Tensor:
+        bits = (self.mask.unsqueeze(-1) >> torch.arange(32, device=self.mask.device, dtype=torch.int32)) & 1
+        sel = bits.flatten(2)[:, :, :self.n_k].bool()
+        assert bool((sel.sum(-1) == self.n_sel).all())
+        return torch.nonzero(sel)[:, 2].view(sel.shape[0], sel.shape[1], self.n_sel)
+
+    def cpu(self) -> torch.Tensor:
+        return self.indices().cpu()
+
+
+def topk_lists(scores: torch.Tensor, sparsity: float, block: int = BLOCK, blocks_per_segment: int = None):
+    """BSA:211-224 + group_lists in ONE launch (wf_bsa_topk_lists): scores [heads, n_q, n_k] bf16 (a view of the padded gating buffer) ->
+    (lists, counts, max_entries, SelectionMask).  Same lists as group_lists(select_topk(scores, sparsity)) when no two scores tie at the
+    n_sel-th place (then: ascending block index here)."""
+    Hh, nq, nk = scores.shape
+    n = int((1 - sparsity) * nk)
+    if n < 1:
+        raise ValueError(f"sparsity {sparsity} leaves no key block of {nk}")
+    assert scores.dtype == torch.bfloat16 and scores.stride(2) == 1 and scores.stride(0) == nq * scores.stride(1)
+    gs = 256 // block
+    ng = (nq + gs - 1) // gs
+    mx = min(gs * n, nk)
+    lists = torch.empty((Hh, ng, mx), dtype=torch.int32, device=scores.device)
+    counts = torch.empty((Hh, ng), dtype=torch.int32, device=scores.device)
+    mask = torch.empty((Hh, nq, (nk + 31) // 32), dtype=torch.int32, device=scores.device)
+    call("wf_bsa_topk_lists", scores.data_ptr(), scores.stride(1), Hh, nq, nk, n, block, blocks_per_segment or nk, lists.data_ptr(),
+         counts.data_ptr(), mx, mask.data_ptr(), ops.stream())
+    return lists, counts, mx, SelectionMask(mask, nk, n)
+
+
+def sparse_attention_topk(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, scores: torch.Tensor, sparsity: float,
+                          scale: float, block: int = BLOCK) -> SelectionMask:
+    """sparse_attention with the top-k selection of `scores` [heads, Lq / block, n_k_blocks] made on the way (two launches, no torch ops)."""
+    Hh, Lq, _ = q.shape
+    if k.dim() == 4:
+        Lkp, seg = k.shape[0] * k.shape[2], k.shape[2]
+    else:
+        Lkp = seg = k.shape[1]
+    lists, counts, mx, sel = topk_lists(scores, sparsity, block, seg // block)
+    call("wf_attn_bsa_fwd", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), Hh, Lq, Lkp, seg, out.stride(0), float(scale),
+         lists.data_ptr(), counts.data_ptr(), mx, block, ops.stream())
+    return sel
 
 
 def sparse_attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, block_indices: torch.Tensor, scale: float,

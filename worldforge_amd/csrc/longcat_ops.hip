@@ -203,6 +203,113 @@ __global__ void k_gather_rows(const uint16_t* __restrict__ in, int64_t ld_in, co
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Block selection of the sparse attention (bsa_interface.py:211-224): top n_sel of n_k block scores per query block, turned straight
+// into the per-workgroup lists wf_attn_bsa_fwd walks (worldforge_amd/bsa.py group_lists: union of the g query blocks of a workgroup in
+// ascending block order, entry = physical block * 2^g + selection flags).  One workgroup per (head, group of g query blocks).
+// Per query block: exact n_sel-th largest bf16 score by a two-pass radix select on the 16 score bits (histogram of the high byte, then
+// of the low byte inside the boundary bin), everything above it selected, ties at it by ascending block index (what torch's radix
+// top-k does on a GPU).  No sort, no host round trip; replaces torch.topk + ~15 small integer tensor ops per layer.
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr int TK_MAXK = 2048;  // key blocks per row (98 560 tokens / 64 = 1540)
+__device__ __forceinline__ uint32_t bf16_sort_key(uint16_t b) { return (b & 0x8000u) ? (uint16_t)~b : (uint16_t)(b | 0x8000u); }  // ascending
+// exclusive scan of one int per thread over the 256 threads of the workgroup; returns the prefix, *total = sum of all
+__device__ __forceinline__ int block_exscan(int v, int* sm /* >= 4 ints */, int* total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += u;
+  }
+  __syncthreads();  // sm may still be read by the previous scan
+  if (lane == 63) sm[wv] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < wv; ++i) base += sm[i];
+  *total = sm[0] + sm[1] + sm[2] + sm[3];
+  return base + inc - v;
+}
+__global__ __launch_bounds__(256) void k_bsa_topk_lists(const uint16_t* __restrict__ scores, long ld, int n_q, int n_k, int n_sel, int gs,
+                                                        int bps, int heads, int* __restrict__ lists, int* __restrict__ counts,
+                                                        int max_entries, uint32_t* __restrict__ sel_mask) {
+  __shared__ uint16_t key[TK_MAXK];
+  __shared__ uint8_t flags[TK_MAXK];
+  __shared__ int hist[256];
+  __shared__ int sc[4];
+  __shared__ int pick[2];  // boundary bin, elements still to take inside it
+  const int grp = blockIdx.x, head = blockIdx.y, tid = threadIdx.x;
+  const int per = (n_k + 255) / 256;  // contiguous chunk of block indices per thread
+  const int b0 = tid * per, b1 = min(b0 + per, n_k);
+  for (int b = tid; b < n_k; b += 256) flags[b] = 0;
+  for (int r = 0; r < gs; ++r) {
+    const int qb = grp * gs + r;
+    if (qb >= n_q) break;  // (uniform)
+    const uint16_t* row = scores + ((size_t)head * n_q + qb) * ld;
+    __syncthreads();
+    for (int b = tid; b < n_k; b += 256) key[b] = (uint16_t)bf16_sort_key(row[b]);
+    // two radix passes: byte 1 over all keys, byte 0 inside the boundary bin
+    int need = n_sel;
+    uint32_t prefix = 0;  // high byte of the boundary value after pass 0
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      hist[tid] = 0;
+      __syncthreads();
+      for (int b = tid; b < n_k; b += 256) {
+        const uint32_t kx = key[b];
+        if (pass == 0)
+          atomicAdd(&hist[kx >> 8], 1);
+        else if ((kx >> 8) == prefix)
+          atomicAdd(&hist[kx & 255], 1);
+      }
+      __syncthreads();
+      if (tid == 0) {  // walk the 256 bins from the top: 256 steps, once per row and pass
+        int left = need, bin = 255;
+        while (bin > 0 && hist[bin] < left) left -= hist[bin--];
+        pick[0] = bin;
+        pick[1] = left;
+      }
+      __syncthreads();
+      if (pass == 0) prefix = (uint32_t)pick[0];
+      need = pick[1];
+      __syncthreads();
+    }
+    const uint32_t T = (prefix << 8) | (uint32_t)pick[0];  // the n_sel-th largest key; `need` of the keys equal to it are taken
+    int eq = 0;
+    for (int b = b0; b < b1; ++b) eq += key[b] == T;
+    int tot;
+    int before = block_exscan(eq, sc, &tot);
+    for (int b = b0; b < b1; ++b) {
+      const uint32_t kx = key[b];
+      bool take = kx > T;
+      if (kx == T) take = before++ < need;
+      if (take) flags[b] |= (uint8_t)(1u << r);  // this thread owns block b: no race
+    }
+    if (sel_mask) {
+      __syncthreads();
+      const int nw = (n_k + 31) / 32;
+      for (int w = tid; w < nw; w += 256) {
+        uint32_t m = 0;
+        for (int i = 0; i < 32 && w * 32 + i < n_k; ++i) m |= (uint32_t)((flags[w * 32 + i] >> r) & 1u) << i;
+        sel_mask[((size_t)head * n_q + qb) * nw + w] = m;
+      }
+    }
+  }
+  __syncthreads();
+  int mine = 0;
+  for (int b = b0; b < b1; ++b) mine += flags[b] != 0;
+  int total;
+  int pos = block_exscan(mine, sc, &total);
+  int* out = lists + ((size_t)head * gridDim.x + grp) * max_entries;
+  for (int b = b0; b < b1; ++b)
+    if (flags[b]) {
+      const int phys = (b / bps) * (heads * bps) + head * bps + b % bps;
+      out[pos++] = (phys << gs) | (int)flags[b];
+    }
+  for (int i = total + tid; i < max_entries; i += 256) out[i] = 0;  // never walked (count below): a valid block all the same
+  if (tid == 0) counts[head * gridDim.x + grp] = total;
+}
+
 }  // namespace
 
 extern "C" int wf_lc_mean_pool_blocks(const void* in, void* out, int H, int L, int block, void* stream) {
@@ -211,6 +318,21 @@ extern "C" int wf_lc_mean_pool_blocks(const void* in, void* out, int H, int L, i
   WF_CHECK_ARG(H > 0 && L > 0 && L % block == 0, "wf_lc_mean_pool_blocks: L (%d) must be whole %d-token blocks", L, block);
   hipLaunchKernelGGL(k_lc_mean_pool, dim3(L / block, H), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in, (uint16_t*)out, L, block);
   WF_LAUNCH_CHECK("wf_lc_mean_pool_blocks");
+  return WF_OK;
+}
+
+extern "C" int wf_bsa_topk_lists(const void* scores, int64_t ld, int heads, int n_q, int n_k, int n_sel, int block, int blocks_per_segment,
+                                 int* lists, int* counts, int max_entries, uint32_t* sel_mask, void* stream) {
+  WF_CHECK_ARG(scores && lists && counts, "wf_bsa_topk_lists: null pointer");
+  WF_CHECK_ARG(block == 128 || block == 64, "wf_bsa_topk_lists: block must be 128 or 64");
+  WF_CHECK_ARG(heads > 0 && n_q > 0 && n_k > 0 && n_k <= TK_MAXK && ld >= n_k, "wf_bsa_topk_lists: n_k=%d must be in 1..%d, ld >= n_k", n_k, TK_MAXK);
+  WF_CHECK_ARG(n_sel >= 1 && n_sel <= n_k, "wf_bsa_topk_lists: n_sel=%d must be in 1..n_k=%d", n_sel, n_k);
+  const int gs = 256 / block;
+  WF_CHECK_ARG(blocks_per_segment > 0 && max_entries >= ((long)gs * n_sel < n_k ? gs * n_sel : n_k),
+               "wf_bsa_topk_lists: max_entries=%d must hold min(g * n_sel, n_k) entries", max_entries);
+  hipLaunchKernelGGL(k_bsa_topk_lists, dim3((n_q + gs - 1) / gs, heads), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)scores, (long)ld,
+                     n_q, n_k, n_sel, gs, blocks_per_segment, heads, lists, counts, max_entries, sel_mask);
+  WF_LAUNCH_CHECK("wf_bsa_topk_lists");
   return WF_OK;
 }
 

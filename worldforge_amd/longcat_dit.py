@@ -18,6 +18,7 @@ KV-cache continuation (LCA:147-181), block-sparse attention (LCA:57-66), sequenc
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Dict, Optional, Tuple
@@ -393,6 +394,7 @@ class LongCatVideoTransformer3DModel:
                     return bsa.select_topk(scores, float(sparsity)), None
                 return bsa.select_cdf(scores, float(cdf_thr), None if sparsity is None else float(sparsity))
 
+            fused_topk = cdf_thr is None and not os.environ.get("WF_BSA_TORCH_SELECT")  # (the env switch keeps the torch.topk path testable)
             self.last_bsa_indices = []
 
         for i in range(cfg.depth):
@@ -422,14 +424,16 @@ class LongCatVideoTransformer3DModel:
                     kk, vv = kh_all, vt_all
                 kcmp = kcmp[:, :L_all // blk].contiguous()
                 picked = []
-                if nc > 0:
-                    idx, lens = select(bsa.block_scores(bsa.mean_pool(qh_c, blk), kcmp[:, :nc_all // blk].contiguous()))
-                    bsa.sparse_attention(qh_c, kk, vv, ao[:nc], idx, scale, nc_all // blk, lens, blk)
-                    picked.append(idx if lens is None else (idx, lens))
-                if L - nc > 0:
-                    idx, lens = select(bsa.block_scores(bsa.mean_pool(qh_n, blk), kcmp))
-                    bsa.sparse_attention(qh_n, kk, vv, ao[nc:], idx, scale, L_all // blk, lens, blk)
-                    picked.append(idx if lens is None else (idx, lens))
+                for nrows, qrows, orows, nkb in ((nc, qh_c, ao[:nc], nc_all // blk), (L - nc, qh_n, ao[nc:], L_all // blk)):
+                    if nrows == 0:
+                        continue
+                    sc = bsa.block_scores(bsa.mean_pool(qrows, blk), kcmp if nkb == L_all // blk else kcmp[:, :nkb].contiguous())
+                    if fused_topk and nkb <= bsa.TOPK_MAX_BLOCKS:  # selection + list building in one kernel
+                        picked.append(bsa.sparse_attention_topk(qrows, kk, vv, orows, sc, float(sparsity), scale, blk))
+                    else:
+                        idx, lens = select(sc)
+                        bsa.sparse_attention(qrows, kk, vv, orows, idx, scale, nkb, lens, blk)
+                        picked.append(idx if lens is None else (idx, lens))
                 self.last_bsa_indices.append(picked)
             else:
                 self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_c, 0, nc)
