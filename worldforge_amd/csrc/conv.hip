@@ -544,6 +544,7 @@ struct ConvW4Args {
   // as [hi | lo] (Cs = 2/3 Cin) and its hi slices are read twice.
   long row_stride, slice_stride;
   int pix_stride, nsa;
+  int walk;  // 0 = one contiguous chunk of the tile list per workgroup, 1 = XCD-cooperative (see k_conv_w4)
 };
 
 // DBG (ablation builds only, -DWF_CONV_ABLATE + WF_CONV_DEBUG=<bits>; wrong results): bit 0 = no in-loop LDS-DMA, bit 1 = no in-loop weight
@@ -573,8 +574,22 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
     xx = (sidx % pa.tiles_x) * WX;
     yy = (sidx / pa.tiles_x) * WY;
   };
-  const int chunk = (ntile + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int tile_begin = (int)blockIdx.x * chunk, tile_end = min(ntile, tile_begin + chunk);
+  int tile_begin, tile_end, tile_step = 1;
+  if (pa.walk == 1 && (gridDim.x & 7) == 0) {
+    // XCD-cooperative walk: workgroups are dealt to the 8 XCDs round-robin (blockIdx.x % 8 -- gridDim.x is a multiple of 8, so the
+    // blockIdx.y planes land on the same XCD); an XCD takes one contiguous eighth of the list and its workgroups take CONSECUTIVE
+    // items of it (consecutive frames of one window) at the same time, stride = workgroups per XCD: the three patch frames of a tile
+    // are wanted by the two neighbours on the same L2 at about the same moment instead of 3 x from HBM / MALL a whole tile apart
+    const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3, nl = (int)gridDim.x >> 3;
+    const int per = (ntile + 7) / 8;
+    tile_begin = xcd * per + j;
+    tile_end = min(ntile, (xcd + 1) * per);
+    tile_step = nl;
+  } else {
+    const int chunk = (ntile + (int)gridDim.x - 1) / (int)gridDim.x;
+    tile_begin = (int)blockIdx.x * chunk;
+    tile_end = min(ntile, tile_begin + chunk);
+  }
   if (tile_begin >= tile_end) return;
 
 #ifdef WF_CONV_TIMING
@@ -669,11 +684,11 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   const unsigned long long tc1 = __builtin_readcyclecounter();
   unsigned long long t_wait = 0, t_main = 0, t_epi = 0, n_tiles = 0;
 #endif
-  for (int tile = tile_begin; tile < tile_end; ++tile) {
+  for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
 #ifdef WF_CONV_TIMING
   const unsigned long long tt0 = __builtin_readcyclecounter();
 #endif
-  const int tile_n = tile + 1;
+  const int tile_n = tile + tile_step;
   const bool has_next = tile_n < tile_end;
   int tn = t, yn = y0, xn = x0;
 #pragma unroll
@@ -956,6 +971,10 @@ extern "C" int wf_conv3d_333(const void* in, const void* w_packed, const float* 
   wa.tiles_x = (Wi + WX - 1) / WX;
   wa.tiles_y = (Ho + WY - 1) / WY;
   wa.nsa = Cin_stored / 16;
+  {
+    static const int walk_env = [] { const char* e = getenv("WF_CONV_WALK"); return e ? atoi(e) : 1; }();  // default: XCD-cooperative (WF_CONV_WALK=0: contiguous chunks)
+    wa.walk = walk_env;
+  }
 
   if (layout == 0) {
     wa.row_stride = (long)Wi * Cin_stored; wa.pix_stride = Cin_stored; wa.slice_stride = 16;
