@@ -1,0 +1,17 @@
+set -x
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+pmc() { name=$1; shift; C=96 X3=1 N=2 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $R/gpurun_out/r2_pmc_conv_walk/$name -o pmc -- python3 $R/tools/conv_once.py > $R/gpurun_out/r2_pmc_conv_walk_$name.log 2>&1; echo "pmc $name rc=$?"; }
+pmc mfma SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+pmc wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU
+pmc fetch FETCH_SIZE
+pmc tcc TCC_HIT_sum TCC_MISS_sum
+cd $R
+python tools/pmc_summary.py gpurun_out/r2_pmc_conv_walk/* --kernel k_conv_w4 > gpurun_out/r2_pmc_conv_walk_summary.txt 2>&1; cat gpurun_out/r2_pmc_conv_walk_summary.txt
+python - <<'PY'
+import csv,glob
+for f in glob.glob('gpurun_out/r2_pmc_conv_walk/mfma/*kernel_trace.csv'):
+    for r in csv.DictReader(open(f)):
+        if 'k_conv_w4' in r['Kernel_Name']: print('conv dur ms',(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6)
+PY
+find gpurun_out/r2_pmc_conv_walk -type f -size +2M -delete
