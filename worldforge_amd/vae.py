@@ -45,6 +45,7 @@ LATENTS_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743, 3
                1.1253, 2.8251, 1.9160]  # vae.py:633-636
 
 BF, F32 = torch.bfloat16, torch.float32
+_LOG_CONV = bool(os.environ.get("WF_VAE_LOG_CONV"))  # debug: one line per convolution (layer, shape, operand layout)
 
 
 def encoder_plan() -> List[Tuple]:
@@ -358,6 +359,9 @@ class AutoencoderKLWan:
                  ob.data_ptr() if ob is not None else None, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, k[0], k[1], k[2], st, ss, pt,
                  ps if ph is None else ph, ps, 1 if up2 else 0, 1 if tsplit else 0, self._zero_page().data_ptr(), ops.stream())
         self.flops_last += 2 * To * Ho * Wo * Cout * k[0] * k[1] * k[2] * Cin
+        if _LOG_CONV:
+            print(f"[vae conv] {p}: k={tuple(k)} st={st} ss={ss} up2={up2} tsplit={tsplit} in={(Ti, Hi, Wi, Cin)} out={(To, Ho, Wo, Cout)} "
+                  f"layout={layout}", flush=True)
         return of, ob
 
     def _packed333(self, p, Cout, Cin):
