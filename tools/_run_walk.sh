@@ -1,13 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out
-WF_VAE_LOG_CONV=1 python - > gpurun_out/convlog.txt 2>&1 <<'PY'
-import torch
-from worldforge_amd.vae import AutoencoderKLWan
-dev = torch.device("cuda:0")
-vae = AutoencoderKLWan(dev).init_random(seed=1)
-z = torch.randn(1, 16, 21, 60, 104, device=dev)
-video = torch.rand(1, 3, 81, 480, 832, device=dev) * 2 - 1
-print("== decode"); vae.decode(z, return_dict=False)
-print("== encode"); vae.encode(video).latent_dist.mode()
-PY
-grep -v amdgpu gpurun_out/convlog.txt | grep -v "k=(3, 3, 3) st=1 ss=1 up2=False tsplit=False.*layout=1"
+python bench.py --height 720 --width 1280 --steps 2 --warmup 0 --no-cpu-baseline > gpurun_out/r2_h_c3_bench.json 2> gpurun_out/c3.err
+python bench.py --workload longcat --no-cpu-baseline > gpurun_out/r2_h_longcat_bench.json 2> gpurun_out/lc.err
+python bench.py --workload longcat --distill --no-cpu-baseline > gpurun_out/r2_h_longcat_distill_bench.json 2> gpurun_out/lcd.err
+for f in gpurun_out/r2_h_c3_bench.json gpurun_out/r2_h_longcat_bench.json gpurun_out/r2_h_longcat_distill_bench.json; do cut -c1-200 $f; done
+tail -2 gpurun_out/c3.err gpurun_out/lc.err gpurun_out/lcd.err | grep -v amdgpu
