@@ -4,9 +4,13 @@ Restates /root/reference/longcat_for_worldforge/longcat_video/block_sparse_atten
   rearrange_THW_to_3d_block / rearrange_3d_block_to_THW :600-610, mean_pooling_compression :169-179, cal_score :181-185,
   get_select_indices_topk_from_score :211-224, _attention_bsa.forward :538-560, flash_attn_bsa_3d :612-659.
 The permutes, the pooling and the top-k selection are pinned against those functions imported from the reference
-(tests/golden/g14_bsa.npz, tools/make_goldens.py bsa).  The sparse attention itself is a Triton GPU kernel in the reference
-(flash_attn_bsa_varlen_mask.py:174-285, not runnable here): it is restated from its source as what it computes -- for every query
-block, softmax(q k^T * sm_scale) over the keys of the selected key blocks only -- PARITY OF THAT STEP WITH THE TRITON KERNEL IS UNPINNED.
+(tests/golden/g14_bsa.npz, tools/make_goldens.py bsa).  The sparse attention itself is a Triton kernel in the reference
+(flash_attn_bsa_varlen_mask.py:174-285): it is restated as what it computes -- for every query block, softmax(q k^T * sm_scale) over the
+keys of the selected key blocks only, p cast to the value dtype before P V, row sums from the uncast p, 0 for an empty selection -- and
+PINNED (round 2) against that kernel itself: Triton's interpreter (TRITON_INTERPRET=1; triton-rocm 3.6 is in the image) executes the
+reference's unmodified @triton.jit functions on CPU tensors, launched by the reference's own attn_fwd_bsa_varlen_triton / flash_attn_bsa /
+flash_attn_bsa_3d -- tests/golden/g18_bsa_triton.npz (tools/make_goldens.py bsa_triton; fp32 and fp16 tensors, 128- and 64-token blocks,
+variable-length and empty lists, the 3D-block interface).
 """
 from __future__ import annotations
 
@@ -53,9 +57,10 @@ def select_cdf(q_cmp: torch.Tensor, k_cmp: torch.Tensor, cdf_threshold: float, s
 
 
 def sparse_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_indices: torch.Tensor, block_q: int, block_k: int,
-                     scale: float, block_lens: torch.Tensor = None) -> torch.Tensor:
+                     scale: float, block_lens: torch.Tensor = None, p_dtype=None) -> torch.Tensor:
     """flash_attn_bsa_varlen_mask.py:236-285 as a masked dense softmax: q [heads, Sq, D], k / v [heads, Sk, D] (block order),
-    block_indices [heads, Sq / block_q, n_sel] -> [heads, Sq, D] in q's dtype."""
+    block_indices [heads, Sq / block_q, n_sel] -> [heads, Sq, D] in q's dtype.  p_dtype: the kernel's `p.to(v.dtype)` (:259) for half
+    tensors -- the un-normalised probabilities are rounded to it before P V while the row sums keep the fp32 p (:255)."""
     Hh, Sq, D = q.shape
     Sk = k.shape[1]
     nq, nk = Sq // block_q, Sk // block_k
@@ -68,9 +73,16 @@ def sparse_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_in
     mask = allow.repeat_interleave(block_q, dim=1).repeat_interleave(block_k, dim=2)
     s = torch.einsum("hqd,hkd->hqk", q.float(), k.float()) * scale
     s = s.masked_fill(~mask, float("-inf"))
-    p = torch.softmax(s, dim=-1)
-    p = torch.where(mask.any(dim=-1, keepdim=True), p, torch.zeros_like(p))  # empty selection: acc / l = 0 / 1 in the reference's kernel
-    return torch.einsum("hqk,hkd->hqd", p, v.float()).to(q.dtype)
+    if p_dtype is None:
+        p = torch.softmax(s, dim=-1)
+        p = torch.where(mask.any(dim=-1, keepdim=True), p, torch.zeros_like(p))  # empty selection: acc / l = 0 / 1 in the reference's kernel
+        return torch.einsum("hqk,hkd->hqd", p, v.float()).to(q.dtype)
+    m = s.max(dim=-1, keepdim=True).values
+    m = torch.where(torch.isfinite(m), m, torch.zeros_like(m))
+    pu = torch.exp(s - m)                      # un-normalised, <= 1 (the kernel's running max makes its p <= 1 too)
+    l = pu.sum(dim=-1, keepdim=True)
+    acc = torch.einsum("hqk,hkd->hqd", pu.to(p_dtype).float(), v.float())
+    return (acc / torch.where(l > 0, l, torch.ones_like(l))).to(q.dtype)
 
 
 def flash_attn_bsa_3d(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, shape_q: Tuple[int, int, int], shape_k: Tuple[int, int, int],

@@ -191,3 +191,38 @@ def lora_state(cfg, seed=33, dim=8):
                 sd[name + ".lora_up.weight"] = torch.randn(o, dim, generator=g) * 0.3
             sd[name + ".alpha_scale"] = torch.tensor(0.5)
     return sd
+
+
+# ---- block-sparse attention cases of tests/golden/g18_bsa_triton.npz (tools/make_goldens.py bsa_triton) ---------------------------------
+# name: heads, Sq, Sk, block, dtype; inputs are drawn from a seeded CPU generator and rounded to bf16-representable values (fp16 for the
+# fp16 case), so that the reference's kernel (fp32 arithmetic in the Triton interpreter) and the HIP kernel (bf16 tensors) see the same numbers
+BSA_TRITON_CASES = {
+    "k128": dict(H=2, Sq=384, Sk=640, block=128, dtype="f32", sparsity=0.6, seed=101),      # gating + top-k + kernel (flash_attn_bsa)
+    "k64": dict(H=2, Sq=256, Sk=384, block=64, dtype="f32", sparsity=0.5, seed=102),        # 64-token blocks (BLOCK_N_LG=64 preset)
+    "varlen": dict(H=2, Sq=384, Sk=512, block=128, dtype="f32", sparsity=None, seed=103),   # hand-made variable-length lists incl. empty rows
+    "half": dict(H=1, Sq=256, Sk=384, block=128, dtype="f16", sparsity=0.4, seed=104),      # half inputs: p is cast to the value dtype before P V
+    "thw": dict(H=2, Sq=512, Sk=512, block=128, dtype="f32", sparsity=0.5, seed=105, grid=(4, 8, 16), chunk=(4, 4, 8)),  # flash_attn_bsa_3d
+}
+
+
+def bsa_triton_inputs(name):
+    """-> q [H, Sq, 128], k, v [H, Sk, 128] float32 tensors holding bf16- (fp16-) representable values."""
+    import torch
+    c = BSA_TRITON_CASES[name]
+    g = torch.Generator().manual_seed(c["seed"])
+    half = torch.float16 if c["dtype"] == "f16" else torch.bfloat16
+    q = torch.randn(c["H"], c["Sq"], 128, generator=g)
+    k = torch.randn(c["H"], c["Sk"], 128, generator=g) + 0.5 * torch.randn(c["H"], 1, 128, generator=g)
+    v = torch.randn(c["H"], c["Sk"], 128, generator=g)
+    return tuple(t.to(half).float() for t in (q, k, v))
+
+
+def bsa_varlen_lists(name):
+    """The hand-made selection of the "varlen" case: sorted-by-nothing index rows + per-row counts (0 = empty selection)."""
+    import torch
+    c = BSA_TRITON_CASES[name]
+    nq, nk = c["Sq"] // c["block"], c["Sk"] // c["block"]
+    g = torch.Generator().manual_seed(c["seed"] + 1000)
+    idx = torch.stack([torch.stack([torch.randperm(nk, generator=g) for _ in range(nq)]) for _ in range(c["H"])])
+    lens = torch.tensor([[0, 1, nk], [2, 0, 3]][:c["H"]], dtype=torch.int32)[:, :nq]
+    return idx, lens

@@ -45,3 +45,16 @@ def test_dit_twin_golden_regenerates(mg, tmp_path, golden_dir):
 def test_executed_vae_class_golden_regenerates(mg, tmp_path, golden_dir):
     mg.g_vae_akw(out_dir=str(tmp_path))
     _same(tmp_path / "g8b_vae_akw.npz", os.path.join(golden_dir, "g8b_vae_akw.npz"))
+
+
+def test_triton_sparse_attention_golden_regenerates(tmp_path, golden_dir):
+    """g18: the reference's Triton kernel through Triton's interpreter.  TRITON_INTERPRET must be in the environment before triton is
+    imported, so the recipe runs in its own process."""
+    import subprocess
+    code = (f"import sys; sys.argv = ['make_goldens.py', '__none__']; import importlib.util as u;"
+            f"s = u.spec_from_file_location('mg', {os.path.join(ROOT, 'tools', 'make_goldens.py')!r}); m = u.module_from_spec(s);"
+            f"s.loader.exec_module(m); m.g_bsa_triton(out_dir={str(tmp_path)!r})")
+    env = dict(os.environ, TRITON_INTERPRET="1", TORCHDYNAMO_DISABLE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    _same(tmp_path / "g18_bsa_triton.npz", os.path.join(golden_dir, "g18_bsa_triton.npz"))

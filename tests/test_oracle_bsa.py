@@ -54,3 +54,61 @@ def test_cdf_selection_equals_reference():
     a = obsa.sparse_attention(q, k, v, idx, 128, 128, 0.1, block_lens=torch.tensor([[1, 2]]))
     b = obsa.sparse_attention(q, k, v, torch.tensor([[[1], [0]]]), 128, 128, 0.1)
     assert torch.equal(a[:, :128], b[:, :128]) and not torch.equal(a[:, 128:], b[:, 128:])
+
+
+# ---- the reference's Triton kernel itself (g18: executed by Triton's interpreter on CPU tensors, tools/make_goldens.py bsa_triton) -------------
+G18 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g18_bsa_triton.npz"))
+
+
+def _g18_inputs(name):
+    from tests.fakes import bsa_triton_inputs
+    q, k, v = bsa_triton_inputs(name)
+    sums = np.array([q.double().sum().item(), k.double().sum().item(), v.double().sum().item()])
+    assert np.allclose(sums, G18[f"{name}_insum"], rtol=0, atol=1e-6), "seeded inputs drifted from the ones the fixture was recorded on"
+    return q, k, v
+
+
+def test_sparse_attention_equals_the_reference_triton_kernel():
+    """fp32 tensors: the restatement (masked dense softmax) == the kernel's online softmax over the selected blocks, to fp32 rounding."""
+    from tests.fakes import BSA_TRITON_CASES
+    for name in ("k128", "k64", "varlen"):
+        c = BSA_TRITON_CASES[name]
+        q, k, v = _g18_inputs(name)
+        idx = torch.from_numpy(G18[f"{name}_idx"])
+        lens = torch.from_numpy(G18[f"{name}_lens"]) if name == "varlen" else None
+        got = obsa.sparse_attention(q, k, v, idx, c["block"], c["block"], 128 ** -0.5, lens)[:, ::4]
+        assert np.abs(got.numpy() - G18[f"{name}_out"]).max() <= 2e-6, name
+        if name != "varlen":  # the selection the reference made == the oracle's own (pooling + scores + top-k)
+            own = obsa.select_topk(obsa.mean_pool(q, c["block"]), obsa.mean_pool(k, c["block"]), c["sparsity"])
+            assert np.array_equal(own.numpy(), G18[f"{name}_idx"]) and (G18[f"{name}_lens"] == own.shape[-1]).all()
+    # empty selections give exact zeros (acc = 0, l = 1 in the kernel), full-length rows the dense softmax
+    lens = G18["varlen_lens"]
+    out = G18["varlen_out"]
+    blk_rows = 128 // 4
+    for h in range(lens.shape[0]):
+        for b in range(lens.shape[1]):
+            if lens[h, b] == 0:
+                assert not out[h, b * blk_rows:(b + 1) * blk_rows].any()
+
+
+def test_half_tensors_round_p_before_the_value_product():
+    """fp16 tensors (flash_attn_bsa_varlen_mask.py:259 `p.to(v.dtype)`): with p rounded to fp16 before P V and the row sums taken from the
+    fp32 p the restatement lands within fp16 output rounding of the kernel; without the rounding it is measurably further away."""
+    from tests.fakes import BSA_TRITON_CASES
+    c = BSA_TRITON_CASES["half"]
+    q, k, v = _g18_inputs("half")
+    idx = torch.from_numpy(G18["half_idx"])
+    want = G18["half_out"]
+    got = obsa.sparse_attention(q, k, v, idx, c["block"], c["block"], 128 ** -0.5, p_dtype=torch.float16)[:, ::4].half().float().numpy()
+    plain = obsa.sparse_attention(q, k, v, idx, c["block"], c["block"], 128 ** -0.5)[:, ::4].numpy()
+    assert np.abs(got - want).max() <= 1.5e-3          # fp16 output spacing at |o| < 2 is 9.8e-4
+    assert np.abs(got - want).mean() <= np.abs(plain - want).mean() * 1.05
+
+
+def test_3d_block_interface_equals_reference():
+    """flash_attn_bsa_3d (bsa_interface.py:612-659): 3D-block permute -> gating -> top-k -> sparse kernel -> inverse permute."""
+    from tests.fakes import BSA_TRITON_CASES
+    c = BSA_TRITON_CASES["thw"]
+    q, k, v = _g18_inputs("thw")
+    got = obsa.flash_attn_bsa_3d(q, k, v, c["grid"], c["grid"], sparsity=c["sparsity"], chunk_q=c["chunk"], chunk_k=c["chunk"])[:, ::4]
+    assert np.abs(got.numpy() - G18["thw_out"]).max() <= 2e-6

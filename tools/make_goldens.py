@@ -7,6 +7,8 @@
                                            # i2v trajectories, run-time LoRA, refine-pass trajectories)
   TORCHDYNAMO_DISABLE=1 python tools/make_goldens.py bsa | bsa_cdf                          # g14, g14b (block-sparse gating helpers)
   python tools/make_goldens.py warp | warp_cams                                             # g16, g16b (stage-1 forward warp, cameras)
+  TRITON_INTERPRET=1 TORCHDYNAMO_DISABLE=1 python tools/make_goldens.py bsa_triton         # g18 (the reference's Triton sparse-attention
+                                           # kernel itself, executed on CPU tensors by Triton's interpreter)
 
 The reference is imported through tools/refshim (a stub `diffusers` with base classes only); its DiT / VAE / encoders
 are replaced by the deterministic fakes of tests/fakes.py, so the recorded trajectories pin the *sampler state machine*
@@ -689,6 +691,48 @@ def g_bsa_cdf():
 
 if __name__ == "__main__" and "bsa_cdf" in sys.argv[1:]:
     g_bsa_cdf()
+
+
+# ------------------------------------------------------------------------------------------------------------
+def g_bsa_triton(out_dir=OUT):
+    """G18: the reference's block-sparse attention forward -- its Triton kernels (_attn_fwd_bsa_varlen_align, flash_attn_bsa_varlen_mask.py:
+    174-285) launched by its own attn_fwd_bsa_varlen_triton / flash_attn_bsa / flash_attn_bsa_3d (bsa_interface.py:290-341, 535-560,
+    612-659), unmodified, on CPU tensors through Triton's interpreter (TRITON_INTERPRET=1 must be set BEFORE triton is imported:
+    @triton.jit then yields interpreted functions).  fp32 and fp16 tensors (the interpreter's bf16 path returns garbage).  Every 4th
+    output row is stored; inputs are regenerated from tests/fakes.bsa_triton_inputs, their sums are stored to catch generator drift."""
+    assert os.environ.get("TRITON_INTERPRET") == "1", "run with TRITON_INTERPRET=1 TORCHDYNAMO_DISABLE=1"
+    _longcat_paths()
+    from longcat_video.block_sparse_attention import bsa_interface as B
+    from tests.fakes import BSA_TRITON_CASES, bsa_triton_inputs, bsa_varlen_lists
+
+    out = {}
+    for name, c in BSA_TRITON_CASES.items():
+        q, k, v = (t.unsqueeze(0) for t in bsa_triton_inputs(name))
+        if c["dtype"] == "f16":
+            q, k, v = q.half(), k.half(), v.half()
+        blk, scale = c["block"], 128 ** -0.5
+        if name == "thw":
+            o = B.flash_attn_bsa_3d(q, k, v, c["grid"], c["grid"], sparsity=c["sparsity"], chunk_3d_shape_q=list(c["chunk"]),
+                                    chunk_3d_shape_k=list(c["chunk"]))
+        elif name == "varlen":
+            idx, lens = bsa_varlen_lists(name)
+            o, lse = B.attn_fwd_bsa_varlen_triton(q, k, v, scale, idx.unsqueeze(0), lens.unsqueeze(0), blk, blk, 0.5)
+            out[f"{name}_idx"], out[f"{name}_lens"] = idx.numpy(), lens.numpy()
+        else:
+            qc, kc = B.mean_pooling_compression(q, blk), B.mean_pooling_compression(k, blk)
+            idx, lens = B.get_select_indices(qc, kc, c["sparsity"], None)
+            o, lse = B.attn_fwd_bsa_varlen_triton(q, k, v, scale, idx, lens, blk, blk, c["sparsity"])
+            assert torch.equal(o, B.flash_attn_bsa(q, k, v, blk, blk, c["sparsity"], None, scale))  # the autograd entry is the same path
+            out[f"{name}_idx"], out[f"{name}_lens"] = idx[0].numpy(), lens[0].numpy()
+        assert torch.isfinite(o.float()).all()
+        out[f"{name}_out"] = o[0, :, ::4].float().numpy()
+        out[f"{name}_insum"] = np.array([q.double().sum().item(), k.double().sum().item(), v.double().sum().item()])
+    np.savez_compressed(os.path.join(out_dir, "g18_bsa_triton.npz"), **out)
+    print("g18", {k: v.shape for k, v in out.items() if k.endswith("_out")})
+
+
+if __name__ == "__main__" and "bsa_triton" in sys.argv[1:]:
+    g_bsa_triton()
 
 
 # ------------------------------------------------------------------------------------------------------------
