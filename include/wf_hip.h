@@ -327,6 +327,22 @@ size_t wf_crack_fill_workspace_bytes(int n, int H, int W);
 int wf_crack_fill(const void* img, const void* mask, const float* depth, void* out_img, void* out_mask, float* out_depth, int n, int H,
                   int W, int min_neighbors, int min_valid_neighbors, int num_segments, void* workspace, void* stream);
 
+/* ---- stage-1 of the dynamic-scene path: DepthCrafter point-cloud renderer (DepthCrafter/utils.py, warp_depthcrafter.py:255-288) ------- */
+/* project_points_to_image_pytorch (utils.py:103-171): pytorch3d PointsRasterizer(radius, points_per_pixel = 10) -> idx[..., 0] = the
+ * covering point of smallest view depth per pixel -> image = features[idx], mask = idx != -1 -> 5 x 5 opening of the mask (morph) ->
+ * image zeroed outside it.  points f32 [n][3] (world), features f32 [n][F], drop (NULL or u8 [n]: 1 = point removed by the edge filter);
+ * camera = 16 floats in pytorch3d's convention {R' (9, row-major, view = p R' + T'), T' (3), focal' (2), principal' (2)}, i.e. the result
+ * of _cameras_from_opencv_projection for the reference's (extrinsic, K, image size) -- computed by the host (worldforge_amd/warp.py).
+ * out_image f32 [H][W][F], out_mask u8 [H][W].  pytorch3d / OpenCV are absent from the reference tree: parity with them is unpinned. */
+size_t wf_points_render_workspace_bytes(int H, int W);
+int wf_points_render(const float* points, const float* features, const void* drop, int n, int F, const float* camera, int H, int W,
+                     float radius, int morph, float* out_image, void* out_mask, void* workspace, void* stream);
+/* filter_edge_points (utils.py:523-567): out_drop u8 [H][W] = dilate_{2 d + 1}(Sobel magnitude / its maximum > edge_threshold) |
+ * (max - min of the depth over the (2 r + 1)^2 window > jump_threshold); depth f32 [H][W].  d = edge_dilation, r = neighbor_radius. */
+size_t wf_depth_edge_mask_workspace_bytes(int H, int W);
+int wf_depth_edge_mask(const float* depth, int H, int W, double edge_threshold, int edge_dilation, float jump_threshold, int neighbor_radius,
+                       void* out_drop, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,3 +128,71 @@ def test_crack_fill_after_the_splat_of_a_camera_path():
     fi, fm, fd = warp.crack_fill(gi, gm, gd, min_valid_neighbors=2)
     want_m = np.stack([ocf.warp_frame_fill(wi[f], wm[f], wd[f], ocf.RUN_WARP_PARAMS)[1] for f in range(len(cams))])
     np.testing.assert_array_equal(fm.cpu().numpy(), want_m)
+
+
+# ---- DepthCrafter point-cloud renderer (wf_points_render / wf_depth_edge_mask) against oracle/pointrender.py (both unpinned: pytorch3d / cv2) ----
+def _pr_scene(H, W, seed=0):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    disp = (0.3 + 0.2 * np.sin(xx / 40.0) + 0.25 * (yy > H // 2) + 0.15 * ((xx // 64) % 2) + 0.02 * rng.random((H, W))).astype(np.float32)
+    depth = (1.0 / (disp + 0.1)).astype(np.float32)
+    rgb = rng.random((H, W, 3)).astype(np.float32)
+    K = np.array([[525, 0, W / 2], [0, 525, H / 2], [0, 0, 1]], dtype=np.float32)
+    return rgb, depth, K
+
+
+def test_depth_edge_mask_equals_oracle():
+    import numpy as np
+    from oracle import pointrender as opr
+    from worldforge_amd import warp
+    for H, W in ((320, 512), (97, 131), (576, 1024)):
+        _, depth, _ = _pr_scene(H, W, seed=H)
+        got = warp.depth_edge_mask(torch.from_numpy(depth).to(DEV)).cpu().numpy().astype(bool)
+        want = opr.edge_filter_mask(depth)
+        assert (got != want).mean() <= 1e-5, (H, W, (got != want).sum())   # (a magnitude within an ulp of the threshold may fall either way)
+    flat = torch.full((32, 48), 2.0, device=DEV)
+    assert not warp.depth_edge_mask(flat).any()
+
+
+@pytest.mark.parametrize("H,W,move,edge", [(320, 512, 0.0, False), (320, 512, 0.08, True), (576, 1024, -0.05, True), (400, 400, 0.03, False),
+                                           (512, 320, 0.04, True)])
+def test_points_render_equals_oracle(H, W, move, edge):
+    """Same float32 projection sequence on both sides: the nearest-point index per pixel -- hence image and mask -- must agree except where a
+    point sits within float rounding of the disc edge (bounded at 1e-4 of the pixels)."""
+    import numpy as np
+    from oracle import pointrender as opr
+    from worldforge_amd import warp
+    rgb, depth, K = _pr_scene(H, W, seed=3)
+    cam = np.eye(4)
+    cam[0, 3] = move
+    cam[1, 3] = -move / 2
+    th = 0.03 if move else 0.0
+    cam[:3, :3] = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    img, mask = warp.render_depthcrafter_frame(torch.from_numpy(rgb).to(DEV), torch.from_numpy(depth).to(DEV), cam, K, edge_filter=edge)
+    wimg, wmask = opr.render_frame(rgb, depth, cam, K, edge)
+    img, mask = img.cpu().numpy(), mask.cpu().numpy()
+    assert mask.shape == wmask.shape == (H, W, 1) and img.shape == (H, W, 3)
+    assert (mask != wmask).mean() <= 1e-4
+    same = (mask == wmask)[..., 0]
+    assert (np.abs(img - wimg).max(-1)[same] > 0).mean() <= 1e-4
+    assert not img[mask[..., 0] == 0].any()
+    if move:
+        assert 0.3 < mask.mean() < 1.0
+
+
+def test_points_render_without_opening_and_with_dropped_points():
+    import numpy as np
+    from oracle import pointrender as opr
+    from worldforge_amd import warp
+    H, W = 320, 480
+    rgb, depth, K = _pr_scene(H, W, seed=9)
+    pts = opr.unproject(depth, K)
+    drop = (np.random.default_rng(1).random(H * W) < 0.3)
+    cam = np.eye(4)
+    cam[0, 3] = 0.02
+    img, mask = warp.points_render(torch.from_numpy(pts).to(DEV), torch.from_numpy(rgb.reshape(-1, 3)).to(DEV), cam, K, (H, W), morph=False,
+                                   drop=torch.from_numpy(drop.astype(np.uint8)).to(DEV))
+    wimg, wmask = opr.project_points_to_image(pts[~drop], rgb.reshape(-1, 3)[~drop], cam, K, (H, W), morph=False)
+    assert (mask.cpu().numpy() != wmask).mean() <= 1e-4
+    assert (np.abs(img.cpu().numpy() - wimg).max(-1) > 0).mean() <= 2e-4

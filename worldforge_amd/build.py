@@ -38,6 +38,7 @@ SOURCES = {
     "conv.hip": [],
     "warp.hip": ["-ffp-contract=off"],
     "crackfill.hip": ["-ffp-contract=off"],
+    "pointrender.hip": ["-ffp-contract=off"],
 }
 
 

@@ -132,3 +132,66 @@ def crack_fill(images: torch.Tensor, masks: torch.Tensor, depths: torch.Tensor, 
     if bool(few.any()):  # once per camera path, outside any loop
         oi[few], om[few], od[few] = images[few], masks[few], depths[few]
     return oi, om, od
+
+
+# ---- dynamic scenes: the DepthCrafter warper's per-frame point-cloud render (DepthCrafter/warp_depthcrafter.py:255-288) ------------------
+def pytorch3d_camera(extrinsic, K, size_hw) -> np.ndarray:
+    """The 16 floats wf_points_render takes: pytorch3d's view of the reference's (extrinsic, K, image size), i.e. what
+    pytorch3d.utils.camera_conversions._cameras_from_opencv_projection builds at DepthCrafter/utils.py:119-124 -- R' = R^T with its first two
+    columns negated, T' = (-tx, -ty, tz), focal / s, -(principal - (W, H) / 2) / s with s = min(W, H) / 2, all float32."""
+    H, W = int(size_hw[0]), int(size_hw[1])
+    E = np.asarray(extrinsic, dtype=np.float64)
+    R, t = E[:3, :3].astype(np.float32), E[:3, 3].astype(np.float32)
+    Kf = np.asarray(K, dtype=np.float32)
+    s = np.float32(min(W, H)) / np.float32(2.0)
+    Rp = R.T.copy()
+    Rp[:, :2] *= np.float32(-1)
+    Tp = t.copy()
+    Tp[:2] *= np.float32(-1)
+    focal = np.array([Kf[0, 0], Kf[1, 1]], dtype=np.float32) / s
+    p0 = -(np.array([Kf[0, 2], Kf[1, 2]], dtype=np.float32) - np.array([W, H], dtype=np.float32) / np.float32(2.0)) / s
+    return np.concatenate([Rp.reshape(-1), Tp, focal, p0]).astype(np.float32)
+
+
+def depth_edge_mask(depth: torch.Tensor, edge_threshold: float = 0.1, edge_dilation: int = 3, depth_jump_threshold: float = 0.3,
+                    neighbor_check_radius: int = 2) -> torch.Tensor:
+    """filter_edge_points (DepthCrafter/utils.py:523-567): depth f32 [H, W] (device) -> u8 [H, W], 1 = the pixel's point is dropped."""
+    from ._ffi import lib
+    H, W = depth.shape
+    depth = depth.to(torch.float32).contiguous()
+    ws = torch.empty(int(lib().wf_depth_edge_mask_workspace_bytes(H, W)), dtype=torch.uint8, device=depth.device)
+    out = torch.empty((H, W), dtype=torch.uint8, device=depth.device)
+    call("wf_depth_edge_mask", depth.data_ptr(), H, W, float(edge_threshold), int(edge_dilation), float(depth_jump_threshold),
+         int(neighbor_check_radius), out.data_ptr(), ws.data_ptr(), ops.stream())
+    return out
+
+
+def points_render(points: torch.Tensor, features: torch.Tensor, extrinsic, K, size_hw, morph: bool = True, radius: float = 0.005,
+                  drop: torch.Tensor = None):
+    """project_points_to_image_pytorch (DepthCrafter/utils.py:103-171): points f32 [n, 3], features f32 [n, F] (device), extrinsic 4x4 and K
+    3x3 (host), -> (image f32 [H, W, F], mask u8 [H, W, 1]) on the device.  drop: u8 [n], 1 = point removed beforehand (edge filter)."""
+    from ._ffi import lib
+    H, W = int(size_hw[0]), int(size_hw[1])
+    points, features = points.to(torch.float32).contiguous(), features.to(torch.float32).contiguous()
+    n, F = features.shape
+    assert tuple(points.shape) == (n, 3)
+    cam = pytorch3d_camera(extrinsic, K, (H, W))
+    ws = torch.empty(int(lib().wf_points_render_workspace_bytes(H, W)), dtype=torch.uint8, device=points.device)
+    img = torch.empty((H, W, F), dtype=torch.float32, device=points.device)
+    mask = torch.empty((H, W), dtype=torch.uint8, device=points.device)
+    call("wf_points_render", points.data_ptr(), features.data_ptr(), drop.contiguous().data_ptr() if drop is not None else None, n, F,
+         cam.ctypes.data, H, W, float(radius), 1 if morph else 0, img.data_ptr(), mask.data_ptr(), ws.data_ptr(), ops.stream())
+    return img, mask.unsqueeze(-1)
+
+
+def render_depthcrafter_frame(rgb: torch.Tensor, depth_frame: torch.Tensor, cam, K, edge_filter: bool = True, **edge_kw):
+    """One iteration of warp_depthcrafter.py:255-288: rgb f32 [H, W, 3] in [0, 1], depth_frame f32 [H, W] (= 1 / (disparity + 0.1)),
+    cam 4x4, K 3x3 -> (rendered image f32 [H, W, 3], mask u8 [H, W, 1]); the reference skips the edge filter for frame 0."""
+    H, W = depth_frame.shape
+    Kf = np.asarray(K, dtype=np.float32)
+    d = depth_frame.to(torch.float32)
+    ii = torch.arange(H, device=d.device, dtype=torch.float32).view(H, 1)
+    jj = torch.arange(W, device=d.device, dtype=torch.float32).view(1, W)
+    pts = torch.stack(((jj - float(Kf[0, 2])) * d / float(Kf[0, 0]), (ii - float(Kf[1, 2])) * d / float(Kf[1, 1]), d), dim=-1).reshape(-1, 3)
+    drop = depth_edge_mask(d, **edge_kw).reshape(-1) if edge_filter else None
+    return points_render(pts, rgb.reshape(-1, 3), cam, K, (H, W), morph=True, drop=drop)
