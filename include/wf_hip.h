@@ -217,9 +217,10 @@ int wf_lc_gate_residual(void* x, const void* y, int64_t ldy, const float* gate, 
                         const int* group_index, int L, int C, void* stream);
 /* RMSNorm_FP32 over each head's 128 channels (LCB:40-52 as used at LCA:111 and LCA:231) + optional interleaved 3D RoPE
  * (LCR:32-36, 101-120; cos/sin tables [L][64] f32 per rotation pair, NULL -> none), written head-major for wf_attn_fwd:
- * in bf16 [L, ld] (head h at columns h*128) -> out bf16 [H][Lout][128] (rows L..Lout untouched); weight f32 [128]. */
+ * in bf16 [L, ld] (head h at columns h*128) -> out bf16 [H][Lout][128] (rows L..Lout untouched); weight f32 [128].  out_scale multiplies the
+ * result in front of its one bf16 rounding (1 = none; softmax_scale * log2(e) for the queries of wf_attn_fwd's softmax_scale = 0 form). */
 int wf_lc_norm_heads(const void* in, int64_t ld, const float* weight, const float* cos_tab, const float* sin_tab, void* out, int L,
-                     int Lout, int H, float eps, void* stream);
+                     int Lout, int H, float eps, float out_scale, void* stream);
 /* FeedForwardSwiGLU gate (LCB:36-37): in bf16 [L, ld] with w1 x in columns [0, Hd) and w3 x in [Hd, 2 Hd) ->
  * out bf16 [L, Hd] = silu(w1 x) * w3 x. */
 int wf_lc_swiglu(const void* in, int64_t ld, void* out, int L, int Hd, void* stream);

@@ -88,7 +88,14 @@ def test_norm_heads(L, H, rope):
     view = sd[:Lr, C:2 * C]
     wd_, cd, sn = w.to(DEV), cos.to(DEV), sin.to(DEV)  # held: a temporary would be freed before the kernel reads it
     call("wf_lc_norm_heads", view.data_ptr(), sd.stride(0), wd_.data_ptr(), cd.data_ptr() if rope else None,
-         sn.data_ptr() if rope else None, out.data_ptr(), Lr, Lr + 3, H, 1e-6, ops.stream())
+         sn.data_ptr() if rope else None, out.data_ptr(), Lr, Lr + 3, H, 1e-6, 1.0, ops.stream())
+    # out_scale folds the attention's softmax_scale * log2(e) in front of the one rounding: == bf16(scale * unrounded result) to 1 ulp
+    sc = 1.4426950408889634 / 128 ** 0.5
+    out_s = torch.zeros((H, Lr + 3, 128), dtype=BF, device=DEV)
+    call("wf_lc_norm_heads", view.data_ptr(), sd.stride(0), wd_.data_ptr(), cd.data_ptr() if rope else None,
+         sn.data_ptr() if rope else None, out_s.data_ptr(), Lr, Lr + 3, H, 1e-6, sc, ops.stream())
+    ref_s = out[:, :Lr].float().cpu() * sc
+    assert ((out_s[:, :Lr].float().cpu() - ref_s).abs() <= 2 ** -7 * ref_s.abs() + 1e-30).all()   # two bf16 roundings apart at most
     q = src[:Lr, C:2 * C].view(Lr, H, 128).permute(1, 0, 2)  # [H, L, D] bf16
     want = olc.rms_norm_head(q, w.to(BF))
     if rope:

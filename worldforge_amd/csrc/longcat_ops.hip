@@ -121,7 +121,7 @@ __global__ void k_lc_gate_resid(uint16_t* __restrict__ x, const uint16_t* __rest
 // y = bf16(bf16(x * rsqrt(mean(x^2) + eps)) * w); RoPE on pairs (2p, 2p+1) with angle table entries cos/sin[row][p] in fp32 -> bf16.
 __global__ __launch_bounds__(256) void k_lc_heads(const uint16_t* __restrict__ in, long ld, const float* __restrict__ w,
                                                   const float* __restrict__ cs, const float* __restrict__ sn,
-                                                  uint16_t* __restrict__ out, int L, int Lout, int H, float eps) {
+                                                  uint16_t* __restrict__ out, int L, int Lout, int H, float eps, float out_scale) {
   const int row = blockIdx.x;
   const int head = blockIdx.y * 16 + (threadIdx.x >> 4), within = threadIdx.x & 15;
   if (head >= H) return;
@@ -148,6 +148,10 @@ __global__ __launch_bounds__(256) void k_lc_heads(const uint16_t* __restrict__ i
       y[2 * k] = re;
       y[2 * k + 1] = im;
     }
+  }
+  if (out_scale != 1.0f) {  // pre-scaled Q for the attention kernel's exp2-domain form (wf_attn_fwd softmax_scale = 0): folded in front of the one rounding
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y[k] *= out_scale;
   }
   *reinterpret_cast<u32x4*>(out + ((size_t)head * Lout + row) * 128 + within * 8) = pack8(y);
 }
@@ -385,7 +389,7 @@ extern "C" int wf_lc_gate_residual(void* x, const void* y, int64_t ldy, const fl
 }
 
 extern "C" int wf_lc_norm_heads(const void* in, int64_t ld, const float* weight, const float* cos_tab, const float* sin_tab, void* out,
-                                int L, int Lout, int H, float eps, void* stream) {
+                                int L, int Lout, int H, float eps, float out_scale, void* stream) {
   WF_CHECK_ARG(in && weight && out, "wf_lc_norm_heads: null pointer");
   WF_CHECK_ARG(H > 0 && ld % 8 == 0 && Lout >= L, "wf_lc_norm_heads: H > 0, ld %% 8 == 0, Lout >= L");
   WF_CHECK_ARG((cos_tab == nullptr) == (sin_tab == nullptr), "wf_lc_norm_heads: cos/sin must both be given or both null");
@@ -393,7 +397,7 @@ extern "C" int wf_lc_norm_heads(const void* in, int64_t ld, const float* weight,
                "wf_lc_norm_heads: 16-byte alignment");
   if (L == 0) return WF_OK;
   hipLaunchKernelGGL(k_lc_heads, dim3(L, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in, ld, weight, cos_tab,
-                     sin_tab, (uint16_t*)out, L, Lout, H, eps);
+                     sin_tab, (uint16_t*)out, L, Lout, H, eps, out_scale);
   WF_LAUNCH_CHECK("wf_lc_norm_heads");
   return WF_OK;
 }

@@ -28,7 +28,7 @@ import torch
 
 from . import ops
 from ._ffi import WF_BF16, WF_F32, call
-from .dit import EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_F32_ACC, _pad64, attention, gemm
+from .dit import EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_F32_ACC, _pad64, attention, gemm, head_max_norm2
 
 
 @dataclass
@@ -253,14 +253,14 @@ class LongCatVideoTransformer3DModel:
         call("wf_lc_gate_residual", x.data_ptr(), y.data_ptr(), y.stride(0), gate.data_ptr() if gate is not None else None, gate_ld,
              rows_per_group, row0, gidx.data_ptr() if gidx is not None and gate is not None else None, L, C, ops.stream())
 
-    def _heads(self, src, col0, weight, cos, sin, out, r0, r1):
+    def _heads(self, src, col0, weight, cos, sin, out, r0, r1, out_scale=1.0):
         """Rows [r0, r1) of columns [col0, col0 + C) of src -> out [H, Lout, 128] rows [0, r1 - r0)."""
         if r1 <= r0:
             return
         view = src[r0:r1, col0:col0 + self.cfg.hidden_size]
         call("wf_lc_norm_heads", view.data_ptr(), src.stride(0), weight.data_ptr(),
              cos[r0:r1].data_ptr() if cos is not None else None, sin[r0:r1].data_ptr() if sin is not None else None,
-             out.data_ptr(), r1 - r0, out.shape[1], self.cfg.num_heads, float(self.cfg.eps), ops.stream())
+             out.data_ptr(), r1 - r0, out.shape[1], self.cfg.num_heads, float(self.cfg.eps), float(out_scale), ops.stream())
 
     def _vt(self, src, col0, out, L):
         view = src[:, col0:col0 + self.cfg.hidden_size]
@@ -371,9 +371,18 @@ class LongCatVideoTransformer3DModel:
         qh_n = _buf("qh_n", (H, max(L - nc, 1), 128), bf)  # (a rank of a sequence-parallel job may hold condition rows only)
         kh = _buf("kh", (H, Sp, 128), bf, zero=True)
         vt = _buf("vt", (H, Sp // 64, 128, 64), bf)
+        # dense self-attention (no block gating on Q): as in the Wan DiT (dit.py), softmax_scale * log2(e) is folded into Q by its producer and
+        # the kernel runs its exp2-domain form (softmax_scale = 0), without max tracking where the per-head norm bound allows it.  The
+        # block-sparse pass keeps the in-kernel scale: its Q also feeds the gating.  WF_ATTN_PRESCALE=0 / WF_ATTN_TRACK_MAX=1 as in dit.py.
+        prescale = (not use_bsa) and os.environ.get("WF_ATTN_PRESCALE", "1") != "0" and os.environ.get("WF_ATTN_KERNEL", "") != "w8"
+        q_scale, sa_scale = (scale * 1.4426950408889634, 0.0) if prescale else (1.0, scale)
+        km = _buf("kmax2", (H,), f32) if prescale and os.environ.get("WF_ATTN_TRACK_MAX", "0") != "1" else None
+        qm_c = _buf("qmax2_c", (H,), f32) if km is not None else None
+        qm_n = _buf("qmax2_n", (H,), f32) if km is not None else None
         if comm is not None:
             kh_all = _buf("kh_all", (comm.world, H, Sp, 128), bf)
             vt_all = _buf("vt_all", (comm.world, H, Sp // 64, 128, 64), bf)
+            km_all = _buf("kmax2_all", (comm.world, H), f32) if km is not None else None
         ao = _buf("ao", (L, C), bf)
         ys = _buf("ys", (L, C), bf)
         qc = _buf("qc", (L, C), bf)
@@ -436,21 +445,29 @@ class LongCatVideoTransformer3DModel:
                         picked.append(idx if lens is None else (idx, lens))
                 self.last_bsa_indices.append(picked)
             else:
-                self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_c, 0, nc)
-                self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_n, nc, L)
+                self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_c, 0, nc, out_scale=q_scale)
+                self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_n, nc, L, out_scale=q_scale)
                 self._heads(qkv, C, W[p + "attn.k_norm"], cos, sin, kh, 0, L)
                 self._vt(qkv, 2 * C, vt, L)
-                kk, vv = kh, vt
+                kk, vv, kmx = kh, vt, km
+                if km is not None:  # zero rows past L do not raise a maximum: the whole (padded) shard is scanned
+                    head_max_norm2(kh, Sp, km)
                 if comm is not None:
                     evs = (comm.all_gather_async(kh_all, kh), comm.all_gather_async(vt_all, vt))
+                    if km is not None:
+                        evs = evs + (comm.all_gather_async(km_all, km),)
                     for ev in evs:
                         if ev is not None:
                             torch.cuda.current_stream().wait_event(ev)
-                    kk, vv = kh_all, vt_all
+                    kk, vv, kmx = kh_all, vt_all, (km_all if km is not None else None)
                 if nc > 0:
-                    attention(qh_c, kk, vv, ao[:nc], nc_all, scale)  # condition tokens see condition tokens only (LCA:127-131)
+                    if km is not None:
+                        head_max_norm2(qh_c, nc, qm_c)
+                    attention(qh_c, kk, vv, ao[:nc], nc_all, sa_scale, kmax2=kmx, qmax2=qm_c)  # condition tokens see condition tokens only (LCA:127-131)
                 if L - nc > 0:
-                    attention(qh_n, kk, vv, ao[nc:], L_all, scale, profile=True)  # noise tokens see everything (LCA:133-134)
+                    if km is not None:
+                        head_max_norm2(qh_n, L - nc, qm_n)
+                    attention(qh_n, kk, vv, ao[nc:], L_all, sa_scale, profile=True, kmax2=kmx, qmax2=qm_n)  # noise tokens see everything (LCA:133-134)
             gemm(ao, W[p + "attn.proj.w"], W[p + "attn.proj.b"], ys, EPI_BF16)
             self._resid(x, ys, gate_msa, ald, tpf, row0=lo, gidx=gidx)
             # ---- cross-attention on the noise tokens (LCD:108-111, LCA:218-276) ----
