@@ -267,6 +267,13 @@ int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, void* O, int H
 int wf_conv3d_cl(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_bf16, int Ti,
                  int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st, int ss, int pt, int ph,
                  int pw, int up2, int tsplit, const void* zero_page, void* stream);
+/* wf_conv3d_cl whose output pixel (t, y, x) of the [To, Ho, Wo] grid lands at pixel (t, sy * y + oy, sx * x + ox) of a [To, out_H, out_W]
+ * tensor (resid, if given, is read at the same place).  Lets the nearest-2x upsample + 3 x 3 convolution of Resample (vae.py:76-86) run as
+ * its four phases: output (2 y + py, 2 x + px) only ever sees source rows {y - 1 + py, y + py} and columns {x - 1 + px, x + px}, with the
+ * 3 x 3 taps that fall on the same source pixel summed beforehand -- 2 x 2 convolutions on the source grid, 4 / 9 of the multiply-adds. */
+int wf_conv3d_cl_scatter(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_bf16, int Ti, int Hi,
+                         int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st, int ss, int pt, int ph, int pw,
+                         const void* zero_page, int out_H, int out_W, int sy, int oy, int sx, int ox, void* stream);
 /* The FLOP-heavy layers (3x3x3, stride 1, causal: every ResidualBlock conv, vae.py:186-220) with the input patch resident in LDS:
  * an 8 x 64 pixel tile of one output frame x 96 output channels per workgroup, all 27 taps read the (3 x 10 x 66)-pixel patch of a
  * 16-channel slice from LDS.  Weights in the re-packed layout [27][Cin/16][Cout][16] produced by wf_conv3d_pack333 from

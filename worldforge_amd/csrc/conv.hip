@@ -48,7 +48,17 @@ struct ConvArgs {
   int up2;         // read input through nearest 2x spatial upsample
   int tsplit;      // Resample 'upsample3d' (vae.py:134-137): channel half h of output frame t goes to frame 1 + 2*t + h
   int silu_out;    // unused (reserved)
+  // output scatter (osy == 0: none): output pixel (t, y, x) of the [To, Ho, Wo] grid is written to pixel (t, osy * y + ooy, osx * x + oox)
+  // of a [To, oH, oW] tensor -- the four phases of a nearest-2x-upsample + 3 x 3 convolution are 2 x 2 convolutions on the source grid
+  int osy, ooy, osx, oox, oH, oW;
 };
+__device__ __forceinline__ size_t out_pixel(const ConvArgs& a, long m) {
+  if (a.osy == 0) return (size_t)m;
+  const long hw = (long)a.Ho * a.Wo;
+  const long t = m / hw, pix = m - t * hw;
+  const int y = (int)(pix / a.Wo), x = (int)(pix - (long)y * a.Wo);
+  return ((size_t)t * a.oH + (size_t)(a.osy * y + a.ooy)) * a.oW + (size_t)(a.osx * x + a.oox);
+}
 
 __global__ __launch_bounds__(CNT, 2) void k_conv(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -199,7 +209,7 @@ __global__ __launch_bounds__(CNT, 2) void k_conv(ConvArgs a) {
           const int half = co >= chalf ? 1 : 0;
           o = ((size_t)(1 + 2 * t + half) * hw + pix) * chalf + (co - half * chalf);
         } else {
-          o = (size_t)m * a.Cout + co;
+          o = out_pixel(a, m) * a.Cout + co;
         }
         if (a.resid) {
           const f32x4 rr = *reinterpret_cast<const f32x4*>(a.resid + o);
@@ -482,7 +492,7 @@ __global__ __launch_bounds__(QT, 2) void k_conv_pp(ConvPPArgs pa) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] += bb[q];
         }
-        const size_t o = (size_t)m * a.Cout + co;
+        const size_t o = out_pixel(a, m) * a.Cout + co;
         if (a.resid) {
           const f32x4 rr = *reinterpret_cast<const f32x4*>(a.resid + o);
 #pragma unroll
@@ -866,9 +876,9 @@ __global__ void k_conv_small(SmallConvArgs a) {
 
 }  // namespace
 
-extern "C" int wf_conv3d_cl(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_bf16,
-                            int Ti, int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st,
-                            int ss, int pt, int ph, int pw, int up2, int tsplit, const void* zero_page, void* stream) {
+static int conv3d_cl_impl(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_bf16,
+                          int Ti, int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st,
+                          int ss, int pt, int ph, int pw, int up2, int tsplit, const void* zero_page, const int* scatter, void* stream) {
   WF_CHECK_ARG(in && w && (out_f32 || out_bf16), "wf_conv3d_cl: null pointer");
   WF_CHECK_ARG(Cin % CBK == 0, "wf_conv3d_cl: Cin (%d) must be a multiple of 32 (use wf_conv3d_small otherwise)", Cin);
   WF_CHECK_ARG(Cout % 4 == 0, "wf_conv3d_cl: Cout (%d) must be a multiple of 4", Cout);
@@ -888,6 +898,13 @@ extern "C" int wf_conv3d_cl(const void* in, const void* w, const float* bias, co
   a.kt = kt; a.kh = kh; a.kw = kw;
   a.st = st; a.ss = ss; a.pt = pt; a.ph = ph; a.pw = pw;
   a.up2 = up2; a.tsplit = tsplit; a.silu_out = 0;
+  a.osy = a.ooy = a.osx = a.oox = a.oH = a.oW = 0;
+  if (scatter) {  // {out_H, out_W, sy, oy, sx, ox}
+    WF_CHECK_ARG(!tsplit && scatter[2] >= 1 && scatter[4] >= 1 && scatter[3] >= 0 && scatter[5] >= 0 &&
+                     scatter[2] * (Ho - 1) + scatter[3] < scatter[0] && scatter[4] * (Wo - 1) + scatter[5] < scatter[1],
+                 "wf_conv3d_cl_scatter: the scattered grid does not fit the output tensor");
+    a.oH = scatter[0]; a.oW = scatter[1]; a.osy = scatter[2]; a.ooy = scatter[3]; a.osx = scatter[4]; a.oox = scatter[5];
+  }
   // stride-1, no upsample / frame interleave, big enough to fill the chip: the 512-pixel ping-pong kernel (needs a zero page
   // for the out-of-range taps of its DMA gather and chunk-granular 32-bit offsets)
   static const bool no_pp = getenv("WF_CONV_NO_PP") != nullptr;
@@ -906,6 +923,22 @@ extern "C" int wf_conv3d_cl(const void* in, const void* w, const float* bias, co
   hipLaunchKernelGGL(k_conv, grid, dim3(CNT), 2 * CBUF, (hipStream_t)stream, a);
   WF_LAUNCH_CHECK("wf_conv3d_cl");
   return WF_OK;
+}
+
+extern "C" int wf_conv3d_cl(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_bf16,
+                            int Ti, int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st,
+                            int ss, int pt, int ph, int pw, int up2, int tsplit, const void* zero_page, void* stream) {
+  return conv3d_cl_impl(in, w, bias, resid, out_f32, out_bf16, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, kt, kh, kw, st, ss, pt, ph, pw, up2, tsplit,
+                        zero_page, nullptr, stream);
+}
+
+extern "C" int wf_conv3d_cl_scatter(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_bf16,
+                                    int Ti, int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st,
+                                    int ss, int pt, int ph, int pw, const void* zero_page, int out_H, int out_W, int sy, int oy, int sx,
+                                    int ox, void* stream) {
+  const int scatter[6] = {out_H, out_W, sy, oy, sx, ox};
+  return conv3d_cl_impl(in, w, bias, resid, out_f32, out_bf16, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, kt, kh, kw, st, ss, pt, ph, pw, 0, 0,
+                        zero_page, scatter, stream);
 }
 
 extern "C" int wf_conv3d_small(const void* in, int in_dtype, const float* w, const float* bias, float* out_f32, void* out_bf16,
@@ -967,6 +1000,7 @@ extern "C" int wf_conv3d_333(const void* in, const void* w_packed, const float* 
   a.kt = a.kh = a.kw = 3;
   a.st = a.ss = 1; a.pt = 2; a.ph = ph; a.pw = 1;
   a.up2 = a.tsplit = a.silu_out = 0;
+  a.osy = a.ooy = a.osx = a.oox = a.oH = a.oW = 0;
   wa.zeros = (const uint16_t*)zero_page;
   wa.tiles_x = (Wi + WX - 1) / WX;
   wa.tiles_y = (Ho + WY - 1) / WY;

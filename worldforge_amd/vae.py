@@ -247,6 +247,21 @@ class AutoencoderKLWan:
         def gamma(p):
             W[p] = sd[p].reshape(-1).to(device=dev, dtype=F32).contiguous()
 
+        def up_phases(p):
+            """Nearest-2x upsample + 3 x 3 conv (vae.py:76-86) as four 2 x 2 convolutions on the source grid: output (2y + py, 2x + px) reads
+            source rows {y - 1 + py, y + py}; the 3 x 3 taps landing on the same source pixel are summed here, in fp32, before the operand
+            split -- 4 / 9 of the multiply-adds, same result up to fp32 re-association."""
+            w = sd[p + ".weight"].to(F32)
+            if w.dim() == 5:
+                w = w[:, :, 0]
+            groups = (([0], [1, 2]), ([0, 1], [2]))  # [phase][source offset] -> the 3-tap indices that read it
+            for py in range(2):
+                for px in range(2):
+                    wp = torch.stack([torch.stack([sum(w[:, :, dy, dx] for dy in groups[py][a] for dx in groups[px][b]) for b in range(2)], dim=-1)
+                                      for a in range(2)], dim=-2)  # [Cout, Cin, 2, 2]
+                    W[f"{p}.ph{py}{px}.w"] = operand(wp.permute(0, 2, 3, 1).reshape(wp.shape[0], 4, wp.shape[1]))
+
+        first_up = True
         for plan in (encoder_plan(), decoder_plan()):
             for kind, p, cin, cout in plan:
                 if kind == "conv_in":
@@ -264,6 +279,12 @@ class AutoencoderKLWan:
                     lin(p + ".proj")
                 elif kind in ("down2d", "down3d", "up2d", "up3d"):
                     mfma_conv(p + ".resample.1")
+                    if kind.startswith("up"):
+                        # every upsampling conv but the first (small, and its row slabs of the sharded decoder may start on an odd row) runs
+                        # as four phase convolutions; WF_VAE_UP2_PHASES=0 keeps the gathered 3 x 3 form everywhere
+                        if not first_up and os.environ.get("WF_VAE_UP2_PHASES", "1") != "0":
+                            up_phases(p + ".resample.1")
+                        first_up = False
                     if kind.endswith("3d"):
                         mfma_conv(p + ".time_conv")
                 elif kind == "head":
@@ -531,7 +552,25 @@ class AutoencoderKLWan:
         T, H, Wd, _ = x.shape
         xb = self._time_up(self._operand(x), p, C) if temporal else self._operand(x)
         Tn = xb.shape[0]
+        if p + ".resample.1.ph00.w" in self.w:
+            return self._up_phases(xb, p + ".resample.1", Tn, H, 2 * H, 0, C // 2)
         out, _ = self._conv(xb, p + ".resample.1", Tn, 2 * H, 2 * Wd, C // 2, (1, 3, 3), ps=1, up2=True)
+        return out
+
+    def _up_phases(self, xb, p, T, n_rows, out_rows, row_off, Cout):
+        """The four phase convolutions of an upsampling conv.  xb [T, Hs, W, Cin] bf16: the whole image (Hs = n_rows, row_off = 0) or a row
+        slab whose first row is source row s0 while the first output row belongs to source row y0 / 2 (row_off = s0 - y0 / 2 <= 0: halo rows
+        above).  Writes out [T, out_rows, 2W, Cout] fp32: phase (py, px) computes n_rows x W outputs from source rows {y - 1 + py, y + py}
+        (top padding 1 - py + row_off) and scatters them to rows 2 j + py, columns 2 x + px."""
+        _, Hs, Wd, Cin = xb.shape
+        out = torch.empty((T, out_rows, 2 * Wd, Cout), dtype=F32, device=xb.device)
+        W = self.w
+        for py in range(2):
+            for px in range(2):
+                call("wf_conv3d_cl_scatter", xb.data_ptr(), W[f"{p}.ph{py}{px}.w"].data_ptr(), W[p + ".b"].data_ptr(), None, out.data_ptr(), None,
+                     T, Hs, Wd, Cin, T, n_rows, Wd, Cout, 1, 2, 2, 1, 1, 0, 1 - py + row_off, 1 - px, self._zero_page().data_ptr(),
+                     out_rows, 2 * Wd, 2, py, 2, px, ops.stream())
+        self.flops_last += 4 * 2 * T * n_rows * Wd * Cout * 4 * Cin
         return out
 
     def _run(self, x, plan):
@@ -648,6 +687,11 @@ class AutoencoderKLWan:
             if s0 + xsrc_b.shape[1] > h_src:
                 xsrc_b[:, -1].zero_()
         T, _, Wd, _ = xsrc_b.shape
+        if p + ".resample.1.ph00.w" in self.w:
+            # output rows y0 .. y0 + Ho (both even here): phase py computes source rows y0/2 .. y0/2 + Ho/2, reading slab rows
+            # (y + a - 1 + py) - s0 for its two taps a: the slab starts y0/2 - s0 rows above the first of them
+            assert y0 % 2 == 0 and Ho % 2 == 0
+            return self._up_phases(xsrc_b, p + ".resample.1", T, Ho // 2, Ho, s0 - y0 // 2, C // 2)
         out, _ = self._conv(xsrc_b, p + ".resample.1", T, Ho, 2 * Wd, C // 2, (1, 3, 3), ps=1, ph=1 + 2 * s0 - y0, up2=True)
         return out
 
