@@ -344,3 +344,25 @@ def test_product_selection_and_sparse_attention_equal_reference_path():
             got = out.float().cpu().view(c["Sq"], c["H"], 128).permute(1, 0, 2)[:, ::4].numpy()
             want = G[f"{name}_out"]
             assert abs(got - want).max() <= 1e-2 * abs(want).max(), name
+
+
+@pytest.mark.parametrize("Hh,nq,nk,sparsity,block", [(2, 3, 1, 0.0, 128), (1, 4, 9, 0.0, 64), (2, 2, 2048, 0.99, 128)])
+def test_fused_topk_edge_shapes(Hh, nq, nk, sparsity, block):
+    """One key block, every block selected (n_sel = n_k), the LDS limit of 2048 key blocks; and the refusals."""
+    from worldforge_amd import bsa
+    g = torch.Generator().manual_seed(nk)
+    sc = torch.randn(Hh, nq, nk, generator=g).to(BF).to(DEV)
+    lists, counts, mx, sel = bsa.topk_lists(sc, sparsity, block)
+    idx = bsa.select_topk(sc, sparsity)
+    wl, wc, wmx = bsa.group_lists(idx, nk, None, block)
+    assert mx == wmx and torch.equal(counts, wc)
+    if sparsity == 0.0:
+        live = torch.arange(mx, device=DEV).view(1, 1, -1) < counts.unsqueeze(-1)
+        assert torch.equal(torch.where(live, lists, 0), torch.where(live, wl, 0))
+        assert torch.equal(sel.cpu(), torch.arange(nk).expand(Hh, nq, nk))
+    else:  # random bf16 scores tie at the boundary now and then: the selected SCORES must be the top ones
+        got = torch.gather(sc.float().cpu(), 2, sel.cpu()).sort(-1).values
+        want = torch.gather(sc.float().cpu(), 2, idx.cpu()).sort(-1).values
+        assert torch.equal(got, want)
+    with pytest.raises(RuntimeError):
+        bsa.topk_lists(torch.zeros(1, 1, 2049, dtype=BF, device=DEV), 0.5, 128)

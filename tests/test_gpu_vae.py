@@ -329,3 +329,46 @@ def test_diffusers_layout_checkpoint_loads_and_matches_executed_class(name, gold
         mu_ref, dec_ref = torch.from_numpy(b[f"{name}_mu"]), torch.from_numpy(b[f"{name}_dec"])
         assert _rel(mu, mu_ref) <= tol_rel and _rel(dec, dec_ref) <= tol_rel, (precision, _rel(mu, mu_ref), _rel(dec, dec_ref))
         assert (dec - dec_ref).abs().max().item() <= tol_abs
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(T=2, H=10, W=12, cin=32, cout=8),          # small: the generic kernel (M < 64 x 512)
+    dict(T=3, H=96, W=128, cin=64, cout=96),        # large enough for the ping-pong kernel
+    dict(T=2, H=33, W=70, cin=96, cout=48),         # ragged tiles, partial output-channel block
+])
+def test_upsample_conv_as_four_phase_convs(cfg):
+    """wf_conv3d_cl_scatter: the four 2 x 2 phase convolutions (taps pre-summed) == nearest-2x upsample + 3 x 3 conv (vae.py:76-86), and
+    == the gathered form wf_conv3d_cl(up2 = 1) of the same bf16 operands up to the pre-summed weights' bf16 rounding."""
+    from worldforge_amd import _ffi, ops
+    g = torch.Generator().manual_seed(11)
+    T, H, W, cin, cout = cfg["T"], cfg["H"], cfg["W"], cfg["cin"], cfg["cout"]
+    x = torch.randn(T, H, W, cin, generator=g).to(BF)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
+    b = torch.randn(cout, generator=g) * 0.1
+    xu = torch.nn.functional.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2, mode="nearest")
+    ref = torch.nn.functional.conv2d(xu, w, b, padding=1).permute(0, 2, 3, 1)            # [T, 2H, 2W, cout]
+    xd, bd = x.to(DEV), b.to(DEV)
+    zp = torch.zeros(64, dtype=BF, device=DEV)
+    out = torch.full((T, 2 * H, 2 * W, cout), float("nan"), dtype=F32, device=DEV)
+    groups = (([0], [1, 2]), ([0, 1], [2]))
+    keep = []
+    for py in range(2):
+        for px in range(2):
+            wp = torch.stack([torch.stack([sum(w[:, :, dy, dx] for dy in groups[py][a] for dx in groups[px][bb]) for bb in range(2)], dim=-1)
+                              for a in range(2)], dim=-2)
+            wk = wp.permute(0, 2, 3, 1).reshape(cout, 4, cin).to(BF).contiguous().to(DEV)
+            keep.append(wk)
+            _ffi.call("wf_conv3d_cl_scatter", xd.data_ptr(), wk.data_ptr(), bd.data_ptr(), None, out.data_ptr(), None, T, H, W, cin, T, H, W, cout,
+                      1, 2, 2, 1, 1, 0, 1 - py, 1 - px, zp.data_ptr(), 2 * H, 2 * W, 2, py, 2, px, ops.stream())
+    got = out.cpu()
+    assert torch.isfinite(got).all()                                                     # every output pixel written exactly by one phase
+    tol = 1e-2 * max(1.0, ref.abs().max().item())                                        # bf16 weights (the sums are rounded once more)
+    assert (got - ref).abs().max().item() <= tol
+    w3 = w.permute(0, 2, 3, 1).reshape(cout, 9, cin).to(BF).contiguous().to(DEV)
+    gathered = torch.empty_like(out)
+    _ffi.call("wf_conv3d_cl", xd.data_ptr(), w3.data_ptr(), bd.data_ptr(), None, gathered.data_ptr(), None, T, H, W, cin, T, 2 * H, 2 * W, cout,
+              1, 3, 3, 1, 1, 0, 1, 1, 1, 0, zp.data_ptr(), ops.stream())
+    assert (gathered.cpu() - ref).abs().max().item() <= tol
+    with pytest.raises(RuntimeError):   # a scattered grid that does not fit the output tensor is refused
+        _ffi.call("wf_conv3d_cl_scatter", xd.data_ptr(), keep[0].data_ptr(), bd.data_ptr(), None, out.data_ptr(), None, T, H, W, cin, T, H, W, cout,
+                  1, 2, 2, 1, 1, 0, 1, 1, zp.data_ptr(), 2 * H - 1, 2 * W, 2, 1, 2, 0, ops.stream())
