@@ -365,6 +365,11 @@ def main(argv=None):
     ap.add_argument("--distill", action="store_true",
                     help="with --workload longcat: the distilled 16-step schedule without CFG (BASELINE config 4's first half; the "
                          "cfg_step_lora is a weight fold and does not change the cost)")
+    ap.add_argument("--as-rank-of", type=int, default=0, metavar="N",
+                    help="NOT a contract line: run, on this one GPU, the work of ONE rank of an N-rank job (parallel.LoopbackComm: collectives "
+                         "served from local data, values meaningless) and report that rank's step time -- the compute-bound ceiling of the "
+                         "N-GPU throughput.  --as-rank picks the rank (default N // 2: halo rows on both sides)")
+    ap.add_argument("--as-rank", type=int, default=-1)
     ap.add_argument("--workload", default="wan", choices=["wan", "longcat"],
                     help="wan = the BASELINE metric (default); longcat = the same contract on LongCat-Video 13.6B guided i2v (config 4's model)")
     a = ap.parse_args(argv)
@@ -387,6 +392,10 @@ def main(argv=None):
 
     # WF_FORCE_COMM=1: a one-rank process group, so that a one-GPU box runs the sharded code path over RCCL itself (debug / CI aid)
     comm = parallel.init(world, rank, local_rank) if (world > 1 or os.environ.get("WF_FORCE_COMM")) else None
+    if a.as_rank_of > 1:
+        if world != 1:
+            raise SystemExit("bench.py: --as-rank-of is a one-process mode")
+        comm = parallel.LoopbackComm(a.as_rank_of, a.as_rank if a.as_rank >= 0 else a.as_rank_of // 2)
 
     cfg = wdit.DiTConfig.wan_i2v_14b()
     cfg.num_layers = a.layers
@@ -458,7 +467,7 @@ def main(argv=None):
         # for the K / V^T exchange (= the communication NOT hidden under the other CFG branch's layer)
         mine = torch.tensor([sum(attn_ms) / max(len(attn_ms), 1), attn_flop, sum(comm_ms) / max(len(comm_ms), 1), float(len(comm_ms))],
                             dtype=torch.float64, device=device)
-        allr = torch.empty((world, 4), dtype=torch.float64, device=device)
+        allr = torch.empty((comm.world, 4), dtype=torch.float64, device=device)
         comm.all_gather(allr, mine)
         per_rank = [{"rank": r, "attn_avg_ms": v[0], "attn_tflops": (v[1] / (v[0] * 1e-3) / 1e12) if v[0] > 0 else None,
                      "comm_exposed_ms_per_layer": v[2], "layers_timed": int(v[3])} for r, v in enumerate(allr.cpu().tolist())]
@@ -493,6 +502,12 @@ def main(argv=None):
         if guided_ms and plain_ms:
             g, p = out["guided_step_ms"], out["plain_step_ms"]
             out["job50_steps_per_s"] = 50.0 / ((15 * g + 35 * p) / 1e3)
+        if a.as_rank_of > 1:  # one simulated rank: label it so that it cannot be mistaken for a measurement of N GPUs
+            out["metric"] += f" -- ONE simulated rank of {a.as_rank_of}: compute and local copies only, NOT a contract line"
+            out["simulated_rank_of"], out["simulated_rank"] = a.as_rank_of, comm.rank
+            out["config"]["parallelism"] = (f"rank {comm.rank} of sp{a.as_rank_of} on one GPU (parallel.LoopbackComm: collectives served from local "
+                                            "data); value = what the N-GPU job would reach if communication were free")
+            per_rank = per_rank[comm.rank:comm.rank + 1] if per_rank else per_rank
         if per_rank is not None:
             out["per_rank"] = per_rank
         if attn_ms:

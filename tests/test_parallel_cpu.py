@@ -88,3 +88,22 @@ def test_kv_split_choice_depends_on_shapes_only():
     assert kv_splits(40, 75600, 75600) == 1          # 720p, one GPU
     assert kv_splits(40, 4524, 4524) == 1            # short KV sweep: never split
     assert kv_splits(40, 32760, 512) == 1            # cross-attention
+
+
+def test_loopback_comm_serves_collectives_locally():
+    """parallel.LoopbackComm: one process standing in for one rank of N (bench.py --as-rank-of): all_gather fills every slot with the local
+    tensor, the other collectives are no-ops; same call surface as Comm."""
+    import torch
+    from worldforge_amd import parallel
+    c = parallel.LoopbackComm(4, 2)
+    assert (c.world, c.rank) == (4, 2)
+    x = torch.arange(6, dtype=torch.float32).view(2, 3)
+    out = torch.empty(4, 2, 3)
+    assert c.all_gather(out, x) is out and all(torch.equal(out[i], x) for i in range(4))
+    out2 = torch.zeros(4, 2, 3)
+    assert c.all_gather_async(out2, x + 1) is None and torch.equal(out2[3], x + 1)   # no stream on CPU: synchronous
+    t = torch.tensor([3.0])
+    assert c.all_reduce_max(t) is t and c.broadcast(t) is t
+    c.barrier()
+    for name in ("all_gather", "all_gather_async", "broadcast", "barrier", "all_reduce_max"):
+        assert hasattr(parallel.Comm, name) and hasattr(c, name)

@@ -1237,17 +1237,28 @@ __global__ __launch_bounds__(256) void k_head_max_norm2(const uint16_t* __restri
   const int r0 = blockIdx.x * rows_per_block, r1 = min(L, r0 + rows_per_block);
   const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;  // 16 lanes x 16 bytes = one 256-byte row
   float best = 0.f;
-  for (int r = r0 + grp; r < r1; r += 16) {
-    const u32x4 w4 = *reinterpret_cast<const u32x4*>(X + ((size_t)head * Lp + r) * D + sub * 8);
-    float sq = 0.f;
+  // four rows per 16-lane group and trip: the loads are issued together, the four shuffle reductions interleave (a pure streaming pass:
+  // 8 workgroups per head of 512 rows with one dependent load per trip ran at 1 TB/s)
+  for (int r = r0 + grp; r < r1; r += 64) {
+    u32x4 w4[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float lo = __uint_as_float(w4[e] << 16), hi = __uint_as_float(w4[e] & 0xffff0000u);
-      sq += lo * lo + hi * hi;
+    for (int u = 0; u < 4; ++u) {
+      const int rr = r + 16 * u;
+      w4[u] = rr < r1 ? *reinterpret_cast<const u32x4*>(X + ((size_t)head * Lp + rr) * D + sub * 8) : u32x4{0u, 0u, 0u, 0u};
     }
+    float sq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-    best = fmaxf(best, sq);
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = __uint_as_float(w4[u][e] << 16), hi = __uint_as_float(w4[u][e] & 0xffff0000u);
+        sq[u] += lo * lo + hi * hi;
+      }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sq[u] += __shfl_xor(sq[u], o, 64);
+    best = fmaxf(fmaxf(best, fmaxf(sq[0], sq[1])), fmaxf(sq[2], sq[3]));
   }
   best = wave_max(best);
   if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out + head), __float_as_uint(best));
@@ -1257,7 +1268,7 @@ __global__ __launch_bounds__(256) void k_head_max_norm2(const uint16_t* __restri
 extern "C" int wf_head_max_norm2(const void* X, int H, int L, int Lp, float* out, void* stream) {
   WF_CHECK_ARG(X && out, "wf_head_max_norm2: null pointer");
   WF_CHECK_ARG(H > 0 && L > 0 && Lp >= L, "wf_head_max_norm2: bad sizes H=%d L=%d Lp=%d", H, L, Lp);
-  const int rows_per_block = 512;
+  const int rows_per_block = 128;
   hipLaunchKernelGGL(k_head_max_norm2, dim3((L + rows_per_block - 1) / rows_per_block, H), dim3(256), 0, (hipStream_t)stream,
                      (const uint16_t*)X, L, Lp, rows_per_block, out);
   WF_LAUNCH_CHECK("wf_head_max_norm2");

@@ -99,6 +99,34 @@ class Comm:
         return t
 
 
+class LoopbackComm:
+    """ONE process standing in for rank `rank` of a `world`-rank job: every collective is served from the caller's own data (all_gather
+    fills every slot with the local tensor, on the communication stream like the real one), so a one-GPU box runs exactly the kernels, shapes
+    and launch sequence of one rank of an N-GPU job -- compute and local copies only, no interconnect; the VALUES are meaningless (every
+    "peer" shard is a copy of this rank's).  `bench.py --as-rank-of N` times it: the per-rank step time is the compute-bound ceiling of the
+    scaling curve, measured instead of guessed while no multi-GPU node is available."""
+
+    def __init__(self, world: int, rank: int = 0):
+        self.world, self.rank, self.group = world, rank, None
+        self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
+        assert out.shape[0] == self.world and tuple(out.shape[1:]) == tuple(inp.shape)
+        out.copy_(inp.unsqueeze(0).expand_as(out))
+        return out
+
+    all_gather_async = Comm.all_gather_async
+
+    def broadcast(self, t: torch.Tensor, src: int = 0):
+        return t
+
+    def barrier(self):
+        pass
+
+    def all_reduce_max(self, t: torch.Tensor):
+        return t
+
+
 def init(world: int, rank: int, local_rank: int, backend: Optional[str] = None) -> Comm:
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
