@@ -306,8 +306,11 @@ int wf_split_bf16x3(const float* src, int64_t ld_src, void* dst, int64_t ld_dst,
 /* wf_rms_silu_cl with the side-0 three-term output ([npix, 3C] bf16) written directly. */
 int wf_rms_silu_cl_x3(const float* x, const float* gamma, void* out_x3, size_t npix, int C, int silu, void* stream);
 /* wf_rms_silu_cl writing the slice-major conv operand of wf_conv3d_333 (layout 1): x f32 [npix, C] (npix = whole rows of W pixels)
- * -> bf16 [npix / W][C/16][W][16]; split != 0: the fp32-class operand stored as [hi | lo] slices, [npix / W][2C/16][W][16]. */
-int wf_rms_silu_cl_blocked(const float* x, const float* gamma, void* out, size_t npix, int C, int silu, int W, int split, void* stream);
+ * -> bf16 [npix / W][C/16][W][16]; split != 0: the fp32-class operand stored as [hi | lo] slices, [npix / W][2C/16][W][16].
+ * halo_rows = Hs > 0 (row slabs of the sharded VAE, x = [T][Hs][W][C]): the output is the halo-padded operand [T][Hs + 2][...] and row
+ * (t, y) is written to (t, y + 1); the two halo rows of every frame are left to the caller (neighbours' rows / zeros). */
+int wf_rms_silu_cl_blocked(const float* x, const float* gamma, void* out, size_t npix, int C, int silu, int W, int split, int halo_rows,
+                           void* stream);
 /* wf_softmax_rows with f32 probabilities (vae.py:252-256 in fp32) / wf_transpose_bf16 on f32. */
 int wf_softmax_rows_f32(const float* S, int lds, float* P, int ldp, int M, int N, float scale, void* stream);
 int wf_transpose_f32(const float* in, int ld_in, float* out, int ld_out, int R, int C, void* stream);

@@ -18,7 +18,7 @@ namespace {
 template <int G, bool SPLIT = false>
 __global__ __launch_bounds__(256) void k_rms_silu(const float* __restrict__ x, const float* __restrict__ gamma,
                                                   uint16_t* __restrict__ out_bf16, float* __restrict__ out_f32, int C,
-                                                  float scale, int silu, size_t npix, int Wrow = 0) {
+                                                  float scale, int silu, size_t npix, int Wrow = 0, int halo_rows = 0) {
   constexpr int PPW = 64 / G;  // pixels per wave
   const int lane = threadIdx.x & 63;
   const int sub = lane & (G - 1), q = lane / G;
@@ -61,8 +61,10 @@ __global__ __launch_bounds__(256) void k_rms_silu(const float* __restrict__ x, c
         }
         if (Wrow > 0) {
           // slice-major operand for wf_conv3d_333 (layout 1): [row = p / W][stored slice][x][16]; SPLIT stores [hi | lo] slices
-          const size_t row = p / (size_t)Wrow;
+          size_t row = p / (size_t)Wrow;
           const int xx = (int)(p - row * (size_t)Wrow);
+          // halo_rows = rows per frame Hs of a row slab: the output is the halo-padded operand [T][Hs + 2][...], row (t, y) -> (t, y + 1)
+          if (halo_rows > 0) row += 2 * (row / (size_t)halo_rows) + 1;
           const int S = C >> 4, stot = SPLIT ? 2 * S : S;
           uint16_t* o = out_bf16 + ((row * stot + (id >> 2)) * (size_t)Wrow + xx) * 16 + (id & 3) * 4;
           const u32x2 hi = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
@@ -321,7 +323,9 @@ extern "C" int wf_cl_to_ncthw(const float* in, float* out, int C, int ld, size_t
 }
 
 extern "C" int wf_rms_silu_cl_blocked(const float* x, const float* gamma, void* out, size_t npix, int C, int silu, int W, int split,
-                                      void* stream) {
+                                      int halo_rows, void* stream) {
+  WF_CHECK_ARG(halo_rows >= 0 && (halo_rows == 0 || (npix / (size_t)(W > 0 ? W : 1)) % (size_t)halo_rows == 0),
+               "wf_rms_silu_cl_blocked: halo_rows=%d must divide the number of rows", halo_rows);
   WF_CHECK_ARG(x && gamma && out, "wf_rms_silu_cl_blocked: null pointer");
   WF_CHECK_ARG(C % 16 == 0 && C > 0 && C <= 1024, "wf_rms_silu_cl_blocked: C=%d must be a multiple of 16 and <= 1024", C);
   WF_CHECK_ARG(W > 0 && npix % (size_t)W == 0, "wf_rms_silu_cl_blocked: npix must be whole rows of W=%d pixels", W);
@@ -336,9 +340,9 @@ extern "C" int wf_rms_silu_cl_blocked(const float* x, const float* gamma, void* 
 #define WF_RMS_BLOCKED(GG)                                                                                                          \
   do {                                                                                                                              \
     if (split)                                                                                                                      \
-      hipLaunchKernelGGL((k_rms_silu<GG, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, nof, C, sc, silu, npix, W);  \
+      hipLaunchKernelGGL((k_rms_silu<GG, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, nof, C, sc, silu, npix, W, halo_rows);  \
     else                                                                                                                            \
-      hipLaunchKernelGGL((k_rms_silu<GG, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, nof, C, sc, silu, npix, W); \
+      hipLaunchKernelGGL((k_rms_silu<GG, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, nof, C, sc, silu, npix, W, halo_rows); \
   } while (0)
   if (G == 8) WF_RMS_BLOCKED(8);
   else if (G == 16) WF_RMS_BLOCKED(16);

@@ -413,15 +413,16 @@ class AutoencoderKLWan:
         self.flops_last += 2 * To * Ho * Wo * Cout * k[0] * k[1] * k[2] * Cin
         return out
 
-    def _rms(self, x, gamma, silu=True, blocked=False):
+    def _rms(self, x, gamma, silu=True, blocked=False, halo=False):
         """RMS_norm (+ SiLU) of the f32 stream -> the next layer's matrix-core operand.  blocked: the slice-major operand of the 3x3x3
         kernel, [T,H,C/16,W,16] (fp32-class mode: [hi | lo] slices, [T,H,2C/16,W,16])."""
         C = x.shape[-1]
         if blocked and C % 32 == 0 and not os.environ.get("WF_CONV_NO_W4"):
             T, H, Wd, _ = x.shape
-            out = torch.empty((T, H, (2 if self.x3 else 1) * C // 16, Wd, 16), dtype=BF, device=x.device)
+            # halo: the kernel writes rows 1 .. H of a [T, H + 2, ...] slab operand directly (row slabs: _halo_fill adds the neighbours' rows)
+            out = torch.empty((T, H + (2 if halo else 0), (2 if self.x3 else 1) * C // 16, Wd, 16), dtype=BF, device=x.device)
             call("wf_rms_silu_cl_blocked", x.data_ptr(), gamma.data_ptr(), out.data_ptr(), x.numel() // C, C, 1 if silu else 0, Wd,
-                 1 if self.x3 else 0, ops.stream())
+                 1 if self.x3 else 0, H if halo else 0, ops.stream())
             return out
         if self.x3:
             out = torch.empty(tuple(x.shape[:-1]) + (3 * C,), dtype=BF, device=x.device)
@@ -602,10 +603,16 @@ class AutoencoderKLWan:
     def _halo_pad(self, a):
         """a [T,Hs,W,C] (or slice-major [T,Hs,S,W,16]) bf16 -> [T,Hs+2,...] with the neighbours' boundary rows (zeros at the image
         boundary)."""
-        comm = self.comm
         T, Hs = a.shape[:2]
         out = torch.empty((T, Hs + 2) + tuple(a.shape[2:]), dtype=a.dtype, device=a.device)
         out[:, 1:Hs + 1].copy_(a)
+        return self._halo_fill(out)
+
+    def _halo_fill(self, out):
+        """out [T,Hs+2,...] whose rows 1 .. Hs are this rank's: rows 0 and Hs+1 <- the neighbours' boundary rows (zeros at the image edge)."""
+        comm = self.comm
+        T, Hs = out.shape[0], out.shape[1] - 2
+        a = out[:, 1:Hs + 1]
         mine = torch.stack([a[:, 0], a[:, Hs - 1]])  # [2,T,W,C]
         allb = torch.empty((comm.world,) + tuple(mine.shape), dtype=a.dtype, device=a.device)
         comm.all_gather(allb, mine.contiguous())
@@ -618,6 +625,13 @@ class AutoencoderKLWan:
         else:
             out[:, Hs + 1].zero_()
         return out
+
+    def _halo_operand(self, x, gamma):
+        """RMS_norm + SiLU of a row slab as the halo-padded conv operand: the norm kernel writes the slab's own rows in place (no copy)."""
+        C = x.shape[-1]
+        if C % 32 == 0 and not os.environ.get("WF_CONV_NO_W4"):
+            return self._halo_fill(self._rms(x, gamma, blocked=True, halo=True))
+        return self._halo_pad(self._rms(x, gamma, blocked=True))
 
     def _rows_from_full(self, x, r0, r1):
         """Rows [r0, r1) of a replicated [T,H,W,C] tensor with zero rows outside the image -> contiguous slab."""
@@ -637,10 +651,10 @@ class AutoencoderKLWan:
     def _res_slab(self, x, p, cin, cout):
         T, Hs, Wd, _ = x.shape
         W = self.w
-        a = self._halo_pad(self._rms(x, W[p + ".residual.0.gamma"], blocked=True))
+        a = self._halo_operand(x, W[p + ".residual.0.gamma"])
         y, _ = self._conv(a, p + ".residual.2", T, Hs, Wd, cout, (3, 3, 3), pt=2, ps=1, ph=0)
         del a
-        a2 = self._halo_pad(self._rms(y, W[p + ".residual.3.gamma"], blocked=True))
+        a2 = self._halo_operand(y, W[p + ".residual.3.gamma"])
         del y
         if cin != cout:
             xb = self._operand(x)
@@ -749,7 +763,7 @@ class AutoencoderKLWan:
                 h_cur *= 2
             elif kind == "head":
                 Tn, Hn, Wn, _ = x.shape
-                a = self._halo_pad(self._rms(x, self.w[p + ".0.gamma"], blocked=True))
+                a = self._halo_operand(x, self.w[p + ".0.gamma"])
                 x, _ = self._conv(a, p + ".2", Tn, Hn, Wn, (cout + 31) // 32 * 32, (3, 3, 3), pt=2, ps=1, ph=0)
         y = self._gather_rows(x)
         Fo, Ho, Wo, Cy = y.shape
