@@ -208,7 +208,8 @@ def test_vae_protocol_and_errors(model):
 from tests.fakes import SimComm as _SimComm  # noqa: E402
 
 
-@pytest.mark.parametrize("P,H", [(2, 64), (4, 64), (8, 64), (2, 24)])   # (2, 24): odd slab height at the decoder entry
+# (2, 24): odd slab height at the decoder entry; (8, 96): 12 latent rows on 8 ranks = the low-resolution stage in 4 row groups of 2 ranks
+@pytest.mark.parametrize("P,H", [(2, 64), (4, 64), (8, 64), (2, 24), (8, 96)])
 def test_row_sharded_vae_equals_unsharded(P, H, model):
     import threading
     from worldforge_amd.vae import AutoencoderKLWan
@@ -281,21 +282,21 @@ def test_fp32_mode_encode_decode_vs_twin_goldens(name, model_fp32, golden_dir):
     assert (dec - dec_ref).abs().max().item() <= 1e-3
 
 
-@pytest.mark.parametrize("P", [2, 4])
-def test_fp32_mode_row_sharded_equals_unsharded(P, model_fp32):
+@pytest.mark.parametrize("P,H", [(2, 64), (4, 64), (8, 96)])   # (8, 96): the low-resolution stage in 4 row groups of 2 ranks each
+def test_fp32_mode_row_sharded_equals_unsharded(P, H, model_fp32):
     """The row-slab (multi-GPU) VAE in the fp32-class mode: P simulated ranks == one rank, bit for bit."""
     from tests.test_gpu_multirank import _run_ranks
     from worldforge_amd.vae import AutoencoderKLWan
     g = torch.Generator().manual_seed(21)
-    x = (torch.rand(1, 3, 9, 64, 96, generator=g) * 2 - 1).to(DEV)
-    z = torch.randn(1, 16, 3, 8, 12, generator=g).to(DEV)
+    x = (torch.rand(1, 3, 9, H, 96, generator=g) * 2 - 1).to(DEV)
+    z = torch.randn(1, 16, 3, H // 8, 12, generator=g).to(DEV)
     mu0 = model_fp32.encode(x).latent_dist.mode().clone()
     dec0 = model_fp32.decode(z, return_dict=False)[0].clone()
 
     def run(comm):
         v = AutoencoderKLWan(DEV, comm=comm, precision="fp32")
         v.w = model_fp32.w
-        assert v.can_shard(8)
+        assert v.can_shard(H // 8)
         return v.encode(x).latent_dist.mode().clone(), v.decode(z, return_dict=False)[0].clone()
 
     for r, (mu, dec) in enumerate(_run_ranks(P, run)):

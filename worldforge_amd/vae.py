@@ -184,6 +184,7 @@ class AutoencoderKLWan:
         self.x3 = precision == "fp32"  # three-term split operands
         self.device = torch.device(device)
         self.comm = comm  # row-slab sharding of the high-resolution stages over the ranks of `comm` (parallel.Comm or a stand-in)
+        self._reps = 1    # ranks per row group while a sharded stage runs (see _row_groups)
         self.config = SimpleNamespace(z_dim=Z_DIM, latents_mean=LATENTS_MEAN, latents_std=LATENTS_STD)
         self.temperal_downsample = list(T_DOWN)
         self.w: Dict[str, torch.Tensor] = {}
@@ -475,56 +476,61 @@ class AutoencoderKLWan:
         out, _ = self._conv(a2, p + ".residual.6", T, H, Wd, cout, (3, 3, 3), pt=2, ps=1, resid=h)
         return out
 
-    def _attn(self, x, p):
-        """vae.py:223-262: per-frame single-head attention over the H*W positions (C = 384)."""
+    def _attn(self, x, p, rows=None):
+        """vae.py:223-262: per-frame single-head attention over the H*W positions (C = 384).  rows = (r0, r1): only the query rows r0 .. r1
+        of every frame are computed (keys / values: the whole frame) and the updated rows are returned as a slab [T, r1 - r0, W, C] -- the
+        row-group sharded low-resolution stage; per output element the arithmetic is that of the whole-frame call."""
         T, H, Wd, C = x.shape
         hw = H * Wd
         hwp = (hw + 7) // 8 * 8  # K / N padding for the MFMA GEMMs; padded score columns are never read by the softmax
         W = self.w
         a = self._rms(x, W[p + ".norm.gamma"], silu=False)
+        q0, q1 = (0, hw) if rows is None else (rows[0] * Wd, rows[1] * Wd)
+        nq = q1 - q0
+        if rows is not None:
+            x = x[:, rows[0]:rows[1]].contiguous()
         if self.x3:
-            return self._attn_x3(x, p, a)
+            return self._attn_x3(x, p, a, hw, hwp, q0, nq)
         qkv = torch.empty((T * hw + 8, 3 * C), dtype=BF, device=x.device)  # +8 rows: the padded K rows stay in-bounds
         qkv[T * hw:].zero_()
         gemm(a.view(-1, C), W[p + ".to_qkv.w"], W[p + ".to_qkv.b"], qkv[:T * hw], EPI_BF16)
         del a
-        S = torch.empty((hw, hwp), dtype=F32, device=x.device)
-        P = torch.empty((hw, hwp), dtype=BF, device=x.device)
+        S = torch.empty((nq, hwp), dtype=F32, device=x.device)
+        P = torch.empty((nq, hwp), dtype=BF, device=x.device)
         Vt = torch.empty((C, hwp), dtype=BF, device=x.device)
-        O = torch.empty((T * hw, C), dtype=BF, device=x.device)
+        O = torch.empty((T * nq, C), dtype=BF, device=x.device)
         scale = 1.0 / math.sqrt(C)
         for t in range(T):
             blk = qkv[t * hw:t * hw + hwp]
-            gemm(blk[:hw, 0:C], blk[:, C:2 * C], None, S, EPI_F32)
-            call("wf_softmax_rows", S.data_ptr(), hwp, P.data_ptr(), hwp, hw, hw, float(scale), ops.stream())
+            gemm(blk[q0:q1, 0:C], blk[:, C:2 * C], None, S, EPI_F32)
+            call("wf_softmax_rows", S.data_ptr(), hwp, P.data_ptr(), hwp, nq, hw, float(scale), ops.stream())
             call("wf_transpose_bf16", blk[:, 2 * C:].data_ptr(), 3 * C, Vt.data_ptr(), hwp, hw, C, ops.stream())
-            gemm(P, Vt, None, O[t * hw:(t + 1) * hw], EPI_BF16)
+            gemm(P, Vt, None, O[t * nq:(t + 1) * nq], EPI_BF16)
         gemm(O, W[p + ".proj.w"], W[p + ".proj.b"], x.view(-1, C), EPI_F32_ACC)  # x + proj(attn)  (vae.py:262)
-        self.flops_last += T * (4 * hw * hw * C) + 2 * T * hw * C * 4 * C
+        self.flops_last += T * (4 * nq * hw * C) + 2 * T * hw * C * 3 * C + 2 * T * nq * C * C
         return x
 
-    def _attn_x3(self, x, p, a):
-        """_attn with fp32-class contractions: q / k / v, the scores and the probabilities stay f32 and are split per use."""
-        T, H, Wd, C = x.shape
-        hw = H * Wd
-        hwp = (hw + 7) // 8 * 8
+    def _attn_x3(self, x, p, a, hw, hwp, q0, nq):
+        """_attn with fp32-class contractions: q / k / v, the scores and the probabilities stay f32 and are split per use.  x: the rows that
+        are updated ([T, rows, W, C]: the whole frames, or the query-row slab); a: the normalised WHOLE frames."""
+        T, C = x.shape[0], x.shape[-1]
         W = self.w
         qkv = torch.zeros((T * hw + 8, 3 * C), dtype=F32, device=x.device)
         gemm(a.view(-1, 3 * C), W[p + ".to_qkv.w"], W[p + ".to_qkv.b"], qkv[:T * hw], EPI_F32)
         del a
-        S = torch.empty((hw, hwp), dtype=F32, device=x.device)
-        P = torch.empty((hw, hwp), dtype=F32, device=x.device)
+        S = torch.empty((nq, hwp), dtype=F32, device=x.device)
+        P = torch.empty((nq, hwp), dtype=F32, device=x.device)
         Vt = torch.empty((C, hwp), dtype=F32, device=x.device)
-        Of = torch.empty((T * hw, C), dtype=F32, device=x.device)
+        Of = torch.empty((T * nq, C), dtype=F32, device=x.device)
         scale = 1.0 / math.sqrt(C)
         for t in range(T):
             blk = qkv[t * hw:t * hw + hwp]
-            gemm(self._operand(blk[:hw, 0:C], 0), self._operand(blk[:, C:2 * C], 1), None, S, EPI_F32)
-            call("wf_softmax_rows_f32", S.data_ptr(), hwp, P.data_ptr(), hwp, hw, hw, float(scale), ops.stream())
+            gemm(self._operand(blk[q0:q0 + nq, 0:C], 0), self._operand(blk[:, C:2 * C], 1), None, S, EPI_F32)
+            call("wf_softmax_rows_f32", S.data_ptr(), hwp, P.data_ptr(), hwp, nq, hw, float(scale), ops.stream())
             call("wf_transpose_f32", blk[:, 2 * C:].data_ptr(), 3 * C, Vt.data_ptr(), hwp, hw, C, ops.stream())
-            gemm(self._operand(P, 0), self._operand(Vt, 1), None, Of[t * hw:(t + 1) * hw], EPI_F32)
+            gemm(self._operand(P, 0), self._operand(Vt, 1), None, Of[t * nq:(t + 1) * nq], EPI_F32)
         gemm(self._operand(Of), W[p + ".proj.w"], W[p + ".proj.b"], x.view(-1, C), EPI_F32_ACC)
-        self.flops_last += 3 * (T * (4 * hw * hw * C) + 2 * T * hw * C * 4 * C)
+        self.flops_last += 3 * (T * (4 * nq * hw * C) + 2 * T * hw * C * 3 * C + 2 * T * nq * C * C)
         return x
 
     def _down(self, x, p, C, temporal):
@@ -616,12 +622,14 @@ class AutoencoderKLWan:
         mine = torch.stack([a[:, 0], a[:, Hs - 1]])  # [2,T,W,C]
         allb = torch.empty((comm.world,) + tuple(mine.shape), dtype=a.dtype, device=a.device)
         comm.all_gather(allb, mine.contiguous())
-        if comm.rank > 0:
-            out[:, 0].copy_(allb[comm.rank - 1, 1])
+        reps = self._reps  # ranks per row group (1: every rank its own slab; > 1: `reps` consecutive ranks hold the same slab)
+        up, down = comm.rank - reps, comm.rank + reps
+        if up >= 0:
+            out[:, 0].copy_(allb[up, 1])
         else:
             out[:, 0].zero_()
-        if comm.rank < comm.world - 1:
-            out[:, Hs + 1].copy_(allb[comm.rank + 1, 0])
+        if down < comm.world:
+            out[:, Hs + 1].copy_(allb[down, 0])
         else:
             out[:, Hs + 1].zero_()
         return out
@@ -646,7 +654,21 @@ class AutoencoderKLWan:
         comm = self.comm
         allr = torch.empty((comm.world,) + tuple(slab.shape), dtype=slab.dtype, device=slab.device)
         comm.all_gather(allr, slab.contiguous())
-        return allr.permute(1, 0, 2, 3, 4).reshape(slab.shape[0], comm.world * slab.shape[1], slab.shape[2], slab.shape[3]).contiguous()
+        if self._reps > 1:  # one copy per row group
+            allr = allr[::self._reps]
+        return allr.permute(1, 0, 2, 3, 4).reshape(slab.shape[0], allr.shape[0] * slab.shape[1], slab.shape[2], slab.shape[3]).contiguous()
+
+    def _row_groups(self, h: int, even: bool = False) -> int:
+        """Row groups for a stage of h rows: the largest divisor G of the world size with h % G == 0 (and an even number of rows per group
+        if a stride-2 conv follows); world / G consecutive ranks then compute the same slab (the low-resolution stage: 60 rows on 8 ranks =
+        4 groups of 15, computed twice each, instead of the whole stage on every rank).  WF_VAE_LOWRES_REPLICATED=1: 1 (the old scheme)."""
+        if os.environ.get("WF_VAE_LOWRES_REPLICATED"):
+            return 1
+        P = self.comm.world
+        for G in range(P, 0, -1):
+            if P % G == 0 and h % G == 0 and (not even or (h // G) % 2 == 0):
+                return G
+        return 1
 
     def _res_slab(self, x, p, cin, cout):
         T, Hs, Wd, _ = x.shape
@@ -744,7 +766,24 @@ class AutoencoderKLWan:
         x = self._latent_in(x, T, h, w)
         plan = decoder_plan()
         first_up = next(i for i, e in enumerate(plan) if e[0] in ("up2d", "up3d"))
-        x = self._run(x, plan[:first_up])                      # stage 0 replicated: [T,h,w,384] fp32
+        G = self._row_groups(h)
+        if G > 1:
+            # stage 0 (conv_in, 5 residual blocks, the mid-block attention at h x w) in G row groups of h / G rows, world / G ranks per group
+            self._reps = P // G
+            try:
+                g, Hg = rank // self._reps, h // G
+                kind, p, cin, cout = plan[0]
+                x, _ = self._conv(self._rows_from_full(x, g * Hg - 1, (g + 1) * Hg + 1), p, T, Hg, w, cout, (3, 3, 3), pt=2, ps=1, ph=0)
+                for kind, p, cin, cout in plan[1:first_up]:
+                    if kind == "res":
+                        x = self._res_slab(x, p, cin, cout)
+                    else:  # attention: the keys / values are the whole frame, the queries this group's rows
+                        x = self._attn(self._gather_rows(x), p, rows=(g * Hg, (g + 1) * Hg))
+                x = self._gather_rows(x)                       # whole frames on every rank again: [T,h,w,384] fp32
+            finally:
+                self._reps = 1
+        else:
+            x = self._run(x, plan[:first_up])                  # stage 0 replicated: [T,h,w,384] fp32
         kind, p, cin, cout = plan[first_up]
         Hs = 2 * h // P                                        # my rows at the next resolution
         y0 = rank * Hs
@@ -790,8 +829,31 @@ class AutoencoderKLWan:
                 x = self._res_slab(x, p, cin, cout)
             else:
                 x = self._down_slab(x, p, cin, kind == "down3d")
-        x = self._gather_rows(x)                                # replicated from the last downsample on
-        y = self._run(x, plan[last_down:])
+        x = self._gather_rows(x)                                # whole frames at the resolution of the last downsample
+        G = self._row_groups(x.shape[1], even=True)
+        if G > 1:
+            # the last downsample and everything after it (4 residual blocks, the mid-block attention, the head) in G row groups
+            self._reps = P // G
+            try:
+                g, Hg = rank // self._reps, x.shape[1] // G
+                x = x[:, g * Hg:(g + 1) * Hg].contiguous()
+                for kind, p, cin, cout in plan[last_down:]:
+                    if kind == "res":
+                        x = self._res_slab(x, p, cin, cout)
+                    elif kind in ("down2d", "down3d"):
+                        x = self._down_slab(x, p, cin, kind == "down3d")
+                    elif kind == "attn":
+                        Hc = x.shape[1]
+                        x = self._attn(self._gather_rows(x), p, rows=(g * Hc, (g + 1) * Hc))
+                    else:  # head
+                        Tn, Hn, Wn, _ = x.shape
+                        a = self._halo_operand(x, self.w[p + ".0.gamma"])
+                        x, _ = self._conv(a, p + ".2", Tn, Hn, Wn, (cout + 31) // 32 * 32, (3, 3, 3), pt=2, ps=1, ph=0)
+                y = self._gather_rows(x)
+            finally:
+                self._reps = 1
+        else:
+            y = self._run(x, plan[last_down:])
         T, h, w, _ = y.shape
         q = self._small_conv(y, "conv1", T, h, w, 2 * Z_DIM, (1, 1, 1))
         out = torch.empty((2 * Z_DIM, T, h, w), dtype=F32, device=self.device)
