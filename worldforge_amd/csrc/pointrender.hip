@@ -121,7 +121,7 @@ __global__ void k_sobel_mag(const float* __restrict__ d, double* __restrict__ ma
     const unsigned long long b = (unsigned long long)__double_as_longlong(m);
     if (m == m && b > lm) lm = b;
   }
-  if (lm) atomicMax(gmax, lm);
+  if (lm && lm > __builtin_nontemporal_load(gmax)) atomicMax(gmax, lm);  // (same-address atomics serialise: only while the maximum still grows)
 }
 __global__ void k_edge_thresh(const double* __restrict__ mag, const unsigned long long* __restrict__ gmax, double thr, unsigned char* __restrict__ e,
                               size_t hw) {
