@@ -406,6 +406,24 @@ class LongCatVideoTransformer3DModel:
             fused_topk = cdf_thr is None and not os.environ.get("WF_BSA_TORCH_SELECT")  # (the env switch keeps the torch.topk path testable)
             self.last_bsa_indices = []
 
+        # sequence-parallel jobs: the caption K / V^T of layer i are computed by rank i (mod P) only and all-gathered once per forward (see
+        # dit.py: work that does not shrink with the token shard); WF_CTX_REPLICATED=1 keeps every rank computing all layers
+        ctx_shared = ctx_events = None
+        if comm is not None and comm.world > 1 and os.environ.get("WF_CTX_REPLICATED", "0") != "1":
+            P_, nl = comm.world, (cfg.depth + comm.world - 1) // comm.world
+            loc = [_buf("ckv_loc0", (nl, H, Ltp, 128), bf, zero=True), _buf("ckv_loc1", (nl, H, Ltp // 64, 128, 64), bf)]
+            allb = [_buf(f"ckv_all{j}", (P_,) + tuple(t.shape), bf) for j, t in enumerate(loc)]
+            for j in range(nl):
+                i = comm.rank + P_ * j
+                if i >= cfg.depth:
+                    break
+                p = f"blocks.{i}."
+                gemm(y, W[p + "cross_attn.kv_linear.w"], W[p + "cross_attn.kv_linear.b"], kvt, EPI_BF16)
+                self._heads(kvt, 0, W[p + "cross_attn.k_norm"], None, None, loc[0][j], 0, n_txt)
+                self._vt(kvt, C, loc[1][j], n_txt)
+            ctx_events = [comm.all_gather_async(a_, l_) for a_, l_ in zip(allb, loc)]
+            ctx_shared = (allb, P_)
+
         for i in range(cfg.depth):
             p = f"blocks.{i}."
             m = ada[:, i * 6 * C:(i + 1) * 6 * C]
@@ -475,10 +493,19 @@ class LongCatVideoTransformer3DModel:
                 self._ln(x[nc:], W[p + "norm.w"], W[p + "norm.b"], 0, 0, False, hbuf[nc:])
                 gemm(hbuf[nc:], W[p + "cross_attn.q_linear.w"], W[p + "cross_attn.q_linear.b"], qc[nc:], EPI_BF16)
                 self._heads(qc, 0, W[p + "cross_attn.q_norm"], None, None, qh_n, nc, L)
-                gemm(y, W[p + "cross_attn.kv_linear.w"], W[p + "cross_attn.kv_linear.b"], kvt, EPI_BF16)
-                self._heads(kvt, 0, W[p + "cross_attn.k_norm"], None, None, kth, 0, n_txt)
-                self._vt(kvt, C, vtt, n_txt)
-                attention(qh_n, kth, vtt, ao[nc:], n_txt, scale)
+                if ctx_shared is not None:
+                    if ctx_events is not None:
+                        for ev in ctx_events:
+                            if ev is not None:
+                                torch.cuda.current_stream().wait_event(ev)
+                        ctx_events = None
+                    kth_i, vtt_i = (a_[i % ctx_shared[1], i // ctx_shared[1]] for a_ in ctx_shared[0])
+                else:
+                    gemm(y, W[p + "cross_attn.kv_linear.w"], W[p + "cross_attn.kv_linear.b"], kvt, EPI_BF16)
+                    self._heads(kvt, 0, W[p + "cross_attn.k_norm"], None, None, kth, 0, n_txt)
+                    self._vt(kvt, C, vtt, n_txt)
+                    kth_i, vtt_i = kth, vtt
+                attention(qh_n, kth_i, vtt_i, ao[nc:], n_txt, scale)
                 gemm(ao[nc:], W[p + "cross_attn.proj.w"], W[p + "cross_attn.proj.b"], ys[nc:], EPI_BF16)
                 self._resid(x[nc:], ys[nc:], None, 0, 0)
             # ---- SwiGLU FFN (LCD:113-120, LCB:36-37) ----
