@@ -545,25 +545,29 @@ class WanTransformer3DModel:
         # the token shard -- 3 % of a rank's GPU time at 8 ranks when every rank computes all 40 layers' (measured).  Each
         # rank computes the layers i = rank (mod P) only, the finished kernel operands ([H, rows, 128] keys, blocked V^T) are all-gathered
         # once per forward on the communication stream; layer i then reads slot [i % P][i // P].  Same kernels per layer: bit-identical.
-        ctx_shared = None
-        if comm is not None and comm.world > 1 and ctx_kv is None and os.environ.get("WF_CTX_REPLICATED", "0") != "1":
+        ctx_shared = ctx_events = None
+        share_ctx = comm is not None and comm.world > 1 and ctx_kv is None and os.environ.get("WF_CTX_REPLICATED", "0") != "1"
+
+        def launch_context():
+            """Called once, right after layer 0's K / V^T exchange has been launched: the context gathers queue BEHIND it on the communication
+            stream (layer 0's self-attention needs its keys first, the context is not read before layer 0's cross-attention)."""
             P_, nl = comm.world, (cfg.num_layers + comm.world - 1) // comm.world
             loc = [_buf("ckv_loc0", (nl, H, Lt, 128), bf, zero=True), _buf("ckv_loc1", (nl, H, Lt // 64, 128, 64), bf),
                    _buf("ckv_loc2", (nl, H, Li, 128), bf, zero=True), _buf("ckv_loc3", (nl, H, Li // 64, 128, 64), bf)]
             allb = [_buf(f"ckv_all{j}", (P_,) + tuple(t.shape), bf) for j, t in enumerate(loc)]
             for j in range(nl):
-                i = comm.rank + P_ * j
-                if i >= cfg.num_layers:
+                li = comm.rank + P_ * j
+                if li >= cfg.num_layers:
                     break
-                p = f"blocks.{i}."
-                gemm(ctx_t, W[p + "cross_attn.kv.w"], W[p + "cross_attn.kv.b"], kvt, EPI_BF16)
-                self._heads(kvt, 0, W[p + "cross_attn.norm_k"], None, None, loc[0][j], Lt)
+                pl = f"blocks.{li}."
+                gemm(ctx_t, W[pl + "cross_attn.kv.w"], W[pl + "cross_attn.kv.b"], kvt, EPI_BF16)
+                self._heads(kvt, 0, W[pl + "cross_attn.norm_k"], None, None, loc[0][j], Lt)
                 self._vt(kvt, d, loc[1][j], Lt)
-                gemm(ctx_i, W[p + "cross_attn.kv_img.w"], W[p + "cross_attn.kv_img.b"], kvi, EPI_BF16)
-                self._heads(kvi, 0, W[p + "cross_attn.norm_k_img"], None, None, loc[2][j], n_img)
+                gemm(ctx_i, W[pl + "cross_attn.kv_img.w"], W[pl + "cross_attn.kv_img.b"], kvi, EPI_BF16)
+                self._heads(kvi, 0, W[pl + "cross_attn.norm_k_img"], None, None, loc[2][j], n_img)
                 self._vt(kvi, d, loc[3][j], n_img)
-            ctx_events = [comm.all_gather_async(a_, l_) for a_, l_ in zip(allb, loc)]
-            ctx_shared = (allb, P_)
+            return (allb, P_), [comm.all_gather_async(a_, l_) for a_, l_ in zip(allb, loc)]
+
         for i in range(cfg.num_layers):
             p = f"blocks.{i}."
             # e = modulation + e0 (model.py:298)
@@ -590,6 +594,8 @@ class WanTransformer3DModel:
                 if km is not None:  # every shard's per-head max |k|^2 travels with it (40 floats per rank)
                     head_max_norm2(kh, L, km)
                     ev_m = comm.all_gather_async(km_all, km)
+                if i == 0 and share_ctx:
+                    ctx_shared, ctx_events = launch_context()
                 yield i
                 gemm(hbuf, W[p + "qkv.w"][:d], W[p + "qkv.b"][:d], qkv[:, :d], EPI_BF16)
                 self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L, out_scale=q_scale)
