@@ -281,7 +281,7 @@ def test_longcat_dit_fused_selection_equals_torch_selection(monkeypatch):
     x, cap = _rand((16, T, h, w), 11).to(BF).to(DEV), _rand((20, 64), 12).to(BF).to(DEV)
     ts = [0.0] * ncl + [400.0] * (T - ncl)
     a = m.forward_tokens(x, ts, cap, None, ncl).clone()
-    pa = [[i.cpu() for i in layer] for layer in m.last_bsa_indices]
+    pa = [[i.cpu().sort(-1).values for i in layer] for layer in m.last_bsa_indices]   # (sorted: the test also runs with the switch preset)
     monkeypatch.setenv("WF_BSA_TORCH_SELECT", "1")
     b = m.forward_tokens(x, ts, cap, None, ncl)
     pb = [[i.cpu().sort(-1).values for i in layer] for layer in m.last_bsa_indices]

@@ -138,6 +138,7 @@ def test_attention(H, Lq, Lk):
     assert _rel(out, 2 * ref) <= 1.5e-2
 
 
+@pytest.mark.skipif(os.environ.get("WF_ATTN_KERNEL") == "w8", reason="KV splits need the one-wave-per-SIMD kernel (the entry point refuses loudly)")
 @pytest.mark.parametrize("H,Lq,Lk,nsplit,segs", [(2, 300, 1000, 2, 1), (1, 256, 4524, 3, 1), (3, 77, 640, 2, 1), (2, 500, 1024, 2, 4),
                                                   (1, 128, 8192 + 37, 8, 1)])
 def test_attention_kv_splits(H, Lq, Lk, nsplit, segs):
