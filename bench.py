@@ -378,6 +378,8 @@ def main(argv=None):
         sys.exit(launch_ranks(a.gpus, argv))
     claim_stdout()
     if a.workload == "longcat":
+        if a.as_rank_of > 1:
+            raise SystemExit("bench.py: --as-rank-of is wired for --workload wan only")
         return main_longcat(a)
 
     rank, local_rank, world = rank_env(a)
