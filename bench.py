@@ -27,10 +27,67 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS_BF16 = 2500.0  # dense, MI355X_MICROARCH.md
-# HBM bytes per self-attention launch at the C2 shape, measured on the timed kernel (k_attn_w4<4>, un-tracked body) with rocprofv3 PMC passes
-# (profiles/r2_attn_pmc.md): FETCH_SIZE 1 474 710 KB x 2 (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md) +
-# WRITE_SIZE 327 600 KB.  Algorithmic minimum 1.34e9.
-ATTN_TRAFFIC_BYTES_C2 = int(1474675 * 1024 * 2 + 327600 * 1024)  # k_attn_w4<4>; k_attn_w4<0> measured 1474710 / 327600
+# PMC side fields of the roofline object (HBM traffic per launch, MFMA pipe utilisation, effective clock) come from SEPARATE rocprofv3
+# --pmc passes over tools/attn_once.py (the guide forbids mixing counters with the timed run); their summary is the tracked file below,
+# written by tools/pmc_summary.py --json.  They are emitted only when this run launches the very kernel / shape the file describes.
+ATTN_PMC_FILE = os.path.join(ROOT, "profiles", "attn_pmc_latest.json")
+
+
+def attn_pmc_fields(kernel: str, L: int, heads: int, world: int, simulated: bool):
+    """-> dict of roofline side fields, or all-None when the tracked PMC summary does not describe this launch."""
+    none = {"traffic": None, "traffic_source": None, "mfma_util_pmc": None, "clock_ghz_pmc": None}
+    try:
+        with open(ATTN_PMC_FILE) as f:
+            pmc = json.load(f)
+    except (OSError, ValueError):
+        return none
+    if simulated or world != 1 or pmc.get("kernel") != kernel or pmc.get("tokens") != L or pmc.get("heads") != heads:
+        return none
+    return {"traffic": pmc.get("traffic_bytes_per_launch"),
+            "traffic_source": f"{os.path.relpath(ATTN_PMC_FILE, ROOT)} <- {pmc.get('source')}: rocprofv3 --pmc passes of {pmc.get('kernel')} at this shape, "
+                              "FETCH_SIZE x2 (gfx950 wide-read correction, MI355X_MICROARCH.md) + WRITE_SIZE; separate passes, not collected during this run",
+            "mfma_util_pmc": pmc.get("mfma_util"), "clock_ghz_pmc": pmc.get("clock_ghz")}
+
+
+def tracked_body_ms(model, L: int, heads: int, n: int = 6):
+    """Average launch time of the SAME self-attention on the DiT's own resident Q / K / V^T of the last layer, with the norm bounds withheld:
+    the kernel then runs its max-tracking body -- what a checkpoint with larger q / k norms would select.  Measured after the timed region."""
+    from worldforge_amd import dit as wdit
+    ws = {k[0]: v for k, v in model._ws.items()}
+    if not all(k in ws for k in ("qh", "kh", "vt", "ao")):
+        return None
+    evs = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        wdit.attention(ws["qh"], ws["kh"], ws["vt"], ws["ao"], L, 0.0, nsplit=1)
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs[1:])
+    return ms[len(ms) // 2]
+
+
+def flf_gate_ms(sch, pipe_latent_shape, device):
+    """GPU time of one FLF gate (SCHED:338-437) with either motion backend on latents of the job's shape: the like-for-like cost of the
+    default Farneback branch against the golden-pinned temporal-difference branch (2 gates per guided step)."""
+    from worldforge_amd import flf
+    g = torch.Generator(device=device).manual_seed(5)
+    a = torch.randn(pipe_latent_shape, generator=g, device=device)
+    b = a + 0.3 * torch.randn(pipe_latent_shape, generator=g, device=device)
+    out = {}
+    for backend in ("farneback", "tdiff"):
+        sel = flf.VideoMotionPCASelector(flow_backend=backend)
+        ms = []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sel.select_motion_related_channels(pred_original_sample=a, video_latents=b, mask=None, keep_channels=12, current_step=12,
+                                               total_steps=50, use_optical_flow=True, static=True)
+            torch.cuda.synchronize()
+            ms.append(1e3 * (time.perf_counter() - t0))
+        out[backend] = sorted(ms[1:])[1]
+    return out
 
 
 def synthetic_inputs(F, H, W, device, seed=42):
@@ -273,8 +330,8 @@ def launch_ranks(n: int, argv, script: str = None) -> int:
     import subprocess
 
     share = bool(os.environ.get("WF_SHARE_GPU"))
-    have = torch.cuda.device_count()  # counting devices does not initialise the GPU
-    if not share and have < n:
+    have = visible_gpu_count()  # from the environment / sysfs: no torch.cuda call, nothing that could initialise HIP in the launcher
+    if not share and have is not None and have < n:
         print(f"bench.py: --gpus {n} but only {have} GPU(s) visible (WF_SHARE_GPU=1 WF_COMM_BACKEND=gloo runs all ranks on one GPU "
               "as a debug configuration)", file=sys.stderr)
         return 2
@@ -306,6 +363,27 @@ def launch_ranks(n: int, argv, script: str = None) -> int:
             if p.poll() is None:
                 p.kill()
     return rc
+
+
+def visible_gpu_count():
+    """GPUs this process tree may use, WITHOUT touching the HIP runtime: the *_VISIBLE_DEVICES lists if set, else the KFD topology
+    (a node with simd_count > 0 is a GPU).  None if neither source is readable (the pre-check is then skipped: a rank that finds no
+    device fails non-zero and the launcher propagates it)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        return n
+    except (OSError, ValueError):
+        return None
 
 
 _JSON_FD = None
@@ -348,7 +426,7 @@ def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=10)  # default window: 3 guided + 7 plain = the 30 % mix of the 50-step job
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=81)
     ap.add_argument("--height", type=int, default=480)
@@ -359,9 +437,10 @@ def main(argv=None):
                     help="FLF motion backend: farneback (default) = what the installed reference executes, as the GPU restatement of "
                          "cv2.calcOpticalFlowFarneback (parity with a real cv2 unpinned); tdiff = the branch the reference runs only "
                          "when `import cv2` fails (golden-pinned)")
-    ap.add_argument("--vae-precision", default="fp32", choices=["fp32", "bf16"],
-                    help="fp32 (default): fp32-class VAE contractions as the reference's fp32 VAE (INFER:185-189) -- three-term split bf16 "
-                         "operands on the matrix cores, 3x the VAE MFMA work; bf16: every VAE operand rounded to bf16 (faster, 2^-9 per operand)")
+    ap.add_argument("--vae-precision", default="bf16x3", choices=["bf16x3", "fp32", "bf16"],
+                    help="bf16x3 (default; 'fp32' is the old name of the same mode): fp32-CLASS VAE contractions standing in for the reference's "
+                         "fp32 VAE (INFER:185-189) -- three-term split bf16 operands on the matrix cores, ~2^-16 per product, 3x the VAE MFMA "
+                         "work; bf16: every VAE operand rounded to bf16 (faster, 2^-9 per operand)")
     ap.add_argument("--distill", action="store_true",
                     help="with --workload longcat: the distilled 16-step schedule without CFG (BASELINE config 4's first half; the "
                          "cfg_step_lora is a weight fold and does not change the cost)")
@@ -373,6 +452,8 @@ def main(argv=None):
     ap.add_argument("--workload", default="wan", choices=["wan", "longcat"],
                     help="wan = the BASELINE metric (default); longcat = the same contract on LongCat-Video 13.6B guided i2v (config 4's model)")
     a = ap.parse_args(argv)
+    if a.vae_precision == "fp32":
+        a.vae_precision = "bf16x3"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: become the launcher.  Nothing above or in here initialises the GPU in this process.
         sys.exit(launch_ranks(a.gpus, argv))
@@ -495,7 +576,11 @@ def main(argv=None):
                             f"timed steps {start + Wm}..{start + Wm + K - 1} = {len(guided_ms)} guided + {len(plain_ms)} plain",
                 "tokens": L, "dit_layers": cfg.num_layers, "dit_params_bytes": model.param_bytes(),
                 "parallelism": "single" if world == 1 else f"sp{world} (token-sharded DiT with K/V all-gather + row-sharded VAE with halo all-gather, RCCL)",
-                "flow_backend": a.flow_backend, "vae_precision": a.vae_precision,
+                "flow_backend": a.flow_backend,
+                # the Farneback branch is what an installed reference executes, but its GPU statement is checked against the
+                # in-repo restatement of OpenCV only (no cv2 in the image or the reference tree); the tdiff branch is golden-pinned
+                "flow_backend_parity": "oracle-only (cv2 unpinned)" if a.flow_backend == "farneback" else "reference goldens (g4, g6)",
+                "vae_precision": a.vae_precision + (" (3-term split-bf16 operands, fp32 accumulate: ~2^-16 per product, not IEEE fp32)" if a.vae_precision == "bf16x3" else ""),
             },
             "guided_step_ms": sum(guided_ms) / len(guided_ms) if guided_ms else None,
             "plain_step_ms": sum(plain_ms) / len(plain_ms) if plain_ms else None,
@@ -515,16 +600,33 @@ def main(argv=None):
         if attn_ms:
             avg = sum(attn_ms) / len(attn_ms)
             ach = attn_flop / (avg * 1e-3) / 1e12
-            out["roofline"] = {"kernel": ("k_attn<0>" if os.environ.get("WF_ATTN_KERNEL") == "w8" else ("k_attn_w4<0>" if os.environ.get("WF_ATTN_PRESCALE", "1") == "0" else "k_attn_w4<4> (pre-scaled Q)"))
-                                         + " (DiT self-attention, model.py:149-154)",
+            kern = ("k_attn<0>" if os.environ.get("WF_ATTN_KERNEL") == "w8" else
+                    ("k_attn_w4<0>" if os.environ.get("WF_ATTN_PRESCALE", "1") == "0" else "k_attn_w4<4>"))
+            body = "" if kern != "k_attn_w4<4>" else (", max-tracking body" if os.environ.get("WF_ATTN_TRACK_MAX", "0") == "1" else ", un-tracked body (selected by the per-head norm bounds)")
+            out["roofline"] = {"kernel": kern + (" (pre-scaled Q" + body + ")" if kern == "k_attn_w4<4>" else "") + " (DiT self-attention, model.py:149-154)",
                                "bound": "mfma", "achieved": ach,
                                "peak": MFMA_PEAK_TFLOPS_BF16, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS_BF16,
-                               "traffic": ATTN_TRAFFIC_BYTES_C2 if (L == 32760 and world == 1 and cfg.num_heads == 40 and os.environ.get("WF_ATTN_KERNEL") != "w8") else None,
-                               "traffic_source": "rocprofv3 PMC of k_attn_w4<0> at this shape: FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, profiles/r2_attn_pmc.md (separate counter passes, not collected during this run)",
-                               "mfma_util_pmc": 0.733 if os.environ.get("WF_ATTN_PRESCALE", "1") != "0" else 0.651,
-                               "clock_ghz_pmc": 1.77 if os.environ.get("WF_ATTN_PRESCALE", "1") != "0" else 1.84,
+                               **attn_pmc_fields(kern, L, cfg.num_heads, world, a.as_rank_of > 1),
                                "launches": len(attn_ms), "avg_launch_ms": avg,
                                "flop_per_launch": attn_flop}
+            if kern == "k_attn_w4<4>" and world == 1 and a.as_rank_of <= 1:
+                tms = tracked_body_ms(model, L, cfg.num_heads)
+                if tms:
+                    out["roofline"]["tracked_body_avg_launch_ms"] = tms
+                    out["roofline"]["tracked_body_frac"] = attn_flop / (tms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS_BF16
+        if world == 1 and a.as_rank_of <= 1:
+            out["flf_gate_ms"] = flf_gate_ms(sch, (1, 16, T, a.height // 8, a.width // 8), device)
+        if per_rank is not None and plain_ms:
+            # one DiT layer of one forward on this rank ~ plain step / (2 forwards x layers); the K / V^T exchange is meant to hide under
+            # the other CFG branch's layer: more than 10 % of a layer exposed means the overlap is NOT working on this node
+            layer_ms = out["plain_step_ms"] / (2.0 * cfg.num_layers)
+            worst = max(r["comm_exposed_ms_per_layer"] for r in per_rank)
+            out["comm_exposed_frac_of_layer"] = worst / layer_ms
+            if worst > 0.10 * layer_ms and a.as_rank_of <= 1:
+                out["comm_exposed_over_budget"] = True
+                print(f"bench.py: WARNING: K / V^T exchange exposed {worst:.2f} ms per layer = {100 * worst / layer_ms:.0f} % of a "
+                      f"{layer_ms:.2f} ms layer (budget 10 %): communication is NOT hidden under compute on this node -- run tools/comm_probe.py",
+                      file=sys.stderr)
         if a.layers != 40:
             out["invalid_reason"] = f"debug run with {a.layers} DiT layers (the named model has 40)"
         if not a.no_cpu_baseline and world == 1:

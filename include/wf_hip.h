@@ -172,6 +172,10 @@ int wf_head_max_norm2(const void* X, int H, int L, int Lp, float* out, void* str
  * them exactly): fills the chip when Lq is short, e.g. one rank's token shard of the sequence-parallel DiT (Lq = 4096 at 8 ranks:
  * 640 workgroups on 256 CUs).  workspace: wf_attn_split_workspace_bytes(H, Lq, nsplit) bytes, 16-byte aligned. */
 size_t wf_attn_split_workspace_bytes(int H, int Lq, int nsplit);
+/* Test hook: counters2 = device uint32[2] (or NULL = off, the default).  While set, every workgroup of a pre-scaled-Q launch
+ * (wf_attn_fwd / wf_attn_fwd_split with softmax_scale = 0) adds 1 to counters2[0] if it ran the max-tracking body and to counters2[1]
+ * if it ran the un-tracked one -- lets a parity test assert WHICH body it compared with the oracle.  Process-global, not thread-safe. */
+int wf_attn_debug_body_counter(void* counters2);
 int wf_attn_fwd_split(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len, int ldo,
                       float softmax_scale, int accumulate, int nsplit, void* workspace, const float* kmax2, int kmax_n, const float* qmax2,
                       int qmax_n, void* stream);

@@ -170,6 +170,55 @@ def forward(W: Dict[str, torch.Tensor], cfg: DiTConfig, x: torch.Tensor, t: torc
     return head_unpatchify(tok, e, W, cfg, grid).float()
 
 
+def block_rows(x, rows, e0, context, W, i, cfg: DiTConfig, ang, head_chunk: int = 8):
+    """block() (model.py:278-317) for the query rows `rows` only.  Self-attention is global over the sequence (model.py:130-159), so the
+    keys and values are still computed from EVERY token; everything after it is row-local.  Used to check one real-width layer at the
+    full token count of BASELINE configs[1] / [2], where block() itself would need ~1e14 flop on the CPU.  Pinned against block() in
+    tests/test_oracle_dit.py."""
+    p = f"blocks.{i}"
+    L, R = x.shape[0], len(rows)
+    n, d = cfg.num_heads, cfg.dim // cfg.num_heads
+    e = (W[p + ".modulation"][0] + e0).chunk(6, dim=0)
+    h = layer_norm(x, cfg.eps).float() * (1 + e[1]) + e[0]
+    sp = p + ".self_attn"
+    q = rms_norm(_lin(h[rows], W, sp + ".q"), W[sp + ".norm_q.weight"], cfg.eps).view(R, n, d)
+    k = rms_norm(_lin(h, W, sp + ".k"), W[sp + ".norm_k.weight"], cfg.eps).view(L, n, d)
+    v = _lin(h, W, sp + ".v").view(L, n, d)
+    o = torch.empty((R, n, d), dtype=torch.float32)
+    for h0 in range(0, n, head_chunk):  # bounds the fp64 RoPE temporaries
+        hs = slice(h0, min(n, h0 + head_chunk))
+        o[:, hs] = attention(rope_apply(q[:, hs], ang[rows]), rope_apply(k[:, hs], ang), v[:, hs])
+    xr = x[rows] + _lin(o.reshape(R, cfg.dim), W, sp + ".o") * e[2]
+    xr = xr + cross_attention_i2v(layer_norm(xr, cfg.eps, W[p + ".norm3.weight"], W[p + ".norm3.bias"]), context, W, p + ".cross_attn", cfg)
+    hh = layer_norm(xr, cfg.eps).float() * (1 + e[4]) + e[3]
+    y = _lin(F.gelu(_lin(hh, W, p + ".ffn.0"), approximate="tanh"), W, p + ".ffn.2")
+    return xr + y * e[5]
+
+
+def forward_rows(W: Dict[str, torch.Tensor], cfg: DiTConfig, x: torch.Tensor, t: torch.Tensor, context: torch.Tensor,
+                 clip_fea: torch.Tensor, rows) -> torch.Tensor:
+    """forward() of a ONE-layer model, evaluated at the tokens `rows` only -> the head's output rows [len(rows), prod(patch) * out_dim]
+    in (p_t, p_h, p_w, c) order (what model.py:584-607 un-patchifies): token (f, h, w) covers velocity[c, f + p_t, 2h + p_h, 2w + p_w]."""
+    assert cfg.num_layers == 1, "rows of a deeper model depend on every token of the previous layer"
+    rows = torch.as_tensor(rows, dtype=torch.long)
+    tok, grid = patchify(x.float(), W, cfg)
+    e, e0, ctx = embed_condition(t, context.float(), clip_fea.float(), W, cfg)
+    ang = rope_tables(cfg.dim // cfg.num_heads, *grid)
+    xr = block_rows(tok, rows, e0, ctx, W, 0, cfg, ang)
+    em = (W["head.modulation"][0] + e.unsqueeze(0)).chunk(2, dim=0)
+    return _lin(layer_norm(xr, cfg.eps) * (1 + em[1]) + em[0], W, "head.head").float()
+
+
+def token_patches(v: torch.Tensor, cfg: DiTConfig, rows) -> torch.Tensor:
+    """The inverse of model.py:584-607 at selected tokens: velocity [out_dim, T, H, W] -> [len(rows), prod(patch) * out_dim] in the
+    head's (p_t, p_h, p_w, c) order, for comparing a full forward with forward_rows."""
+    pt, ph, pw = cfg.patch
+    C, T, Hh, Ww = v.shape
+    f, h, w = T // pt, Hh // ph, Ww // pw
+    u = v.view(C, f, pt, h, ph, w, pw).permute(1, 3, 5, 2, 4, 6, 0).reshape(f * h * w, pt * ph * pw * C)
+    return u[torch.as_tensor(rows, dtype=torch.long)]
+
+
 def random_weights(cfg: DiTConfig, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
     """Synthetic weights of the right shapes: N(0, 0.02^2)-ish linears scaled by fan-in, random head."""
     g = torch.Generator().manual_seed(seed)

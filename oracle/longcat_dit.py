@@ -225,6 +225,81 @@ def forward(W: Dict[str, torch.Tensor], cfg: LongCatConfig, latents: torch.Tenso
     return x.float()
 
 
+def forward_rows(W: Dict[str, torch.Tensor], cfg: LongCatConfig, latents: torch.Tensor, timesteps: torch.Tensor, caption: torch.Tensor,
+                 caption_mask: torch.Tensor, num_cond_latents: int, rows) -> torch.Tensor:
+    """forward() of a ONE-block model at the tokens `rows` only (dense attention) -> the final layer's rows [len(rows), p_h p_w C_out] in
+    (p_h, p_w, c) order.  The keys / values of the self-attention (LCA:105-145) still come from every token; condition rows see the
+    condition keys only (LCA:123-138) and receive no cross-attention (LCA:262-276).  For the GPU check of one released-width block at the
+    37 440-token grid of BASELINE configs[3]; pinned against forward() in tests/test_oracle_longcat.py."""
+    assert cfg.depth == 1, "rows of a deeper model depend on every token of the previous block"
+    rows = torch.as_tensor(rows, dtype=torch.long)
+    Cin, T, Hh, Ww = latents.shape
+    pt, ph, pw = cfg.patch_size
+    nh, nw = Hh // ph, Ww // pw
+    C, H = cfg.hidden_size, cfg.num_heads
+    D = C // H
+    tpf = nh * nw
+    nc = num_cond_latents * tpf
+    x = F.conv3d(latents[None].float(), W["x_embedder.proj.weight"].float(), W["x_embedder.proj.bias"].float(), stride=cfg.patch_size)
+    x = x.flatten(2).transpose(1, 2)[0]
+    L = x.shape[0]
+    tf = timestep_embedding(timesteps.float().flatten(), cfg.frequency_embedding_size)
+    t = F.linear(F.silu(F.linear(tf, W["t_embedder.mlp.0.weight"].float(), W["t_embedder.mlp.0.bias"].float())),
+                 W["t_embedder.mlp.2.weight"].float(), W["t_embedder.mlp.2.bias"].float())
+    y = F.linear(F.gelu(F.linear(caption, W["y_embedder.y_proj.0.weight"], W["y_embedder.y_proj.0.bias"]), approximate="tanh"),
+                 W["y_embedder.y_proj.2.weight"], W["y_embedder.y_proj.2.bias"])
+    if caption_mask is not None:
+        y = y * caption_mask[:, None].to(y.dtype) if cfg.text_tokens_zero_pad else y[caption_mask != 0]
+    ang = rope_angles(D, T, nh, nw)
+    p = "blocks.0."
+    mod = F.linear(F.silu(t.float()), W[p + "adaLN_modulation.1.weight"].float(), W[p + "adaLN_modulation.1.bias"].float())
+    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = mod.chunk(6, dim=-1)
+    frame = rows // tpf
+
+    def mod_rows(xr, shift, scale):  # modulate() on selected rows
+        return (layer_norm(xr.float()) * (scale[frame] + 1) + shift[frame]).to(xr.dtype)
+
+    # self-attention: k, v from every token, q from the sampled rows
+    hm = modulate(x, shift_msa, scale_msa, tpf)
+    wq, bq = W[p + "attn.qkv.weight"], W[p + "attn.qkv.bias"]
+    kv = F.linear(hm, wq[C:], bq[C:]).view(L, 2, H, D).permute(1, 2, 0, 3)
+    k, v = rope_apply(rms_norm_head(kv[0], W[p + "attn.k_norm.weight"]), ang), kv[1]
+    q = F.linear(hm[rows], wq[:C], bq[:C]).view(-1, H, D).permute(1, 0, 2)
+    q = rope_apply(rms_norm_head(q, W[p + "attn.q_norm.weight"]), ang[rows])
+    is_c = rows < nc
+    o = torch.empty((len(rows), C), dtype=x.dtype)
+    if is_c.any():
+        o[is_c] = attention(q[:, is_c], k[:, :nc], v[:, :nc], D ** -0.5)
+    if (~is_c).any():
+        o[~is_c] = attention(q[:, ~is_c], k, v, D ** -0.5)
+    xs = F.linear(o, W[p + "attn.proj.weight"], W[p + "attn.proj.bias"])
+    xr = (x[rows].float() + gate_msa[frame] * xs.float()).to(x.dtype)
+    # cross-attention on the noise rows (condition rows receive zeros)
+    xn = layer_norm(xr, W[p + "pre_crs_attn_norm.weight"], W[p + "pre_crs_attn_norm.bias"])
+    cp = p + "cross_attn."
+    qc = F.linear(xn[~is_c], W[cp + "q_linear.weight"], W[cp + "q_linear.bias"]).view(-1, H, D)
+    kvc = F.linear(y, W[cp + "kv_linear.weight"], W[cp + "kv_linear.bias"]).view(-1, 2, H, D)
+    qc, kc = rms_norm_head(qc, W[cp + "q_norm.weight"]), rms_norm_head(kvc[:, 0], W[cp + "k_norm.weight"])
+    oc = attention(qc.transpose(0, 1), kc.transpose(0, 1), kvc[:, 1].transpose(0, 1), D ** -0.5)
+    ca = torch.zeros_like(xr)
+    ca[~is_c] = F.linear(oc, W[cp + "proj.weight"], W[cp + "proj.bias"])
+    xr = xr + ca
+    xs = swiglu(W, p + "ffn.", mod_rows(xr, shift_mlp, scale_mlp))
+    xr = (xr.float() + gate_mlp[frame] * xs.float()).to(xr.dtype)
+    mod = F.linear(F.silu(t), W["final_layer.adaLN_modulation.1.weight"].float(), W["final_layer.adaLN_modulation.1.bias"].float())
+    shift, scale = mod.chunk(2, dim=-1)
+    return F.linear(mod_rows(xr, shift, scale).float(), W["final_layer.linear.weight"].float(), W["final_layer.linear.bias"].float()).float()
+
+
+def token_patches(v: torch.Tensor, cfg: LongCatConfig, rows) -> torch.Tensor:
+    """The inverse of LCD:371-392 at selected tokens: velocity [C_out, T, H, W] -> [len(rows), p_h p_w C_out] in (p_h, p_w, c) order."""
+    _, ph, pw = cfg.patch_size
+    Co, T, Hh, Ww = v.shape
+    nh, nw = Hh // ph, Ww // pw
+    u = v.view(Co, T, nh, ph, nw, pw).permute(1, 2, 4, 3, 5, 0).reshape(T * nh * nw, ph * pw * Co)
+    return u[torch.as_tensor(rows, dtype=torch.long)]
+
+
 def random_weights(cfg: LongCatConfig, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
     """Synthetic state dict with the reference's names and shapes; values are bf16-representable so that the HIP path (bf16
     weights) and this fp32 oracle see identical parameters."""

@@ -31,3 +31,21 @@ def test_rope_table_layout():
     assert torch.equal(ang[0, :22], ang[4 * 5 - 1, :22]) and not torch.equal(ang[0, :22], ang[4 * 5, :22])
     assert torch.equal(ang[0, 22:43], ang[4, 22:43]) and not torch.equal(ang[0, 22:43], ang[5, 22:43])
     assert not torch.equal(ang[0, 43:], ang[1, 43:])
+
+
+def test_forward_rows_equals_forward_at_the_sampled_tokens():
+    """oracle.dit.forward_rows (the row-sampled statement used for the full-token-count GPU check) against the pinned forward()."""
+    cfg = odit.DiTConfig(dim=384, ffn_dim=640, num_heads=3, num_layers=1, text_dim=64)
+    W = odit.random_weights(cfg, seed=13)
+    g = torch.Generator().manual_seed(4)
+    T, h, w = 3, 6, 10
+    x = torch.randn(36, T, h, w, generator=g)
+    ctx, clip = torch.randn(40, 64, generator=g), torch.randn(257, 1280, generator=g)
+    full = odit.forward(W, cfg, x, torch.tensor(749), ctx, clip)
+    rows = [0, 1, 14, 15, 29, 30, 44]
+    got = odit.forward_rows(W, cfg, x, torch.tensor(749), ctx, clip, rows)
+    want = odit.token_patches(full, cfg, rows)
+    assert got.shape == want.shape == (len(rows), 64)
+    assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    with pytest.raises(AssertionError):
+        odit.forward_rows(W, odit.DiTConfig(dim=384, ffn_dim=640, num_heads=3, num_layers=2, text_dim=64), x, torch.tensor(749), ctx, clip, rows)

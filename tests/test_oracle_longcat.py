@@ -57,3 +57,25 @@ def test_lora_fold_equals_reference_runtime_lora():
     want = torch.from_numpy(L["out"])
     assert (got - want).abs().max() / want.abs().max() < 2e-5
     assert (want - torch.from_numpy(L["out_base"])).abs().mean() > 0.05  # the LoRA really changes the output
+
+
+@pytest.mark.parametrize("ncond,zpad", [(1, False), (0, False), (2, True)])
+def test_forward_rows_equals_forward_at_the_sampled_tokens(ncond, zpad):
+    """oracle.longcat_dit.forward_rows (the row-sampled statement used for the full-size GPU check) against the pinned forward()."""
+    cfg = olc.LongCatConfig(hidden_size=256, depth=1, num_heads=2, caption_channels=64, adaln_tembed_dim=64, text_tokens_zero_pad=zpad)
+    W = olc.random_weights(cfg, seed=5)
+    g = torch.Generator().manual_seed(6)
+    T, h, w = 4, 8, 12
+    x = torch.randn(16, T, h, w, generator=g)
+    cap = torch.randn(24, 64, generator=g)
+    mask = torch.zeros(24, dtype=torch.int64)
+    mask[:17] = 1
+    ts = torch.full((T,), 637.0)
+    ts[:ncond] = 0
+    full = olc.forward(W, cfg, x, ts, cap, mask, num_cond_latents=ncond)
+    tpf = (h // 2) * (w // 2)
+    rows = [0, 1, tpf - 1, tpf, tpf + 5, 2 * tpf - 1, 2 * tpf, 4 * tpf - 1]
+    got = olc.forward_rows(W, cfg, x, ts, cap, mask, ncond, rows)
+    want = olc.token_patches(full, cfg, rows)
+    assert got.shape == want.shape == (len(rows), 64)
+    assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())

@@ -97,7 +97,7 @@ def run_hip(precision, Wd_, Wv, ocfg, inputs, Fr, H, Wd, steps, guide, flow_back
                generator=torch.manual_seed(42), prompt_embeds=text, negative_prompt_embeds=neg, image_embeds=img, output_type="np",
                video_ref=ref, mask=mask, static=True, guided=True, resample_steps=2, guide_steps=guide, omega=4.0, omega_resample=4.0,
                resample_round=guide, use_pca_channel_selection=True, callback_on_step_end=on_step_end)
-    return torch.from_numpy(out.frames)[0], lat, [(s, c) for s, c, _ in sch.flf_log], [sim for _, _, sim in sch.flf_log]
+    return torch.from_numpy(out.frames)[0], lat, [(e[0], e[1]) for e in sch.flf_log], [e[2] for e in sch.flf_log]
 
 
 def run_oracle(Wd_, Wv, ocfg, inputs, Fr, H, Wd, steps, guide, flow_backend):

@@ -78,6 +78,8 @@ struct AttnArgs {
   const float* kmax2;
   const float* qmax2;
   int kmax_n, qmax_n;
+  // test hook (wf_attn_debug_body_counter): device uint32[2], [0] += workgroups that ran the tracked body, [1] += the un-tracked one; NULL = off
+  unsigned int* dbg_body;
 };
 
 #ifdef WF_ATTN_TIMING
@@ -1089,9 +1091,11 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
         float kn2 = 0.f, qn2 = 0.f;
         for (int i = 0; i < a.kmax_n; ++i) kn2 = fmaxf(kn2, a.kmax2[i * a.H + head]);
         for (int i = 0; i < a.qmax_n; ++i) qn2 = fmaxf(qn2, a.qmax2[i * a.H + head]);
-        fast = qn2 * kn2 <= 2500.0f;  // B <= 50; false for NaN
+        fast = qn2 * kn2 <= 2500.0f;  // B <= 50.  Non-finite rows: k_head_max_norm2 reports +inf for a row holding a NaN or an inf, and
+                                      // inf * x is inf (or NaN for x = 0), for which `<=` is false -> the tracked body
       }
     }
+    if (a.dbg_body && threadIdx.x == 0) atomicAdd(a.dbg_body + (fast ? 1 : 0), 1u);
     if (__builtin_amdgcn_readfirstlane((int)fast))
       attn_w4_body<4, true>(a);
     else
@@ -1140,6 +1144,8 @@ __global__ void k_attn_merge(AttnArgs a) {
 
 }  // namespace
 
+static unsigned int* g_dbg_body = nullptr;  // wf_attn_debug_body_counter
+
 static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len, int ldo,
                        float softmax_scale, int accumulate, int nsplit, void* workspace, const float* kmax2, int kmax_n, const float* qmax2,
                        int qmax_n, void* stream, const char* who) {
@@ -1183,6 +1189,7 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
   a.qmax2 = qmax2;
   a.kmax_n = kmax2 ? kmax_n : 0;
   a.qmax_n = qmax2 ? qmax_n : 0;
+  a.dbg_body = g_dbg_body;
   const int hslots = (H + 7) / 8;
   const int grid = hslots * a.n_qblk * 8;
   const size_t lds = 4 * (K_TILE_BYTES + V_TILE_BYTES);
@@ -1259,6 +1266,10 @@ __global__ __launch_bounds__(256) void k_head_max_norm2(const uint16_t* __restri
 #pragma unroll
       for (int u = 0; u < 4; ++u) sq[u] += __shfl_xor(sq[u], o, 64);
     best = fmaxf(fmaxf(best, fmaxf(sq[0], sq[1])), fmaxf(sq[2], sq[3]));
+    // fmaxf drops NaNs: a row holding a NaN (or an inf) must still push the attention kernel onto its tracked body -> report +inf
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (!(sq[u] <= 3.0e38f)) best = INFINITY;
   }
   // one atomic per workgroup at most, and only while the running maximum still grows: atomics on the 40 per-head words serialise in the
   // L2 (four per workgroup x 256 workgroups per head cost 100 us of a 137 us pass at 32 760 rows)
@@ -1321,6 +1332,7 @@ extern "C" int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, voi
   a.tiles_per_split = 0;
   a.kmax2 = a.qmax2 = nullptr;
   a.kmax_n = a.qmax_n = 0;
+  a.dbg_body = nullptr;
   const int grid = ((H + 7) / 8) * a.n_qblk * 8;
   // default: the one-wave-per-SIMD kernel (k_attn_w4<3>); WF_ATTN_KERNEL=w8 selects the two-waves-per-SIMD form (k_attn<2>)
   static const int use_w4 = [] {
@@ -1332,6 +1344,11 @@ extern "C" int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, voi
   else
     hipLaunchKernelGGL(k_attn<2>, dim3(grid), dim3(NT), 4 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream, a);
   WF_LAUNCH_CHECK("wf_attn_bsa_fwd");
+  return WF_OK;
+}
+
+extern "C" int wf_attn_debug_body_counter(void* counters2) {
+  g_dbg_body = (unsigned int*)counters2;
   return WF_OK;
 }
 

@@ -159,6 +159,7 @@ class WanImageToVideoPipeline:
             sch.derivative_history = []
 
         tr = self.tracer
+        tr.reset()  # `self.timing` and the WF_TRACE log describe THIS call only
         sch.tracer = tr
         if start_step:
             # bench window: enter the schedule at `start_step` (UniPC restarts at order 1 there, like step 0)
@@ -187,31 +188,29 @@ class WanImageToVideoPipeline:
                         sch.lower_order_nums -= 1
                     sch.this_order = sch.last_this_order
                 latent_model_input = self._model_input(latents, condition, transformer_dtype)
-                _rng = tr.range("dit_cfg", step=i, round=r)
-                _rng.__enter__()
-                pair = getattr(self.transformer, "forward_cfg_pair", None) if self.do_classifier_free_guidance else None
-                if pair is not None:
-                    # same two calls as below, advanced in lock-step so that under sequence parallelism each branch's K / V
-                    # exchange overlaps the other branch's compute (dit.forward_tokens_pair); identical results
-                    noise_pred, noise_uncond = pair(hidden_states=latent_model_input, timestep=timestep_for_transformer,
-                                                    encoder_hidden_states=prompt_embeds,
-                                                    negative_encoder_hidden_states=negative_prompt_embeds,
-                                                    encoder_hidden_states_image=image_embeds)
-                else:
-                    noise_pred = self.transformer(hidden_states=latent_model_input, timestep=timestep_for_transformer,
-                                                  encoder_hidden_states=prompt_embeds,
-                                                  encoder_hidden_states_image=image_embeds, attention_kwargs=attention_kwargs,
-                                                  return_dict=False)[0]
+                with tr.range("dit_cfg", step=i, round=r):
+                    pair = getattr(self.transformer, "forward_cfg_pair", None) if self.do_classifier_free_guidance else None
+                    if pair is not None:
+                        # same two calls as below, advanced in lock-step so that under sequence parallelism each branch's K / V
+                        # exchange overlaps the other branch's compute (dit.forward_tokens_pair); identical results
+                        noise_pred, noise_uncond = pair(hidden_states=latent_model_input, timestep=timestep_for_transformer,
+                                                        encoder_hidden_states=prompt_embeds,
+                                                        negative_encoder_hidden_states=negative_prompt_embeds,
+                                                        encoder_hidden_states_image=image_embeds)
+                    else:
+                        noise_pred = self.transformer(hidden_states=latent_model_input, timestep=timestep_for_transformer,
+                                                      encoder_hidden_states=prompt_embeds,
+                                                      encoder_hidden_states_image=image_embeds, attention_kwargs=attention_kwargs,
+                                                      return_dict=False)[0]
+                        if self.do_classifier_free_guidance:
+                            noise_uncond = self.transformer(hidden_states=latent_model_input, timestep=timestep_for_transformer,
+                                                            encoder_hidden_states=negative_prompt_embeds,
+                                                            encoder_hidden_states_image=image_embeds,
+                                                            attention_kwargs=attention_kwargs, return_dict=False)[0]
                     if self.do_classifier_free_guidance:
-                        noise_uncond = self.transformer(hidden_states=latent_model_input, timestep=timestep_for_transformer,
-                                                        encoder_hidden_states=negative_prompt_embeds,
-                                                        encoder_hidden_states_image=image_embeds,
-                                                        attention_kwargs=attention_kwargs, return_dict=False)[0]
-                if self.do_classifier_free_guidance:
-                    noise_pred = ops.cfg_combine(noise_pred, noise_uncond, guidance_scale)
-                    if r < 1:
-                        sch.derivative_history.append(noise_pred)
-                _rng.__exit__(None, None, None)
+                        noise_pred = ops.cfg_combine(noise_pred, noise_uncond, guidance_scale)
+                        if r < 1:
+                            sch.derivative_history.append(noise_pred)
                 with tr.range("scheduler_step", step=i, round=r):
                     scheduler_output = sch.step(noise_pred, t, latents, mask=mask,
                                                 guided=guided and i < guide_steps and r < resample_steps,

@@ -260,16 +260,17 @@ class UniPCMultistepScheduler:
                     pred_original_sample=x0, video_latents=ops.cast(enc, x0.dtype), mask=None, keep_channels=12,
                     current_step=kwargs.get("current_step", 0), total_steps=kwargs.get("total_steps", 50),
                     use_optical_flow=kwargs.get("use_optical_flow", True), static=static)
+            free = list(channels)
             if self.flf_replay is not None:
                 # analysis only (tools/vae_precision_study.py): the gate is a discrete decision on 16 nearly tied similarities, so
                 # two arithmetically close runs can swap different channels; replaying one run's decisions in the other separates
                 # the arithmetic error of the path from the decision flips.  The gate above still ran (and is logged below).
-                free = channels
                 channels = list(self.flf_replay.get(int(kwargs.get("current_step", 0)), free))
             ops.channel_swap_(enc, x0, channels)
-            if self.flf_log is not None:  # trace: (outer step, swapped channels, the 16 similarities)
-                self.flf_log.append((int(kwargs.get("current_step", 0)), list(channels),
-                                     None if self._pca_selector.last_similarities is None else self._pca_selector.last_similarities.copy()))
+            if self.flf_log is not None:  # trace: (outer step, the gate's own decision, the 16 similarities, the channels actually swapped)
+                self.flf_log.append((int(kwargs.get("current_step", 0)), free,
+                                     None if self._pca_selector.last_similarities is None else self._pca_selector.last_similarities.copy(),
+                                     list(channels)))
         return ops.cast(enc, x0.dtype)
 
     # ---- SCHED:1423-1536 ---------------------------------------------------------------------------------

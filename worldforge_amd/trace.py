@@ -32,6 +32,11 @@ class Tracer:
         t.path = path
         return t
 
+    def reset(self):
+        """Forget the records of earlier calls (open ranges of an aborted call included)."""
+        self.records = []
+        self._pending = []
+
     @contextlib.contextmanager
     def range(self, name: str, **tags):
         if not self.enabled:

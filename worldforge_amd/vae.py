@@ -17,9 +17,11 @@ precision (the reference loads the VAE with torch_dtype=torch.float32, INFER:185
   "bf16"  -- every matrix-core operand (activation and weight) rounded to bf16: 2^-9 relative per operand.  Opt-in fast mode: over a
              guided job's 31 decode -> encode round trips this noise is enough to flip near-tied FLF gate decisions
              (tools/vae_precision_study.py).
-  "fp32"  -- DEFAULT.  fp32-class contractions on the bf16 matrix cores: every operand x is carried as hi = bf16(x), lo = bf16(x - hi) and every
-             contraction as hi.hi + lo.hi + hi.lo in fp32 accumulators (wf_split_bf16x3: activations [hi | lo | hi], weights
-             [hi | hi | lo] on 3x the channels, the SAME conv / GEMM kernels; dropped terms <= 2^-16 relative).  3x the MFMA work.
+  "bf16x3" -- DEFAULT.  fp32-CLASS contractions on the bf16 matrix cores, NOT IEEE fp32: every operand x is carried as hi = bf16(x),
+             lo = bf16(x - hi) and every contraction as hi.hi + lo.hi + hi.lo in fp32 accumulators (wf_split_bf16x3: activations
+             [hi | lo | hi], weights [hi | hi | lo] on 3x the channels, the SAME conv / GEMM kernels; the dropped lo.lo term and the
+             rounding of lo leave ~2^-16 relative per product, against 2^-24 for true fp32).  3x the MFMA work.  "fp32" is accepted as
+             an alias (rounds 1-2 called the mode that) and maps to "bf16x3".
 """
 from __future__ import annotations
 
@@ -177,11 +179,13 @@ class _LatentDist:
 class AutoencoderKLWan:
     dtype = torch.float32
 
-    def __init__(self, device="cuda:0", comm=None, precision: str = "fp32"):
-        if precision not in ("bf16", "fp32"):
-            raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
+    def __init__(self, device="cuda:0", comm=None, precision: str = "bf16x3"):
+        if precision == "fp32":  # the earlier name of the same mode
+            precision = "bf16x3"
+        if precision not in ("bf16", "bf16x3"):
+            raise ValueError(f"precision must be 'bf16' or 'bf16x3' (alias 'fp32'), got {precision!r}")
         self.precision = precision
-        self.x3 = precision == "fp32"  # three-term split operands
+        self.x3 = precision == "bf16x3"  # three-term split operands
         self.device = torch.device(device)
         self.comm = comm  # row-slab sharding of the high-resolution stages over the ranks of `comm` (parallel.Comm or a stand-in)
         self._reps = 1    # ranks per row group while a sharded stage runs (see _row_groups)
@@ -301,7 +305,7 @@ class AutoencoderKLWan:
         return self.load_state_dict(diffusers_to_twin_state_dict(sd))
 
     @classmethod
-    def from_pretrained(cls, path: str, device="cuda:0", comm=None, precision: str = "fp32", subfolder: str = "vae"):
+    def from_pretrained(cls, path: str, device="cuda:0", comm=None, precision: str = "bf16x3", subfolder: str = "vae"):
         """`AutoencoderKLWan.from_pretrained(model_id, subfolder="vae", torch_dtype=torch.float32)` (INFER:185-189) from a local
         diffusers checkpoint directory: reads `<path>/<subfolder>/*.safetensors` (sharded or not) with checkpoint.load_dir."""
         from . import checkpoint
