@@ -175,7 +175,7 @@ def decision_margin(sims, step):
 
 
 def study(dim=1024, ffn_dim=2048, heads=8, layers=4, Fr=17, H=128, Wd=128, steps=20, guide=15, flow_backend="farneback",
-          with_oracle=False, verbose=True, fixture=None, save_fixture=None, oracle_only=False):
+          with_oracle=False, verbose=True, fixture=None, save_fixture=None, oracle_only=False, skip_bf16=False):
     """fixture: an .npz written by an earlier `--oracle --save-fixture` run (oracle frames / latents / gate decisions for exactly
     this job) used instead of running the CPU oracle again."""
     import numpy as np
@@ -199,8 +199,8 @@ def study(dim=1024, ffn_dim=2048, heads=8, layers=4, Fr=17, H=128, Wd=128, steps
         print(f"oracle: {time.time() - t0:.0f} s -> {save_fixture}; gates {orc[2]}")
         return res
     t0 = time.time()
-    fa, la, ca, sa = run_hip("bf16", *args)
-    fb, lb, cb, sb = run_hip("fp32", *args)
+    fb, lb, cb, sb = run_hip("bf16x3", *args)
+    fa, la, ca, sa = (fb, lb, cb, sb) if skip_bf16 else run_hip("bf16", *args)   # skip_bf16: the "bf16vae" keys repeat the default mode
     res["hip_s"] = time.time() - t0
     res["free_running"] = {
         "psnr_bf16vae_vs_fp32vae_db": psnr(fa, fb), "flf_gates": len(ca), "flf_swapping_gates": sum(1 for _, c in cb if c),
@@ -237,9 +237,9 @@ def study(dim=1024, ffn_dim=2048, heads=8, layers=4, Fr=17, H=128, Wd=128, steps
             "latent_db_fp32vae_vs_oracle_per_step": [round(db(b, c), 1) for b, c in zip(lb, lc)]})
     # the same job with the gate decisions of the parity target replayed: what the ARITHMETIC of the path contributes
     target = dict(orc[2]) if orc is not None else dict(cb)
-    ra, lra, _, _ = run_hip("bf16", *args, replay=target)
-    rb, lrb, _, _ = run_hip("fp32", *args, replay=target)
-    rep = {"decisions_from": "oracle" if orc is not None else "fp32-class VAE run", "psnr_bf16vae_vs_fp32vae_db": psnr(ra, rb),
+    rb, lrb, _, _ = run_hip("bf16x3", *args, replay=target)
+    ra, lra = (rb, lrb) if skip_bf16 else run_hip("bf16", *args, replay=target)[:2]
+    rep = {"decisions_from": ("fixture" if fixture is not None else "oracle") if orc is not None else "fp32-class VAE run", "psnr_bf16vae_vs_fp32vae_db": psnr(ra, rb),
            "latent_db_bf16_vs_fp32vae_per_step": [round(db(a, b), 1) for a, b in zip(lra, lrb)]}
     if orc is not None:
         rep.update({"psnr_bf16vae_vs_oracle_db": psnr(sel(ra), orc[0]), "psnr_fp32vae_vs_oracle_db": psnr(sel(rb), orc[0]),

@@ -241,11 +241,20 @@ class FlowMatchEulerDiscreteScheduler:
             return pred_original_sample
         x0 = pred_original_sample
         mean, std = vae.config.latents_mean, vae.config.latents_std
-        decoded = vae.decode(ops.latent_denorm(x0, mean, std), return_dict=False)[0]
-        if tuple(video_latents.shape) != tuple(decoded.shape) or mask.shape[1] != 1 or tuple(mask.shape[2:]) != tuple(decoded.shape[2:]):
-            return pred_original_sample
-        fused = ops.blend_pixels(video_latents, mask, decoded)
-        enc = vae.encode(fused).latent_dist.mode()
+        if getattr(vae, "comm", None) is not None and hasattr(vae, "decode_blend_encode") and x0.dim() == 5 and x0.shape[0] == 1 \
+                and vae.can_shard(x0.shape[3]):
+            # row-sharded VAE: the decoded video is never gathered (vae.decode_blend_encode); the decoded size follows from the latent's
+            tds, sds = 2 ** sum(vae.temperal_downsample), 2 ** len(vae.temperal_downsample)
+            dshape = (1, 3, (x0.shape[2] - 1) * tds + 1, x0.shape[3] * sds, x0.shape[4] * sds)
+            if tuple(video_latents.shape) != dshape or mask.shape[1] != 1 or tuple(mask.shape[2:]) != dshape[2:]:
+                return pred_original_sample
+            enc = vae.decode_blend_encode(ops.latent_denorm(x0, mean, std), video_latents, mask).mode()
+        else:
+            decoded = vae.decode(ops.latent_denorm(x0, mean, std), return_dict=False)[0]
+            if tuple(video_latents.shape) != tuple(decoded.shape) or mask.shape[1] != 1 or tuple(mask.shape[2:]) != tuple(decoded.shape[2:]):
+                return pred_original_sample
+            fused = ops.blend_pixels(video_latents, mask, decoded)
+            enc = vae.encode(fused).latent_dist.mode()
         if tuple(enc.shape) != tuple(x0.shape):
             return pred_original_sample
         enc = ops.latent_norm(enc, mean, std, const_dtype=x0.dtype)

@@ -244,14 +244,25 @@ class UniPCMultistepScheduler:
         x0 = pred_original_sample
         mean, std = vae.config.latents_mean, vae.config.latents_std
         tr, step = self.tracer, kwargs.get("current_step", 0)
-        with tr.range("vae_decode", step=step):
-            decoded = vae.decode(ops.latent_denorm(x0, mean, std), return_dict=False)[0]
-        with tr.range("blend", step=step):
-            ref, m = align_reference(video_latents, mask, decoded.shape)
-            fused = ops.blend_pixels(ref, m, decoded)
-        with tr.range("vae_encode", step=step):
-            enc = vae.encode(fused).latent_dist.mode()
-            enc = ops.latent_norm(enc, mean, std, const_dtype=x0.dtype)
+        if getattr(vae, "comm", None) is not None and hasattr(vae, "decode_blend_encode") and x0.dim() == 5 and x0.shape[0] == 1 \
+                and vae.can_shard(x0.shape[3]):
+            # row-sharded VAE: decode -> blend -> encode on this rank's row slab, nothing pixel-sized is gathered (vae.decode_blend_encode)
+            with tr.range("vae_roundtrip_sharded", step=step):
+                tds = 2 ** sum(vae.temperal_downsample)
+                sds = 2 ** len(vae.temperal_downsample)
+                shape = (1, 3, (x0.shape[2] - 1) * tds + 1, x0.shape[3] * sds, x0.shape[4] * sds)
+                ref, m = align_reference(video_latents, mask, shape)
+                enc = vae.decode_blend_encode(ops.latent_denorm(x0, mean, std), ref, m).mode()
+                enc = ops.latent_norm(enc, mean, std, const_dtype=x0.dtype)
+        else:
+            with tr.range("vae_decode", step=step):
+                decoded = vae.decode(ops.latent_denorm(x0, mean, std), return_dict=False)[0]
+            with tr.range("blend", step=step):
+                ref, m = align_reference(video_latents, mask, decoded.shape)
+                fused = ops.blend_pixels(ref, m, decoded)
+            with tr.range("vae_encode", step=step):
+                enc = vae.encode(fused).latent_dist.mode()
+                enc = ops.latent_norm(enc, mean, std, const_dtype=x0.dtype)
         if kwargs.get("use_pca_channel_selection") and not kwargs.get("resampling", False):
             if self._pca_selector is None:
                 self._pca_selector = VideoMotionPCASelector(flow_backend=self.flow_backend)

@@ -761,7 +761,8 @@ class AutoencoderKLWan:
         P = self.comm.world
         return (2 * H_lat) % P == 0 and (8 * H_lat) % (4 * P) == 0
 
-    def _decode_one_sharded(self, z: torch.Tensor) -> torch.Tensor:
+    def _decode_one_sharded(self, z: torch.Tensor, gather: bool = True) -> torch.Tensor:
+        """gather=False: return this rank's row slab [3, F, 8h/P, 8w] (rows rank * 8h/P ...) instead of the gathered video."""
         comm = self.comm
         P, rank = comm.world, comm.rank
         C, T, h, w = z.shape
@@ -808,22 +809,29 @@ class AutoencoderKLWan:
                 Tn, Hn, Wn, _ = x.shape
                 a = self._halo_operand(x, self.w[p + ".0.gamma"])
                 x, _ = self._conv(a, p + ".2", Tn, Hn, Wn, (cout + 31) // 32 * 32, (3, 3, 3), pt=2, ps=1, ph=0)
-        y = self._gather_rows(x)
+        y = self._gather_rows(x) if gather else x.contiguous()
         Fo, Ho, Wo, Cy = y.shape
         out = torch.empty((3, Fo, Ho, Wo), dtype=F32, device=self.device)
         call("wf_cl_to_ncthw", y.data_ptr(), out.data_ptr(), 3, Cy, Fo * Ho * Wo, 1.0, ops.stream())
         return out
 
-    def _encode_one_sharded(self, video: torch.Tensor) -> torch.Tensor:
+    def _encode_one_sharded(self, video: torch.Tensor, slab: torch.Tensor = None) -> torch.Tensor:
+        """video [3,F,H,W] replicated on every rank -- or slab [3,F,H/P,W]: only this rank's rows (rank * H/P ...), the halo rows of the
+        first convolution then come from the neighbours by all-gather like every later layer's (same operand values: bit-identical)."""
         comm = self.comm
         P, rank = comm.world, comm.rank
-        C, Fr, H, Wd = video.shape
-        xfull = self._video_in(video)
         plan = encoder_plan()
-        Hs = H // P
-        y0 = rank * Hs
-        xpad = self._rows_from_full(xfull, y0 - 1, y0 + Hs + 1)
-        del xfull
+        if slab is not None:
+            C, Fr, Hs, Wd = slab.shape
+            H = Hs * P
+            xpad = self._halo_pad(self._video_in(slab))
+        else:
+            C, Fr, H, Wd = video.shape
+            xfull = self._video_in(video)
+            Hs = H // P
+            y0 = rank * Hs
+            xpad = self._rows_from_full(xfull, y0 - 1, y0 + Hs + 1)
+            del xfull
         kind, p, cin, cout = plan[0]
         x, _ = self._conv(xpad, p, Fr, Hs, Wd, cout, (3, 3, 3), pt=2, ps=1, ph=0)
         downs = [i for i, e in enumerate(plan) if e[0] in ("down2d", "down3d")]
@@ -916,6 +924,37 @@ class AutoencoderKLWan:
         out = torch.empty((3, Fo, Ho, Wo), dtype=F32, device=self.device)
         call("wf_cl_to_ncthw", y.data_ptr(), out.data_ptr(), 3, Cy, Fo * Ho * Wo, 1.0, ops.stream())
         return out
+
+    def _row_slab_of(self, t: torch.Tensor, y0: int, Hs: int) -> torch.Tensor:
+        """Rows [y0, y0 + Hs) of a [1,C,F,H,W] tensor as a contiguous slab, kept while the tensor is unchanged (the reference video and the
+        mask are the same objects for all 30 injections of a job)."""
+        key = (t.data_ptr(), t._version, tuple(t.shape), y0, Hs)
+        cache = self.__dict__.setdefault("_slab_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            while len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+            hit = cache[key] = (t, t[:, :, :, y0:y0 + Hs].contiguous())  # `t` is held so that its storage cannot be recycled under the key
+        return hit[1]
+
+    @torch.no_grad()
+    def decode_blend_encode(self, z: torch.Tensor, ref: torch.Tensor, mask: torch.Tensor):
+        """The pixel round trip of one IRR injection: decode (SCHED:1285) -> blend the warped reference in (SCHED:1375-1381) -> encode
+        (SCHED:1384) -> the posterior.  z [1,16,T,h,w]; ref [1,3,F,H,W] / mask [1,1,F,H,W] fp32, already aligned to the decoded size.
+        One GPU: exactly decode(), ops.blend_pixels(), encode().  Row-sharded (comm): the decoded video is NOT gathered -- the blend is
+        element-wise per pixel, so each rank blends and re-encodes its own row slab (the encoder's first halo comes from the neighbours);
+        only latent-resolution tensors are gathered.  Bit-identical to the gathered form."""
+        z = z.to(device=self.device, dtype=F32).contiguous()
+        if z.shape[0] != 1 or not self.can_shard(z.shape[3]):
+            dec = self.decode(z, return_dict=False)[0]
+            return self.encode(ops.blend_pixels(ref, mask, dec)).latent_dist
+        self.flops_last = 0
+        slab = self._decode_one_sharded(z[0], gather=False)               # [3, F, Hs, W]
+        Hs = slab.shape[2]
+        y0 = self.comm.rank * Hs
+        fused = ops.blend_pixels(self._row_slab_of(ref, y0, Hs), self._row_slab_of(mask, y0, Hs), slab.unsqueeze(0))
+        mom = self._encode_one_sharded(None, slab=fused[0]).unsqueeze(0)
+        return _LatentDist(mom[:, :Z_DIM].contiguous(), mom[:, Z_DIM:])
 
     @torch.no_grad()
     def encode(self, x: torch.Tensor, return_dict: bool = True):
