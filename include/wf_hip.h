@@ -342,6 +342,17 @@ size_t wf_crack_fill_workspace_bytes(int n, int H, int W);
 int wf_crack_fill(const void* img, const void* mask, const float* depth, void* out_img, void* out_mask, float* out_depth, int n, int H,
                   int W, int min_neighbors, int min_valid_neighbors, int num_segments, void* workspace, void* stream);
 
+/* fill_small_cracks in full (vggt/modules/utils_warp.py:386-455) -- what warp_single_img runs INSTEAD of the depth-aware filling for a view
+ * with <= 100 splatted depths (:957-962, 973-981): step 1 = 3 x 3 closing + mean of the valid 8-neighbours (>= min_valid_neighbors of them);
+ * step 2 (has_depth_conf != 0 and step 1 filled fewer than half of the holes) = the 4-connected hole components of <= min(max_crack_size, 4)
+ * pixels in scipy.ndimage.label order, pixel by pixel, from the valid 3 x 3 neighbours whose original_depth (the SOURCE view's map, indexed at
+ * the target pixel as the reference does) is within depth_threshold of the pixel's -- sequential, one lane.  One view: img u8 [H][W][3],
+ * mask u8 [H][W], original_depth f32 [H][W] (may be NULL when has_depth_conf == 0) -> out_img u8, out_mask u8.  The image is float32 (u8 / 255)
+ * through both steps and quantised once ((x * 255) truncated), as the reference.  workspace: wf_fill_small_cracks_workspace_bytes(H, W). */
+size_t wf_fill_small_cracks_workspace_bytes(int H, int W);
+int wf_fill_small_cracks(const void* img, const void* mask, const float* original_depth, int has_depth_conf, void* out_img, void* out_mask,
+                         int H, int W, float depth_threshold, int max_crack_size, int min_valid_neighbors, void* workspace, void* stream);
+
 /* ---- stage-1 of the dynamic-scene path: DepthCrafter point-cloud renderer (DepthCrafter/utils.py, warp_depthcrafter.py:255-288) ------- */
 /* project_points_to_image_pytorch (utils.py:103-171): pytorch3d PointsRasterizer(radius, points_per_pixel = 10) -> idx[..., 0] = the
  * covering point of smallest view depth per pixel -> image = features[idx], mask = idx != -1 -> 5 x 5 opening of the mask (morph) ->

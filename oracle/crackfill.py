@@ -54,6 +54,38 @@ def fill_small_cracks(image: np.ndarray, mask: np.ndarray, min_valid_neighbors: 
     return filled_image, filled_mask
 
 
+def fill_small_cracks_depth_guided(image: np.ndarray, mask: np.ndarray, original_depth: np.ndarray, use_depth_conf: bool,
+                                   depth_threshold: float = 0.1, max_crack_size: int = 5, min_valid_neighbors: int = 3):
+    """:386-455 in full, as warp_single_img calls it for a view with <= 100 splatted depths (:973-981): step 1 above, then -- when a
+    depth-confidence map was given (only its PRESENCE matters, :433) and step 1 filled fewer than half of the holes -- step 2: the 4-connected
+    hole components (scipy.ndimage.label, the real one) of <= min(max_crack_size, 4) pixels are filled pixel by pixel, in label order and
+    np.where order, from the valid 3 x 3 neighbours whose ORIGINAL depth (the source view's map, indexed at the target pixel, as the
+    reference does) is within depth_threshold of the pixel's; every fill is visible to the pixels after it."""
+    holes = mask == 0
+    filled_image, filled_mask = fill_small_cracks(image, mask, min_valid_neighbors)
+    if not np.any(holes):
+        return filled_image, filled_mask
+    morph_count = int(np.sum((filled_mask != 0) & holes))
+    if use_depth_conf and morph_count < np.sum(holes) * 0.5:
+        H, W = mask.shape
+        labeled, num = ndimage.label(filled_mask == 0)
+        sizes = np.bincount(labeled.ravel(), minlength=num + 1)
+        for hole_id in np.nonzero((sizes <= max_crack_size) & (sizes <= 4))[0]:
+            if hole_id == 0:
+                continue
+            ys, xs = np.where(labeled == hole_id)
+            for y, x in zip(ys, xs):
+                y0, y1, x0, x1 = max(0, y - 1), min(H, y + 2), max(0, x - 1), min(W, x + 2)
+                valid = filled_mask[y0:y1, x0:x1] > 0
+                if np.sum(valid) >= min_valid_neighbors:
+                    dd = np.abs(original_depth[y0:y1, x0:x1][valid] - original_depth[y, x])
+                    ok = dd <= depth_threshold
+                    if np.sum(ok) >= min_valid_neighbors:
+                        filled_image[y, x] = np.mean(filled_image[y0:y1, x0:x1][valid][ok], axis=0)
+                        filled_mask[y, x] = 1
+    return filled_image, filled_mask
+
+
 def depth_estimation(depth: np.ndarray, newly: np.ndarray) -> np.ndarray:
     """:539-564."""
     if not np.any(newly):
@@ -135,13 +167,18 @@ def depth_aware_crack_filling(image: np.ndarray, mask: np.ndarray, depth: np.nda
     return mi, mm, md
 
 
-def warp_frame_fill(img_u8: np.ndarray, mask_u8: np.ndarray, depth: np.ndarray, params=None, num_segments: int = 5):
-    """The per-frame step of warp_single_img :954-985 on a splatted view: u8 image -> f32 / 255 -> fill -> (x * 255).astype(u8)."""
+def warp_frame_fill(img_u8: np.ndarray, mask_u8: np.ndarray, depth: np.ndarray, params=None, num_segments: int = 5,
+                    original_depth: np.ndarray = None, use_depth_conf: bool = False):
+    """The per-frame step of warp_single_img :954-985 on a splatted view: u8 image -> f32 / 255 -> fill -> (x * 255).astype(u8).
+    original_depth / use_depth_conf: the source view's filtered depth map and whether a confidence map exists -- read only on the
+    <= 100-splatted-depths path (:973-981)."""
     if np.sum(~np.isnan(depth)) > 100:
         fi, fm, fd = depth_aware_crack_filling(img_u8.astype(np.float32) / 255.0, mask_u8, depth, params, num_segments)
-    else:  # fill_small_cracks with depth_conf: the depth-guided second step is not restated (needs the confidence map)
+    else:
         p = dict(DEFAULT_PARAMS)
         p.update(params or {})
-        fi, fm = fill_small_cracks(img_u8.astype(np.float32) / 255.0, mask_u8, p["min_valid_neighbors"])
+        od = original_depth if original_depth is not None else np.zeros(mask_u8.shape, dtype=np.float32)
+        fi, fm = fill_small_cracks_depth_guided(img_u8.astype(np.float32) / 255.0, mask_u8, od, use_depth_conf and original_depth is not None,
+                                                p["depth_threshold"], p["max_crack_size"], p["min_valid_neighbors"])
         fd = depth
     return (fi * 255).astype(np.uint8), fm.astype(np.uint8), fd

@@ -26,3 +26,12 @@ def case_inputs(c, seed=42):
     ne = torch.randn(1, 16, 32, generator=g).to(torch.bfloat16)
     ie = torch.randn(1, 8, 16, generator=g)
     return image, ref, mask, pe, ne, ie
+
+
+# fill_small_cracks cases of tests/golden/g23_fill_small_cracks.npz (tools/make_goldens.py small_cracks): name -> (a confidence map exists,
+# max_crack_size, min_valid_neighbors, depth_threshold).  With the shipped min_valid_neighbors (3; run_warp.py passes 2) step 1 fills every
+# hole step 2 could reach; the stricter counts make the depth-guided sequential step do work.
+SMALL_CRACK_CASES = {
+    "conf": (True, 5, 3, 0.1), "noconf": (False, 5, 3, 0.1), "conf_mvn2": (True, 6, 2, 0.1), "conf_mvn6_small": (True, 2, 6, 0.1),
+    "noconf_mvn7": (False, 5, 7, 0.1), "conf_mvn7": (True, 5, 7, 0.1), "conf_mvn7_thr1": (True, 5, 7, 1.0), "conf_mvn7_size1": (True, 1, 7, 1.0),
+}

@@ -196,3 +196,51 @@ def test_points_render_without_opening_and_with_dropped_points():
     wimg, wmask = opr.project_points_to_image(pts[~drop], rgb.reshape(-1, 3)[~drop], cam, K, (H, W), morph=False)
     assert (mask.cpu().numpy() != wmask).mean() <= 1e-4
     assert (np.abs(img.cpu().numpy() - wimg).max(-1) > 0).mean() <= 2e-4
+
+
+def test_small_crack_fill_equals_reference_recorded_outputs():
+    """wf_fill_small_cracks (the <= 100-splatted-depths path of warp_single_img, utils_warp.py:973-981) against G23 = the reference's own
+    fill_small_cracks on that view, 8 parameter sets incl. ones where the depth-guided sequential step fills pixels: masks exact, colours
+    within one grey level after the single (x * 255) quantisation."""
+    from oracle import crackfill as ocf
+    from tests.cases import SMALL_CRACK_CASES
+    from worldforge_amd import warp
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g23_fill_small_cracks.npz"))
+    img_u8 = (g["img"] * 255).astype(np.uint8)
+    img_f = img_u8.astype(np.float32) / 255.0            # the reference's float image of the u8 view (:956)
+    mask, depth = g["mask"], g["depth"]
+    for name, (has_conf, mcs, mvn, thr) in SMALL_CRACK_CASES.items():
+        want_i, want_m = ocf.fill_small_cracks_depth_guided(img_f, mask, depth, has_conf, thr, mcs, mvn)
+        assert np.array_equal(want_m, g[f"{name}_mask"]), name       # same fill decisions as the recorded run (colours differ: u8 input here)
+        oi, om = warp.small_crack_fill(torch.from_numpy(img_u8).to(DEV), torch.from_numpy(mask).to(DEV), torch.from_numpy(depth).to(DEV),
+                                       has_conf, thr, mcs, mvn)
+        assert np.array_equal(om.cpu().numpy(), g[f"{name}_mask"]), name
+        want_u8 = (want_i * 255).astype(np.uint8)
+        assert np.abs(oi.cpu().numpy().astype(np.int32) - want_u8.astype(np.int32)).max() <= 1, name
+
+
+def test_crack_fill_routes_nearly_empty_views_through_the_small_crack_path():
+    """A camera path whose last view has <= 100 splatted pixels: crack_fill must return fill_small_cracks' result for it (depth untouched)
+    and the depth-aware result for the others."""
+    from oracle import crackfill as ocf
+    from worldforge_amd import warp
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g23_fill_small_cracks.npz"))
+    H, W = g["mask"].shape
+    rs = np.random.default_rng(3)
+    full_img = (rs.random((H, W, 3)) * 255).astype(np.uint8)
+    full_mask = (rs.random((H, W)) > 0.1).astype(np.uint8)
+    full_depth = np.where(full_mask > 0, 2.0 + rs.random((H, W)), np.nan).astype(np.float32)
+    sparse_img = (g["img"] * 255).astype(np.uint8)
+    sparse_mask = g["mask"]
+    sparse_depth = np.where(sparse_mask > 0, g["depth"], np.nan).astype(np.float32)
+    imgs = torch.from_numpy(np.stack([full_img, sparse_img])).to(DEV)
+    masks = torch.from_numpy(np.stack([full_mask, sparse_mask])).to(DEV)
+    depths = torch.from_numpy(np.stack([full_depth, sparse_depth])).to(DEV)
+    od = torch.from_numpy(g["depth"]).to(DEV)
+    oi, om, odp = warp.crack_fill(imgs, masks, depths, min_valid_neighbors=7, original_depth=od, has_depth_conf=True)
+    wi, wm, wd = ocf.warp_frame_fill(sparse_img, sparse_mask, sparse_depth, dict(min_valid_neighbors=7), original_depth=g["depth"], use_depth_conf=True)
+    assert np.array_equal(om[1].cpu().numpy(), wm) and int(wm.sum()) > int(sparse_mask.sum())
+    assert np.abs(oi[1].cpu().numpy().astype(np.int32) - wi.astype(np.int32)).max() <= 1
+    assert torch.equal(torch.isnan(odp[1]), torch.isnan(depths[1]))
+    fi, fm, fd = ocf.warp_frame_fill(full_img, full_mask, full_depth, dict(min_valid_neighbors=7))
+    assert np.array_equal(om[0].cpu().numpy(), fm)

@@ -104,3 +104,21 @@ def test_two_pixel_thick_near_structures_survive():
     fi, fm, fd = cf.depth_aware_crack_filling(img, mask, depth, cf.RUN_WARP_PARAMS)
     np.testing.assert_allclose(fi[8:10, 4:12], 0.9)
     np.testing.assert_allclose(fd[8:10, 4:12], 1.0)
+
+
+def test_fill_small_cracks_with_depth_guided_step_equals_reference():
+    """G23: the reference's own fill_small_cracks (utils_warp.py:386-455, imported unmodified; its two OpenCV stencils served by this
+    oracle's restatements, everything else -- ndimage.label, the size rules, the sequential depth-guided fill -- the reference's code) on a
+    <= 100-pixel view, 8 parameter sets incl. ones where step 2 fills pixels."""
+    import os
+    from tests.cases import SMALL_CRACK_CASES
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g23_fill_small_cracks.npz"))
+    img, mask, depth = g["img"], g["mask"], g["depth"]
+    assert int(mask.sum()) <= 100
+    step2 = 0
+    for name, (has_conf, mcs, mvn, thr) in SMALL_CRACK_CASES.items():
+        fi, fm = cf.fill_small_cracks_depth_guided(img, mask, depth, has_conf, thr, mcs, mvn)
+        assert np.array_equal(fm, g[f"{name}_mask"]), name
+        np.testing.assert_array_equal(fi, g[f"{name}_img"], err_msg=name)
+        step2 += int(fm.sum() - cf.fill_small_cracks(img, mask, mvn)[1].sum())
+    assert step2 >= 5   # the depth-guided step did fill pixels in some of the cases

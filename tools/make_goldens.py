@@ -794,3 +794,53 @@ def g_warp_cams():
 
 if __name__ == "__main__" and "warp_cams" in sys.argv[1:]:
     g_warp_cams()
+
+
+# ------------------------------------------------------------------------------------------------------------
+def small_cracks_case(seed=9, H=40, W=56):
+    """A nearly empty splatted view (<= 100 valid pixels, the trigger of utils_warp.py:957-962 else-branch) built to exercise BOTH steps of
+    fill_small_cracks: a few compact islands of valid pixels with 1-4 pixel holes inside them, and depth steps across some holes."""
+    g = np.random.default_rng(seed)
+    img = g.random((H, W, 3)).astype(np.float32)
+    mask = np.zeros((H, W), dtype=np.uint8)
+    for (y, x, h, w) in ((3, 4, 5, 6), (20, 30, 5, 5), (30, 8, 4, 6), (10, 44, 4, 5)):       # 99 pixels before the holes are cut
+        mask[y:y + h, x:x + w] = 1
+    # a 1 x 3 and a 3 x 1 line (with min_valid_neighbors 7 step 1 fills the ends, step 2 then the middle, which by then has 8 valid
+    # neighbours), a single pixel, a 2 x 2 block
+    for (y, x) in ((5, 5), (5, 6), (5, 7), (21, 32), (22, 32), (23, 32), (31, 10), (11, 45), (11, 46), (12, 45), (12, 46)):
+        mask[y, x] = 0
+    depth = (2.0 + 0.02 * g.standard_normal((H, W))).astype(np.float32)
+    depth[20:26, 33:] += 0.5        # a depth step beside the vertical line: three of its neighbours fail the depth test
+    return img, mask, depth
+
+
+def g_small_cracks():
+    """G23: vggt/modules/utils_warp.py fill_small_cracks (:386-455), unmodified, on a <= 100-pixel view, with and without a confidence map.
+    `import cv2` is served by a stand-in whose filter2D / morphologyEx are oracle/crackfill.py's restatements (OpenCV is absent: step 1's two
+    stencils stay unpinned); everything the golden adds -- ndimage.label, the size rules, the sequential depth-guided fill of step 2 -- is the
+    reference's own numpy / scipy code."""
+    import types
+    from oracle import crackfill as ocf
+    cv2 = types.ModuleType("cv2")
+    cv2.MORPH_CLOSE = 3
+    cv2.morphologyEx = lambda m, op, k: ocf.close3(m)
+    cv2.filter2D = lambda im, dd, k, **kw: ocf.filter2d(im, k, "reflect" if kw.get("borderType") else "reflect101")
+    sys.modules["cv2"] = cv2
+    sys.path.insert(0, "/root/reference/vggt")
+    from modules import utils_warp as UW
+    img, mask, depth = small_cracks_case()
+    out = dict(img=img, mask=mask, depth=depth)
+    # with the shipped parameters (min_valid_neighbors 3 or 2) step 1 already fills every hole step 2 could reach (a 4-connected hole of <= 4
+    # pixels is enclosed by valid pixels, so each of its pixels has >= 3 valid neighbours); stricter counts make step 2 do the work
+    from tests.cases import SMALL_CRACK_CASES
+    for name, (has_conf, mcs, mvn, thr) in SMALL_CRACK_CASES.items():
+        conf = np.ones_like(depth) if has_conf else None
+        fi, fm = UW.fill_small_cracks(img, mask, depth, depth_conf=conf, depth_threshold=thr, max_crack_size=mcs, min_valid_neighbors=mvn)
+        out[f"{name}_img"], out[f"{name}_mask"] = fi, fm
+        f1, m1 = ocf.fill_small_cracks(img, mask, mvn)
+        print("g23", name, int(fm.sum() - mask.sum()), "pixels filled,", int(fm.sum() - m1.sum()), "of them by step 2")
+    np.savez_compressed(os.path.join(OUT, "g23_fill_small_cracks.npz"), **out)
+
+
+if __name__ == "__main__" and "small_cracks" in sys.argv[1:]:
+    g_small_cracks()

@@ -272,6 +272,193 @@ __global__ void k_cf_merge(CFArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// fill_small_cracks in full (utils_warp.py:386-455), the path warp_single_img takes for a view with <= 100 splatted depths (:973-981):
+//   step 1 (parallel)  3 x 3 closing of the mask; a newly covered pixel with >= min_valid_neighbors valid 8-neighbours takes their mean;
+//   step 2 (only with a confidence map and when step 1 filled fewer than half of the holes): the 4-connected hole components of
+//          <= min(max_crack_size, 4) pixels, in scipy.ndimage.label order (raster order of their first pixel), their pixels in np.where
+//          (raster) order; a pixel is filled with the mean of the valid 3 x 3 neighbours whose ORIGINAL depth (the source view's map, indexed
+//          at the target pixel: the reference's own indexing) is within depth_threshold of its own, if >= min_valid_neighbors of them
+//          qualify; every fill is visible to the pixels after it -- a sequential rule, so ONE lane walks the (few) small components.
+// The image is carried as float32 (u8 / 255) through both steps and quantised once at the end, as the reference does.
+// ------------------------------------------------------------------------------------------------------------------------------------
+struct FSArgs {
+  const uint8_t* img;    // [H, W, 3]
+  const uint8_t* mask;   // [H, W]
+  const float* odepth;   // [H, W] original (source-view) depth
+  uint8_t* out_img;
+  uint8_t* out_mask;
+  float* fimg;           // [H, W, 3] f32 working image
+  uint8_t* small;        // [H, W]: bit 0 = pixel of a small hole component, bit 1 = its first pixel in raster order
+  unsigned* cnt;         // [0] holes of the input mask, [1] pixels filled by step 1
+  int H, W, mvn, max_crack, use_depth;
+  float thr;
+};
+
+__device__ __forceinline__ bool fs_valid(const uint8_t* m, int y, int x, int H, int W) {
+  return y >= 0 && y < H && x >= 0 && x < W && m[(size_t)y * W + x] != 0;
+}
+
+__global__ void k_fs_step1(FSArgs a) {
+  const size_t np = (size_t)a.H * a.W;
+  unsigned holes = 0, morph = 0;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (size_t)gridDim.x * blockDim.x) {
+    const int y = (int)(p / a.W), x = (int)(p % a.W);
+    float v[3];
+    for (int c = 0; c < 3; ++c) v[c] = (float)a.img[p * 3 + c] / 255.0f;
+    uint8_t mo = a.mask[p];
+    if (mo == 0) {
+      ++holes;
+      // closing (border ignored by dilate and erode): every in-image 3 x 3 neighbour has a valid pixel in its own in-image neighbourhood
+      bool closed = true;
+      for (int dy = -1; dy <= 1 && closed; ++dy)
+        for (int dx = -1; dx <= 1 && closed; ++dx) {
+          const int qy = y + dy, qx = x + dx;
+          if (qy < 0 || qy >= a.H || qx < 0 || qx >= a.W) continue;
+          bool any = false;
+          for (int ey = -1; ey <= 1 && !any; ++ey)
+            for (int ex = -1; ex <= 1 && !any; ++ex) any = fs_valid(a.mask, qy + ey, qx + ex, a.H, a.W);
+          closed = any;
+        }
+      if (closed) {
+        // cv2.filter2D with the 8-neighbour kernel, BORDER_REFLECT_101; sums in double, stored as float (as ndimage.correlate does)
+        double cnt = 0.0, s[3] = {0.0, 0.0, 0.0};
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx) {
+            if (!dy && !dx) continue;
+            const size_t q = (size_t)refl101(y + dy, a.H) * a.W + refl101(x + dx, a.W);
+            if (a.mask[q]) {
+              cnt += 1.0;
+              for (int c = 0; c < 3; ++c) s[c] += (double)((float)a.img[q * 3 + c] / 255.0f);
+            }
+          }
+        if ((float)cnt >= (float)a.mvn) {
+          const float safe = fmaxf((float)cnt, 1e-6f);
+          for (int c = 0; c < 3; ++c) v[c] = (float)s[c] / safe;
+          mo = 1;
+          ++morph;
+        }
+      }
+    }
+    for (int c = 0; c < 3; ++c) a.fimg[p * 3 + c] = v[c];
+    a.out_mask[p] = mo;
+    a.small[p] = 0;
+  }
+  if (holes) atomicAdd(&a.cnt[0], holes);
+  if (morph) atomicAdd(&a.cnt[1], morph);
+}
+
+// the 4-connected component of the hole pixel p0 in mask m, explored up to `cap` pixels: returns its size (cap + 1 = larger) and its pixels
+__device__ __forceinline__ int fs_component(const uint8_t* m, int H, int W, int p0, int* px, int cap) {
+  int n = 1;
+  px[0] = p0;
+  for (int i = 0; i < n && n <= cap; ++i) {
+    const int y = px[i] / W, x = px[i] % W;
+    const int ny[4] = {y - 1, y + 1, y, y}, nx[4] = {x, x, x - 1, x + 1};
+    for (int k = 0; k < 4 && n <= cap; ++k) {
+      if (ny[k] < 0 || ny[k] >= H || nx[k] < 0 || nx[k] >= W) continue;
+      const int q = ny[k] * W + nx[k];
+      if (m[q]) continue;
+      bool seen = false;
+      for (int j = 0; j < n; ++j) seen |= px[j] == q;
+      if (!seen) px[n++] = q;
+    }
+  }
+  return n;
+}
+
+__global__ void k_fs_small(FSArgs a) {
+  if (!a.use_depth || !((float)a.cnt[1] < (float)a.cnt[0] * 0.5f)) return;  // :433
+  const int lim = a.max_crack < 4 ? a.max_crack : 4;
+  const size_t np = (size_t)a.H * a.W;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (size_t)gridDim.x * blockDim.x) {
+    if (a.out_mask[p]) continue;
+    int px[6];
+    const int n = fs_component(a.out_mask, a.H, a.W, (int)p, px, 4);
+    if (n > lim) continue;
+    int first = px[0];
+    for (int j = 1; j < n; ++j) first = min(first, px[j]);
+    a.small[p] = (uint8_t)(1 | (first == (int)p ? 2 : 0));
+  }
+}
+
+__global__ void k_fs_step2(FSArgs a) {  // one lane: the rule is sequential; the components it visits are few and tiny
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (!a.use_depth || !((float)a.cnt[1] < (float)a.cnt[0] * 0.5f)) return;
+  const int np = a.H * a.W;
+  for (int p = 0; p < np; ++p) {
+    if (!(a.small[p] & 2)) continue;
+    int px[6];
+    const int n = fs_component(a.out_mask, a.H, a.W, p, px, 4);  // (unchanged since k_fs_small: fills never merge or split hole components' pixels of OTHER components)
+    for (int i = 1; i < n; ++i) {  // np.where order = raster order
+      const int key = px[i];
+      int j = i - 1;
+      while (j >= 0 && px[j] > key) { px[j + 1] = px[j]; --j; }
+      px[j + 1] = key;
+    }
+    for (int i = 0; i < n; ++i) {
+      const int y = px[i] / a.W, x = px[i] % a.W;
+      if (a.out_mask[px[i]]) continue;
+      const float dc = a.odepth[px[i]];
+      int nvalid = 0, nok = 0;
+      float s[3] = {0.f, 0.f, 0.f};
+      for (int yy = max(0, y - 1); yy < min(a.H, y + 2); ++yy)
+        for (int xx = max(0, x - 1); xx < min(a.W, x + 2); ++xx) {
+          const size_t q = (size_t)yy * a.W + xx;
+          if (!a.out_mask[q]) continue;
+          ++nvalid;
+          if (fabsf(a.odepth[q] - dc) <= a.thr) {
+            ++nok;
+            for (int c = 0; c < 3; ++c) s[c] += a.fimg[q * 3 + c];
+          }
+        }
+      if (nvalid >= a.mvn && nok >= a.mvn) {
+        for (int c = 0; c < 3; ++c) a.fimg[(size_t)px[i] * 3 + c] = s[c] / (float)nok;
+        a.out_mask[px[i]] = 1;
+      }
+    }
+  }
+}
+
+__global__ void k_fs_out(FSArgs a) {
+  const size_t n = (size_t)a.H * a.W * 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    a.out_img[i] = (uint8_t)(a.fimg[i] * 255.0f);
+}
+
+}  // namespace
+
+extern "C" size_t wf_fill_small_cracks_workspace_bytes(int H, int W) {
+  if (H <= 0 || W <= 0) return 0;
+  return (size_t)H * W * 3 * sizeof(float) + (size_t)H * W + 64;
+}
+
+extern "C" int wf_fill_small_cracks(const void* img, const void* mask, const float* original_depth, int has_depth_conf, void* out_img,
+                                    void* out_mask, int H, int W, float depth_threshold, int max_crack_size, int min_valid_neighbors,
+                                    void* workspace, void* stream) {
+  WF_CHECK_ARG(img && mask && out_img && out_mask && workspace, "wf_fill_small_cracks: null pointer");
+  WF_CHECK_ARG(!has_depth_conf || original_depth, "wf_fill_small_cracks: the depth-guided step needs the source view's depth map");
+  WF_CHECK_ARG(H >= 2 && W >= 2 && (size_t)H * W < (1u << 31), "wf_fill_small_cracks: bad sizes H=%d W=%d", H, W);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned char* ws = (unsigned char*)workspace;
+  FSArgs a;
+  a.img = (const uint8_t*)img; a.mask = (const uint8_t*)mask; a.odepth = original_depth;
+  a.out_img = (uint8_t*)out_img; a.out_mask = (uint8_t*)out_mask;
+  a.fimg = (float*)ws;
+  a.small = ws + (size_t)H * W * 3 * sizeof(float);
+  a.cnt = (unsigned*)(ws + ((size_t)H * W * 3 * sizeof(float) + (size_t)H * W + 15) / 16 * 16);
+  a.H = H; a.W = W; a.mvn = min_valid_neighbors; a.max_crack = max_crack_size; a.use_depth = has_depth_conf ? 1 : 0; a.thr = depth_threshold;
+  if (hipMemsetAsync(a.cnt, 0, 2 * sizeof(unsigned), st) != hipSuccess) return check_hip(hipGetLastError(), "wf_fill_small_cracks: memset");
+  const dim3 grid((unsigned)std::min<size_t>(((size_t)H * W + 255) / 256, 1024)), blk(256);
+  hipLaunchKernelGGL(k_fs_step1, grid, blk, 0, st, a);
+  hipLaunchKernelGGL(k_fs_small, grid, blk, 0, st, a);
+  hipLaunchKernelGGL(k_fs_step2, dim3(1), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(k_fs_out, grid, blk, 0, st, a);
+  WF_LAUNCH_CHECK("wf_fill_small_cracks");
+  return WF_OK;
+}
+
+namespace {
 }  // namespace
 
 extern "C" size_t wf_crack_fill_workspace_bytes(int n, int H, int W) {

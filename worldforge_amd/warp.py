@@ -115,11 +115,14 @@ def camera_path(direction: str, extrinsic, degree: float, frame_num: int, look_a
 
 
 def crack_fill(images: torch.Tensor, masks: torch.Tensor, depths: torch.Tensor, min_neighbors: int = 4, min_valid_neighbors: int = 3,
-               num_segments: int = 5):
-    """Depth-aware crack filling of splatted views (utils_warp.py depth_aware_crack_filling :647-691 as warp_single_img applies it per view,
-    :954-985): images u8 [n,H,W,3], masks u8 [n,H,W], depths f32 [n,H,W] (NaN = empty), as forward_splat returns them -> the same three,
-    filled.  Defaults = create_default_crack_params(None) (:694-704); run_warp.py passes min_valid_neighbors = 2 (:54, 294).  Views with
-    <= 100 splatted pixels take the reference's depth-confidence path (:973-981), which is not built: they are returned as they are."""
+               num_segments: int = 5, original_depth: torch.Tensor = None, has_depth_conf: bool = False, depth_threshold: float = 0.1,
+               max_crack_size: int = 5):
+    """Crack filling of splatted views as warp_single_img applies it per view (utils_warp.py:954-985): images u8 [n,H,W,3], masks u8
+    [n,H,W], depths f32 [n,H,W] (NaN = empty), as forward_splat returns them -> the same three, filled.  Views with more than 100 splatted
+    depths take depth_aware_crack_filling (:647-691); the others fill_small_cracks (:386-455, `small_crack_fill` below) with the SOURCE
+    view's filtered depth map `original_depth` [H,W] and `has_depth_conf` (whether the caller has a confidence map: only its presence
+    matters, :433) -- their depth is returned unchanged, as in the reference.  Defaults = create_default_crack_params(None) (:694-704);
+    run_warp.py passes min_valid_neighbors = 2, max_crack_size = 6 (:50-59, 294)."""
     n, H, W, _ = images.shape
     assert images.dtype == torch.uint8 and masks.dtype == torch.uint8 and depths.dtype == torch.float32
     images, masks, depths = images.contiguous(), masks.contiguous(), depths.contiguous()
@@ -130,8 +133,28 @@ def crack_fill(images: torch.Tensor, masks: torch.Tensor, depths: torch.Tensor, 
          int(min_neighbors), int(min_valid_neighbors), int(num_segments), ws.data_ptr(), ops.stream())
     few = (~torch.isnan(depths)).flatten(1).sum(1) <= 100
     if bool(few.any()):  # once per camera path, outside any loop
-        oi[few], om[few], od[few] = images[few], masks[few], depths[few]
+        for i in torch.nonzero(few).flatten().tolist():
+            oi[i], om[i] = small_crack_fill(images[i], masks[i], original_depth, has_depth_conf, depth_threshold, max_crack_size,
+                                            min_valid_neighbors)
+            od[i] = depths[i]
     return oi, om, od
+
+
+def small_crack_fill(image: torch.Tensor, mask: torch.Tensor, original_depth: torch.Tensor = None, has_depth_conf: bool = False,
+                     depth_threshold: float = 0.1, max_crack_size: int = 5, min_valid_neighbors: int = 3):
+    """fill_small_cracks (utils_warp.py:386-455) of ONE view: image u8 [H,W,3], mask u8 [H,W]; original_depth f32 [H,W] (the source view's
+    filtered depth) is read by the depth-guided second step, which runs only when a confidence map exists (has_depth_conf)."""
+    from ._ffi import lib
+    H, W, _ = image.shape
+    if has_depth_conf and original_depth is None:
+        raise ValueError("small_crack_fill: has_depth_conf needs original_depth (the source view's filtered depth map)")
+    image, mask = image.contiguous(), mask.contiguous()
+    od = original_depth.to(torch.float32).contiguous() if original_depth is not None else None
+    ws = torch.empty(int(lib().wf_fill_small_cracks_workspace_bytes(H, W)), dtype=torch.uint8, device=image.device)
+    oi, om = torch.empty_like(image), torch.empty_like(mask)
+    call("wf_fill_small_cracks", image.data_ptr(), mask.data_ptr(), od.data_ptr() if od is not None else None, 1 if has_depth_conf else 0,
+         oi.data_ptr(), om.data_ptr(), H, W, float(depth_threshold), int(max_crack_size), int(min_valid_neighbors), ws.data_ptr(), ops.stream())
+    return oi, om
 
 
 # ---- dynamic scenes: the DepthCrafter warper's per-frame point-cloud render (DepthCrafter/warp_depthcrafter.py:255-288) ------------------
