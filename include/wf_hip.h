@@ -172,6 +172,13 @@ int wf_head_max_norm2(const void* X, int H, int L, int Lp, float* out, void* str
  * them exactly): fills the chip when Lq is short, e.g. one rank's token shard of the sequence-parallel DiT (Lq = 4096 at 8 ranks:
  * 640 workgroups on 256 CUs).  workspace: wf_attn_split_workspace_bytes(H, Lq, nsplit) bytes, 16-byte aligned. */
 size_t wf_attn_split_workspace_bytes(int H, int Lq, int nsplit);
+/* WanI2VCrossAttention (model.py:202-229) in ONE launch: O = softmax(Q K1^T s) V1 + softmax(Q K2^T s) V2 for the image context (K1, 257
+ * keys) and the text context (K2, 512 keys), where the reference runs two flash_attention calls and adds (model.py:220-227).  K [H][Lk1p +
+ * Lk2p][128] holds context 1 (kv_len1 valid rows of Lk1p, zero-padded to whole 64-key tiles) followed by context 2; Vt [H][(Lk1p + Lk2p) /
+ * 64][128][64] likewise (wf_v_transpose_seg).  Q is read once and O written once; context 1's normalised result is rounded to bf16 and kept
+ * in registers across the seam, so the result is bit-identical to wf_attn_fwd(context 1) followed by wf_attn_fwd(context 2, accumulate). */
+int wf_attn_cross2_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lk1p, int kv_len1, int Lk2p, int kv_len2,
+                       int ldo, float softmax_scale, void* stream);
 /* Test hook: counters2 = device uint32[2] (or NULL = off, the default).  While set, every workgroup of a pre-scaled-Q launch
  * (wf_attn_fwd / wf_attn_fwd_split with softmax_scale = 0) adds 1 to counters2[0] if it ran the max-tracking body and to counters2[1]
  * if it ran the un-tracked one -- lets a parity test assert WHICH body it compared with the oracle.  Process-global, not thread-safe. */
@@ -196,6 +203,9 @@ int wf_rmsnorm_heads(const void* in, int ld, const float* weight, const float* c
 
 /* V [L, ld] bf16 (head h at columns h*128) -> Vt [H][Lp/64][128][64] bf16, keys >= L zero-filled. */
 int wf_v_transpose(const void* V, int ld, void* Vt, int L, int Lp, int H, void* stream);
+/* The same into a destination whose heads are head_stride_tiles 64-key tiles apart (Vt points at the segment's first tile of head 0): the
+ * two contexts of wf_attn_cross2_fwd share one buffer. */
+int wf_v_transpose_seg(const void* V, int ld, void* Vt, int L, int Lp, int H, int head_stride_tiles, void* stream);
 
 /* model.py:534-537 patch embedding as a GEMM: x bf16 [Cin,T,Hh,Ww] -> tokens bf16 [T*(Hh/2)*(Ww/2), Cin*4] (k = c*4+ph*2+pw). */
 int wf_patchify(const void* x, void* tokens, int Cin, int T, int Hh, int Ww, void* stream);

@@ -138,6 +138,69 @@ def test_attention(H, Lq, Lk):
     assert _rel(out, 2 * ref) <= 1.5e-2
 
 
+@pytest.mark.skipif(os.environ.get("WF_ATTN_KERNEL") == "w8", reason="the fused two-context kernel is a variant of the one-wave-per-SIMD kernel")
+@pytest.mark.parametrize("H,Lq,n1,n2", [(40, 1000, 257, 512),      # the DiT's shapes: 257 CLIP tokens (5 tiles, 1 valid key in the last), 512 text rows
+                                        (2, 300, 40, 64),          # context 1 is a single ragged tile (the prologue masks it)
+                                        (3, 77, 128, 500),         # ragged context 2, seam after an even number of tiles
+                                        (1, 4524, 65, 129),        # both ragged, odd tile counts
+                                        (2, 513, 320, 64)])
+def test_fused_two_context_cross_attention_is_bit_identical_to_two_launches(H, Lq, n1, n2):
+    """wf_attn_cross2_fwd (model.py:202-229 in one launch) == wf_attn_fwd(context 1) + wf_attn_fwd(context 2, accumulate), bit for bit, and
+    both match the fp32 statement softmax(q k1^T) v1 + softmax(q k2^T) v2."""
+    from worldforge_amd import dit
+    scale = 1 / math.sqrt(128)
+    pad = lambda n: (n + 63) // 64 * 64  # noqa: E731
+    q = _rand((H, Lq, 128), 20).to(BF)
+    ks = [_rand((H, n, 128), 21 + i).to(BF) for i, n in enumerate((n1, n2))]
+    vs = [_rand((H, n, 128), 23 + i).to(BF) for i, n in enumerate((n1, n2))]
+    kp, vt = [], []
+    for k, v, n in zip(ks, vs, (n1, n2)):
+        kk = torch.zeros((H, pad(n), 128), dtype=BF)
+        kk[:, :n] = k
+        vv = torch.zeros((H, pad(n), 128), dtype=BF)
+        vv[:, :n] = v
+        kp.append(kk.to(DEV))
+        vt.append(vv.view(H, pad(n) // 64, 64, 128).transpose(2, 3).contiguous().to(DEV))
+    two = torch.full((Lq, H * 128), float("nan"), dtype=BF, device=DEV)
+    dit.attention(q.to(DEV), kp[0], vt[0], two, n1, scale)
+    dit.attention(q.to(DEV), kp[1], vt[1], two, n2, scale, accumulate=True)
+    kc = torch.cat(kp, dim=1).contiguous()
+    vtc = torch.cat(vt, dim=1).contiguous()
+    one = torch.full((Lq, H * 128), float("nan"), dtype=BF, device=DEV)
+    dit.cross_attention2(q.to(DEV), kc, vtc, one, pad(n1), n1, n2, scale)
+    assert torch.isfinite(one).all()
+    assert torch.equal(one, two), (one.float() - two.float()).abs().max()
+    ref = _attn_ref(q.float(), ks[0].float(), vs[0].float(), scale) + _attn_ref(q.float(), ks[1].float(), vs[1].float(), scale)
+    assert _rel(one, ref) <= 1.5e-2, _rel(one, ref)
+    # garbage in the padded key rows of either context must not leak
+    kc2 = kc.clone()
+    if pad(n1) > n1:
+        kc2[:, n1:pad(n1)] = 1e4
+    if pad(n2) > n2:
+        kc2[:, pad(n1) + n2:] = -1e4
+    again = torch.empty_like(one)
+    dit.cross_attention2(q.to(DEV), kc2, vtc, again, pad(n1), n1, n2, scale)
+    assert torch.equal(again, one)
+
+
+@pytest.mark.skipif(os.environ.get("WF_ATTN_KERNEL") == "w8", reason="needs the one-wave-per-SIMD kernel")
+def test_dit_forward_with_fused_cross_attention_equals_two_launch_form(monkeypatch):
+    """The whole DiT forward (2 layers, ragged text length) is bit-identical with WF_CROSS_FUSED=1 (default) and =0, and the producers write
+    the concatenated [image | text] key / value buffers through strided destinations (lout / wf_v_transpose_seg)."""
+    from worldforge_amd import dit
+    cfg = dit.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    T, Hh, Ww = 3, 16, 20
+    x = _rand((36, T, Hh, Ww), 60).to(BF).to(DEV)
+    ctx, clip = _rand((30, 64), 61).to(BF).to(DEV), _rand((257, 1280), 62).to(BF).to(DEV)
+    m = dit.WanTransformer3DModel(cfg, DEV).init_random(5)
+    monkeypatch.setenv("WF_CROSS_FUSED", "1")
+    a = m.forward_tokens(x, 500.0, ctx, clip).clone()
+    m._ws.clear()
+    monkeypatch.setenv("WF_CROSS_FUSED", "0")
+    b = m.forward_tokens(x, 500.0, ctx, clip).clone()
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 @pytest.mark.skipif(os.environ.get("WF_ATTN_KERNEL") == "w8", reason="KV splits need the one-wave-per-SIMD kernel (the entry point refuses loudly)")
 @pytest.mark.parametrize("H,Lq,Lk,nsplit,segs", [(2, 300, 1000, 2, 1), (1, 256, 4524, 3, 1), (3, 77, 640, 2, 1), (2, 500, 1024, 2, 4),
                                                   (1, 128, 8192 + 37, 8, 1)])

@@ -140,6 +140,9 @@ bad("wf_attn_fwd", Q, K, V, O, H, Lq, 1000, 1000, 1000, H * 128, 0.0884, 0, None
 bad("wf_attn_fwd_split", Q, K, V, O, H, Lq, Lkp, 1000, Lkp, H * 128, 0.0, 0, 2, None, None, 0, None, 0, None)   # split without workspace
 bad("wf_attn_fwd", Q + 2, K, V, O, H, Lq, Lkp, 1000, Lkp, H * 128, 0.0884, 0, None, 0, None, 0, None)    # misaligned Q
 ok("wf_head_max_norm2", K, H, 1000, Lkp, f32(H), None)
+ok("wf_attn_cross2_fwd", Q, buf(2 * H * 832 * 128), buf(2 * H * 832 * 128), O, H, Lq, 320, 257, 512, 512, H * 128, 0.0884, None)
+bad("wf_attn_cross2_fwd", Q, K, V, O, H, Lq, 320, 200, 512, 512, H * 128, 0.0884, None)                  # context 1 leaves a whole tile empty
+bad("wf_attn_cross2_fwd", Q, K, V, O, H, Lq, 320, 257, 512, 512, H * 128, 0.0, None)                     # the fused kernel applies the scale itself
 nq, nk, nsel = 7, 9, 3
 sc = buf(2 * 2 * nq * 16)
 mx = min(2 * nsel, nk)
@@ -154,6 +157,8 @@ L, C = 300, 5120
 ok("wf_ln_modulate", f32(L * C), f32(C), f32(C), buf(2 * L * C), BF, L, C, 1e-6, 1, None)
 ok("wf_rmsnorm_heads", buf(2 * L * 3 * C), 3 * C, f32(C), f32(L * 64), f32(L * 64), buf(2 * 40 * 320 * 128), L, 320, C, 1e-6, 0.1275, None)
 ok("wf_v_transpose", buf(2 * L * 3 * C), 3 * C, buf(2 * 40 * 320 * 128), L, 320, 40, None)
+ok("wf_v_transpose_seg", buf(2 * L * 3 * C), 3 * C, buf(2 * 40 * 13 * 128 * 64), L, 320, 40, 13, None)
+bad("wf_v_transpose_seg", buf(2 * L * 3 * C), 3 * C, buf(64), L, 320, 40, 4, None)                        # head stride shorter than the segment
 bad("wf_v_transpose", buf(64), 8, buf(64), 4, 100, 1, None)                                               # Lp not a multiple of 64
 ok("wf_patchify", buf(2 * 36 * 3 * 8 * 12), buf(2 * 3 * 4 * 6 * 144), 36, 3, 8, 12, None)
 ok("wf_unpatchify", f32(3 * 4 * 6 * 64), f32(16 * 3 * 8 * 12), 16, 3, 8, 12, None)

@@ -78,6 +78,9 @@ struct AttnArgs {
   const float* kmax2;
   const float* qmax2;
   int kmax_n, qmax_n;
+  // KIND 5 (two-context cross-attention, model.py:202-229): the key sequence is [n1 tiles of context 1 (kv_len1 valid keys) | the tiles of
+  // context 2 (kv_len valid keys)]; the softmax is taken over each context separately and the two results are summed
+  int kv_len1, n1;
   // test hook (wf_attn_debug_body_counter): device uint32[2], [0] += workgroups that ran the tracked body, [1] += the un-tracked one; NULL = off
   unsigned int* dbg_body;
 };
@@ -491,6 +494,18 @@ __global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
 // ======================================================================================================================================
 constexpr int NT4 = 256;
 
+// one rounding each, whatever -ffp-contract says (HIP's __fmul_rn / __fadd_rn are plain operators and may still be fused into an fma)
+__device__ __forceinline__ float mul_rn(float a, float b) {
+  float r;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+  float r;
+  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // NOMAX (KIND 4 only, chosen per workgroup by the kernel below): no running-max tracking after tile 0 -- the reference max of every row
 // stays the first tile's for the whole sweep.
 template <int KIND, bool NOMAX>
@@ -573,7 +588,7 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
     for (int i = 0; i < 4; ++i) pf[x][i] = as_bf16x8(u32x4{0u, 0u, 0u, 0u});
   }
   const float c = PS ? 1.0f : a.scale_log2;
-  const int ntiles_all = (a.kv_len + KB - 1) / KB;
+  const int ntiles_all = (KIND == 5 ? a.n1 : 0) + (a.kv_len + KB - 1) / KB;
   const int split = blockIdx.y;
   const int t_begin = split * a.tiles_per_split;                         // first KV tile of this split (absolute)
   int ntiles_ = min(a.tiles_per_split, ntiles_all - t_begin);            // tiles of this split (>= 1 by construction of the grid)
@@ -596,7 +611,8 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
     }
   }
   const int ntiles = ntiles_;
-  const bool ragged = KIND != 3 && (a.kv_len & (KB - 1)) != 0;
+  const bool ragged = KIND != 3 && KIND != 5 && (a.kv_len & (KB - 1)) != 0;
+  const bool rag1 = KIND == 5 && (a.kv_len1 & (KB - 1)) != 0, rag2 = KIND == 5 && (a.kv_len & (KB - 1)) != 0;  // ragged last tile of either context
 
   // Element offset / LDS slot of the tile being staged (wave-uniform), advanced one tile at a time: a handful of scalar
   // instructions, no division.  Past the last tile the pieces are still issued (no branch in the MFMA stream): they re-read the last
@@ -748,6 +764,19 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
         for (int r = 0; r < 16; ++r) {
           int key = (t_begin + t) * KB + 32 * kb + 16 * (r >> 3) + 8 * hi + (r & 7);
           if (key >= a.kv_len) sb[B][x][kb][r] = -INFINITY;
+        }
+  };
+
+  auto mask_tail = [&](auto BC, int tile_in_ctx, int len) {  // KIND 5: scores of keys >= len of a context's last tile -> -inf
+    constexpr int B = decltype(BC)::value;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int key = tile_in_ctx * KB + 32 * kb + 16 * (r >> 3) + 8 * hi + (r & 7);
+          if (key >= len) sb[B][x][kb][r] = -INFINITY;
         }
   };
 
@@ -932,6 +961,10 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
         // mask of the last tile must be in place before its row max
         if (ragged && t_begin + t + 1 == ntiles_all - 1) mask_ragged(std::integral_constant<int, 1 - B>{}, t + 1);
         if constexpr (KIND == 3) mask_unselected(std::integral_constant<int, 1 - B>{}, e_mask);
+        if constexpr (KIND == 5) {
+          if (rag1 && t + 1 == a.n1 - 1) mask_tail(std::integral_constant<int, 1 - B>{}, t + 1, a.kv_len1);
+          if (rag2 && t + 1 == ntiles - 1) mask_tail(std::integral_constant<int, 1 - B>{}, t + 1 - a.n1, a.kv_len);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -960,6 +993,46 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
       for (int i = 0; i < PF4; ++i) ring[i] = kread(sK2, i);  // K(t+2) was staged during tile t-1: readable only now
     }
   };
+  // KIND 5: the seam between the two contexts, run after the last tile of context 1 (its P.V is complete; the scores of context 2's first
+  // tile are already in buffer NB).  Context 1's result is normalised and rounded to bf16 exactly as a stand-alone launch would store it
+  // (64 packed registers instead of a round trip through HBM), then O, l and the reference max start afresh -- m from the new scores
+  // alone, as the prologue of a stand-alone launch takes it: the fused result is bit-identical to "context 1, then context 2 with accumulate".
+  uint32_t stash[2][4][8];
+  auto seam = [&](auto NBC) {
+    constexpr int NB = decltype(NBC)::value;
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");  // asm MFMA write -> v_accvgpr_read
+    for_const<2>([&](auto XC) {
+      constexpr int X = decltype(XC)::value;
+      float l = l_run[X];
+      l += __shfl_xor(l, 32, 64);
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        f32x16 tmp = o[X][db];
+        asm volatile("" : "+v"(tmp));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          stash[X][db][2 * g] = pack_bf16x2(mul_rn(tmp[4 * g + 0], inv), mul_rn(tmp[4 * g + 1], inv));
+          stash[X][db][2 * g + 1] = pack_bf16x2(mul_rn(tmp[4 * g + 2], inv), mul_rn(tmp[4 * g + 3], inv));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmp[r] = 0.f;
+        asm volatile("" : "+v"(tmp));
+        o[X][db] = tmp;
+        asm volatile("" : "+a"(o[X][db]));
+      }
+      l_run[X] = 0.f;
+      float m = sb[NB][X][0][0];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, sb[NB][X][kb][r]);
+      const unsigned mu = __float_as_uint(m);
+      auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+      m_run[X] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      mcq[X] = c * m_run[X];
+    });
+  };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
 
@@ -983,6 +1056,9 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
     }
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
     if (ragged && t_begin == ntiles_all - 1) mask_ragged(B0{}, 0);
+    if constexpr (KIND == 5) {
+      if (rag1 && a.n1 == 1) mask_tail(B0{}, 0, a.kv_len1);
+    }
     if constexpr (KIND == 3) mask_unselected(B0{}, __builtin_amdgcn_readfirstlane(bsa[0]));
     const float m0 = rowmax_now(B0{}, std::integral_constant<int, 0>{});
     const float m1 = rowmax_now(B0{}, std::integral_constant<int, 1>{});
@@ -1009,8 +1085,16 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
     int slot = 0;
     for (int t = 0; t < ntiles; t += 2) {
       tile(B0{}, t, slot);
+      if constexpr (KIND == 5) {
+        if (t == a.n1 - 1) seam(B1{});
+      }
       slot = slot + 1 == NBUF ? 0 : slot + 1;
-      if (t + 1 < ntiles) tile(B1{}, t + 1, slot);
+      if (t + 1 < ntiles) {
+        tile(B1{}, t + 1, slot);
+        if constexpr (KIND == 5) {
+          if (t + 1 == a.n1 - 1) seam(B0{});
+        }
+      }
       slot = slot + 1 == NBUF ? 0 : slot + 1;
     }
   }
@@ -1058,14 +1142,22 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int d = db * 32 + 8 * g + 4 * hi;
-          float v0 = ov[4 * g + 0] * inv, v1 = ov[4 * g + 1] * inv, v2 = ov[4 * g + 2] * inv,
-                v3 = ov[4 * g + 3] * inv;
-          if (a.accumulate) {
+          // the normalisation and the accumulation are two roundings (__fmul_rn / __fadd_rn: never contracted into one fma), so that the
+          // fused two-context kernel (KIND 5) and the two-launch form (accumulate) produce the same bits
+          float v0 = mul_rn(ov[4 * g + 0], inv), v1 = mul_rn(ov[4 * g + 1], inv), v2 = mul_rn(ov[4 * g + 2], inv),
+                v3 = mul_rn(ov[4 * g + 3], inv);
+          if constexpr (KIND == 5) {  // + context 1's stored (bf16) result
+            const uint32_t o0 = stash[x][db][2 * g], o1 = stash[x][db][2 * g + 1];
+            v0 = add_rn(v0, __uint_as_float(o0 << 16));
+            v1 = add_rn(v1, __uint_as_float(o0 & 0xffff0000u));
+            v2 = add_rn(v2, __uint_as_float(o1 << 16));
+            v3 = add_rn(v3, __uint_as_float(o1 & 0xffff0000u));
+          } else if (a.accumulate) {
             u32x2 old = *reinterpret_cast<const u32x2*>(op + d);
-            v0 += __uint_as_float(old[0] << 16);
-            v1 += __uint_as_float(old[0] & 0xffff0000u);
-            v2 += __uint_as_float(old[1] << 16);
-            v3 += __uint_as_float(old[1] & 0xffff0000u);
+            v0 = add_rn(v0, __uint_as_float(old[0] << 16));
+            v1 = add_rn(v1, __uint_as_float(old[0] & 0xffff0000u));
+            v2 = add_rn(v2, __uint_as_float(old[1] << 16));
+            v3 = add_rn(v3, __uint_as_float(old[1] & 0xffff0000u));
           }
           u32x2 pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
           *reinterpret_cast<u32x2*>(op + d) = pk;
@@ -1190,6 +1282,8 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
   a.kmax_n = kmax2 ? kmax_n : 0;
   a.qmax_n = qmax2 ? qmax_n : 0;
   a.dbg_body = g_dbg_body;
+  a.kv_len1 = 0;
+  a.n1 = 0;
   const int hslots = (H + 7) / 8;
   const int grid = hslots * a.n_qblk * 8;
   const size_t lds = 4 * (K_TILE_BYTES + V_TILE_BYTES);
@@ -1333,6 +1427,8 @@ extern "C" int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, voi
   a.kmax2 = a.qmax2 = nullptr;
   a.kmax_n = a.qmax_n = 0;
   a.dbg_body = nullptr;
+  a.kv_len1 = 0;
+  a.n1 = 0;
   const int grid = ((H + 7) / 8) * a.n_qblk * 8;
   // default: the one-wave-per-SIMD kernel (k_attn_w4<3>); WF_ATTN_KERNEL=w8 selects the two-waves-per-SIMD form (k_attn<2>)
   static const int use_w4 = [] {
@@ -1344,6 +1440,51 @@ extern "C" int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, voi
   else
     hipLaunchKernelGGL(k_attn<2>, dim3(grid), dim3(NT), 4 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream, a);
   WF_LAUNCH_CHECK("wf_attn_bsa_fwd");
+  return WF_OK;
+}
+
+extern "C" int wf_attn_cross2_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lk1p, int kv_len1, int Lk2p,
+                                  int kv_len2, int ldo, float softmax_scale, void* stream) {
+  WF_CHECK_ARG(Q && K && Vt && O, "wf_attn_cross2_fwd: null pointer");
+  WF_CHECK_ARG(H > 0 && Lq > 0, "wf_attn_cross2_fwd: empty problem");
+  WF_CHECK_ARG(Lk1p > 0 && Lk1p % KB == 0 && kv_len1 > Lk1p - KB && kv_len1 <= Lk1p,
+               "wf_attn_cross2_fwd: context 1 must fill its %d padded rows up to the last 64-key tile (kv_len1 = %d)", Lk1p, kv_len1);
+  WF_CHECK_ARG(Lk2p > 0 && Lk2p % KB == 0 && kv_len2 > Lk2p - KB && kv_len2 <= Lk2p,
+               "wf_attn_cross2_fwd: context 2 must fill its %d padded rows up to the last 64-key tile (kv_len2 = %d)", Lk2p, kv_len2);
+  WF_CHECK_ARG(ldo % 4 == 0 && ldo >= H * D, "wf_attn_cross2_fwd: bad ldo %d", ldo);
+  WF_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O) & 15) == 0, "wf_attn_cross2_fwd: 16-byte alignment");
+  WF_CHECK_ARG(softmax_scale > 0.0f, "wf_attn_cross2_fwd: softmax_scale must be positive (the scale is applied inside the kernel)");
+  AttnArgs a;
+  a.Q = (const uint16_t*)Q;
+  a.K = (const uint16_t*)K;
+  a.Vt = (const uint16_t*)Vt;
+  a.O = (uint16_t*)O;
+  a.H = H;
+  a.Lq = Lq;
+  a.Lkp = Lk1p + Lk2p;
+  a.kv_len = kv_len2;
+  a.seg_len = a.Lkp;
+  a.ldo = ldo;
+  a.n_qblk = ceil_div(Lq, QB);
+  a.scale_log2 = softmax_scale * 1.4426950408889634f;
+  a.accumulate = 0;
+  a.prio_mode = 0;
+  a.nsplit = 1;
+  a.tiles_per_split = a.Lkp / KB;
+  a.o_part = nullptr;
+  a.ml_part = nullptr;
+  a.bsa_list = nullptr;
+  a.bsa_cnt = nullptr;
+  a.bsa_max = 0;
+  a.bsa_shift = 2;
+  a.kmax2 = a.qmax2 = nullptr;
+  a.kmax_n = a.qmax_n = 0;
+  a.dbg_body = nullptr;
+  a.kv_len1 = kv_len1;
+  a.n1 = Lk1p / KB;
+  const int grid = ((H + 7) / 8) * a.n_qblk * 8;
+  hipLaunchKernelGGL(k_attn_w4<5>, dim3(grid, 1), dim3(NT4), 5 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream, a);
+  WF_LAUNCH_CHECK("wf_attn_cross2_fwd");
   return WF_OK;
 }
 

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(128) void k_rms_heads(const uint16_t* __restrict__ 
 // V [L, ld] bf16 (columns head*128 + d) -> Vt [H][Lp/64][128][64]; keys >= L are written as zeros.
 // grid (Lp/64, H), 256 threads; 64x128 tile through LDS (row stride 130 halfwords to spread banks).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_vt(const uint16_t* __restrict__ V, int ld, uint16_t* __restrict__ Vt, int L, int Lp) {
+__global__ __launch_bounds__(256) void k_vt(const uint16_t* __restrict__ V, int ld, uint16_t* __restrict__ Vt, int L, int hstride) {
   __shared__ uint16_t tile[64][136];
   const int kt = blockIdx.x, head = blockIdx.y;
   const int tid = threadIdx.x;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_vt(const uint16_t* __restrict__ V, int 
   }
   __syncthreads();
   // store: 128 d-rows x 8 chunks of 8 keys -> 1024 chunks, 4 per thread
-  uint16_t* dst = Vt + ((size_t)head * (Lp >> 6) + kt) * (128 * 64);
+  uint16_t* dst = Vt + ((size_t)head * hstride + kt) * (128 * 64);  // hstride = 64-key tiles per head in the destination
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int id = tid + 256 * i;
@@ -257,8 +257,18 @@ extern "C" int wf_v_transpose(const void* V, int ld, void* Vt, int L, int Lp, in
   WF_CHECK_ARG(V && Vt, "wf_v_transpose: null pointer");
   WF_CHECK_ARG(Lp % 64 == 0 && Lp >= L && ld % 8 == 0, "wf_v_transpose: Lp must be a multiple of 64 and >= L");
   if (Lp == 0) return WF_OK;
-  hipLaunchKernelGGL(k_vt, dim3(Lp / 64, H), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)V, ld, (uint16_t*)Vt, L, Lp);
+  hipLaunchKernelGGL(k_vt, dim3(Lp / 64, H), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)V, ld, (uint16_t*)Vt, L, Lp / 64);
   WF_LAUNCH_CHECK("wf_v_transpose");
+  return WF_OK;
+}
+
+extern "C" int wf_v_transpose_seg(const void* V, int ld, void* Vt, int L, int Lp, int H, int head_stride_tiles, void* stream) {
+  WF_CHECK_ARG(V && Vt, "wf_v_transpose_seg: null pointer");
+  WF_CHECK_ARG(Lp % 64 == 0 && Lp >= L && ld % 8 == 0, "wf_v_transpose_seg: Lp must be a multiple of 64 and >= L");
+  WF_CHECK_ARG(head_stride_tiles >= Lp / 64, "wf_v_transpose_seg: head stride (%d tiles) shorter than the segment (%d)", head_stride_tiles, Lp / 64);
+  if (Lp == 0) return WF_OK;
+  hipLaunchKernelGGL(k_vt, dim3(Lp / 64, H), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)V, ld, (uint16_t*)Vt, L, head_stride_tiles);
+  WF_LAUNCH_CHECK("wf_v_transpose_seg");
   return WF_OK;
 }
 

@@ -128,6 +128,17 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
     return out
 
 
+def cross_attention2(q: torch.Tensor, kc: torch.Tensor, vtc: torch.Tensor, out: torch.Tensor, Lk1p: int, kv_len1: int, kv_len2: int, scale: float):
+    """WanI2VCrossAttention's two attentions (model.py:220-227) in one launch (wf_attn_cross2_fwd): q [H,Lq,128]; kc [H, Lk1p + Lk2p, 128] =
+    context 1 (kv_len1 valid rows, zero-padded to Lk1p) then context 2; vtc [H, (Lk1p + Lk2p) / 64, 128, 64] -> out [Lq, H*128] bf16."""
+    H, Lq, D = q.shape
+    Lkp = kc.shape[1]
+    assert D == 128 and kc.shape == (H, Lkp, 128) and vtc.shape == (H, Lkp // 64, 128, 64) and kc.is_contiguous() and vtc.is_contiguous()
+    call("wf_attn_cross2_fwd", q.data_ptr(), kc.data_ptr(), vtc.data_ptr(), out.data_ptr(), H, Lq, Lk1p, kv_len1, Lkp - Lk1p, kv_len2,
+         out.stride(0), float(scale), ops.stream())
+    return out
+
+
 def rope_tables(head_dim: int, f: int, h: int, w: int, theta: float = 10000.0):
     """model.py:32-39 + 478-485 + 57-62: cos/sin [f*h*w, head_dim/2], computed in fp64 on the host, stored fp32."""
     c = head_dim // 2
@@ -429,18 +440,23 @@ class WanTransformer3DModel:
              L, C, float(eps), 1 if plus_one else 0, ops.stream())
         return out
 
-    def _heads(self, src, col0, weight, cos, sin, out, L, out_scale: float = 1.0):
-        """RMSNorm(+RoPE) of columns [col0, col0+dim) of src [L, ld] -> out [H, Lout, 128]; out_scale: see wf_rmsnorm_heads."""
+    def _heads(self, src, col0, weight, cos, sin, out, L, out_scale: float = 1.0, lout: Optional[int] = None):
+        """RMSNorm(+RoPE) of columns [col0, col0+dim) of src [L, ld] -> out [H, Lout, 128]; out_scale: see wf_rmsnorm_heads.  lout: rows
+        between two heads of the destination when `out` is a row range of a larger [H, lout, 128] buffer (the fused cross-attention keys)."""
         C = self.cfg.dim
         view = src[:, col0:col0 + C]
         call("wf_rmsnorm_heads", view.data_ptr(), src.stride(0), weight.data_ptr(), cos.data_ptr() if cos is not None else None,
-             sin.data_ptr() if sin is not None else None, out.data_ptr(), L, out.shape[1], C, float(self.cfg.eps), float(out_scale),
-             ops.stream())
+             sin.data_ptr() if sin is not None else None, out.data_ptr(), L, out.shape[1] if lout is None else lout, C, float(self.cfg.eps),
+             float(out_scale), ops.stream())
 
-    def _vt(self, src, col0, out, L):
+    def _vt(self, src, col0, out, L, hstride: Optional[int] = None):
+        """hstride: 64-key tiles between two heads of the destination when `out` is a tile range of a larger buffer."""
         view = src[:, col0:col0 + self.cfg.dim]
-        call("wf_v_transpose", view.data_ptr(), src.stride(0), out.data_ptr(), L, out.shape[1] * 64, self.cfg.num_heads,
-             ops.stream())
+        if hstride is None:
+            call("wf_v_transpose", view.data_ptr(), src.stride(0), out.data_ptr(), L, out.shape[1] * 64, self.cfg.num_heads, ops.stream())
+        else:
+            call("wf_v_transpose_seg", view.data_ptr(), src.stride(0), out.data_ptr(), L, out.shape[1] * 64, self.cfg.num_heads, hstride,
+                 ops.stream())
 
     def forward_tokens(self, x_in: torch.Tensor, t_value: float, text: torch.Tensor, img: torch.Tensor) -> torch.Tensor:
         """x_in [in_dim, T, h, w] bf16; text [<=512, text_dim]; img [n_img, img_dim] -> velocity [out_dim, T, h, w] f32."""
@@ -532,13 +548,28 @@ class WanTransformer3DModel:
         qc = _buf("qc", (L, d), bf)
         ffh = _buf("ffh", (L, cfg.ffn_dim), bf)
         Lt, Li = cfg.text_len, _pad64(n_img)
+        # the two cross-attentions of a layer (image context, then text context, summed: model.py:220-227) as ONE launch over a concatenated
+        # key / value buffer [image tiles | text tiles] (wf_attn_cross2_fwd; bit-identical to the two launches, WF_CROSS_FUSED=0 keeps those)
+        fused = os.environ.get("WF_CROSS_FUSED", "1") != "0" and os.environ.get("WF_ATTN_KERNEL", "") != "w8"
+        Lc = Li + Lt
         kvt = _buf("kvt", (cfg.text_len, 2 * d), bf)
         kvi = _buf("kvi", (n_img, 2 * d), bf)
         kth = _buf("kth", (H, Lt, 128), bf, zero=True)
         vtt = _buf("vtt", (H, Lt // 64, 128, 64), bf)
         kih = _buf("kih", (H, Li, 128), bf, zero=True)
         vti = _buf("vti", (H, Li // 64, 128, 64), bf)
+        kc = _buf("kc", (H, Lc, 128), bf, zero=True) if fused else None
+        vtc = _buf("vtc", (H, Lc // 64, 128, 64), bf) if fused else None
         emod = _buf("emod", (6, d), f32)
+
+        def context_operands(pl, kc_, vtc_):
+            """The fused layout of one layer's prompt-context keys / values: rows [0, Li) image, [Li, Li + Lt) text."""
+            gemm(ctx_i, W[pl + "cross_attn.kv_img.w"], W[pl + "cross_attn.kv_img.b"], kvi, EPI_BF16)
+            self._heads(kvi, 0, W[pl + "cross_attn.norm_k_img"], None, None, kc_[:, :Li], n_img, lout=Lc)
+            self._vt(kvi, d, vtc_[:, :Li // 64], n_img, hstride=Lc // 64)
+            gemm(ctx_t, W[pl + "cross_attn.kv.w"], W[pl + "cross_attn.kv.b"], kvt, EPI_BF16)
+            self._heads(kvt, 0, W[pl + "cross_attn.norm_k"], None, None, kc_[:, Li:], Lt, lout=Lc)
+            self._vt(kvt, d, vtc_[:, Li // 64:], Lt, hstride=Lc // 64)
 
         ctx_kv = self._context_kv(text, img)
         # Sequence-parallel jobs: the K / V of the prompt context (text 512 rows, image 257) are the same on every rank and do not shrink with
@@ -552,6 +583,15 @@ class WanTransformer3DModel:
             """Called once, right after layer 0's K / V^T exchange has been launched: the context gathers queue BEHIND it on the communication
             stream (layer 0's self-attention needs its keys first, the context is not read before layer 0's cross-attention)."""
             P_, nl = comm.world, (cfg.num_layers + comm.world - 1) // comm.world
+            if fused:
+                loc = [_buf("ckvf_loc0", (nl, H, Lc, 128), bf, zero=True), _buf("ckvf_loc1", (nl, H, Lc // 64, 128, 64), bf)]
+                allb = [_buf(f"ckvf_all{j}", (P_,) + tuple(t.shape), bf) for j, t in enumerate(loc)]
+                for j in range(nl):
+                    li = comm.rank + P_ * j
+                    if li >= cfg.num_layers:
+                        break
+                    context_operands(f"blocks.{li}.", loc[0][j], loc[1][j])
+                return (allb, P_), [comm.all_gather_async(a_, l_) for a_, l_ in zip(allb, loc)]
             loc = [_buf("ckv_loc0", (nl, H, Lt, 128), bf, zero=True), _buf("ckv_loc1", (nl, H, Lt // 64, 128, 64), bf),
                    _buf("ckv_loc2", (nl, H, Li, 128), bf, zero=True), _buf("ckv_loc3", (nl, H, Li // 64, 128, 64), bf)]
             allb = [_buf(f"ckv_all{j}", (P_,) + tuple(t.shape), bf) for j, t in enumerate(loc)]
@@ -627,7 +667,16 @@ class WanTransformer3DModel:
                             torch.cuda.current_stream().wait_event(ev)
                     ctx_events = None
                 allb, P_ = ctx_shared
-                kth, vtt, kih, vti = (a_[i % P_, i // P_] for a_ in allb)
+                if fused:
+                    kc, vtc = (a_[i % P_, i // P_] for a_ in allb)
+                else:
+                    kth, vtt, kih, vti = (a_[i % P_, i // P_] for a_ in allb)
+            elif kv is None and fused:
+                if ctx_kv is not None:  # own buffers per layer
+                    kc, vtc = torch.zeros((H, Lc, 128), dtype=bf, device=dev), torch.empty((H, Lc // 64, 128, 64), dtype=bf, device=dev)
+                context_operands(p, kc, vtc)
+                if ctx_kv is not None:
+                    ctx_kv[i] = (kc, vtc)
             elif kv is None:
                 if ctx_kv is not None:  # own buffers per layer
                     kth, vtt = torch.zeros((H, Lt, 128), dtype=bf, device=dev), torch.empty((H, Lt // 64, 128, 64), dtype=bf, device=dev)
@@ -640,10 +689,15 @@ class WanTransformer3DModel:
                 self._vt(kvi, d, vti, n_img)
                 if ctx_kv is not None:
                     ctx_kv[i] = (kth, vtt, kih, vti)
+            elif fused:
+                kc, vtc = kv
             else:
                 kth, vtt, kih, vti = kv
-            attention(qh, kih, vti, ao, n_img, scale)
-            attention(qh, kth, vtt, ao, Lt, scale, accumulate=True)
+            if fused:
+                cross_attention2(qh, kc, vtc, ao, Li, n_img, Lt, scale)
+            else:
+                attention(qh, kih, vti, ao, n_img, scale)
+                attention(qh, kth, vtt, ao, Lt, scale, accumulate=True)
             gemm(ao, W[p + "cross_attn.o.w"], W[p + "cross_attn.o.b"], x, EPI_RESID, gate=None)
             # ---- FFN (model.py:311-313) ----
             self._ln(x, emod[4], emod[3], hbuf, cfg.eps, plus_one=True)
