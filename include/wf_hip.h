@@ -292,14 +292,18 @@ int wf_conv3d_cl_scatter(const void* in, const void* w, const float* bias, const
  * an 8 x 64 pixel tile of one output frame x 96 output channels per workgroup, all 27 taps read the (3 x 10 x 66)-pixel patch of a
  * 16-channel slice from LDS.  Weights in the re-packed layout [27][Cin/16][Cout][16] produced by wf_conv3d_pack333 from
  * [Cout][27][Cin].  in [T,Hi,Wi,Cin] bf16 (Hi = Ho for ph = 1; row slabs carry their halo rows: Hi = Ho + 2, ph = 0),
- * out [T,Ho,Wi,Cout]; Cin % 32 == 0, Cout % 32 == 0; zero_page >= 64 bf16 zeros.  Same arithmetic as wf_conv3d_cl.
+ * out [T,Ho,Wi,Cout]; Cin % 32 == 0, Cout % 32 == 0.  zero_page: zeros, zero_page_bytes >= wf_conv3d_333_zero_page_bytes(Wi, Cin_stored,
+ * layout) of them -- the lanes that stage padding pixels read it at the same wave-uniform slice offset the other lanes read the input at
+ * (one 64-bit add per LDS-DMA piece instead of a per-lane select).  Same arithmetic as wf_conv3d_cl.
  * layout 0: in is pixel-major [T,Hi,Wi,Cin_stored]; layout 1: slice-major [T,Hi,Cin_stored/16,Wi,16] (what wf_rms_silu_cl_blocked
  * writes: a patch row of a 16-channel slice is contiguous, so the LDS-DMA gather reads whole cache lines).  Cin_stored = Cin, or
  * 2/3 Cin when the fp32-class three-term operand [hi | lo | hi] (wf_split_bf16x3 side 0) is stored as [hi | lo] and its hi half is
  * read for both K thirds. */
 int wf_conv3d_pack333(const void* w, void* w_packed, int Cout, int Cin, void* stream);
+size_t wf_conv3d_333_zero_page_bytes(int Wi, int Cin_stored, int layout);
 int wf_conv3d_333(const void* in, const void* w_packed, const float* bias, const float* resid, float* out_f32, void* out_bf16, int T,
-                  int Hi, int Wi, int Cin, int Ho, int Cout, int ph, const void* zero_page, int layout, int Cin_stored, void* stream);
+                  int Hi, int Wi, int Cin, int Ho, int Cout, int ph, const void* zero_page, size_t zero_page_bytes, int layout,
+                  int Cin_stored, void* stream);
 /* Direct convolution for the thin layers (3->96, 16->384, 96->3, 384->32, 1x1x1 quant convs; vae.py:288, 316, 392, 421, 505-506).
  * in f32 or bf16 channels-last, w f32 [taps][Cin][Cout]; clamp > 0 clamps the output (autoencoder_kl_wan.py:1222). */
 int wf_conv3d_small(const void* in, int in_dtype, const float* w, const float* bias, float* out_f32, void* out_bf16, int Ti, int Hi,

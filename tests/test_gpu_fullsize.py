@@ -106,7 +106,7 @@ def test_conv3d_c2_sampled_pixels_borders_and_exact_linearity():
     w = _dev_randn((C, C, 3, 3, 3), 301, 1.0 / math.sqrt(27 * C))
     b = _dev_randn((C,), 302, 0.1, F32)
     wk = w.permute(0, 2, 3, 4, 1).reshape(C, 27, C).contiguous()
-    zp = torch.zeros(64, dtype=BF, device=DEV)
+    zp = torch.zeros(4096, dtype=BF, device=DEV)
     of = torch.empty((T, H, W, C), dtype=F32, device=DEV)
 
     wp = torch.empty((27, C // 16, C, 16), dtype=BF, device=DEV)
@@ -114,7 +114,7 @@ def test_conv3d_c2_sampled_pixels_borders_and_exact_linearity():
 
     def run(inp, bias, dst):   # the LDS-resident patch kernel the VAE uses for this layer
         _ffi.call("wf_conv3d_333", inp.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None, None, dst.data_ptr(),
-                  None, T, H, W, C, H, C, 1, zp.data_ptr(), 0, C, ops.stream())
+                  None, T, H, W, C, H, C, 1, zp.data_ptr(), zp.numel() * 2, 0, C, ops.stream())
 
     run(x, b, of)
     pts = [(0, 0, 0), (0, 0, W - 1), (0, H - 1, 0), (T - 1, H - 1, W - 1), (1, 1, 1), (2, 0, 5), (40, 239, 415), (80, 479, 0),

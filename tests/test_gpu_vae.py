@@ -122,11 +122,11 @@ def test_conv3d_333_vs_torch(cfg):
     _ffi.call("wf_conv3d_pack333", wk.data_ptr(), wp.data_ptr(), cout, cin, ops.stream())
     assert torch.equal(wp.permute(2, 0, 1, 3).reshape(cout, 27, cin), wk)
     xd, bd, rd = x.to(DEV), b.to(DEV), resid.to(DEV)
-    zp = torch.zeros(64, dtype=BF, device=DEV)
+    zp = torch.zeros(4096, dtype=BF, device=DEV)
     of = torch.full((T, Ho, W, cout), float("nan"), dtype=F32, device=DEV)
     ob = torch.empty((T, Ho, W, cout), dtype=BF, device=DEV)
     _ffi.call("wf_conv3d_333", xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), rd.data_ptr(), of.data_ptr(), ob.data_ptr(), T, H, W, cin, Ho,
-              cout, 0 if halo else 1, zp.data_ptr(), 0, cin, ops.stream())
+              cout, 0 if halo else 1, zp.data_ptr(), zp.numel() * 2, 0, cin, ops.stream())
     want = ref + resid
     err = (of.cpu() - want).abs().max().item()
     assert err <= 2e-3 * max(1.0, want.abs().max().item()), err

@@ -181,8 +181,10 @@ ok("wf_conv3d_cl", buf(2 * T_ * H_ * W_ * Ci), buf(2 * Co * 27 * Ci), f32(Co), N
    3, 3, 3, 1, 1, 2, 1, 1, 0, 0, zp, None)
 ok("wf_conv3d_pack333", buf(2 * Co * 27 * Ci), buf(2 * 27 * (Ci // 16) * Co * 16), Co, Ci, None)
 ok("wf_conv3d_333", buf(2 * T_ * H_ * W_ * Ci), buf(2 * 27 * (Ci // 16) * Co * 16), f32(Co), None, f32(T_ * H_ * W_ * Co), None, T_, H_, W_, Ci, H_, Co, 1,
-   zp, 0, Ci, None)
-bad("wf_conv3d_333", buf(64), buf(64), None, None, f32(16), None, 1, 4, 4, 24, 4, 96, 1, zp, 0, 24, None)   # Cin not a multiple of 32
+   zp, 4096, 0, Ci, None)
+bad("wf_conv3d_333", buf(64), buf(64), None, None, f32(16), None, 1, 4, 4, 24, 4, 96, 1, zp, 4096, 0, 24, None)
+bad("wf_conv3d_333", buf(2 * T_ * H_ * W_ * Ci), buf(2 * 27 * (Ci // 16) * Co * 16), f32(Co), None, f32(T_ * H_ * W_ * Co), None, T_, H_, W_, Ci, H_, Co, 1,
+    zp, dll.wf_conv3d_333_zero_page_bytes(W_, Ci, 1) - 1, 1, Ci, None)                                   # zero page shorter than the largest slice offset   # Cin not a multiple of 32
 ok("wf_conv3d_small", f32(T_ * H_ * W_ * 16), F, f32(16 * 32), f32(32), f32(T_ * H_ * W_ * 32), None, T_, H_, W_, 16, T_, H_, W_, 32, 1, 1, 1, 1, 1, 0, 0,
    0.0, None)
 npix = T_ * H_ * W_

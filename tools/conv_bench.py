@@ -21,13 +21,13 @@ def bench(T, H, W, cin, cout, layout=1, x3=False, iters=3, resid=False):
     b = torch.randn(cout, device=dev)
     r = torch.randn(T, H, W, cout, device=dev) if resid else None
     out = torch.empty(T, H, W, cout, device=dev)
-    zp = torch.zeros(64, dtype=BF, device=dev)
+    zp = torch.zeros(1 << 20, dtype=BF, device=dev)
     wp = torch.empty((27, K // 16, cout, 16), dtype=BF, device=dev)
     _ffi.call("wf_conv3d_pack333", w.data_ptr(), wp.data_ptr(), cout, K, ops.stream())
 
     def run():
         _ffi.call("wf_conv3d_333", x.data_ptr(), wp.data_ptr(), b.data_ptr(), r.data_ptr() if resid else None, out.data_ptr(), None, T, H, W,
-                  K, H, cout, 1, zp.data_ptr(), layout, Cs, ops.stream())
+                  K, H, cout, 1, zp.data_ptr(), zp.numel() * 2, layout, Cs, ops.stream())
     run(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()

@@ -11,10 +11,10 @@ x = torch.randn(T, H, W, Cs, device="cuda:0").to(BF).view(T, H, W, Cs // 16, 16)
 w = (torch.randn(C, 27, K, device="cuda:0") / math.sqrt(K * 27)).to(BF)
 b = torch.randn(C, device="cuda:0")
 out = torch.empty(T, H, W, C, device="cuda:0")
-zp = torch.zeros(64, dtype=BF, device="cuda:0")
+zp = torch.zeros(1 << 20, dtype=BF, device="cuda:0")
 wp = torch.empty((27, K // 16, C, 16), dtype=BF, device="cuda:0")
 _ffi.call("wf_conv3d_pack333", w.data_ptr(), wp.data_ptr(), C, K, ops.stream())
 for _ in range(N):
-    _ffi.call("wf_conv3d_333", x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, out.data_ptr(), None, T, H, W, K, H, C, 1, zp.data_ptr(), 1, Cs,
+    _ffi.call("wf_conv3d_333", x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, out.data_ptr(), None, T, H, W, K, H, C, 1, zp.data_ptr(), zp.numel() * 2, 1, Cs,
               ops.stream())
 torch.cuda.synchronize()

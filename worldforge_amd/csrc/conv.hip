@@ -607,9 +607,7 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
 #endif
   // ---- LDS-DMA sources of this wave's 16 patch pieces: lane-load q = (16 w + j) * 64 + lane -> patch pixel q >> 1, chunk q & 1 ----
   const uint16_t* psrc[16];
-  uint32_t pvalid = 0;
   auto compute_psrc = [&](int tt0, int yy0, int xx0) {
-    pvalid = 0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int q = (wid * 16 + j) * 64 + lane;
@@ -619,7 +617,6 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
       const int tt = tt0 - 2 + f, yy = yy0 - a.ph + r, xx = xx0 - 1 + cc;
       const bool ok = p < PATCH_PX && tt >= 0 && yy >= 0 && yy < a.Hi && xx >= 0 && xx < a.Wi;
       psrc[j] = ok ? a.in + ((size_t)tt * a.Hi + yy) * pa.row_stride + (size_t)xx * pa.pix_stride + ch * 8 : pa.zeros;
-      pvalid |= ok ? (1u << j) : 0u;
     }
   };
   decode(tile_begin, t, y0, x0);
@@ -627,10 +624,12 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_offset(smem));
   auto dma_piece = [&](int cs, int j) {  // piece j of the patch of K slice cs -> buffer cs & 1 (stored slice cs mod nsa)
     const int acs = cs >= pa.nsa ? cs - pa.nsa : cs;
-    const uint16_t* src = psrc[j] + (((pvalid >> j) & 1u) ? (size_t)acs * pa.slice_stride : (size_t)0);
+    // ONE wave-uniform slice offset for every lane (a single 64-bit add per piece, no per-lane select): the lanes of out-of-range pixels
+    // point at the zero page, which the caller makes at least (nsa - 1) * slice_stride elements + 16 bytes long (checked by wf_conv3d_333)
+    const uint16_t* src = psrc[j] + (size_t)acs * pa.slice_stride;
     // issued from inline asm: with the builtin hipcc drains vmcnt(0) in front of every later ds_read (it cannot prove that the DMA's
     // LDS destination does not alias it), i.e. every few MFMAs here.  Ordering is ours: vmcnt + barrier at the end of the slice.
-    glds16_async(src, smem_base + (uint32_t)((cs & 1) * PATCH_BUF + (wid * 16 + j) * 1024));
+    glds16_async_m0(src, smem_base + (uint32_t)((cs & 1) * PATCH_BUF + (wid * 16 + j) * 1024));
   };
 
   // ---- fragment addressing ----
@@ -977,10 +976,22 @@ extern "C" int wf_conv3d_pack333(const void* w, void* w_packed, int Cout, int Ci
   return WF_OK;
 }
 
+extern "C" size_t wf_conv3d_333_zero_page_bytes(int Wi, int Cin_stored, int layout) {
+  // the lanes of padding pixels read the zero page at the same wave-uniform slice offset as the lanes of real pixels read the input
+  const size_t slice_stride = layout == 1 ? (size_t)Wi * 16 : (size_t)16;
+  const size_t nsa = Cin_stored > 0 ? (size_t)Cin_stored / 16 : 1;
+  return (nsa - 1) * slice_stride * 2 + 64;
+}
+
 extern "C" int wf_conv3d_333(const void* in, const void* w_packed, const float* bias, const float* resid, float* out_f32,
                              void* out_bf16, int T, int Hi, int Wi, int Cin, int Ho, int Cout, int ph, const void* zero_page,
-                             int layout, int Cin_stored, void* stream) {
+                             size_t zero_page_bytes, int layout, int Cin_stored, void* stream) {
   WF_CHECK_ARG(in && w_packed && zero_page && (out_f32 || out_bf16), "wf_conv3d_333: null pointer");
+  {
+    const size_t need = wf_conv3d_333_zero_page_bytes(Wi, Cin_stored, layout);
+    WF_CHECK_ARG(zero_page_bytes >= need, "wf_conv3d_333: zero page of %zu bytes, this shape needs %zu (wf_conv3d_333_zero_page_bytes)",
+                 zero_page_bytes, need);
+  }
   WF_CHECK_ARG(Cin % 32 == 0 && Cout % 32 == 0, "wf_conv3d_333: Cin (%d) and Cout (%d) must be multiples of 32", Cin, Cout);
   WF_CHECK_ARG(layout == 0 || layout == 1, "wf_conv3d_333: layout must be 0 (pixel-major) or 1 (slice-major)");
   WF_CHECK_ARG(Cin_stored == Cin || (Cin % 3 == 0 && Cin_stored == Cin / 3 * 2 && Cin_stored % 16 == 0),

@@ -34,6 +34,7 @@ from typing import Dict, List, Tuple
 import torch
 
 from . import ops
+from . import _ffi
 from ._ffi import WF_BF16, WF_F32, call
 from .dit import EPI_BF16, EPI_F32, EPI_F32_ACC, gemm
 
@@ -374,10 +375,11 @@ class AutoencoderKLWan:
                 and Cin % 32 == 0 and Cout % 32 == 0 and not os.environ.get("WF_CONV_NO_W4")):
             # the FLOP-heavy layers: LDS-resident input patch kernel on re-packed weights (packed once per layer, cached).  Chosen by
             # layer type only, never by size: a row slab of the sharded VAE must run the same arithmetic as the whole image
+            zp = self._zero_page(int(_ffi.lib().wf_conv3d_333_zero_page_bytes(Wi, Cst, layout)))
             call("wf_conv3d_333", x.data_ptr(), self._packed333(p, Cout, Cin).data_ptr(), W[p + ".b"].data_ptr(),
                  resid.data_ptr() if resid is not None else None, of.data_ptr() if of is not None else None,
                  ob.data_ptr() if ob is not None else None, Ti, Hi, Wi, Cin, Ho, Cout, ps if ph is None else ph,
-                 self._zero_page().data_ptr(), layout, Cst, ops.stream())
+                 zp.data_ptr(), zp.numel() * 2, layout, Cst, ops.stream())
         else:
             assert layout == 0, "slice-major operands are for the 3x3x3 stride-1 kernel only"
             call("wf_conv3d_cl", x.data_ptr(), W[p + ".w"].data_ptr(), W[p + ".b"].data_ptr(),
@@ -402,10 +404,12 @@ class AutoencoderKLWan:
             cache[p] = hit = (w, out)
         return hit[1]
 
-    def _zero_page(self):
+    def _zero_page(self, nbytes: int = 128):
+        """Zeros for the convolutions' padding taps.  wf_conv3d_333 reads it at the wave-uniform slice offset of its LDS-DMA pieces
+        (wf_conv3d_333_zero_page_bytes: up to (Cin_stored / 16 - 1) x W x 32 bytes), so the page grows to the largest request seen."""
         z = getattr(self, "_zeros", None)
-        if z is None:
-            z = self._zeros = torch.zeros(64, dtype=BF, device=self.device)
+        if z is None or z.numel() * 2 < nbytes:
+            z = self._zeros = torch.zeros(max(1 << 20, (nbytes + 1) // 2), dtype=BF, device=self.device)
         return z
 
     def _small_conv(self, x, p, To, Ho, Wo, Cout, k, pt=0, ps=0, clamp=0.0, out_dtype=F32):
