@@ -498,6 +498,253 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The same ping-pong kernel on v_mfma_f32_16x16x32_bf16 (round 3, opt-in: WF_GEMM_MFMA=16).  On N(0,1) operands every MFMA-bound kernel
+// of this engine runs at the socket's power limit, and a bare stream of 16x16x32 does 12-13 % more flops under that limit than one of
+// 32x32x16 (profiles/r3_gemm_energy.md: half the accumulator read-modify-write per flop).  Same tiles, same LDS images and DMA, same
+// operand bytes read from LDS per flop (that ratio belongs to the wave tile, not to the MFMA shape); a 64-wide K tile is two k steps of 32
+// instead of four of 16, so the fp32 accumulation ORDER over K differs from the 32x32x16 kernels (results equal up to fp32 rounding).
+// ------------------------------------------------------------------------------------------------------------------
+template <int EPI, int NI>
+__global__ __launch_bounds__(PT, 2) void k_gemm_pp16(GemmArgs a) {
+  using G = PPGeom<NI>;
+  constexpr int NJ = G::NJ, NWP = G::NWP, NP = G::NP, W_TILE = G::W_TILE, BUF = G::BUF;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // XCD-aware tile assignment (4 x 4 super-tiles of 256 x 256 tiles per XCD pass)
+  const int smt = (a.mt + 3) >> 2, snt = (a.nt + 3) >> 2;
+  const int nsuper = smt * snt;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, j = b >> 3;
+  const int gid = (j >> 4) * 8 + xcd;
+  if (gid >= nsuper) return;
+  const int within = j & 15;
+  const int tm = (gid / snt) * 4 + (within >> 2);
+  const int tn = (gid % snt) * 4 + (within & 3);
+  if (tm >= a.mt || tn >= a.nt) return;
+  const int m0 = tm * PM, n0 = tn * G::PNT;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const bool groupB = wid >= 4;
+  const int wfi = NJ == 4 ? (wid & 3) : (wid >> 2);  // wave index along features
+  const int wti = NJ == 4 ? (wid >> 2) : (wid & 3);  // wave index along tokens
+  const int wf0 = wfi * NI * 32, wt0 = wti * NJ * 32;  // wave tile origin inside the workgroup tile
+
+  // ---- LDS-DMA geometry: an operand tile = rows x 128 B = pieces of 1 KiB (8 rows); wave w moves pieces NWP*w.. of W and
+  // 4w..4w+3 of X.  lane -> (row = 8*piece + lane/8, slot = lane%8) receives source chunk slot ^ ((row >> 1) & 7).
+  const uint16_t* srcW[NWP];
+  const uint16_t* srcX[4];
+#pragma unroll
+  for (int i = 0; i < NWP; ++i) {
+    const int row = 8 * (wid * NWP + i) + (lane >> 3), slot = lane & 7;
+    srcW[i] = a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw + (slot ^ ((row >> 1) & 7)) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * (wid * 4 + i) + (lane >> 3), slot = lane & 7;
+    srcX[i] = a.X + (size_t)min(m0 + row, a.M - 1) * a.ldx + (slot ^ ((row >> 1) & 7)) * 8;
+  }
+  auto dma_piece = [&](int kt, int i) {  // i in 0..NP-1: W pieces first, then the 4 X pieces
+    unsigned char* base = smem + (kt & 1) * BUF;
+    if (i < NWP)
+      glds16(srcW[i] + (size_t)kt * PK, base + (wid * NWP + i) * 1024);
+    else
+      glds16(srcX[i - NWP] + (size_t)kt * PK, base + W_TILE + (wid * 4 + i - NWP) * 1024);
+  };
+  auto dma = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) dma_piece(kt, i);
+  };
+
+  // ---- fragment addressing ------------------------------------------------------------------------------------------------
+  // 16 x 16 x 32 fragments: lane -> row (l & 15) of a 16-row tile, k-group (l >> 4) of the 32-wide k step; every fragment row is the lane's
+  // row l15 plus a multiple of 16, so one swizzle term serves all of them.  A "half" of a 64-wide K tile is ONE k step here.
+  constexpr int NA = 2 * NI, NB = 2 * NJ;  // 16-row feature tiles / 16-column token tiles per wave
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int sw = (l15 >> 1) & 7;
+  const int offW = (wf0 + l15) * 128, offX = W_TILE + (wt0 + l15) * 128;
+  f32x4 acc[NA][NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int jx = 0; jx < NB; ++jx) acc[i][jx] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 fw[NA], fx[NB];
+  auto read_half = [&](int kt, int half) {
+    const unsigned char* base = smem + (kt & 1) * BUF;
+    const int c = ((4 * half + kg) ^ sw) << 4;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) fw[i] = *reinterpret_cast<const u32x4*>(base + offW + i * 2048 + c);
+#pragma unroll
+    for (int jx = 0; jx < NB; ++jx) fx[jx] = *reinterpret_cast<const u32x4*>(base + offX + jx * 2048 + c);
+  };
+  // 2*NI*NJ MFMAs on register operands; optionally the NP LDS-DMA pieces of tile `dma_kt` are issued in the gaps (one behind
+  // every second MFMA: the MFMA pipe hides their issue cost, and the read phases stay pure LDS reads)
+  auto mma_half = [&](int dma_kt) {
+    __builtin_amdgcn_s_setprio(1);  // the MFMA phase outranks the co-resident wave's LDS phase at the issue arbiter
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int jx = 0; jx < NB; ++jx) {
+        acc[i][jx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(fw[i]), as_bf16x8(fx[jx]), acc[i][jx], 0, 0, 0);
+        const int idx = i * NB + jx;
+        if (dma_kt >= 0 && (idx & 3) == 3 && (idx >> 2) < NP) dma_piece(dma_kt, idx >> 2);  // a piece behind every fourth (16-cycle) MFMA
+      }
+    if (dma_kt >= 0) {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto bar = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  auto drain = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  const int nk = a.K / PK;
+  dma(0);
+  drain();
+  bar();
+  if (!groupB) {
+    for (int kt = 0; kt < nk; ++kt) {
+      read_half(kt, 0);
+      bar();  // 4kt+1
+      mma_half(kt + 1 < nk ? kt + 1 : -1);  // DMA of tile kt+1 rides in the MFMA gaps (its buffer is free since barrier 4kt)
+      bar();  // 4kt+2
+      read_half(kt, 1);
+      bar();  // 4kt+3
+      mma_half(-1);
+      drain();
+      bar();  // 4kt+4
+    }
+    bar();
+  } else {
+    if (nk > 1) dma(1);
+    bar();  // 1
+    for (int kt = 0; kt < nk; ++kt) {
+      read_half(kt, 0);
+      bar();  // 4kt+2
+      mma_half(-1);
+      bar();  // 4kt+3
+      read_half(kt, 1);
+      drain();
+      bar();  // 4kt+4
+      mma_half(kt + 2 < nk ? kt + 2 : -1);
+      bar();  // 4kt+5
+    }
+  }
+
+  // ---- epilogue through LDS: row-contiguous global accesses ------------------------------------------------------------------
+  // In the accumulator layout a lane owns one token row and quads of features, so a store instruction touches 32-64 different rows
+  // (8 / 16 bytes each): 64 such instructions per lane made the epilogue ~20 k cycles per tile, 9 % of a K = 5120 GEMM.  Each wave
+  // therefore transposes its tile through a private LDS region (the operand buffers are free behind the last barrier) in passes of
+  // [NJ*32 tokens][128 B]  (64 bf16 features = two MFMA tiles, or 32 fp32 features = one; an odd last bf16 tile makes a 64-byte
+  // pass) and reads / writes global memory in whole rows of a pass.  Rows are padded by 16 B (144-byte stride) so that neither the
+  // column-wise writes nor the row-wise reads conflict.  No workgroup barrier: the region is wave-private.
+  {
+    constexpr int RS = 144;  // padded row stride in bytes
+    constexpr int ROWS = NJ * 32;
+    unsigned char* stg = smem + wid * G::STG;
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+#pragma unroll
+      for (int i0 = 0; i0 < NI; i0 += 2) {
+        const int nti = (NI - i0) >= 2 ? 2 : 1;  // feature tiles in this pass (compile-time after unrolling)
+#pragma unroll
+        for (int jx = 0; jx < NB; ++jx)
+#pragma unroll
+          for (int ia = 0; ia < 4; ++ia) {   // the 16-row feature tiles of this pass (2 per 32-feature tile)
+            if (ia >= 2 * nti) continue;
+            const int i = 2 * i0 + ia;
+            const int nl = ia * 16 + 4 * kg;  // feature within the pass: the lane's 4 consecutive features
+            const int n = n0 + wf0 + i0 * 32 + nl;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = acc[i][jx][q];
+            if (a.bias && n < a.N) {
+              const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] += bb[q];
+            }
+            if constexpr (EPI == EPI_BF16_GELU) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
+            }
+            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(stg + (jx * 16 + l15) * RS + nl * 2) = pk;
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // row phase: 8 (4) lanes x 16 B per token row, 8 (16) rows per instruction
+        const int lpr = nti * 4;
+        const int lrow = lane / lpr, lch = lane % lpr;
+#pragma unroll
+        for (int r8 = 0; r8 < ROWS * nti / 16; ++r8) {
+          const int row = r8 * (64 / lpr) + lrow;
+          const int m = m0 + wt0 + row;
+          const int n = n0 + wf0 + i0 * 32 + lch * 8;
+          const u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * RS + lch * 16);
+          if (m < a.M && n < a.N) {  // N % 4 == 0: a chunk of 8 features may straddle the edge
+            uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
+            if (n + 8 <= a.N)
+              *reinterpret_cast<u32x4*>(op) = val;
+            else
+              *reinterpret_cast<u32x2*>(op) = u32x2{val[0], val[1]};
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next pass overwrites the staging rows
+      }
+    } else {
+      const int lrow = lane >> 3, lch = lane & 7;  // row phase: 8 rows x 8 chunks of 16 B per instruction
+      // fp32 outputs: one pass of [NJ*32 tokens][32 features] f32 = 128 B per row for every feature tile
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+#pragma unroll
+        for (int jx = 0; jx < NB; ++jx)
+#pragma unroll
+          for (int ia = 0; ia < 2; ++ia) {
+            const int nl = ia * 16 + 4 * kg;
+            const int n = n0 + wf0 + i * 32 + nl;
+            f32x4 v = acc[2 * i + ia][jx];
+            if (a.bias && n < a.N) {
+              const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] += bb[q];
+            }
+            *reinterpret_cast<f32x4*>(stg + (jx * 16 + l15) * RS + nl * 4) = v;
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r8 = 0; r8 < ROWS / 8; ++r8) {
+          const int row = r8 * 8 + lrow;
+          const int m = m0 + wt0 + row;
+          const int n = n0 + wf0 + i * 32 + lch * 4;
+          f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * RS + lch * 16);
+          if (m < a.M && n < a.N) {
+            float* po = reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n;
+            if constexpr (EPI == EPI_F32) {
+              *reinterpret_cast<f32x4*>(po) = v;
+            } else if constexpr (EPI == EPI_F32_ACC) {
+              const f32x4 old = *reinterpret_cast<const f32x4*>(po);
+              *reinterpret_cast<f32x4*>(po) = f32x4{old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
+            } else {
+              const f32x4 old = *reinterpret_cast<const f32x4*>(po);
+              f32x4 gg = {1.f, 1.f, 1.f, 1.f};
+              if (a.gate) gg = *reinterpret_cast<const f32x4*>(a.gate + n);
+              *reinterpret_cast<f32x4*>(po) =
+                  f32x4{old[0] + v[0] * gg[0], old[1] + v[1] * gg[1], old[2] + v[2] * gg[2], old[3] + v[3] * gg[3]};
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next pass overwrites the staging rows
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // One wave per SIMD variant: 256 x 256 tile, 4 waves (2 feature halves x 2 token halves), wave tile 128 features x 128 tokens =
 // 4 x 4 MFMA 32x32x16 tiles = 256 accumulator registers, ALL in AGPRs (inline-asm MFMAs: hipcc picks one accumulator form per
 // function and would otherwise shuttle them through v_accvgpr copies).  With two waves per SIMD (k_gemm_pp) the partner wave's LDS /
@@ -723,7 +970,11 @@ static void launch_pp(GemmArgs a, hipStream_t s) {
   a.nt = ceil_div(a.N, G::PNT);
   const int nsuper = ((a.mt + 3) / 4) * ((a.nt + 3) / 4);
   const int grid = ((nsuper + 7) / 8) * 8 * 16;
-  hipLaunchKernelGGL((k_gemm_pp<EPI, NI>), dim3(grid), dim3(PT), G::LDS, s, a);
+  static const bool mfma16 = [] { const char* e = getenv("WF_GEMM_MFMA"); return e && atoi(e) == 16; }();
+  if (mfma16)
+    hipLaunchKernelGGL((k_gemm_pp16<EPI, NI>), dim3(grid), dim3(PT), G::LDS, s, a);
+  else
+    hipLaunchKernelGGL((k_gemm_pp<EPI, NI>), dim3(grid), dim3(PT), G::LDS, s, a);
 }
 
 // 256- or 320-feature tiles: whichever leaves fewer idle workgroup slots in the last round of `n_cu` concurrent workgroups
