@@ -200,6 +200,12 @@ int wf_ln_modulate(const float* x, const float* mul, const float* add, void* out
  * q * head_dim^-1/2 * log2(e), and wf_attn_fwd is then called with softmax_scale = 0 ("Q is pre-scaled"). */
 int wf_rmsnorm_heads(const void* in, int ld, const float* weight, const float* cos_tab, const float* sin_tab, void* out, int L,
                      int Lout, int C, float eps, float out_scale, void* stream);
+/* The same, and in the same pass max_norm2[h] = max over the L rows of |out row of head h|^2 (of the values as stored, after the bf16
+ * rounding) -- what wf_head_max_norm2 computes with a second pass over the tensor (rows holding NaN / inf report +inf likewise).
+ * ws: wf_rmsnorm_heads_bound_ws_floats(L, C) floats.  C / 128 heads <= 64. */
+size_t wf_rmsnorm_heads_bound_ws_floats(int L, int C);
+int wf_rmsnorm_heads_bound(const void* in, int ld, const float* weight, const float* cos_tab, const float* sin_tab, void* out, int L, int Lout,
+                           int C, float eps, float out_scale, float* ws, float* max_norm2, void* stream);
 
 /* V [L, ld] bf16 (head h at columns h*128) -> Vt [H][Lp/64][128][64] bf16, keys >= L zero-filled. */
 int wf_v_transpose(const void* V, int ld, void* Vt, int L, int Lp, int H, void* stream);

@@ -358,6 +358,31 @@ def test_rmsnorm_heads_out_scale_is_applied_before_the_rounding():
     assert not torch.equal(b.float(), (a.float() * alpha).to(BF).float())   # not the double rounding
 
 
+@pytest.mark.parametrize("L,C,rope", [(300, 5120, True), (77, 256, False), (1030, 1024, True)])
+def test_rmsnorm_heads_bound_equals_the_separate_norm_pass(L, C, rope):
+    """wf_rmsnorm_heads_bound: same output as wf_rmsnorm_heads, and max |row|^2 per head equal to wf_head_max_norm2 of that output (the values
+    as stored; fp32 sums in a different order); a NaN row reports +inf for its head only."""
+    from worldforge_amd import dit
+    H = C // 128
+    m = dit.WanTransformer3DModel(dit.DiTConfig(dim=C, ffn_dim=2 * C, num_heads=H, num_layers=1, text_dim=64), DEV)
+    src = _rand((L, 3 * C), 5).to(BF).to(DEV)
+    w = (1 + 0.05 * _rand((C,), 6)).to(DEV)
+    cos, sin = (m._rope_tables(1, 1, L) if rope else (None, None))
+    Lp = (L + 63) // 64 * 64
+    a = torch.zeros((H, Lp, 128), dtype=BF, device=DEV)
+    b = torch.zeros((H, Lp, 128), dtype=BF, device=DEV)
+    bound = torch.full((H,), -1.0, dtype=F32, device=DEV)
+    m._heads(src, C, w, cos, sin, a, L, out_scale=0.1275)
+    m._heads(src, C, w, cos, sin, b, L, out_scale=0.1275, bound=bound)
+    assert torch.equal(a, b)
+    want = dit.head_max_norm2(a, L, torch.empty(H, dtype=F32, device=DEV))
+    assert torch.allclose(bound, want, rtol=1e-5, atol=0), (bound - want).abs().max()
+    assert float(bound.min()) > 0
+    src[L // 2, C + 128 * (H - 1) + 3] = float("nan")      # one element of the last head's input... the RMS norm spreads it over the whole row
+    m._heads(src, C, w, cos, sin, b, L, out_scale=0.1275, bound=bound)
+    assert torch.isinf(bound).all()                         # (RMS over all channels: every head of that row is NaN -> every head's bound is +inf)
+
+
 def test_ln_modulate_and_affine():
     from worldforge_amd import _ffi, ops
     for C in (256, 1280, 5120):

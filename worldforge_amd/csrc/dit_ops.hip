@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void k_ln_mod(const float* __restrict__ x, con
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void k_rms_heads(const uint16_t* __restrict__ in, int ld, const float* __restrict__ w,
                                                    const float* __restrict__ cs, const float* __restrict__ sn,
-                                                   uint16_t* __restrict__ out, int L, int Lout, int C, float eps, float out_scale) {
+                                                   uint16_t* __restrict__ out, int L, int Lout, int C, float eps, float out_scale,
+                                                   float* __restrict__ norm2_rows) {
   __shared__ float sm[4];
   const int row = blockIdx.x;
   const uint16_t* xr = in + (size_t)row * ld;
@@ -142,7 +143,66 @@ __global__ __launch_bounds__(128) void k_rms_heads(const uint16_t* __restrict__ 
       }
       u32x4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
       *reinterpret_cast<u32x4*>(out + ((size_t)head * Lout + row) * 128 + within * 8) = pk;
+      if (norm2_rows) {
+        // |y|^2 of this (row, head) over the values AS STORED (after the bf16 rounding): the 16 lanes of a head are consecutive lanes of one
+        // wave (id = tid + 128 i, within = tid & 15).  Feeds the per-head norm bound of the attention kernel (wf_head_max_norm2's result)
+        // without a second pass over the tensor.
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float a = __uint_as_float(pk[k] << 16), b = __uint_as_float(pk[k] & 0xffff0000u);
+          q += a * a + b * b;
+        }
+        q += __shfl_xor(q, 8, 64);
+        q += __shfl_xor(q, 4, 64);
+        q += __shfl_xor(q, 2, 64);
+        q += __shfl_xor(q, 1, 64);
+        if (within == 0) norm2_rows[(size_t)row * H + head] = q;
+      }
     }
+  }
+}
+
+// max over the rows of norm2_rows [L][H] -> part [nblk][H] (RB rows per block), then part -> out [H].  Rows holding a NaN / inf report +inf
+// (fmaxf would drop the NaN): the attention kernel must then take its max-tracking body (see k_head_max_norm2 in attention.hip).
+constexpr int NB_RB = 128;
+__device__ __forceinline__ float nb_max(float best, float v) { return !(v <= 3.0e38f) ? INFINITY : fmaxf(best, v); }
+// thread t -> (head h = t % H, slice s = t / H of 256 / H slices); items s, s + ns, ... of [n][H]; the loads of 8 items are issued together
+// (a dependent fmaxf chain would otherwise expose one memory latency per item: the pass is latency-, not bandwidth-bound)
+__device__ __forceinline__ float nb_column_max(const float* __restrict__ src, int n, int H, int h, int s, int ns) {
+  float best = 0.f;
+  int r = s;
+  for (; r + 7 * ns < n; r += 8 * ns) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(r + u * ns) * H + h];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) best = nb_max(best, v[u]);
+  }
+  for (; r < n; r += ns) best = nb_max(best, src[(size_t)r * H + h]);
+  return best;
+}
+__global__ __launch_bounds__(256) void k_norm2_part(const float* __restrict__ rows, int L, int H, float* __restrict__ part) {
+  __shared__ float red[256];
+  const int t = threadIdx.x, h = t % H, s = t / H, ns = 256 / H;
+  const int r0 = blockIdx.x * NB_RB, n = min(L - r0, NB_RB);
+  float best = s < ns ? nb_column_max(rows + (size_t)r0 * H, n, H, h, s, ns) : 0.f;
+  red[t] = best;
+  __syncthreads();
+  if (t < H) {
+    for (int k = 1; k < ns; ++k) best = fmaxf(best, red[k * H + t]);
+    part[(size_t)blockIdx.x * H + t] = best;
+  }
+}
+__global__ __launch_bounds__(256) void k_norm2_final(const float* __restrict__ part, int nblk, int H, float* __restrict__ out) {
+  __shared__ float red[256];
+  const int t = threadIdx.x, h = t % H, s = t / H, ns = 256 / H;
+  float best = s < ns ? nb_column_max(part, nblk, H, h, s, ns) : 0.f;
+  red[t] = best;
+  __syncthreads();
+  if (t < H) {
+    for (int k = 1; k < ns; ++k) best = fmaxf(best, red[k * H + t]);
+    out[t] = best;
   }
 }
 
@@ -248,8 +308,32 @@ extern "C" int wf_rmsnorm_heads(const void* in, int ld, const float* weight, con
   WF_CHECK_ARG((cos_tab == nullptr) == (sin_tab == nullptr), "wf_rmsnorm_heads: cos/sin must both be given or both null");
   if (L == 0) return WF_OK;
   hipLaunchKernelGGL(k_rms_heads, dim3(L), dim3(128), 0, (hipStream_t)stream, (const uint16_t*)in, ld, weight, cos_tab,
-                     sin_tab, (uint16_t*)out, L, Lout, C, eps, out_scale);
+                     sin_tab, (uint16_t*)out, L, Lout, C, eps, out_scale, (float*)nullptr);
   WF_LAUNCH_CHECK("wf_rmsnorm_heads");
+  return WF_OK;
+}
+
+extern "C" size_t wf_rmsnorm_heads_bound_ws_floats(int L, int C) {
+  if (L <= 0 || C <= 0) return 0;
+  const size_t H = (size_t)C / 128;
+  return (size_t)L * H + (size_t)((L + NB_RB - 1) / NB_RB) * H;
+}
+
+extern "C" int wf_rmsnorm_heads_bound(const void* in, int ld, const float* weight, const float* cos_tab, const float* sin_tab, void* out,
+                                      int L, int Lout, int C, float eps, float out_scale, float* ws, float* max_norm2, void* stream) {
+  WF_CHECK_ARG(in && weight && out && ws && max_norm2, "wf_rmsnorm_heads_bound: null pointer");
+  WF_CHECK_ARG(out_scale > 0.0f, "wf_rmsnorm_heads_bound: out_scale must be positive (1 = none)");
+  WF_CHECK_ARG(C % 128 == 0 && C <= 8192 && ld % 8 == 0, "wf_rmsnorm_heads_bound: C=%d must be a multiple of 128 (<= 8192), ld %% 8", C);
+  WF_CHECK_ARG(Lout >= L && L > 0, "wf_rmsnorm_heads_bound: need 0 < L <= Lout");
+  WF_CHECK_ARG((cos_tab == nullptr) == (sin_tab == nullptr), "wf_rmsnorm_heads_bound: cos/sin must both be given or both null");
+  const int H = C / 128, nblk = (L + NB_RB - 1) / NB_RB;
+  float* rows = ws;
+  float* part = ws + (size_t)L * H;
+  hipLaunchKernelGGL(k_rms_heads, dim3(L), dim3(128), 0, (hipStream_t)stream, (const uint16_t*)in, ld, weight, cos_tab,
+                     sin_tab, (uint16_t*)out, L, Lout, C, eps, out_scale, rows);
+  hipLaunchKernelGGL(k_norm2_part, dim3(nblk), dim3(256), 0, (hipStream_t)stream, rows, L, H, part);
+  hipLaunchKernelGGL(k_norm2_final, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nblk, H, max_norm2);
+  WF_LAUNCH_CHECK("wf_rmsnorm_heads_bound");
   return WF_OK;
 }
 

@@ -440,11 +440,21 @@ class WanTransformer3DModel:
              L, C, float(eps), 1 if plus_one else 0, ops.stream())
         return out
 
-    def _heads(self, src, col0, weight, cos, sin, out, L, out_scale: float = 1.0, lout: Optional[int] = None):
+    def _heads(self, src, col0, weight, cos, sin, out, L, out_scale: float = 1.0, lout: Optional[int] = None,
+               bound: Optional[torch.Tensor] = None):
         """RMSNorm(+RoPE) of columns [col0, col0+dim) of src [L, ld] -> out [H, Lout, 128]; out_scale: see wf_rmsnorm_heads.  lout: rows
-        between two heads of the destination when `out` is a row range of a larger [H, lout, 128] buffer (the fused cross-attention keys)."""
+        between two heads of the destination when `out` is a row range of a larger [H, lout, 128] buffer (the fused cross-attention keys).
+        bound: f32 [H] that receives max over the rows of |out row|^2 per head, computed in the same pass (wf_rmsnorm_heads_bound) -- the
+        norm bound of the attention kernel without wf_head_max_norm2's second pass over the tensor."""
         C = self.cfg.dim
         view = src[:, col0:col0 + C]
+        if bound is not None:
+            assert bound.dtype == torch.float32 and bound.numel() == self.cfg.num_heads and bound.is_contiguous()
+            ws = self._buf("heads_bound_ws", (int(_ffi.lib().wf_rmsnorm_heads_bound_ws_floats(L, C)),), torch.float32)
+            call("wf_rmsnorm_heads_bound", view.data_ptr(), src.stride(0), weight.data_ptr(), cos.data_ptr() if cos is not None else None,
+                 sin.data_ptr() if sin is not None else None, out.data_ptr(), L, out.shape[1] if lout is None else lout, C, float(self.cfg.eps),
+                 float(out_scale), ws.data_ptr(), bound.data_ptr(), ops.stream())
+            return
         call("wf_rmsnorm_heads", view.data_ptr(), src.stride(0), weight.data_ptr(), cos.data_ptr() if cos is not None else None,
              sin.data_ptr() if sin is not None else None, out.data_ptr(), L, out.shape[1] if lout is None else lout, C, float(self.cfg.eps),
              float(out_scale), ops.stream())
@@ -540,6 +550,7 @@ class WanTransformer3DModel:
         # keeps the tracking (A/B)
         km = _buf("kmax2", (H,), f32) if prescale and os.environ.get("WF_ATTN_TRACK_MAX", "0") != "1" else None
         qm = _buf("qmax2", (H,), f32) if km is not None else None
+        fused_bound = km is not None and os.environ.get("WF_NORM_BOUND_PASS", "0") != "1"
         if comm is not None:
             kh_all = _buf("kh_all", (comm.world, H, Lp, 128), bf)
             vt_all = _buf("vt_all", (comm.world, H, Lp // 64, 128, 64), bf)
@@ -617,28 +628,30 @@ class WanTransformer3DModel:
             self._ln(x, emod[1], emod[0], hbuf, cfg.eps, plus_one=True)
             if comm is None:
                 gemm(hbuf, W[p + "qkv.w"], W[p + "qkv.b"], qkv, EPI_BF16)
-                self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L, out_scale=q_scale)
-                self._heads(qkv, d, W[p + "self_attn.norm_k"], cos, sin, kh, L)
+                # the per-head norm bounds come out of the producers' own pass (WF_NORM_BOUND_PASS=1: the separate wf_head_max_norm2 passes)
+                self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L, out_scale=q_scale, bound=qm if fused_bound else None)
+                self._heads(qkv, d, W[p + "self_attn.norm_k"], cos, sin, kh, L, bound=km if fused_bound else None)
                 self._vt(qkv, 2 * d, vt, L)
-                if km is not None:
+                if km is not None and not fused_bound:
                     head_max_norm2(kh, L, km)
                     head_max_norm2(qh, L, qm)
                 attention(qh, kh, vt, ao, L, sa_scale, profile=True, kmax2=km, qmax2=qm)
             else:
                 # K and V first, their all-gather runs on the communication stream under the Q projection
                 gemm(hbuf, W[p + "qkv.w"][d:], W[p + "qkv.b"][d:], qkv[:, d:], EPI_BF16)
-                self._heads(qkv, d, W[p + "self_attn.norm_k"], cos, sin, kh, L)
+                self._heads(qkv, d, W[p + "self_attn.norm_k"], cos, sin, kh, L, bound=km if fused_bound else None)
                 self._vt(qkv, 2 * d, vt, L)
                 ev_k = comm.all_gather_async(kh_all, kh)
                 ev_v = comm.all_gather_async(vt_all, vt)
                 if km is not None:  # every shard's per-head max |k|^2 travels with it (40 floats per rank)
-                    head_max_norm2(kh, L, km)
+                    if not fused_bound:
+                        head_max_norm2(kh, L, km)
                     ev_m = comm.all_gather_async(km_all, km)
                 if i == 0 and share_ctx:
                     ctx_shared, ctx_events = launch_context()
                 yield i
                 gemm(hbuf, W[p + "qkv.w"][:d], W[p + "qkv.b"][:d], qkv[:, :d], EPI_BF16)
-                self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L, out_scale=q_scale)
+                self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L, out_scale=q_scale, bound=qm if fused_bound else None)
                 cprof = PROFILE_COMM
                 if cprof is not None:  # exposed communication = how long the compute stream stalls here
                     cw0, cw1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -649,7 +662,7 @@ class WanTransformer3DModel:
                 if cprof is not None:
                     cw1.record()
                     cprof.append((cw0, cw1))
-                if km is not None:  # this rank's own queries only
+                if km is not None and not fused_bound:  # this rank's own queries only
                     head_max_norm2(qh, L, qm)
                 attention(qh, kh_all, vt_all, ao, Lfull, sa_scale, profile=True, kmax2=km_all if km is not None else None, qmax2=qm)
             gemm(ao, W[p + "self_attn.o.w"], W[p + "self_attn.o.b"], x, EPI_RESID, gate=emod[2])
