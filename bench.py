@@ -301,7 +301,7 @@ def main_longcat(a):
             avg = sum(attn_ms) / len(attn_ms)
             flop = 4.0 * (L - tpf) * L * 128 * cfg.num_heads
             ach = flop / (avg * 1e-3) / 1e12
-            lc_kernel = "k_attn<0>" if os.environ.get("WF_ATTN_KERNEL") == "w8" else ("k_attn_w4<0>" if os.environ.get("WF_ATTN_PRESCALE", "1") == "0" else "k_attn_w4<4> (pre-scaled Q)")
+            lc_kernel = "k_attn_w4<0>" if os.environ.get("WF_ATTN_PRESCALE", "1") == "0" else "k_attn_w4<4> (pre-scaled Q)"
             out["roofline"] = {"kernel": lc_kernel + " (LongCat noise-token self-attention, attention.py:133-134)", "bound": "mfma",
                                "achieved": ach, "peak": MFMA_PEAK_TFLOPS_BF16, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS_BF16,
                                "traffic": None, "launches": len(attn_ms), "avg_launch_ms": avg, "flop_per_launch": flop}
@@ -600,8 +600,7 @@ def main(argv=None):
         if attn_ms:
             avg = sum(attn_ms) / len(attn_ms)
             ach = attn_flop / (avg * 1e-3) / 1e12
-            kern = ("k_attn<0>" if os.environ.get("WF_ATTN_KERNEL") == "w8" else
-                    ("k_attn_w4<0>" if os.environ.get("WF_ATTN_PRESCALE", "1") == "0" else "k_attn_w4<4>"))
+            kern = "k_attn_w4<0>" if os.environ.get("WF_ATTN_PRESCALE", "1") == "0" else "k_attn_w4<4>"
             body = "" if kern != "k_attn_w4<4>" else (", max-tracking body" if os.environ.get("WF_ATTN_TRACK_MAX", "0") == "1" else ", un-tracked body (selected by the per-head norm bounds)")
             out["roofline"] = {"kernel": kern + (" (pre-scaled Q" + body + ")" if kern == "k_attn_w4<4>" else "") + " (DiT self-attention, model.py:149-154)",
                                "bound": "mfma", "achieved": ach,

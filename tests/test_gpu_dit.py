@@ -138,7 +138,6 @@ def test_attention(H, Lq, Lk):
     assert _rel(out, 2 * ref) <= 1.5e-2
 
 
-@pytest.mark.skipif(os.environ.get("WF_ATTN_KERNEL") == "w8", reason="the fused two-context kernel is a variant of the one-wave-per-SIMD kernel")
 @pytest.mark.parametrize("H,Lq,n1,n2", [(40, 1000, 257, 512),      # the DiT's shapes: 257 CLIP tokens (5 tiles, 1 valid key in the last), 512 text rows
                                         (2, 300, 40, 64),          # context 1 is a single ragged tile (the prologue masks it)
                                         (3, 77, 128, 500),         # ragged context 2, seam after an even number of tiles
@@ -183,7 +182,6 @@ def test_fused_two_context_cross_attention_is_bit_identical_to_two_launches(H, L
     assert torch.equal(again, one)
 
 
-@pytest.mark.skipif(os.environ.get("WF_ATTN_KERNEL") == "w8", reason="needs the one-wave-per-SIMD kernel")
 def test_dit_forward_with_fused_cross_attention_equals_two_launch_form(monkeypatch):
     """The whole DiT forward (2 layers, ragged text length) is bit-identical with WF_CROSS_FUSED=1 (default) and =0, and the producers write
     the concatenated [image | text] key / value buffers through strided destinations (lout / wf_v_transpose_seg)."""
@@ -201,7 +199,6 @@ def test_dit_forward_with_fused_cross_attention_equals_two_launch_form(monkeypat
     assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
-@pytest.mark.skipif(os.environ.get("WF_ATTN_KERNEL") == "w8", reason="KV splits need the one-wave-per-SIMD kernel (the entry point refuses loudly)")
 @pytest.mark.parametrize("H,Lq,Lk,nsplit,segs", [(2, 300, 1000, 2, 1), (1, 256, 4524, 3, 1), (3, 77, 640, 2, 1), (2, 500, 1024, 2, 4),
                                                   (1, 128, 8192 + 37, 8, 1)])
 def test_attention_kv_splits(H, Lq, Lk, nsplit, segs):

@@ -10,12 +10,8 @@
 //                                    P.V MFMA reads its A operand (d x keys) with plain 16-byte LDS reads, no transpose
 //   O  [Lq][H*128] bf16 (token-major: the A operand of the o-projection GEMM)
 //
-// Two kernels share the layouts and the MFMA formulation below:
-//   k_attn_w4 (default)   one wave per SIMD, 4 waves x 64 query rows, MFMA and softmax hand-placed in ONE instruction stream
-//                         (description at the kernel);
-//   k_attn    (WF_ATTN_KERNEL=w8)  8 waves x 32 query rows, two per SIMD, the first design: two wave groups run
-//                         [M = interleaved QK^T / P.V MFMAs | S = softmax + LDS-DMA issue] one phase apart.
-// Common to both:
+// One kernel, k_attn_w4: one wave per SIMD, 4 waves x 64 query rows, MFMA and softmax hand-placed in ONE instruction stream (description
+// at the kernel).  Its formulation:
 //   * "swapped" QK^T: S^T[key][q] = mfma(A = K tile, B = Q^T), so a lane owns ONE query column and 32 of the 64 scores of
 //     a KV tile: the row max / row sum are in-lane reductions plus one exchange with lane^32 (v_permlane32_swap);
 //   * the K rows are fed to the MFMA with index bits 2 and 3 swapped, which makes the scores a lane holds in registers
@@ -29,8 +25,8 @@
 //     applied to the per-lane SOURCE address because the DMA destination is lane-linear;
 //   * QK^T and P.V MFMAs are interleaved: an MFMA that accumulates into the result of one issued < ~4 issue slots earlier stalls
 //     (QK^T alone, two score accumulators: 850-1050 cycles per 16 MFMAs instead of 512);
-//   * online softmax in fp32 with exp2 and the 1/sqrt(d)*log2(e) scale folded into one FMA; k_attn rescales O whenever a row
-//     maximum of the wave grew, k_attn_w4 defers the rescale until it grew by more than 2^8 (the same m is used for P and for the
+//   * online softmax in fp32 with exp2 and the 1/sqrt(d)*log2(e) scale folded into one FMA; the rescale of O is deferred
+//     until a row maximum grew by more than 2^8 (the same m is used for P and for the
 //     row sum, so the result is exact for any reference m);
 //   * XCD-aware grid: workgroup b runs on XCD b % 8; all query blocks of a head are given to one XCD so its 32 CUs share
 //     that head's K / V^T stream through their L2.
@@ -48,7 +44,6 @@ namespace {
 constexpr int D = 128;
 constexpr int QB = 256;  // query rows per workgroup
 constexpr int KB = 64;   // keys per tile
-constexpr int NT = 512;
 constexpr int K_TILE_BYTES = KB * D * 2;  // 16 KiB
 constexpr int V_TILE_BYTES = D * KB * 2;  // 16 KiB
 
@@ -67,7 +62,7 @@ struct AttnArgs {
   int nsplit, tiles_per_split;
   float* o_part;   // [nsplit][Lq][H*128] f32
   float* ml_part;  // [nsplit][H][Lq][2] f32: reference max m (raw score units), row sum l
-  // block-sparse attention (k_attn<2>): per (head, 256-row query group) a list of 128-key blocks to visit, entry = block * 4 + flags,
+  // block-sparse attention (KIND 3): per (head, 256-row query group) a list of 128-key blocks to visit, entry = block * 4 + flags,
   // flags bit 0 / 1 = the block is selected by the first / second 128-row query block of the group
   const int* bsa_list;  // [H][n_qblk][bsa_max]
   const int* bsa_cnt;   // [H][n_qblk]
@@ -101,384 +96,13 @@ __device__ unsigned long long g_attn_cycles[16];
 
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
-// KIND 0 / 1 only name the launch for profilers: 0 = long K/V (self-attention), 1 = short K/V (<= 1024 keys: the text / image
-// cross-attentions).  Same code; rocprofv3 then reports the two populations separately.
-// KIND 2 = block-sparse attention of the LongCat refine pass (block_sparse_attention/bsa_interface.py:538-560 +
-// flash_attn_bsa_varlen_mask.py:236-285): queries and keys are in 3D-block order, every 128-row query block attends to its own
-// selected 128-key blocks only.  A workgroup holds TWO query blocks (waves 0-3 / 4-7 = the two ping-pong groups); it walks the UNION
-// of their block lists (built on the host side of the C-ABI from the top-k indices), two 64-key tiles per entry, and a wave group
-// sets the scores of a block its query block did not select to -inf (exactly zero probability).  The running max starts at a large
-// finite negative value instead of -inf so that a leading run of masked blocks cannot produce inf - inf.
-template <int KIND>
-__global__ __launch_bounds__(NT, 2) void k_attn(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // LDS: [buf0: K tile | V^T tile][buf1: K tile | V^T tile]
-  constexpr int BUF_BYTES = K_TILE_BYTES + V_TILE_BYTES;
-
-  // ---- XCD-aware (head, q-block) assignment: heads are dealt round-robin to the 8 XCDs -----------------------------
-  const int b = blockIdx.x;
-  const int xcd = b & 7, j = b >> 3;
-  const int hslot = j / a.n_qblk;  // how many heads this XCD has completed
-  const int head = hslot * 8 + xcd;
-  const int qblk = j % a.n_qblk;
-  if (head >= a.H) return;
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int q_row = qblk * QB + wid * 32 + l31;
-  const int q_ld = min(q_row, a.Lq - 1);
-
-  // ---- Q^T B-operand fragments: 8 k-steps x 8 bf16 ---------------------------------------------------------------------
-  bf16x8 qf[8];
-  {
-    const uint16_t* qp = a.Q + ((size_t)head * a.Lq + q_ld) * D;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) qf[s] = as_bf16x8(*reinterpret_cast<const u32x4*>(qp + 16 * s + 8 * hi));
-  }
-
-  // ---- staging: direct global -> LDS copies (no staging VGPRs).  A wave instruction moves 64 x 16 B = 1 KiB to LDS bytes
-  // [base, base + 1 KiB) in lane order; the XOR swizzle of the LDS image is applied to the per-lane SOURCE address.
-  //   K tile  (64 rows x 256 B): 16 pieces of 4 rows;  lane -> (row = 4*piece + lane/16, slot = lane%16) holds chunk slot ^ (row&15)
-  //   V^T tile (128 rows x 128 B): 16 pieces of 8 rows; lane -> (row = 8*piece + lane/8,  slot = lane%8)  holds chunk slot ^ ((row>>1)&7)
-  // 8 waves x 2 pieces each per tile and operand.
-  const int wu = __builtin_amdgcn_readfirstlane(wid);
-  int ksrc[2], vsrc[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int piece = wu * 2 + i;
-    const int kr = 4 * piece + (lane >> 4), ks = lane & 15;
-    ksrc[i] = kr * D + ((ks ^ (kr & 15)) << 3);
-    const int vr = 8 * piece + (lane >> 3), vs = lane & 7;
-    vsrc[i] = vr * KB + ((vs ^ ((vr >> 1) & 7)) << 3);
-  }
-  const int tiles_per_seg = a.seg_len / KB;
-
-  // fragment read offsets
-  int krow_off[2], krow_sw[2];
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    int kr = kb * 32 + swap23(l31);  // K row fed to MFMA row l31 (bits 2,3 swapped)
-    krow_off[kb] = kr * 256;
-    krow_sw[kb] = kr & 15;
-  }
-  int vrow_off[4], vrow_sw[4];
-#pragma unroll
-  for (int db = 0; db < 4; ++db) {
-    int vr = db * 32 + l31;
-    vrow_off[db] = vr * 128;
-    vrow_sw[db] = (vr >> 1) & 7;
-  }
-
-  f32x16 o[4];
-#pragma unroll
-  for (int db = 0; db < 4; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-  float m_run = KIND == 2 ? -1e30f : -INFINITY, l_run = 0.f;
-  const float c = a.scale_log2;
-
-  const int* bsa = nullptr;
-  int ntiles = (a.kv_len + KB - 1) / KB;
-  if constexpr (KIND == 2) {
-    bsa = a.bsa_list + ((size_t)head * a.n_qblk + qblk) * a.bsa_max;
-    ntiles = (a.bsa_shift == 2 ? 2 : 1) * a.bsa_cnt[head * a.n_qblk + qblk];
-    if (ntiles == 0) {
-      // nothing selected by either query block (a cdf-threshold selection may be empty: bsa_interface.py:239-240 with a dominant
-      // block): the reference's kernel then returns acc / l = 0 / 1 (flash_attn_bsa_varlen_mask.py:242-244) -> zeros
-      if (q_row < a.Lq) {
-        uint16_t* op = a.O + (size_t)q_row * a.ldo + head * D;
-        for (int d = hi * 64; d < hi * 64 + 64; d += 8) *reinterpret_cast<u32x4*>(op + d) = u32x4{0u, 0u, 0u, 0u};
-      }
-      return;
-    }
-  }
-  constexpr int PF = 4;  // fragment prefetch depth (LDS reads in flight ahead of the MFMA that consumes them)
-  constexpr int NBUF = 4;
-
-  // LDS: ring of NBUF tile buffers, each [K tile 16 KiB | V^T tile 16 KiB]; tile j lives in buffer j % NBUF.
-  const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_offset(smem));
-  auto stage = [&](int t) {
-    int kt = t;  // KV tile held by ring slot t
-    size_t tile_off;
-    if constexpr (KIND == 2) {  // the list holds PHYSICAL block indices (head and segment already folded in by the host side)
-      if (a.bsa_shift == 2)
-        tile_off = ((size_t)(__builtin_amdgcn_readfirstlane(bsa[t >> 1]) >> 2) * 2 + (t & 1)) * (KB * D);
-      else
-        tile_off = (size_t)(__builtin_amdgcn_readfirstlane(bsa[t]) >> 4) * (KB * D);
-    } else {
-      const int seg = kt / tiles_per_seg;
-      tile_off = ((size_t)(seg * a.H + head) * tiles_per_seg + (kt - seg * tiles_per_seg)) * (KB * D);
-    }
-    const uint32_t base = smem_base + (t % NBUF) * BUF_BYTES + wu * 2048;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      glds16(a.K + tile_off + ksrc[i], smem + (base - smem_base) + i * 1024);
-      glds16(a.Vt + tile_off + vsrc[i], smem + (base - smem_base) + K_TILE_BYTES + i * 1024);
-    }
-  };
-  auto kread = [&](const unsigned char* sKb, int i) {
-    const int kb = i & 1, st = i >> 1;  // alternate the two score accumulators: no back-to-back dependent MFMAs
-    return *reinterpret_cast<const u32x4*>(sKb + krow_off[kb] + (((2 * st + hi) ^ krow_sw[kb]) << 4));
-  };
-  auto vread = [&](const unsigned char* sVb, int i) {
-    const int db = i & 3, m4 = i >> 2;  // rotate over the four output accumulators
-    return *reinterpret_cast<const u32x4*>(sVb + vrow_off[db] + (((2 * m4 + hi) ^ vrow_sw[db]) << 4));
-  };
-  const bool ragged = KIND != 2 && (a.kv_len & (KB - 1)) != 0;
-
-  f32x16 s[2];
-  bf16x8 pf[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) pf[i] = as_bf16x8(u32x4{0u, 0u, 0u, 0u});
-
-  // ---- the three phases of one KV tile (one wave, 32 query rows) ----------------------------------------------------------
-  auto phase_qk = [&](int t) {  // S^T = K Q^T: 16 MFMAs, K fragments PF ahead
-    const unsigned char* sKb = smem + (t % NBUF) * BUF_BYTES;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-    u32x4 ring[PF];
-#pragma unroll
-    for (int i = 0; i < PF; ++i) ring[i] = kread(sKb, i);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const bf16x8 kf = as_bf16x8(ring[i % PF]);
-      if (i + PF < 16) ring[i % PF] = kread(sKb, i + PF);
-      s[i & 1] = mfma32(kf, qf[i >> 1], s[i & 1]);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
-#pragma unroll
-    for (int i = 0; i < 16 - PF; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
-  };
-  auto phase_softmax = [&](int t) {  // online softmax of the 64 scores per query row held by the lane pair (l, l^32)
-    if constexpr (KIND == 2) {
-      const int e = __builtin_amdgcn_readfirstlane(bsa[a.bsa_shift == 2 ? (t >> 1) : t]);
-      const int mine = a.bsa_shift == 2 ? (wu >> 2) : (wu >> 1);  // this wave's query block within the workgroup (128 / 64 rows each)
-      if (!((e >> mine) & 1)) {  // this key block is not in the list of this wave's query block
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) s[kb][r] = -INFINITY;
-      }
-    }
-    if (ragged && t == ntiles - 1) {
-      // lane holds, for query column l31: register r of block kb  <->  key  t*64 + 32*kb + 16*(r>>3) + 8*hi + (r&7)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int key = t * KB + 32 * kb + 16 * (r >> 3) + 8 * hi + (r & 7);
-          if (key >= a.kv_len) s[kb][r] = -INFINITY;
-        }
-    }
-    // four independent max chains (the serial 32-deep chain was latency-bound), then a small tree
-    float mx[4] = {s[0][0], s[0][1], s[1][0], s[1][1]};
-#pragma unroll
-    for (int r = 2; r < 16; r += 2) {
-      mx[0] = fmaxf(mx[0], s[0][r]);
-      mx[1] = fmaxf(mx[1], s[0][r + 1]);
-      mx[2] = fmaxf(mx[2], s[1][r]);
-      mx[3] = fmaxf(mx[3], s[1][r + 1]);
-    }
-    float mloc = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
-    {
-      const unsigned mu = __float_as_uint(mloc);
-      auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);  // {x of lane&31, x of lane|32}: no LDS traffic
-      mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    }
-    const float m_new = fmaxf(m_run, mloc);
-    if (__any(m_new > m_run)) {
-      const float alpha = __builtin_amdgcn_exp2f(c * (m_run - m_new));
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-      l_run *= alpha;
-      m_run = m_new;
-    }
-    const float mc = c * m_run;
-    float ls[4] = {0.f, 0.f, 0.f, 0.f};  // independent partial row sums
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      float p[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        p[r] = __builtin_amdgcn_exp2f(c * s[kb][r] - mc);
-        ls[r & 3] += p[r];
-      }
-#pragma unroll
-      for (int m2 = 0; m2 < 2; ++m2) {
-        u32x4 pk = {pack_bf16x2(p[8 * m2 + 0], p[8 * m2 + 1]), pack_bf16x2(p[8 * m2 + 2], p[8 * m2 + 3]),
-                    pack_bf16x2(p[8 * m2 + 4], p[8 * m2 + 5]), pack_bf16x2(p[8 * m2 + 6], p[8 * m2 + 7])};
-        pf[kb * 2 + m2] = as_bf16x8(pk);
-      }
-    }
-    l_run += (ls[0] + ls[1]) + (ls[2] + ls[3]);
-  };
-  auto phase_pv = [&](int t) {  // O^T += V^T P^T: 16 MFMAs, V^T fragments PF ahead
-    const unsigned char* sVb = smem + (t % NBUF) * BUF_BYTES + K_TILE_BYTES;
-    u32x4 vring[PF];
-#pragma unroll
-    for (int i = 0; i < PF; ++i) vring[i] = vread(sVb, i);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const bf16x8 vf = as_bf16x8(vring[i % PF]);
-      if (i + PF < 16) vring[i % PF] = vread(sVb, i + PF);
-      o[i & 3] = mfma32(vf, pf[i >> 2], o[i & 3]);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x100, PF, 1);
-#pragma unroll
-    for (int i = 0; i < 16 - PF; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, PF, 1);
-  };
-  // M phase: QK^T(tq) and P.V(tp) with their MFMAs interleaved (s0 o0 s1 o1 s0 o2 s1 o3 ...).  A v_mfma_f32_32x32x16_bf16 that
-  // accumulates into the result of an MFMA issued less than ~4 issue slots (~100 cycles) earlier stalls on it; the QK^T stream has
-  // only two accumulators (distance 2 = 64 cycles: measured 850-1050 cycles per 16 MFMAs instead of 512), interleaving the P.V
-  // stream puts 4 slots between MFMAs on the same score accumulator and 8 on the same output accumulator.
-  auto phase_m = [&](int tq, int tp) {
-    const unsigned char* sKb = smem + (tq % NBUF) * BUF_BYTES;
-    const unsigned char* sVb = smem + (tp % NBUF) * BUF_BYTES + K_TILE_BYTES;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-    constexpr int PFM = 2;
-    u32x4 kring[PFM], vring[PFM];
-#pragma unroll
-    for (int i = 0; i < PFM; ++i) {
-      kring[i] = kread(sKb, i);
-      vring[i] = vread(sVb, i);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const bf16x8 kf = as_bf16x8(kring[i % PFM]);
-      if (i + PFM < 16) kring[i % PFM] = kread(sKb, i + PFM);
-      s[i & 1] = mfma32(kf, qf[i >> 1], s[i & 1]);
-      const bf16x8 vf = as_bf16x8(vring[i % PFM]);
-      if (i + PFM < 16) vring[i % PFM] = vread(sVb, i + PFM);
-      o[i & 3] = mfma32(vf, pf[i >> 2], o[i & 3]);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 * PFM, 2);
-#pragma unroll
-    for (int i = 0; i < 16 - PFM; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 2 * PFM, 2);
-  };
-  // workgroup barrier WITHOUT the implicit vmcnt(0) drain of __syncthreads(): LDS-DMA stays in flight across it;
-  // LDS reads of this wave are complete (their results were consumed by MFMAs), so only lgkmcnt needs draining
-  auto bar = [&]() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  };
-
-  auto drain_dma = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-
-  // ---- ping-pong schedule -------------------------------------------------------------------------------------------------
-  // The 8 waves form two groups (waves 0-3 / 4-7: one wave of each group per SIMD).  Both run [QK^T | softmax | P.V] per tile,
-  // separated by workgroup barriers, but group B runs ONE PHASE behind group A.  On every SIMD the VALU-only softmax of one
-  // wave then always coincides with an MFMA phase of the other wave (A softmax || B QK^T,  A P.V || B softmax); only
-  // A's QK^T(t+1) and B's P.V(t) share the matrix pipe.  Barrier k is reached by every wave; all waves issue the LDS-DMA of
-  // tile t+1 right after barrier 3t and drain it before barrier 3t+2, whichever phase they are in (ring of 3 buffers:
-  // the buffer of tile t+1 was last read two tiles ago by either group).
-  const bool groupB = __builtin_amdgcn_readfirstlane(wid) >= 4;
-  if (a.prio_mode == 1 && groupB) __builtin_amdgcn_s_setprio(1);
-  if (a.prio_mode == 2 && !groupB) __builtin_amdgcn_s_setprio(1);
-  stage(0);
-  if (ntiles > 1) stage(1);
-  drain_dma();
-  bar();
-#ifdef WF_ATTN_TIMING
-  unsigned long long tim[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tim_last = __builtin_readcyclecounter();
-  const bool tim_on = lane == 0 && (wid == 0 || wid == 4);
-#endif
-  // Two phases per tile and wave: M(t) = [QK^T(t) then P.V(t-1)] (32 MFMAs + their LDS fragment reads, nothing else) and
-  // S(t) = [online softmax(t) + this wave's LDS-DMA pieces of tile t+2] (VALU / VMEM only).  Group B runs one phase behind
-  // group A, so on every SIMD one wave is always in M and the other in S: the matrix pipe is never shared and never idle by
-  // construction, and the LDS-DMA is issued from the phase where it is cheap (2-4x dearer beside MFMAs + ds_reads).
-  // Ring of 4 tile buffers: the buffer of tile t+2 last held tile t-2, whose V^T was last read in M(t-1) by both groups.
-  if (!groupB) {
-    phase_m(0, 0);  // P is still zero: the P.V half adds exact zeros
-    TMARK(0);
-    bar();
-    TMARK(1);
-    for (int t = 0; t < ntiles; ++t) {
-      if (t + 2 < ntiles) stage(t + 2);
-      phase_softmax(t);
-      TMARK(2);
-      bar();
-      TMARK(3);
-      phase_m(t + 1 < ntiles ? t + 1 : t, t);  // last tile: the QK^T half recomputes scores nobody reads
-      drain_dma();
-      TMARK(0);
-      bar();
-      TMARK(1);
-    }
-    bar();  // matches group B's last phase
-  } else {
-    bar();
-    TMARK(7);
-    phase_m(0, 0);  // P is still zero: the P.V half adds exact zeros
-    TMARK(0);
-    bar();
-    TMARK(1);
-    for (int t = 0; t < ntiles; ++t) {
-      if (t + 2 < ntiles) stage(t + 2);
-      phase_softmax(t);
-      TMARK(2);
-      bar();
-      TMARK(3);
-      phase_m(t + 1 < ntiles ? t + 1 : t, t);  // last tile: the QK^T half recomputes scores nobody reads
-      drain_dma();
-      TMARK(0);
-      bar();
-      TMARK(1);
-    }
-  }
-#ifdef WF_ATTN_TIMING
-  if (tim_on) {
-    tim[6] = ntiles;
-    for (int i = 0; i < 7; ++i) atomicAdd(&g_attn_cycles[(groupB ? 8 : 0) + i], tim[i]);
-  }
-#endif
-
-  // ---- finish: combine the two half-wave partial sums, normalise, store ------------------------------------------------
-  l_run += __shfl_xor(l_run, 32, 64);
-  float inv = 1.0f / l_run;
-  if constexpr (KIND == 2) inv = l_run > 0.f ? inv : 0.f;  // a query block with an empty selection: zeros, as the reference (see above)
-  if (q_row < a.Lq) {
-    uint16_t* op = a.O + (size_t)q_row * a.ldo + head * D;
-#pragma unroll
-    for (int db = 0; db < 4; ++db) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = db * 32 + 8 * g + 4 * hi;
-        float v0 = o[db][4 * g + 0] * inv, v1 = o[db][4 * g + 1] * inv, v2 = o[db][4 * g + 2] * inv,
-              v3 = o[db][4 * g + 3] * inv;
-        if (a.accumulate) {
-          u32x2 old = *reinterpret_cast<const u32x2*>(op + d);
-          v0 += __uint_as_float(old[0] << 16);
-          v1 += __uint_as_float(old[0] & 0xffff0000u);
-          v2 += __uint_as_float(old[1] << 16);
-          v3 += __uint_as_float(old[1] & 0xffff0000u);
-        }
-        u32x2 pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
-        *reinterpret_cast<u32x2*>(op + d) = pk;
-      }
-    }
-  }
-}
+// KIND (k_attn_w4): 0 / 1 only name the launch for profilers (0 = long K/V: self-attention in its in-kernel-scale form, 1 = short K/V
+// <= 1024 keys: stand-alone cross-attention launches); 3 = block-sparse attention of the LongCat refine pass
+// (block_sparse_attention/bsa_interface.py:538-560 + flash_attn_bsa_varlen_mask.py:236-285: queries and keys in 3D-block order, a workgroup
+// walks the UNION of its query blocks' selected key-block lists and masks the blocks a query block did not select with -inf; the running
+// max starts finite so that a leading run of masked blocks cannot give inf - inf); 4 = pre-scaled Q (the DiT self-attention); 5 = the
+// fused two-context cross-attention.  (The first design, an 8-wave two-per-SIMD ping-pong kernel `k_attn`, was kept behind
+// WF_ATTN_KERNEL=w8 through round 2 and removed in round 3: 1100-1160 TFLOP/s against this kernel's 1260-1430)
 
 // ======================================================================================================================================
 // k_attn_w4: one wave per SIMD (4 waves = 256 query rows per workgroup, 64 rows = two 32-row q-blocks a / b per wave, the whole
@@ -568,7 +192,7 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
   f32x16 o[2][4];
   f32x16 sb[2][2][2];  // [buffer][q-block][key block]
   bf16x8 pf[2][4];
-  // KIND 3 (block-sparse, see k_attn<2>): the running max starts finite so that leading masked blocks cannot give inf - inf
+  // KIND 3 (block-sparse): the running max starts finite so that leading masked blocks cannot give inf - inf
   float m_run[2] = {KIND == 3 ? -1e30f : -INFINITY, KIND == 3 ? -1e30f : -INFINITY}, l_run[2] = {0.f, 0.f}, mcq[2] = {0.f, 0.f};
   // KIND 4 ("prescaled"): Q arrives multiplied by softmax_scale * log2(e) (wf_rmsnorm_heads out_scale: applied before the producer's
   // single bf16 rounding, so it costs no precision), i.e. the MFMA result is already in the exp2 domain, and the score accumulators are
@@ -1286,15 +910,8 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
   a.n1 = 0;
   const int hslots = (H + 7) / 8;
   const int grid = hslots * a.n_qblk * 8;
-  const size_t lds = 4 * (K_TILE_BYTES + V_TILE_BYTES);
   const size_t lds_w4 = 5 * (K_TILE_BYTES + V_TILE_BYTES);  // ring of 5 (160 KiB: the whole LDS of a CU)
-  // k_attn_w4 (one wave per SIMD) is the default; WF_ATTN_KERNEL=w8 selects the two-waves-per-SIMD ping-pong kernel k_attn
-  static const int use_w4 = [] {
-    const char* e = getenv("WF_ATTN_KERNEL");
-    return e && e[0] == 'w' && e[1] == '8' ? 0 : 1;
-  }();
   if (nsplit > 1) {
-    WF_CHECK_ARG(use_w4, "%s: KV splits need the k_attn_w4 kernel", who);
     WF_CHECK_ARG(workspace && (((uintptr_t)workspace) & 15) == 0, "%s: nsplit > 1 needs a 16-byte aligned workspace", who);
     int tps = ceil_div(ntiles, nsplit);
     const int ns = ceil_div(ntiles, tps);  // splits that actually get tiles
@@ -1303,22 +920,16 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
     a.o_part = (float*)workspace;
     a.ml_part = a.o_part + (size_t)ns * Lq * H * D;
   }
-  WF_CHECK_ARG(!prescaled || use_w4, "%s: softmax_scale = 0 (pre-scaled Q) needs the k_attn_w4 kernel", who);
-  if (use_w4) {
-    if (prescaled)
-      hipLaunchKernelGGL(k_attn_w4<4>, dim3(grid, a.nsplit), dim3(NT4), lds_w4, (hipStream_t)stream, a);
-    else if (Lkp > 1024)
-      hipLaunchKernelGGL(k_attn_w4<0>, dim3(grid, a.nsplit), dim3(NT4), lds_w4, (hipStream_t)stream, a);
-    else
-      hipLaunchKernelGGL(k_attn_w4<1>, dim3(grid, a.nsplit), dim3(NT4), lds_w4, (hipStream_t)stream, a);
-    if (a.nsplit > 1) {
-      const size_t n = (size_t)Lq * H * (D / 4);
-      hipLaunchKernelGGL(k_attn_merge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
-    }
-  } else if (Lkp > 1024)
-    hipLaunchKernelGGL(k_attn<0>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, a);
+  if (prescaled)
+    hipLaunchKernelGGL(k_attn_w4<4>, dim3(grid, a.nsplit), dim3(NT4), lds_w4, (hipStream_t)stream, a);
+  else if (Lkp > 1024)
+    hipLaunchKernelGGL(k_attn_w4<0>, dim3(grid, a.nsplit), dim3(NT4), lds_w4, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL(k_attn<1>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_attn_w4<1>, dim3(grid, a.nsplit), dim3(NT4), lds_w4, (hipStream_t)stream, a);
+  if (a.nsplit > 1) {
+    const size_t n = (size_t)Lq * H * (D / 4);
+    hipLaunchKernelGGL(k_attn_merge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  }
   WF_LAUNCH_CHECK(who);
   return WF_OK;
 }
@@ -1430,15 +1041,7 @@ extern "C" int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, voi
   a.kv_len1 = 0;
   a.n1 = 0;
   const int grid = ((H + 7) / 8) * a.n_qblk * 8;
-  // default: the one-wave-per-SIMD kernel (k_attn_w4<3>); WF_ATTN_KERNEL=w8 selects the two-waves-per-SIMD form (k_attn<2>)
-  static const int use_w4 = [] {
-    const char* e = getenv("WF_ATTN_KERNEL");
-    return e && e[0] == 'w' && e[1] == '8' ? 0 : 1;
-  }();
-  if (use_w4)
-    hipLaunchKernelGGL(k_attn_w4<3>, dim3(grid, 1), dim3(NT4), 5 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(k_attn<2>, dim3(grid), dim3(NT), 4 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_attn_w4<3>, dim3(grid, 1), dim3(NT4), 5 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream, a);
   WF_LAUNCH_CHECK("wf_attn_bsa_fwd");
   return WF_OK;
 }

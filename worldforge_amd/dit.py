@@ -75,7 +75,7 @@ def kv_splits(H: int, Lq: int, kv_len: int, n_cu: int = 256) -> int:
     """KV splits for the attention launch: the kernel runs one 256-row workgroup per CU, so a launch of W = ceil(Lq/256) * H workgroups
     takes ceil(W / n_cu) rounds; when Lq is short (one rank's token shard of the sequence-parallel DiT: W = 640 at 8 ranks = 2.5
     rounds) splitting the KV sweep in two fills the last round.  A function of the shapes only (never of timing)."""
-    if os.environ.get("WF_ATTN_KERNEL", "") == "w8" or kv_len < 128 * 64:
+    if kv_len < 128 * 64:
         return 1
     w = -(-Lq // 256) * H
     eff = lambda n: (w * n / n_cu) / -(-(w * n) // n_cu)
@@ -514,8 +514,8 @@ class WanTransformer3DModel:
         scale = 1.0 / math.sqrt(128.0)
         # self-attention: softmax_scale * log2(e) is folded into Q by its producer (in front of the one bf16 rounding) and the attention
         # kernel is told so with softmax_scale = 0 (k_attn_w4<4>: score accumulators start from -m); WF_ATTN_PRESCALE=0 keeps the scale
-        # inside the kernel (A/B), as does the two-wave kernel
-        prescale = os.environ.get("WF_ATTN_PRESCALE", "1") != "0" and os.environ.get("WF_ATTN_KERNEL", "") != "w8"
+        # inside the kernel (A/B)
+        prescale = os.environ.get("WF_ATTN_PRESCALE", "1") != "0"
         q_scale, sa_scale = (scale * 1.4426950408889634, 0.0) if prescale else (1.0, scale)
         cos, sin = self._rope_tables(f, h2, w2)
         e, e0, ctx_t, ctx_i = self._embed_condition(t_value, text, img, tag)
@@ -561,7 +561,7 @@ class WanTransformer3DModel:
         Lt, Li = cfg.text_len, _pad64(n_img)
         # the two cross-attentions of a layer (image context, then text context, summed: model.py:220-227) as ONE launch over a concatenated
         # key / value buffer [image tiles | text tiles] (wf_attn_cross2_fwd; bit-identical to the two launches, WF_CROSS_FUSED=0 keeps those)
-        fused = os.environ.get("WF_CROSS_FUSED", "1") != "0" and os.environ.get("WF_ATTN_KERNEL", "") != "w8"
+        fused = os.environ.get("WF_CROSS_FUSED", "1") != "0"
         Lc = Li + Lt
         kvt = _buf("kvt", (cfg.text_len, 2 * d), bf)
         kvi = _buf("kvi", (n_img, 2 * d), bf)

@@ -374,7 +374,7 @@ class LongCatVideoTransformer3DModel:
         # dense self-attention (no block gating on Q): as in the Wan DiT (dit.py), softmax_scale * log2(e) is folded into Q by its producer and
         # the kernel runs its exp2-domain form (softmax_scale = 0), without max tracking where the per-head norm bound allows it.  The
         # block-sparse pass keeps the in-kernel scale: its Q also feeds the gating.  WF_ATTN_PRESCALE=0 / WF_ATTN_TRACK_MAX=1 as in dit.py.
-        prescale = (not use_bsa) and os.environ.get("WF_ATTN_PRESCALE", "1") != "0" and os.environ.get("WF_ATTN_KERNEL", "") != "w8"
+        prescale = (not use_bsa) and os.environ.get("WF_ATTN_PRESCALE", "1") != "0"
         q_scale, sa_scale = (scale * 1.4426950408889634, 0.0) if prescale else (1.0, scale)
         km = _buf("kmax2", (H,), f32) if prescale and os.environ.get("WF_ATTN_TRACK_MAX", "0") != "1" else None
         qm_c = _buf("qmax2_c", (H,), f32) if km is not None else None
