@@ -318,6 +318,7 @@ def main_longcat(a):
         emit_json(out)
     if comm is not None:
         comm.barrier()
+        shutdown_comm()
 
 
 def launch_ranks(n: int, argv, script: str = None) -> int:
@@ -407,6 +408,13 @@ def emit_json(out: dict):
         sys.stdout.flush()
     else:
         os.write(_JSON_FD, data)
+
+
+def shutdown_comm():
+    """Tear the process group down before exit (RCCL otherwise warns about leaked resources; LoopbackComm has none)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def rank_env(a):
@@ -636,6 +644,7 @@ def main(argv=None):
         emit_json(out)
     if comm is not None:
         comm.barrier()
+        shutdown_comm()
 
 
 if __name__ == "__main__":

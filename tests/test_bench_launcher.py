@@ -91,3 +91,31 @@ def test_stdout_carries_only_the_json_line():
     assert r.stdout == '{"metric": "x", "value": 1.5}\n'
     for noise in ("python chatter", "C stdio banner", "child chatter"):
         assert noise in r.stderr
+
+
+def test_comm_probe_parses_rccl_logs_and_gpu_count_needs_no_hip(tmp_path, monkeypatch):
+    """tools/comm_probe.py: the RCCL log summary (channels / AllGather tuning lines), and bench.visible_gpu_count(), which the launchers use
+    instead of torch.cuda.device_count() so that the parent never initialises HIP."""
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    probe = importlib.import_module("comm_probe")
+    log = tmp_path / "rccl.log"
+    log.write_text("host:1:1 [0] NCCL INFO RCCL version 2.26.6-HEAD:64f48b6\n"
+                   "host:1:1 [0] NCCL INFO Channel 00/32 :    0   1   2   3   4   5   6   7\n"
+                   "host:1:1 [0] NCCL INFO Channel 31/32 :    0   7   6   5   4   3   2   1\n"
+                   "host:1:1 [0] NCCL INFO AllGather: 83886080 Bytes -> Algo 1 proto 2 time 612.5\n"
+                   "host:1:1 [0] NCCL INFO AllGather: 83886080 Bytes -> Algo 1 proto 2 time 612.5\n")
+    r = probe.rccl_log_summary(str(log))
+    assert r["channels"] == 32 and r["version"].startswith("RCCL version 2.26") and len(r["tuning"]) == 1 and "Algo 1" in r["tuning"][0]
+    assert probe.rccl_log_summary(str(tmp_path / "missing.log"))["channels"] is None
+    import bench
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2,5")
+    assert bench.visible_gpu_count() == 4
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    for v in ("ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    n = bench.visible_gpu_count()          # from /sys/class/kfd (None where that is unreadable, 0 in a GPU-less container)
+    assert n is None or n >= 0
