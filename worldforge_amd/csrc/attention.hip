@@ -80,18 +80,15 @@ struct AttnArgs {
   unsigned int* dbg_body;
 };
 
+#ifndef WF_ATTN_DMA_PLACE
+#define WF_ATTN_DMA_PLACE 0  // lab only (tools/attn_lab.py): 9 = no LDS-DMA pieces in the tile loop (wrong results; what the pieces cost)
+#endif
+#ifndef WF_ATTN_ABLATE
+#define WF_ATTN_ABLATE 0  // lab only (wrong results): 1 no softmax VALU, 2 no drain / barrier, 4 no LDS fragment reads in the loop
+#endif
 #ifdef WF_ATTN_TIMING
 // Per-phase cycle accounting (debug builds only: python -m worldforge_amd.build with WF_EXTRA_HIPCC_FLAGS=-DWF_ATTN_TIMING).
-// Slots: group*8 + {0 qk, 1 wait after qk, 2 softmax, 3 wait after softmax, 4 pv, 5 wait after pv, 6 tiles}.
-__device__ unsigned long long g_attn_cycles[16];
-#define TMARK(slot)                                                      \
-  do {                                                                   \
-    const unsigned long long now__ = __builtin_readcyclecounter();       \
-    if (tim_on) tim[slot] += now__ - tim_last;                           \
-    tim_last = now__;                                                    \
-  } while (0)
-#else
-#define TMARK(slot) do { } while (0)
+__device__ unsigned long long g_attn_cycles[32];  // k_attn_w4: B*8 + (gap >> 3) for the 8-gap groups of even (B=0) / odd tiles, 16 commit, 17 drain, 18 barrier, 19 tiles
 #endif
 
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
@@ -283,6 +280,15 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
     else
       glds16_saddr(vb_, vbyte[i - 4], smem_base + st_base + K_TILE_BYTES + (i - 4) * 1024);
   };
+  auto stage_piece_c = [&](auto IC) {  // the same for a compile-time piece number (main loop): M0 = slot base + immediate in one s_add_u32
+    constexpr int i = decltype(IC)::value;
+    const unsigned char* kb_ = reinterpret_cast<const unsigned char*>(a.K) + st_off;
+    const unsigned char* vb_ = reinterpret_cast<const unsigned char*>(a.Vt) + st_off;
+    if constexpr (i < 4)
+      glds16_saddr_imm<i * 1024>(kb_, kbyte[i], smem_base + st_base);
+    else
+      glds16_saddr_imm<K_TILE_BYTES + (i - 4) * 1024>(vb_, vbyte[i - 4], smem_base + st_base);
+  };
   auto kread = [&](const unsigned char* sKb, int i) {
     const int kb = i & 1, st = i >> 1;
     return *reinterpret_cast<const u32x4*>(sKb + krow_off[kb] + (((2 * st + hi) ^ krow_sw[kb]) << 4));
@@ -427,8 +433,8 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
   //   LDS-DMA: the 8 pieces of tile t+3 in gaps 2, 6, ..., 30;  fragment rings are refilled across the phase / tile seams.
   constexpr int PF4 = 4;
   u32x4 ring[PF4];
-#ifdef WF_ATTN_TIMING
-  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+#if defined(WF_ATTN_TIMING) && WF_ATTN_TIMING != 2
+  unsigned long long tacc[20] = {};
 #define W4MARK(k) do { const unsigned long long n__ = __builtin_readcyclecounter(); tacc[k] += n__ - tlast; tlast = n__; } while (0)
 #else
 #define W4MARK(k) do { } while (0)
@@ -447,7 +453,7 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
     uint32_t pk[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
     float mx[2][4];
     float mn[2] = {0.f, 0.f};
-#ifdef WF_ATTN_TIMING
+#if defined(WF_ATTN_TIMING) && WF_ATTN_TIMING != 2
     unsigned long long tlast = __builtin_readcyclecounter();
 #endif
     __builtin_amdgcn_sched_barrier(0);
@@ -468,7 +474,7 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
         constexpr int i = g >> 1;  // K fragment i: key block i & 1, k-step i >> 1
         mfma_s(sb_[1 - B][q][i & 1], ring_[i % PF4], qf[q][i >> 1], i < 2, PS ? &minit[q] : nullptr);
         __builtin_amdgcn_sched_barrier(0);  // the gap's VALU must not be hoisted above its MFMA
-        if constexpr (q == 1) {  // fragment i consumed by both q-blocks: refill its slot
+        if constexpr (q == 1 && !(WF_ATTN_ABLATE & 4)) {  // fragment i consumed by both q-blocks: refill its slot
           if constexpr (i + PF4 < 16)
             ring_[i % PF4] = kread(sK1, i + PF4);
           else
@@ -478,7 +484,7 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
         constexpr int i = (g - 32) >> 1;  // V^T fragment i: output block i & 3, key step i >> 2
         mfma_o(o_[q][i & 3], ring_[i % PF4], pf_[q][i >> 2]);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (q == 1) {
+        if constexpr (q == 1 && !(WF_ATTN_ABLATE & 4)) {
           if constexpr (i + PF4 < 16)
             ring_[i % PF4] = vread(sV0, i + PF4);
           else if constexpr (B == 0)  // an odd tile's successor was staged after the last barrier: its ring is filled behind the next one
@@ -492,7 +498,7 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
         (void)&sb_, (void)&pf_, (void)&tq__, (void)&pq_, (void)&ls_, (void)&pk_, (void)&mcq_;
         constexpr int k = decltype(KC)::value;
         constexpr int f = k >> 4, x = (k >> 3) & 1, e = 8 * f + (k & 7);
-        if constexpr (!PS && (50 * k) / 64 == g) {  // stage A (KIND 4: the score register already holds s - m)
+        if constexpr (!(WF_ATTN_ABLATE & 1) && !PS && (50 * k) / 64 == g) {  // stage A (KIND 4: the score register already holds s - m)
           tq__[k] = c * sb_[B][x][e >> 4][e & 15] - mcq_[x];
           asm volatile("" : "+v"(tq__[k]));
         }
@@ -500,9 +506,8 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
       for_const<64>([&](auto KC) {
         (void)&sb_, (void)&pf_, (void)&tq__, (void)&pq_, (void)&ls_, (void)&pk_, (void)&mcq_;
         constexpr int k = decltype(KC)::value;
-        constexpr int ga = (50 * k) / 64;
         constexpr int f = k >> 4, x = (k >> 3) & 1, e = 8 * f + (k & 7);
-        if constexpr (ga + 2 == g) {  // stage C
+        if constexpr (!(WF_ATTN_ABLATE & 1) && (50 * k) / 64 + 2 == g) {  // stage C
           if constexpr (e < 4) {
             ls_[x][e & 3] = pq_[k];  // first element of each partial row sum
           } else {
@@ -522,7 +527,7 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
       for_const<64>([&](auto KC) {
         (void)&sb_, (void)&pf_, (void)&tq__, (void)&pq_, (void)&ls_, (void)&pk_, (void)&mcq_;
         constexpr int k = decltype(KC)::value;
-        if constexpr ((50 * k) / 64 + 1 == g) {  // stage B
+        if constexpr (!(WF_ATTN_ABLATE & 1) && (50 * k) / 64 + 1 == g) {  // stage B
           if constexpr (PS) {
             constexpr int f = k >> 4, x = (k >> 3) & 1, e = 8 * f + (k & 7);
             pq_[k] = __builtin_amdgcn_exp2f(sb_[B][x][e >> 4][e & 15]);
@@ -563,14 +568,14 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
           asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(mn[x]) : "v"(__uint_as_float(sw[0])), "v"(__uint_as_float(sw[1])), "v"(m_run[x]));
         }
       }
-      if constexpr (g == 54 || g == 56) {  // the row sums of this tile are complete (last pack at gap 51)
+      if constexpr (!(WF_ATTN_ABLATE & 1) && (g == 54 || g == 56)) {  // the row sums of this tile are complete (last pack at gap 51)
         constexpr int x = (g - 54) >> 1;
-        l_run[x] += (ls_[x][0] + ls_[x][1]) + (ls_[x][2] + ls_[x][3]);
+        // one v_add_f32 each: left to itself the compiler SLP-packs the fold into v_pk_add_f32 (+ an s_nop), dearer beside MFMAs
+        l_run[x] = add_rn(l_run[x], add_rn(add_rn(ls_[x][0], ls_[x][1]), add_rn(ls_[x][2], ls_[x][3])));
         asm volatile("" : "+v"(l_run[x]));
       }
 #ifdef WF_ATTN_TIMING
-      if constexpr (g == 31) W4MARK(0);
-      if constexpr (g == 63) W4MARK(1);
+      if constexpr ((g & 7) == 7) W4MARK(B * 8 + (g >> 3));
 #endif
       if constexpr (g == 0) {
         stage_next();  // tile t + 3 (or trash): scalar bookkeeping, in the shadow of the first MFMA
@@ -579,7 +584,10 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
           e_mask = __builtin_amdgcn_readfirstlane(bsa[tpe == 2 ? (tn >> 1) : tn]);
         }
       }
-      if constexpr (g >= 2 && g < 32 && (g & 3) == 2) stage_piece((g - 2) >> 2);
+#if WF_ATTN_DMA_PLACE == 0
+      if constexpr (g >= 2 && g < 32 && (g & 3) == 2) stage_piece_c(std::integral_constant<int, ((g - 2) >> 2)>{});
+#elif WF_ATTN_DMA_PLACE == 9  // ablation (results wrong): no pieces in the loop
+#endif
       if constexpr (g == 51) {
         // the new scores were written by asm MFMAs (last one at gap 31): XDL write -> VALU read hazard is long covered; the ragged
         // mask of the last tile must be in place before its row max
@@ -603,18 +611,18 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
       commit(std::integral_constant<int, 0>{}, mn[0]);
       commit(std::integral_constant<int, 1>{}, mn[1]);
     }
-    W4MARK(2);
+    W4MARK(16);
     // One barrier per TWO tiles (after the odd ones).  WAR: the pieces of tile t+3 overwrite the slot of tile t-2, whose last reader
     // ran before the barrier that ended tile t-1 or t-2.  RAW: tile T is staged during tile T-3 and first read for the ring of tile
     // T-1, i.e. at the tail of tile T-2 -- behind the barrier of tile T-3 when that is odd; when T-3 is even, tile T-2 is odd and
     // fills the ring after its own barrier instead (every wave drains its own pieces in front of each barrier).
     if constexpr (B == 1) {
-      drain_dma();
-      W4MARK(3);
-      bar();
-      W4MARK(4);
+      if constexpr (!(WF_ATTN_ABLATE & 2)) drain_dma();
+      W4MARK(17);
+      if constexpr (!(WF_ATTN_ABLATE & 2)) bar();
+      W4MARK(18);
 #pragma unroll
-      for (int i = 0; i < PF4; ++i) ring[i] = kread(sK2, i);  // K(t+2) was staged during tile t-1: readable only now
+      for (int i = 0; i < ((WF_ATTN_ABLATE & 4) ? 0 : PF4); ++i) ring[i] = kread(sK2, i);  // K(t+2) was staged during tile t-1: readable only now
     }
   };
   // KIND 5: the seam between the two contexts, run after the last tile of context 1 (its P.V is complete; the scores of context 2's first
@@ -705,6 +713,9 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
 #pragma unroll
     for (int i = 0; i < PF4; ++i) ring[i] = kread(sK1, i);
   }
+#if defined(WF_ATTN_TIMING) && WF_ATTN_TIMING == 2  // light mode: two s_memtime per workgroup, [20] = cycles of the whole tile loop, [19] = tiles
+  const unsigned long long t_loop0 = __builtin_readcyclecounter();
+#endif
   {
     int slot = 0;
     for (int t = 0; t < ntiles; t += 2) {
@@ -722,10 +733,18 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
       slot = slot + 1 == NBUF ? 0 : slot + 1;
     }
   }
-#ifdef WF_ATTN_TIMING
+#if defined(WF_ATTN_TIMING) && WF_ATTN_TIMING == 2
+  {
+    const unsigned long long t_loop1 = __builtin_readcyclecounter();
+    if (lane == 0 && wid == 0) {
+      atomicAdd(&g_attn_cycles[20], t_loop1 - t_loop0);
+      atomicAdd(&g_attn_cycles[19], (unsigned long long)ntiles);
+    }
+  }
+#elif defined(WF_ATTN_TIMING)
   if (lane == 0 && wid == 0) {
-    for (int i = 0; i < 5; ++i) atomicAdd(&g_attn_cycles[i], tacc[i]);
-    atomicAdd(&g_attn_cycles[6], (unsigned long long)ntiles);
+    for (int i = 0; i < 19; ++i) atomicAdd(&g_attn_cycles[i], tacc[i]);
+    atomicAdd(&g_attn_cycles[19], (unsigned long long)ntiles);
   }
 #endif
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
@@ -922,10 +941,15 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
   }
   if (prescaled)
     hipLaunchKernelGGL(k_attn_w4<4>, dim3(grid, a.nsplit), dim3(NT4), lds_w4, (hipStream_t)stream, a);
+#ifdef WF_ATTN_LAB  // lab builds (tools/attn_lab.py) instantiate the timed kernel only: 5x shorter compile
+  else
+    WF_CHECK_ARG(false, "%s: lab build, pre-scaled self-attention only", who);
+#else
   else if (Lkp > 1024)
     hipLaunchKernelGGL(k_attn_w4<0>, dim3(grid, a.nsplit), dim3(NT4), lds_w4, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(k_attn_w4<1>, dim3(grid, a.nsplit), dim3(NT4), lds_w4, (hipStream_t)stream, a);
+#endif
   if (a.nsplit > 1) {
     const size_t n = (size_t)Lq * H * (D / 4);
     hipLaunchKernelGGL(k_attn_merge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
@@ -1041,7 +1065,11 @@ extern "C" int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, voi
   a.kv_len1 = 0;
   a.n1 = 0;
   const int grid = ((H + 7) / 8) * a.n_qblk * 8;
+#ifdef WF_ATTN_LAB
+  WF_CHECK_ARG(false, "%s: lab build, pre-scaled self-attention only", "wf_attn_bsa_fwd");
+#else
   hipLaunchKernelGGL(k_attn_w4<3>, dim3(grid, 1), dim3(NT4), 5 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream, a);
+#endif
   WF_LAUNCH_CHECK("wf_attn_bsa_fwd");
   return WF_OK;
 }
@@ -1086,7 +1114,11 @@ extern "C" int wf_attn_cross2_fwd(const void* Q, const void* K, const void* Vt, 
   a.kv_len1 = kv_len1;
   a.n1 = Lk1p / KB;
   const int grid = ((H + 7) / 8) * a.n_qblk * 8;
+#ifdef WF_ATTN_LAB
+  WF_CHECK_ARG(false, "%s: lab build, pre-scaled self-attention only", "wf_attn_cross2_fwd");
+#else
   hipLaunchKernelGGL(k_attn_w4<5>, dim3(grid, 1), dim3(NT4), 5 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream, a);
+#endif
   WF_LAUNCH_CHECK("wf_attn_cross2_fwd");
   return WF_OK;
 }
@@ -1110,10 +1142,10 @@ extern "C" int wf_attn_fwd_split(const void* Q, const void* K, const void* Vt, v
 }
 
 #ifdef WF_ATTN_TIMING
-extern "C" int wf_debug_attn_cycles(unsigned long long* out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_attn_cycles), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+extern "C" int wf_debug_attn_cycles(unsigned long long* out32, int reset) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_attn_cycles), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[16] = {};
+    unsigned long long z[32] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_cycles), z, sizeof(z)) != hipSuccess) return -1;
   }
   return 0;

@@ -93,6 +93,17 @@ __device__ __forceinline__ void glds16_saddr(const void* base_uniform, uint32_t 
       : "v"(voff_bytes), "s"(base_uniform), "s"(lds_wave_base_byte)
       : "memory", "m0");
 }
+// the same with the piece's LDS offset as an immediate: M0 = uniform ring-slot base + IMM in ONE scalar instruction
+template <int IMM>
+__device__ __forceinline__ void glds16_saddr_imm(const void* base_uniform, uint32_t voff_bytes, uint32_t lds_slot_base_byte) {
+  asm volatile(
+      "s_add_u32 m0, %2, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(voff_bytes), "s"(base_uniform), "s"(lds_slot_base_byte), "n"(IMM)
+      : "memory", "m0", "scc");
+}
 __device__ __forceinline__ uint32_t lds_offset(const void* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
