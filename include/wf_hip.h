@@ -154,7 +154,8 @@ int wf_gemm_bf16_batched(const void* X, const void* W, void* out, int batch, int
 
 /* flash_attention (attention.py:24-130) as used by model.py:149-154 (self) and :220-222 (cross): fused
  * softmax(Q K^T * softmax_scale) V, no mask, head_dim 128.  Q [H][Lq][128], K [H][Lkp][128] (rows >= kv_len zero),
- * Vt [H][Lkp/64][128][64] (wf_v_transpose), O [Lq][ldo] bf16 with head h at columns h*128.  accumulate != 0: O += result.
+ * Vt [H][Lkp/64][128][64] (wf_v_transpose), O [Lq][ldo] bf16 with head h at columns h*128 (ldo % 8 == 0, O 16-byte aligned: 16-byte stores).
+ * accumulate != 0: O += result.
  * seg_len: Lkp for one contiguous K/V; with sequence parallelism K/V are the all-gathered per-rank shards [P][H][seg_len][128]
  * (seg_len % 64 == 0, Lkp = P*seg_len) and key index = seg*seg_len + row.
  * softmax_scale = 0: Q already carries softmax_scale * log2(e) (wf_rmsnorm_heads out_scale) -- the score accumulators then start

@@ -776,17 +776,24 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
       }
       continue;
     }
-    if (q_row[x] < a.Lq) {
-      uint16_t* op = a.O + (size_t)q_row[x] * a.ldo + head * D;
+    // bf16 store as 8 x dwordx4 per lane and q-block instead of 16 x dwordx2 (a workgroup's store tail is issue-bound): a lane holds
+    // d = 8 g + 4 hi + (0..3) of each 32-wide block; one v_permlane32_swap per dword hands the lower half-wave the partner's group of the
+    // even g and the upper half-wave the partner's group of the odd g, so every lane owns 8 consecutive d = 16 j + 8 hi + (0..7).  Same
+    // values, same roundings: only the storing lane changes.
+    const bool live = q_row[x] < a.Lq;  // the two half-waves hold the same query rows
+    uint16_t* op = a.O + (size_t)q_row[x] * a.ldo + head * D;
 #pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        f32x16 ov = o[x][db];
-        asm volatile("" : "+v"(ov));
+    for (int db = 0; db < 4; ++db) {
+      f32x16 ov = o[x][db];
+      asm volatile("" : "+v"(ov));
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d = db * 32 + 8 * g + 4 * hi;
-          // the normalisation and the accumulation are two roundings (__fmul_rn / __fadd_rn: never contracted into one fma), so that the
-          // fused two-context kernel (KIND 5) and the two-launch form (accumulate) produce the same bits
+      for (int j = 0; j < 2; ++j) {
+        uint32_t pk[2][2];  // [g & 1][dword]
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          const int g = 2 * j + gg;
+          // the normalisation and the accumulation are two roundings (never contracted into one fma), so that the fused two-context
+          // kernel (KIND 5) and the two-launch form (accumulate) produce the same bits
           float v0 = mul_rn(ov[4 * g + 0], inv), v1 = mul_rn(ov[4 * g + 1], inv), v2 = mul_rn(ov[4 * g + 2], inv),
                 v3 = mul_rn(ov[4 * g + 3], inv);
           if constexpr (KIND == 5) {  // + context 1's stored (bf16) result
@@ -796,14 +803,21 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
             v2 = add_rn(v2, __uint_as_float(o1 << 16));
             v3 = add_rn(v3, __uint_as_float(o1 & 0xffff0000u));
           } else if (a.accumulate) {
-            u32x2 old = *reinterpret_cast<const u32x2*>(op + d);
+            u32x2 old = {0u, 0u};
+            if (live) old = *reinterpret_cast<const u32x2*>(op + db * 32 + 8 * g + 4 * hi);
             v0 = add_rn(v0, __uint_as_float(old[0] << 16));
             v1 = add_rn(v1, __uint_as_float(old[0] & 0xffff0000u));
             v2 = add_rn(v2, __uint_as_float(old[1] << 16));
             v3 = add_rn(v3, __uint_as_float(old[1] & 0xffff0000u));
           }
-          u32x2 pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
-          *reinterpret_cast<u32x2*>(op + d) = pk;
+          pk[gg][0] = pack_bf16x2(v0, v1);
+          pk[gg][1] = pack_bf16x2(v2, v3);
+        }
+        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+        if (live) {
+          u32x4 st = {s0[0], s1[0], s0[1], s1[1]};
+          *reinterpret_cast<u32x4*>(op + db * 32 + 16 * j + 8 * hi) = st;
         }
       }
     }
@@ -890,7 +904,7 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
   WF_CHECK_ARG(Lkp % KB == 0 && kv_len <= Lkp, "%s: Lkp (%d) must be a multiple of 64 and >= kv_len (%d)", who, Lkp, kv_len);
   WF_CHECK_ARG(seg_len > 0 && seg_len % KB == 0 && Lkp % seg_len == 0, "%s: seg_len (%d) must be a multiple of 64 dividing Lkp", who,
                seg_len);
-  WF_CHECK_ARG(ldo % 4 == 0 && ldo >= H * D, "%s: bad ldo %d", who, ldo);
+  WF_CHECK_ARG(ldo % 8 == 0 && ldo >= H * D, "%s: ldo %d must be a multiple of 8 (16-byte stores) and >= H * 128", who, ldo);
   WF_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O) & 15) == 0, "%s: 16-byte alignment", who);
   AttnArgs a;
   a.Q = (const uint16_t*)Q;
@@ -1033,7 +1047,7 @@ extern "C" int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, voi
   WF_CHECK_ARG(Lq % block == 0 && Lkp % block == 0, "wf_attn_bsa_fwd: Lq (%d) and Lkp (%d) must be whole %d-token blocks", Lq, Lkp, block);
   WF_CHECK_ARG(seg_len > 0 && seg_len % block == 0 && Lkp % seg_len == 0, "wf_attn_bsa_fwd: seg_len (%d) must be whole blocks dividing Lkp",
                seg_len);
-  WF_CHECK_ARG(ldo % 4 == 0 && ldo >= H * D, "wf_attn_bsa_fwd: bad ldo %d", ldo);
+  WF_CHECK_ARG(ldo % 8 == 0 && ldo >= H * D && (((uintptr_t)O) & 15) == 0, "wf_attn_bsa_fwd: ldo %d must be a multiple of 8 (16-byte stores) and >= H * 128", ldo);
   WF_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O) & 15) == 0, "wf_attn_bsa_fwd: 16-byte alignment");
   AttnArgs a;
   a.Q = (const uint16_t*)Q;
@@ -1082,7 +1096,7 @@ extern "C" int wf_attn_cross2_fwd(const void* Q, const void* K, const void* Vt, 
                "wf_attn_cross2_fwd: context 1 must fill its %d padded rows up to the last 64-key tile (kv_len1 = %d)", Lk1p, kv_len1);
   WF_CHECK_ARG(Lk2p > 0 && Lk2p % KB == 0 && kv_len2 > Lk2p - KB && kv_len2 <= Lk2p,
                "wf_attn_cross2_fwd: context 2 must fill its %d padded rows up to the last 64-key tile (kv_len2 = %d)", Lk2p, kv_len2);
-  WF_CHECK_ARG(ldo % 4 == 0 && ldo >= H * D, "wf_attn_cross2_fwd: bad ldo %d", ldo);
+  WF_CHECK_ARG(ldo % 8 == 0 && ldo >= H * D && (((uintptr_t)O) & 15) == 0, "wf_attn_cross2_fwd: ldo %d must be a multiple of 8 (16-byte stores) and >= H * 128", ldo);
   WF_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O) & 15) == 0, "wf_attn_cross2_fwd: 16-byte alignment");
   WF_CHECK_ARG(softmax_scale > 0.0f, "wf_attn_cross2_fwd: softmax_scale must be positive (the scale is applied inside the kernel)");
   AttnArgs a;
