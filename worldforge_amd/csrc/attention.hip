@@ -233,6 +233,7 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
   }
   const int ntiles = ntiles_;
   const bool ragged = KIND != 3 && KIND != 5 && (a.kv_len & (KB - 1)) != 0;
+  const int rag_t = ragged ? ntiles_all - 2 - t_begin : -1;  // the tile in which the scores of the ragged last tile are produced (one scalar compare per tile)
   const bool rag1 = KIND == 5 && (a.kv_len1 & (KB - 1)) != 0, rag2 = KIND == 5 && (a.kv_len & (KB - 1)) != 0;  // ragged last tile of either context
 
   // Element offset / LDS slot of the tile being staged (wave-uniform), advanced one tile at a time: a handful of scalar
@@ -249,8 +250,8 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
     e_stage = __builtin_amdgcn_readfirstlane(bsa[0]);
     st_off = (size_t)(e_stage >> a.bsa_shift) * tpe * tile_bytes;
   }
-  auto stage_next = [&]() {  // select tile st_tile + 1
-    ++st_tile;
+  auto stage_next = [&]() {  // select tile st_tile + 1.  Branch-free on purpose: the same bookkeeping with a rarely-taken branch for the
+    ++st_tile;               // segment / end-of-split cases (3 scalar instructions + s_cbranch in the common case) measured 22 cycles per tile SLOWER
     const bool live = st_tile < ntiles;
     if constexpr (KIND == 3) {
       if (live) {
@@ -441,10 +442,10 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
 #endif
   auto tile = [&](auto BC, int t, int slot0) {  // slot0 = ring slot of tile t
     constexpr int B = decltype(BC)::value;
-    const int t1 = t + 1 < ntiles ? t + 1 : t;       // past the end: recompute scores nobody reads
-    const int t2 = t + 2 < ntiles ? t + 2 : t1;
-    const int slot1 = t1 == t ? slot0 : (slot0 + 1 == NBUF ? 0 : slot0 + 1);
-    const int slot2 = t2 == t1 ? slot1 : (slot1 + 1 == NBUF ? 0 : slot1 + 1);
+    // past the last tile the next ring slots hold copies of the last tile (stage_next stops advancing, the pieces are still issued):
+    // the scores computed from them are finite and nobody reads them -- no end-of-sequence selects in the tile's scalar preamble
+    const int slot1 = slot0 + 1 == NBUF ? 0 : slot0 + 1;
+    const int slot2 = slot1 + 1 == NBUF ? 0 : slot1 + 1;
     const unsigned char* sK1 = smem + slot1 * BUF_BYTES;                 // K(t+1): read now
     const unsigned char* sV0 = smem + slot0 * BUF_BYTES + K_TILE_BYTES;  // V^T(t)
     const unsigned char* sK2 = smem + slot2 * BUF_BYTES;                 // K(t+2): head of the next tile's ring
@@ -591,11 +592,12 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
       if constexpr (g == 51) {
         // the new scores were written by asm MFMAs (last one at gap 31): XDL write -> VALU read hazard is long covered; the ragged
         // mask of the last tile must be in place before its row max
-        if (ragged && t_begin + t + 1 == ntiles_all - 1) mask_ragged(std::integral_constant<int, 1 - B>{}, t + 1);
+        // (every rare block of the tile loop is marked unlikely: its common case must be the fall-through, see the loop below)
+        if (__builtin_expect(t == rag_t, 0)) mask_ragged(std::integral_constant<int, 1 - B>{}, t + 1);
         if constexpr (KIND == 3) mask_unselected(std::integral_constant<int, 1 - B>{}, e_mask);
         if constexpr (KIND == 5) {
-          if (rag1 && t + 1 == a.n1 - 1) mask_tail(std::integral_constant<int, 1 - B>{}, t + 1, a.kv_len1);
-          if (rag2 && t + 1 == ntiles - 1) mask_tail(std::integral_constant<int, 1 - B>{}, t + 1 - a.n1, a.kv_len);
+          if (__builtin_expect(rag1 && t + 1 == a.n1 - 1, 0)) mask_tail(std::integral_constant<int, 1 - B>{}, t + 1, a.kv_len1);
+          if (__builtin_expect(rag2 && t + 1 == ntiles - 1, 0)) mask_tail(std::integral_constant<int, 1 - B>{}, t + 1 - a.n1, a.kv_len);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -603,11 +605,11 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
     // one test for both q-blocks in the hot path; the (rare) commits re-test per q-block
     if constexpr (NOMAX) {
     } else if constexpr (PS) {
-      if (t + 1 < ntiles && __any(fmaxf(mn[0], mn[1]) > 8.0f)) {
+      if (__builtin_expect(t + 1 < ntiles && __any(fmaxf(mn[0], mn[1]) > 8.0f), 0)) {
         commit_ps(std::integral_constant<int, 0>{}, std::integral_constant<int, 1 - B>{}, mn[0]);
         commit_ps(std::integral_constant<int, 1>{}, std::integral_constant<int, 1 - B>{}, mn[1]);
       }
-    } else if (t + 1 < ntiles && __any(c * fmaxf(mn[0] - m_run[0], mn[1] - m_run[1]) > 8.0f)) {
+    } else if (__builtin_expect(t + 1 < ntiles && __any(c * fmaxf(mn[0] - m_run[0], mn[1] - m_run[1]) > 8.0f), 0)) {
       commit(std::integral_constant<int, 0>{}, mn[0]);
       commit(std::integral_constant<int, 1>{}, mn[1]);
     }
@@ -718,16 +720,31 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
 #endif
   {
     int slot = 0;
-    for (int t = 0; t < ntiles; t += 2) {
+    int t = 0;
+    // a taken branch costs a lone wave ~130 cycles of instruction fetch (lab: the ragged-tile test alone was 5 % of the loop while its
+    // common case was the taken direction): the hot body's back edge is taken once per FOUR tiles
+    if constexpr (NOMAX) {
+      for (; t + 3 < ntiles; t += 4) {
+        tile(B0{}, t, slot);
+        slot = slot + 1 == NBUF ? 0 : slot + 1;
+        tile(B1{}, t + 1, slot);
+        slot = slot + 1 == NBUF ? 0 : slot + 1;
+        tile(B0{}, t + 2, slot);
+        slot = slot + 1 == NBUF ? 0 : slot + 1;
+        tile(B1{}, t + 3, slot);
+        slot = slot + 1 == NBUF ? 0 : slot + 1;
+      }
+    }
+    for (; t < ntiles; t += 2) {
       tile(B0{}, t, slot);
       if constexpr (KIND == 5) {
-        if (t == a.n1 - 1) seam(B1{});
+        if (__builtin_expect(t == a.n1 - 1, 0)) seam(B1{});
       }
       slot = slot + 1 == NBUF ? 0 : slot + 1;
       if (t + 1 < ntiles) {
         tile(B1{}, t + 1, slot);
         if constexpr (KIND == 5) {
-          if (t + 1 == a.n1 - 1) seam(B0{});
+          if (__builtin_expect(t + 1 == a.n1 - 1, 0)) seam(B0{});
         }
       }
       slot = slot + 1 == NBUF ? 0 : slot + 1;
