@@ -264,6 +264,14 @@ int wf_lc_mean_pool_blocks(const void* in, void* out, int H, int L, int block, v
  * = key block b selected by that query block (read back by tests).  n_k <= 2048. */
 int wf_bsa_topk_lists(const void* scores, int64_t ld, int heads, int n_q, int n_k, int n_sel, int block, int blocks_per_segment,
                       int* lists, int* counts, int max_entries, uint32_t* sel_mask, void* stream);
+/* The cdf selection rule (BSA:226-263, get_select_indices_cdf / get_select_indices_cdf_topk) with the same list building: per query
+ * block, the key blocks in descending order of softmax(score / sqrt(128)) as long as their cumulative weight stays <= cdf_threshold
+ * (`searchsorted(cdf, threshold, right=True)`: possibly none), at least n_min of them (int((1 - sparsity) * n_k) of the _topk form, 0
+ * otherwise).  row_counts int32 [heads][n_q] receives the per-row counts; lists / counts / sel_mask as wf_bsa_topk_lists with
+ * max_entries >= n_k.  Weights are summed in descending order with a fixed reduction tree (deterministic); against a sequential cumsum
+ * a count can differ by one where the cumulative weight meets the threshold within fp32 rounding. */
+int wf_bsa_cdf_lists(const void* scores, int64_t ld, int heads, int n_q, int n_k, float cdf_threshold, int n_min, int block,
+                     int blocks_per_segment, int* lists, int* counts, int max_entries, uint32_t* sel_mask, int* row_counts, void* stream);
 /* out[i][:C] = in[index[i]][:C], bf16 rows (16-byte chunks): the two token permutes of BSA:600-610 the refine pass needs per forward
  * (patch tokens into 3D-block order, velocity rows back). */
 int wf_gather_rows_bf16(const void* in, int64_t ld_in, const int* index, void* out, int64_t ld_out, int n_rows, int C, void* stream);

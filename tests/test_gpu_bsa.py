@@ -181,6 +181,55 @@ def test_cdf_threshold_selection_with_empty_and_variable_lists():
             assert got[empty].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("nq,nk,block", [(6, 8, 128), (37, 770, 128), (13, 1540, 64), (5, 2048, 128)])
+def test_cdf_lists_kernel_counts_and_selection_vs_oracle_rule(nq, nk, block):
+    """wf_bsa_cdf_lists (BSA:226-263 on the device: sort + scan in LDS, then the list kernel) against the rule evaluated in float64 on the
+    SAME bf16 scores: a row's count may differ from the exact one only where the cumulative weight meets the threshold within fp32 rounding
+    (the count one lower / higher is then also right), the selected blocks are a valid top-`count` of the row (ties at the boundary in
+    ascending index), the lists are the ascending union per group with the membership bits.  Rows with an empty selection included."""
+    from worldforge_amd import bsa
+    Hh = 3
+    g = torch.Generator().manual_seed(nq * 7 + nk)
+    sc = (torch.randn(Hh, nq, nk, generator=g) * 6).to(BF)
+    sc[0, 0, nk // 2] = 300.0         # one dominant block: weight ~ 1 > threshold -> empty selection without the top-k floor
+    sc[1, 1, :] = 1.0                 # all equal: ties everywhere
+    for thr, sp in ((0.5, None), (0.3, 0.75), (0.9, None)):
+        lists, counts, mx, sel = bsa.cdf_lists(sc.to(DEV).contiguous(), thr, sp, block, nk)
+        idx, lens = sel.cpu()
+        w = torch.softmax(sc.double() / 128 ** 0.5, dim=-1)
+        ws = torch.sort(w, dim=-1, descending=True).values
+        cdf = torch.cumsum(ws, dim=-1)
+        n_min = 0 if sp is None else int((1 - sp) * nk)
+        exact = (cdf <= thr).sum(-1)
+        lo = ((cdf <= thr - 1e-5).sum(-1)).clamp_min(n_min).clamp_max(nk)
+        hi = ((cdf <= thr + 1e-5).sum(-1)).clamp_min(n_min).clamp_max(nk)
+        assert bool(((lens >= lo) & (lens <= hi)).all()), (lens - exact.clamp_min(n_min)).abs().max()
+        if sp is None and thr == 0.5:
+            assert int(lens[0, 0]) == 0
+        scf = sc.float()
+        gs = 256 // block
+        for hh in range(Hh):
+            for q in range(nq):
+                n = int(lens[hh, q])
+                chosen = idx[hh, q, :n]
+                assert len(set(chosen.tolist())) == n
+                if 0 < n < nk:  # a valid top-n: nothing left out beats anything taken
+                    rest = torch.ones(nk, dtype=torch.bool)
+                    rest[chosen] = False
+                    assert float(scf[hh, q][chosen].min()) >= float(scf[hh, q][rest].max())
+        lists, counts = lists.cpu(), counts.cpu()
+        for hh in range(Hh):
+            for grp in range((nq + gs - 1) // gs):
+                want = {}
+                for i in range(gs):
+                    q = grp * gs + i
+                    if q < nq:
+                        for b in idx[hh, q, :int(lens[hh, q])].tolist():
+                            want[b] = want.get(b, 0) | (1 << i)
+                got = lists[hh, grp, :int(counts[hh, grp])].tolist()
+                assert got == [((hh * nk + b) << gs) | m for b, m in sorted(want.items())]
+
+
 @pytest.mark.parametrize("Hh,Sq,Sk,nsel", [(2, 256, 512, 3), (3, 448, 1024, 4), (1, 64, 64, 1), (4, 1088, 2048, 9)])
 def test_sparse_attention_kernel_64_token_blocks(Hh, Sq, Sk, nsel):
     """chunk_3d_shape 4 x 4 x 4: four query blocks per workgroup, one 64-key tile per list entry."""

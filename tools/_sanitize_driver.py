@@ -149,6 +149,10 @@ mx = min(2 * nsel, nk)
 lists, counts, mask = buf(4 * 2 * 4 * mx), buf(4 * 2 * 4), buf(4 * 2 * nq * 1)
 ok("wf_bsa_topk_lists", sc, 16, 2, nq, nk, nsel, 128, nk, lists, counts, mx, mask, None)
 bad("wf_bsa_topk_lists", sc, 16, 2, nq, nk, 0, 128, nk, lists, counts, mx, mask, None)                    # nothing selected
+lists_c = buf(4 * 2 * 4 * nk)
+ok("wf_bsa_cdf_lists", sc, 16, 2, nq, nk, 0.5, 2, 128, nk, lists_c, counts, nk, mask, buf(4 * 2 * nq), None)
+bad("wf_bsa_cdf_lists", sc, 16, 2, nq, nk, 0.5, 2, 128, nk, lists_c, counts, nk - 1, mask, buf(4 * 2 * nq), None)   # a row may take every block
+bad("wf_bsa_cdf_lists", sc, 16, 2, nq, nk, -0.1, 2, 128, nk, lists_c, counts, nk, mask, buf(4 * 2 * nq), None)      # negative threshold
 ok("wf_attn_bsa_fwd", buf(2 * 2 * 896 * 128), buf(2 * 2 * 1152 * 128), buf(2 * 2 * 1152 * 128), buf(2 * 896 * 256), 2, 896, 1152, 1152, 256,
    0.0884, lists, counts, mx, 128, None)
 bad("wf_attn_bsa_fwd", Q, K, V, O, 2, 900, 1152, 1152, 256, 0.0884, lists, counts, mx, 128, None)        # Lq not whole blocks

@@ -71,7 +71,7 @@ def select_topk(scores: torch.Tensor, sparsity: float) -> torch.Tensor:
 
 
 def select_cdf(scores: torch.Tensor, cdf_threshold: float, sparsity=None):
-    """BSA:226-263: softmax(score / sqrt(128)) block weights, descending; as many blocks as the cumulative weight needs to pass
+    """(Torch form, kept for tests and for WF_BSA_TORCH_SELECT=1; the product path is cdf_lists / wf_bsa_cdf_lists.)  BSA:226-263: softmax(score / sqrt(128)) block weights, descending; as many blocks as the cumulative weight needs to pass
     cdf_threshold, at least the top-k count when `sparsity` is given.  Returns (sorted indices [heads, n_q, n_k], counts [heads, n_q])."""
     w = torch.softmax(scores * (1 / 128 ** 0.5), dim=-1)
     ws = torch.sort(w, dim=-1, descending=True)
@@ -154,6 +154,56 @@ def topk_lists(scores: torch.Tensor, sparsity: float, block: int = BLOCK, blocks
     call("wf_bsa_topk_lists", scores.data_ptr(), scores.stride(1), Hh, nq, nk, n, block, blocks_per_segment or nk, lists.data_ptr(),
          counts.data_ptr(), mx, mask.data_ptr(), ops.stream())
     return lists, counts, mx, SelectionMask(mask, nk, n)
+
+
+class SelectionMaskVar:
+    """The selection wf_bsa_cdf_lists made: the mask of SelectionMask plus the per-row counts.  `.cpu()` gives (indices int64 [heads, n_q,
+    max count] -- each row's selected blocks ascending, padded with 0 --, counts [heads, n_q]): the (idx, lens) pair select_cdf returns,
+    up to order."""
+
+    def __init__(self, mask: torch.Tensor, n_k: int, counts: torch.Tensor):
+        self.mask, self.n_k, self.counts = mask, n_k, counts
+
+    def cpu(self):
+        bits = (self.mask.unsqueeze(-1) >> torch.arange(32, device=self.mask.device, dtype=torch.int32)) & 1
+        sel = bits.flatten(2)[:, :, :self.n_k].bool().cpu()
+        lens = self.counts.cpu().long()
+        assert bool((sel.sum(-1) == lens).all())
+        width = max(int(lens.max()), 1)
+        order = torch.sort((~sel).to(torch.uint8), dim=-1, stable=True)[1][..., :width]  # host side, tests only: selected first, ascending
+        keep = torch.arange(width).view(1, 1, -1) < lens.unsqueeze(-1)
+        return torch.where(keep, order, torch.zeros_like(order)), lens
+
+
+def cdf_lists(scores: torch.Tensor, cdf_threshold: float, sparsity=None, block: int = BLOCK, blocks_per_segment: int = None):
+    """BSA:226-263 + group_lists in two launches of one entry point (wf_bsa_cdf_lists), no torch ops: scores [heads, n_q, n_k] bf16 ->
+    (lists, counts, max_entries, SelectionMaskVar)."""
+    Hh, nq, nk = scores.shape
+    n_min = 0 if sparsity is None else int((1 - sparsity) * nk)
+    assert scores.dtype == torch.bfloat16 and scores.stride(2) == 1 and scores.stride(0) == nq * scores.stride(1)
+    gs = 256 // block
+    ng = (nq + gs - 1) // gs
+    lists = torch.empty((Hh, ng, nk), dtype=torch.int32, device=scores.device)
+    counts = torch.empty((Hh, ng), dtype=torch.int32, device=scores.device)
+    rows = torch.empty((Hh, nq), dtype=torch.int32, device=scores.device)
+    mask = torch.empty((Hh, nq, (nk + 31) // 32), dtype=torch.int32, device=scores.device)
+    call("wf_bsa_cdf_lists", scores.data_ptr(), scores.stride(1), Hh, nq, nk, float(cdf_threshold), n_min, block, blocks_per_segment or nk,
+         lists.data_ptr(), counts.data_ptr(), nk, mask.data_ptr(), rows.data_ptr(), ops.stream())
+    return lists, counts, nk, SelectionMaskVar(mask, nk, rows)
+
+
+def sparse_attention_cdf(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, scores: torch.Tensor, cdf_threshold: float,
+                         sparsity, scale: float, block: int = BLOCK) -> SelectionMaskVar:
+    """sparse_attention with the cdf selection of `scores` made on the way (three launches, no torch ops)."""
+    Hh, Lq, _ = q.shape
+    if k.dim() == 4:
+        Lkp, seg = k.shape[0] * k.shape[2], k.shape[2]
+    else:
+        Lkp = seg = k.shape[1]
+    lists, counts, mx, sel = cdf_lists(scores, cdf_threshold, sparsity, block, seg // block)
+    call("wf_attn_bsa_fwd", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), Hh, Lq, Lkp, seg, out.stride(0), float(scale),
+         lists.data_ptr(), counts.data_ptr(), mx, block, ops.stream())
+    return sel
 
 
 def sparse_attention_topk(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, scores: torch.Tensor, sparsity: float,

@@ -234,9 +234,87 @@ __device__ __forceinline__ int block_exscan(int v, int* sm /* >= 4 ints */, int*
   *total = sm[0] + sm[1] + sm[2] + sm[3];
   return base + inc - v;
 }
+// inclusive scan of one float per thread over the 256 threads (fixed order: deterministic); *total = sum of all
+__device__ __forceinline__ float block_incscan_f(float v, float* sm /* >= 4 floats */, float* total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float u = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += u;
+  }
+  __syncthreads();
+  if (lane == 63) sm[wv] = inc;
+  __syncthreads();
+  float base = 0.f;
+  for (int i = 0; i < wv; ++i) base += sm[i];
+  *total = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+  return base + inc;
+}
+// bsa_interface.py:226-263 (get_select_indices_cdf / _cdf_topk): per (head, query block) row, the number of key blocks the cdf rule takes =
+// how many blocks, in descending weight order, have a cumulative softmax(score / sqrt(128)) weight <= cdf_threshold (searchsorted right),
+// at least n_min, at most n_k.  The row's 16-bit score keys are sorted in LDS (bitonic, descending), the weights scanned in that order
+// with a fixed reduction tree: the result is deterministic; against a sequential cumsum it can differ by one block where the cumulative
+// weight crosses the threshold within fp32 rounding.  Which blocks = the top `need` of the row: k_bsa_topk_lists with need_rows.
+__global__ __launch_bounds__(256) void k_bsa_cdf_need(const uint16_t* __restrict__ scores, long ld, int n_q, int n_k, float thr, int n_min,
+                                                      int* __restrict__ need_rows) {
+  __shared__ uint16_t key[TK_MAXK];
+  __shared__ float smf[4];
+  __shared__ int smi[4];
+  const int qb = blockIdx.x, head = blockIdx.y, tid = threadIdx.x;
+  const uint16_t* row = scores + ((size_t)head * n_q + qb) * ld;
+  for (int b = tid; b < TK_MAXK; b += 256) key[b] = b < n_k ? (uint16_t)bf16_sort_key(row[b]) : (uint16_t)0;  // padding sorts last
+  __syncthreads();
+  for (int k2 = 2; k2 <= TK_MAXK; k2 <<= 1)
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < TK_MAXK; i += 256) {
+        const int p = i ^ j;
+        if (p > i) {
+          const uint16_t a = key[i], c = key[p];
+          const bool desc = (i & k2) == 0;
+          if (desc ? a < c : a > c) key[i] = c, key[p] = a;
+        }
+      }
+      __syncthreads();
+    }
+  auto score_of = [](uint16_t kx) {  // inverse of bf16_sort_key -> float
+    const uint16_t b = (kx & 0x8000u) ? (uint16_t)(kx & 0x7fffu) : (uint16_t)~kx;
+    return __uint_as_float((uint32_t)b << 16);
+  };
+  constexpr int PER = TK_MAXK / 256;
+  const float c = 0.08838834764831845f;  // 1 / sqrt(128)
+  const float mx = score_of(key[0]) * c;
+  float e[PER], part = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int p = tid * PER + i;
+    e[i] = p < n_k ? expf(score_of(key[p]) * c - mx) : 0.f;
+    part += e[i];
+  }
+  float total;
+  block_incscan_f(part, smf, &total);
+  float wsum = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    e[i] = e[i] / total;  // the softmax weight, as torch.softmax divides
+    wsum += e[i];
+  }
+  float tot2;
+  float run = block_incscan_f(wsum, smf, &tot2) - wsum;  // cumulative weight in front of this thread's first position
+  int cnt = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    run += e[i];
+    cnt += (tid * PER + i < n_k) && run <= thr;
+  }
+  int tot;
+  block_exscan(cnt, smi, &tot);
+  if (tid == 0) need_rows[(size_t)head * n_q + qb] = min(max(tot, n_min), n_k);
+}
 __global__ __launch_bounds__(256) void k_bsa_topk_lists(const uint16_t* __restrict__ scores, long ld, int n_q, int n_k, int n_sel, int gs,
                                                         int bps, int heads, int* __restrict__ lists, int* __restrict__ counts,
-                                                        int max_entries, uint32_t* __restrict__ sel_mask) {
+                                                        int max_entries, uint32_t* __restrict__ sel_mask,
+                                                        const int* __restrict__ need_rows /* per-row counts (cdf rule) or null */) {
   __shared__ uint16_t key[TK_MAXK];
   __shared__ uint8_t flags[TK_MAXK];
   __shared__ int hist[256];
@@ -253,7 +331,7 @@ __global__ __launch_bounds__(256) void k_bsa_topk_lists(const uint16_t* __restri
     __syncthreads();
     for (int b = tid; b < n_k; b += 256) key[b] = (uint16_t)bf16_sort_key(row[b]);
     // two radix passes: byte 1 over all keys, byte 0 inside the boundary bin
-    int need = n_sel;
+    int need = need_rows ? need_rows[(size_t)head * n_q + qb] : n_sel;  // (uniform)
     uint32_t prefix = 0;  // high byte of the boundary value after pass 0
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
@@ -335,8 +413,26 @@ extern "C" int wf_bsa_topk_lists(const void* scores, int64_t ld, int heads, int 
   WF_CHECK_ARG(blocks_per_segment > 0 && max_entries >= ((long)gs * n_sel < n_k ? gs * n_sel : n_k),
                "wf_bsa_topk_lists: max_entries=%d must hold min(g * n_sel, n_k) entries", max_entries);
   hipLaunchKernelGGL(k_bsa_topk_lists, dim3((n_q + gs - 1) / gs, heads), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)scores, (long)ld,
-                     n_q, n_k, n_sel, gs, blocks_per_segment, heads, lists, counts, max_entries, sel_mask);
+                     n_q, n_k, n_sel, gs, blocks_per_segment, heads, lists, counts, max_entries, sel_mask, (const int*)nullptr);
   WF_LAUNCH_CHECK("wf_bsa_topk_lists");
+  return WF_OK;
+}
+
+extern "C" int wf_bsa_cdf_lists(const void* scores, int64_t ld, int heads, int n_q, int n_k, float cdf_threshold, int n_min, int block,
+                                int blocks_per_segment, int* lists, int* counts, int max_entries, uint32_t* sel_mask, int* row_counts,
+                                void* stream) {
+  WF_CHECK_ARG(scores && lists && counts && row_counts, "wf_bsa_cdf_lists: null pointer");
+  WF_CHECK_ARG(block == 128 || block == 64, "wf_bsa_cdf_lists: block must be 128 or 64");
+  WF_CHECK_ARG(heads > 0 && n_q > 0 && n_k > 0 && n_k <= TK_MAXK && ld >= n_k, "wf_bsa_cdf_lists: n_k=%d must be in 1..%d, ld >= n_k", n_k, TK_MAXK);
+  WF_CHECK_ARG(cdf_threshold >= 0.f && n_min >= 0 && n_min <= n_k, "wf_bsa_cdf_lists: cdf_threshold >= 0, n_min in 0..n_k");
+  WF_CHECK_ARG(blocks_per_segment > 0 && max_entries >= n_k, "wf_bsa_cdf_lists: max_entries=%d must hold n_k=%d entries (a row may take every block)",
+               max_entries, n_k);
+  const int gs = 256 / block;
+  hipLaunchKernelGGL(k_bsa_cdf_need, dim3(n_q, heads), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)scores, (long)ld, n_q, n_k,
+                     cdf_threshold, n_min, row_counts);
+  hipLaunchKernelGGL(k_bsa_topk_lists, dim3((n_q + gs - 1) / gs, heads), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)scores, (long)ld,
+                     n_q, n_k, 0, gs, blocks_per_segment, heads, lists, counts, max_entries, sel_mask, (const int*)row_counts);
+  WF_LAUNCH_CHECK("wf_bsa_cdf_lists");
   return WF_OK;
 }
 

@@ -403,7 +403,7 @@ class LongCatVideoTransformer3DModel:
                     return bsa.select_topk(scores, float(sparsity)), None
                 return bsa.select_cdf(scores, float(cdf_thr), None if sparsity is None else float(sparsity))
 
-            fused_topk = cdf_thr is None and not os.environ.get("WF_BSA_TORCH_SELECT")  # (the env switch keeps the torch.topk path testable)
+            fused_sel = not os.environ.get("WF_BSA_TORCH_SELECT")  # (the env switch keeps the torch selection paths testable)
             self.last_bsa_indices = []
 
         # sequence-parallel jobs: the caption K / V^T of layer i are computed by rank i (mod P) only and all-gathered once per forward (see
@@ -455,8 +455,11 @@ class LongCatVideoTransformer3DModel:
                     if nrows == 0:
                         continue
                     sc = bsa.block_scores(bsa.mean_pool(qrows, blk), kcmp if nkb == L_all // blk else kcmp[:, :nkb].contiguous())
-                    if fused_topk and nkb <= bsa.TOPK_MAX_BLOCKS:  # selection + list building in one kernel
+                    if fused_sel and nkb <= bsa.TOPK_MAX_BLOCKS and cdf_thr is None:  # selection + list building in one kernel
                         picked.append(bsa.sparse_attention_topk(qrows, kk, vv, orows, sc, float(sparsity), scale, blk))
+                    elif fused_sel and nkb <= bsa.TOPK_MAX_BLOCKS:  # the cdf rule: counts (sort + scan in LDS), then the same list kernel
+                        picked.append(bsa.sparse_attention_cdf(qrows, kk, vv, orows, sc, float(cdf_thr),
+                                                               None if sparsity is None else float(sparsity), scale, blk))
                     else:
                         idx, lens = select(sc)
                         bsa.sparse_attention(qrows, kk, vv, orows, idx, scale, nkb, lens, blk)
