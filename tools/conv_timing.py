@@ -1,4 +1,5 @@
-"""Per-segment cycle accounting of k_conv_w4 (needs a -DWF_CONV_TIMING build: WF_LIB=worldforge_amd/_lib/libwf_hip_convtiming.so).
+"""Per-segment cycle accounting of k_conv_w4 (needs a -DWF_CONV_TIMING [-DWF_CONV_ABLATE] build: WF_LIB=worldforge_amd/_lib/lab/libwf_hip_convtiming.so;
+with the ablate build WF_CONV_DEBUG=<bits> picks the variant: 1 no in-loop LDS-DMA, 2 no in-loop weight loads, 4 no LDS fragment reads).
 LAYOUT=0|1 (pixel- / slice-major operand), X3=0|1 (three-term fp32-class operand)."""
 import ctypes, math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,13 +19,13 @@ for (T, H, W, C) in ((81, 480, 832, 96), (81, 240, 416, 192), (41, 120, 208, 384
         x = x.view(T, H, W, Cs // 16, 16).permute(0, 1, 3, 2, 4).contiguous()
     w = (torch.randn(C, 27, K, device="cuda:0") / math.sqrt(K * 27)).to(BF)
     out = torch.empty(T, H, W, C, device="cuda:0")
-    zp = torch.zeros(1024, dtype=BF, device="cuda:0")
+    zp = torch.zeros(1 << 20, dtype=BF, device="cuda:0")
     wp = torch.empty((27, K // 16, C, 16), dtype=BF, device="cuda:0")
     _ffi.call("wf_conv3d_pack333", w.data_ptr(), wp.data_ptr(), C, K, ops.stream())
 
     def run():
         _ffi.call("wf_conv3d_333", x.data_ptr(), wp.data_ptr(), None, None, out.data_ptr(), None, T, H, W, K, H, C, 1, zp.data_ptr(),
-                  LAYOUT, Cs, ops.stream())
+                  zp.numel() * 2, LAYOUT, Cs, ops.stream())
     run(); torch.cuda.synchronize(); lib.wf_debug_conv_cycles(buf, 1); lib.wf_debug_conv_slices(sl)
     run(); torch.cuda.synchronize(); lib.wf_debug_conv_cycles(buf, 1); lib.wf_debug_conv_slices(sl)
     nwg, nt = max(buf[5], 1), max(buf[6], 1)
