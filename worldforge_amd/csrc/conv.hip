@@ -765,45 +765,69 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   const unsigned long long tt1 = __builtin_readcyclecounter();
 #endif
   // ---- epilogue ----
+  // The optional operands (bias, residual, the two output forms) are tile-uniform: the store loop is instantiated for the combinations
+  // the VAE uses and dispatched ONCE per tile.  Tested inside the loop they were ~4 scalar branches per store group, two of them taken in
+  // the common case -- and a taken branch costs a wave that is alone on its SIMD ~130 cycles of instruction fetch: 12 of the epilogue's
+  // 16.7 k cycles (tools/conv_timing.py).
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
+  auto store_tile = [&](auto RC, auto FC, auto HC, auto BC) {
+    // RC / FC / HC / BC: std::integral_constant<int, v>, v = 0 absent, 1 present, 2 decide at run time (generic fallback)
+    constexpr int R = decltype(RC)::value, F = decltype(FC)::value, H = decltype(HC)::value, BI = decltype(BC)::value;
+    const bool has_resid = R == 2 ? a.resid != nullptr : R == 1;
+    const bool has_f32 = F == 2 ? a.out_f32 != nullptr : F == 1;
+    const bool has_bf16 = H == 2 ? a.out_bf16 != nullptr : H == 1;
+    const bool has_bias = BI == 2 ? a.bias != nullptr : BI == 1;
 #pragma unroll
-  for (int pb = 0; pb < 4; ++pb) {
-    const int y = y0 + 2 * wid + (pb >> 1), x = x0 + (pb & 1) * 32 + l31;
-    const bool inb = y < a.Ho && x < a.Wo;
-    const size_t m = ((size_t)t * a.Ho + y) * a.Wo + x;
+    for (int pb = 0; pb < 4; ++pb) {
+      const int y = y0 + 2 * wid + (pb >> 1), x = x0 + (pb & 1) * 32 + l31;
+      const bool inb = y < a.Ho && x < a.Wo;
+      const size_t m = ((size_t)t * a.Ho + y) * a.Wo + x;
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-      f32x16 av = acc[pb][cb];
-      asm volatile("" : "+v"(av));
-      if (!inb) continue;
+      for (int cb = 0; cb < NCB; ++cb) {
+        f32x16 av = acc[pb][cb];
+        asm volatile("" : "+v"(av));
+        if (!inb) continue;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = n0 + cb * 32 + 8 * g + 4 * hi;
-        if (co >= a.Cout) continue;
-        float v[4];
+        for (int g = 0; g < 4; ++g) {
+          const int co = n0 + cb * 32 + 8 * g + 4 * hi;
+          if (__builtin_expect(co >= a.Cout, 0)) continue;
+          float v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = av[4 * g + q];
-        if (a.bias) {
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + co);
+          for (int q = 0; q < 4; ++q) v[q] = av[4 * g + q];
+          if (has_bias) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + co);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] += bb[q];
-        }
-        const size_t o = m * a.Cout + co;
-        if (a.resid) {
-          const f32x4 rr = *reinterpret_cast<const f32x4*>(a.resid + o);
+            for (int q = 0; q < 4; ++q) v[q] += bb[q];
+          }
+          const size_t o = m * a.Cout + co;
+          if (has_resid) {
+            const f32x4 rr = *reinterpret_cast<const f32x4*>(a.resid + o);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] += rr[q];
-        }
-        if (a.out_f32) {
-          f32x4 ov = {v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(a.out_f32 + o) = ov;
-        }
-        if (a.out_bf16) {
-          u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(a.out_bf16 + o) = pk;
+            for (int q = 0; q < 4; ++q) v[q] += rr[q];
+          }
+          if (has_f32) {
+            f32x4 ov = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(a.out_f32 + o) = ov;
+          }
+          if (has_bf16) {
+            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(a.out_bf16 + o) = pk;
+          }
         }
       }
     }
+  };
+  {
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    const bool common = a.bias && a.out_f32 && !a.out_bf16;  // every ResidualBlock conv of the VAE: bias, fp32 activations out
+    if (common && !a.resid)
+      store_tile(I0{}, I1{}, I0{}, I1{});
+    else if (common)
+      store_tile(I1{}, I1{}, I0{}, I1{});
+    else
+      store_tile(I2{}, I2{}, I2{}, I2{});
   }
 #ifdef WF_CONV_TIMING
   t_main += tt1 - tt0;
