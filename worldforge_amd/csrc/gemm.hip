@@ -403,6 +403,20 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
 #pragma unroll
       for (int i0 = 0; i0 < NI; i0 += 2) {
         const int nti = (NI - i0) >= 2 ? 2 : 1;  // feature tiles in this pass (compile-time after unrolling)
+        // the pass's bias quads in one batch (one wait) -- per store group they were serialized L2 round trips; features >= N are never
+        // stored, so their (clamped) bias value does not matter
+        f32x4 bq[2][4];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) bq[ii][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              if (ii < nti) bq[ii][g] = *reinterpret_cast<const f32x4*>(a.bias + min(n0 + wf0 + (i0 + ii) * 32 + 8 * g + 4 * hi, a.N - 4));
+        }
 #pragma unroll
         for (int jx = 0; jx < NJ; ++jx)
 #pragma unroll
@@ -415,12 +429,7 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
               const int n = n0 + wf0 + i0 * 32 + nl;
               float v[4];
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = acc[i][jx][4 * g + q];
-              if (a.bias && n < a.N) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] += bb[q];
-              }
+              for (int q = 0; q < 4; ++q) v[q] = acc[i][jx][4 * g + q] + bq[ii][g][q];
               if constexpr (EPI == EPI_BF16_GELU) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
@@ -454,40 +463,60 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
       // fp32 outputs: one pass of [NJ*32 tokens][32 features] f32 = 128 B per row for every feature tile
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
+        // the pass's four bias quads in one batch (one wait): tested and loaded per store group they were four serialized L2 round trips.
+        // Features >= N are never stored, so their (clamped) bias value does not matter.
+        f32x4 bq[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (a.bias) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(a.bias + min(n0 + wf0 + i * 32 + 8 * g + 4 * hi, a.N - 4));
+        }
 #pragma unroll
         for (int jx = 0; jx < NJ; ++jx)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int nl = 8 * g + 4 * hi;
-            const int n = n0 + wf0 + i * 32 + nl;
-            f32x4 v = {acc[i][jx][4 * g + 0], acc[i][jx][4 * g + 1], acc[i][jx][4 * g + 2], acc[i][jx][4 * g + 3]};
-            if (a.bias && n < a.N) {
-              const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
-#pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] += bb[q];
-            }
+            f32x4 v = {acc[i][jx][4 * g + 0] + bq[g][0], acc[i][jx][4 * g + 1] + bq[g][1], acc[i][jx][4 * g + 2] + bq[g][2],
+                       acc[i][jx][4 * g + 3] + bq[g][3]};
             *reinterpret_cast<f32x4*>(stg + (jx * 32 + l31) * RS + nl * 4) = v;
           }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // Read-modify-write epilogues: ALL the old values of a chunk of rows are loaded before the first store.  Written as one loop
+        // (load, add, store per row) the compiler must keep every load behind the previous row's store -- it cannot know they do not
+        // alias -- and each row waited a full HBM round trip: 40 serialized round trips per wave and tile.  The gate row (the same
+        // features for every row of the pass) is loaded once per pass for the same reason.
+        const int n = n0 + wf0 + i * 32 + lch * 4;
+        f32x4 gg = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (EPI == EPI_RESID) {
+          if (a.gate) gg = *reinterpret_cast<const f32x4*>(a.gate + min(n, a.N - 4));
+        }
+        constexpr int CH = 4;  // rows-of-8 per chunk: 4 x 16 B per lane in flight (8 spill: the accumulators of the later passes are still live)
 #pragma unroll
-        for (int r8 = 0; r8 < ROWS / 8; ++r8) {
-          const int row = r8 * 8 + lrow;
-          const int m = m0 + wt0 + row;
-          const int n = n0 + wf0 + i * 32 + lch * 4;
-          f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * RS + lch * 16);
-          if (m < a.M && n < a.N) {
-            float* po = reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n;
-            if constexpr (EPI == EPI_F32) {
-              *reinterpret_cast<f32x4*>(po) = v;
-            } else if constexpr (EPI == EPI_F32_ACC) {
-              const f32x4 old = *reinterpret_cast<const f32x4*>(po);
-              *reinterpret_cast<f32x4*>(po) = f32x4{old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
-            } else {
-              const f32x4 old = *reinterpret_cast<const f32x4*>(po);
-              f32x4 gg = {1.f, 1.f, 1.f, 1.f};
-              if (a.gate) gg = *reinterpret_cast<const f32x4*>(a.gate + n);
-              *reinterpret_cast<f32x4*>(po) =
-                  f32x4{old[0] + v[0] * gg[0], old[1] + v[1] * gg[1], old[2] + v[2] * gg[2], old[3] + v[3] * gg[3]};
+        for (int c0 = 0; c0 < ROWS / 8; c0 += CH) {
+          f32x4 oldv[CH];
+          if constexpr (EPI != EPI_F32) {
+#pragma unroll
+            for (int r8 = 0; r8 < CH; ++r8) {  // unconditional, clamped: a guard per load would put each in its own block with its own wait
+              const int m = min(m0 + wt0 + (c0 + r8) * 8 + lrow, a.M - 1);
+              oldv[r8] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.out) + (size_t)m * a.ldo + min(n, a.N - 4));
+            }
+          }
+#pragma unroll
+          for (int r8 = 0; r8 < CH; ++r8) {
+            const int row = (c0 + r8) * 8 + lrow;
+            const int m = m0 + wt0 + row;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * RS + lch * 16);
+            if (m < a.M && n < a.N) {
+              float* po = reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n;
+              if constexpr (EPI == EPI_F32) {
+                *reinterpret_cast<f32x4*>(po) = v;
+              } else if constexpr (EPI == EPI_F32_ACC) {
+                const f32x4 old = oldv[r8];
+                *reinterpret_cast<f32x4*>(po) = f32x4{old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
+              } else {
+                const f32x4 old = oldv[r8];
+                *reinterpret_cast<f32x4*>(po) =
+                    f32x4{old[0] + v[0] * gg[0], old[1] + v[1] * gg[1], old[2] + v[2] * gg[2], old[3] + v[3] * gg[3]};
+              }
             }
           }
         }
@@ -716,25 +745,43 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp16(GemmArgs a) {
             *reinterpret_cast<f32x4*>(stg + (jx * 16 + l15) * RS + nl * 4) = v;
           }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // Read-modify-write epilogues: ALL the old values of a chunk of rows are loaded before the first store.  Written as one loop
+        // (load, add, store per row) the compiler must keep every load behind the previous row's store -- it cannot know they do not
+        // alias -- and each row waited a full HBM round trip: 40 serialized round trips per wave and tile.  The gate row (the same
+        // features for every row of the pass) is loaded once per pass for the same reason.
+        const int n = n0 + wf0 + i * 32 + lch * 4;
+        f32x4 gg = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (EPI == EPI_RESID) {
+          if (a.gate) gg = *reinterpret_cast<const f32x4*>(a.gate + min(n, a.N - 4));
+        }
+        constexpr int CH = 4;  // rows-of-8 per chunk: 4 x 16 B per lane in flight (8 spill: the accumulators of the later passes are still live)
 #pragma unroll
-        for (int r8 = 0; r8 < ROWS / 8; ++r8) {
-          const int row = r8 * 8 + lrow;
-          const int m = m0 + wt0 + row;
-          const int n = n0 + wf0 + i * 32 + lch * 4;
-          f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * RS + lch * 16);
-          if (m < a.M && n < a.N) {
-            float* po = reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n;
-            if constexpr (EPI == EPI_F32) {
-              *reinterpret_cast<f32x4*>(po) = v;
-            } else if constexpr (EPI == EPI_F32_ACC) {
-              const f32x4 old = *reinterpret_cast<const f32x4*>(po);
-              *reinterpret_cast<f32x4*>(po) = f32x4{old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
-            } else {
-              const f32x4 old = *reinterpret_cast<const f32x4*>(po);
-              f32x4 gg = {1.f, 1.f, 1.f, 1.f};
-              if (a.gate) gg = *reinterpret_cast<const f32x4*>(a.gate + n);
-              *reinterpret_cast<f32x4*>(po) =
-                  f32x4{old[0] + v[0] * gg[0], old[1] + v[1] * gg[1], old[2] + v[2] * gg[2], old[3] + v[3] * gg[3]};
+        for (int c0 = 0; c0 < ROWS / 8; c0 += CH) {
+          f32x4 oldv[CH];
+          if constexpr (EPI != EPI_F32) {
+#pragma unroll
+            for (int r8 = 0; r8 < CH; ++r8) {  // unconditional, clamped: a guard per load would put each in its own block with its own wait
+              const int m = min(m0 + wt0 + (c0 + r8) * 8 + lrow, a.M - 1);
+              oldv[r8] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.out) + (size_t)m * a.ldo + min(n, a.N - 4));
+            }
+          }
+#pragma unroll
+          for (int r8 = 0; r8 < CH; ++r8) {
+            const int row = (c0 + r8) * 8 + lrow;
+            const int m = m0 + wt0 + row;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * RS + lch * 16);
+            if (m < a.M && n < a.N) {
+              float* po = reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n;
+              if constexpr (EPI == EPI_F32) {
+                *reinterpret_cast<f32x4*>(po) = v;
+              } else if constexpr (EPI == EPI_F32_ACC) {
+                const f32x4 old = oldv[r8];
+                *reinterpret_cast<f32x4*>(po) = f32x4{old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
+              } else {
+                const f32x4 old = oldv[r8];
+                *reinterpret_cast<f32x4*>(po) =
+                    f32x4{old[0] + v[0] * gg[0], old[1] + v[1] * gg[1], old[2] + v[2] * gg[2], old[3] + v[3] * gg[3]};
+              }
             }
           }
         }
