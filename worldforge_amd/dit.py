@@ -67,6 +67,23 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     return out
 
 
+def ffn_padded_features(f: int) -> int:
+    """Rows the FFN-up weight is stored with: the next multiple of 320 when that costs at most 3 % more features (13 824 -> 14 080).
+    `wf_gemm_bf16` runs its 320-feature tile only on N % 320 == 0 (fewer fragment reads per MFMA, and 2.75 instead of 3.4 rounds of 256
+    workgroups at the 8-rank token count); the padding rows are zero (weight and bias), so the padded hidden columns are gelu(0) = 0,
+    FFN-down reads the first `f` columns through the row stride, and every real element is the same K-ordered accumulation as before
+    (the result does not depend on the tile width: tests/test_gpu_dit.py)."""
+    fp = -(-f // 320) * 320
+    return fp if (fp - f) * 100 <= 3 * f and os.environ.get("WF_FFN_PAD", "1") != "0" else f
+
+
+def _pad_rows(t: torch.Tensor, rows: int) -> torch.Tensor:
+    if t.shape[0] == rows:
+        return t
+    pad = torch.zeros((rows - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    return torch.cat([t, pad], 0).contiguous()
+
+
 PROFILE_ATTN = None  # bench.py sets this to a list: (start, end) HIP events around every self-attention launch
 PROFILE_COMM = None  # bench.py (N > 1) sets this to a list: (start, end) HIP events around the compute stream's wait for a layer's K / V^T exchange
 
@@ -256,6 +273,8 @@ class WanTransformer3DModel:
             for n in ("ffn.0", "ffn.2"):
                 W[p + n + ".w"] = mat(p + n + ".weight")
                 W[p + n + ".b"] = vec(p + n + ".bias")
+            fp = ffn_padded_features(cfg.ffn_dim)  # zero rows so that FFN-up runs the 320-feature GEMM tile
+            W[p + "ffn.0.w"], W[p + "ffn.0.b"] = _pad_rows(W[p + "ffn.0.w"], fp), _pad_rows(W[p + "ffn.0.b"], fp)
             W[p + "modulation"] = vec(p + "modulation").reshape(6, cfg.dim).contiguous()
         self.w = W
         return self
@@ -335,7 +354,8 @@ class WanTransformer3DModel:
             for n in ("norm_q", "norm_k", "norm_k_img"):
                 W[p + "cross_attn." + n] = vec(d, 0.05, 1.0)
             W[p + "norm3.w"], W[p + "norm3.b"] = vec(d, 0.05, 1.0), vec(d)
-            W[p + "ffn.0.w"], W[p + "ffn.0.b"] = mat(f, d), vec(f)
+            fp = ffn_padded_features(f)
+            W[p + "ffn.0.w"], W[p + "ffn.0.b"] = _pad_rows(mat(f, d), fp), _pad_rows(vec(f), fp)
             W[p + "ffn.2.w"], W[p + "ffn.2.b"] = mat(d, f), vec(d)
             W[p + "modulation"] = vec(6 * d, 1.0 / math.sqrt(d)).reshape(6, d).contiguous()
         self.w = W
@@ -349,7 +369,8 @@ class WanTransformer3DModel:
         return shard_plan(L, self.comm.world).local_tokens(self.comm.rank)
 
     def param_bytes(self) -> int:
-        return sum(t.numel() * t.element_size() for t in self.w.values())
+        pad = ffn_padded_features(self.cfg.ffn_dim) - self.cfg.ffn_dim  # zero rows of FFN-up (weight bf16 + bias f32) are layout, not parameters
+        return sum(t.numel() * t.element_size() for t in self.w.values()) - self.cfg.num_layers * pad * (self.cfg.dim * 2 + 4)
 
     # ------------------------------------------------------------------------------------------------------------
     # workspaces (allocated once per token count; everything stays resident in HBM)
@@ -557,7 +578,7 @@ class WanTransformer3DModel:
             km_all = _buf("kmax2_all", (comm.world, H), f32) if prescale else None
         ao = _buf("ao", (L, d), bf)
         qc = _buf("qc", (L, d), bf)
-        ffh = _buf("ffh", (L, cfg.ffn_dim), bf)
+        ffh = _buf("ffh", (L, ffn_padded_features(cfg.ffn_dim)), bf)
         Lt, Li = cfg.text_len, _pad64(n_img)
         # the two cross-attentions of a layer (image context, then text context, summed: model.py:220-227) as ONE launch over a concatenated
         # key / value buffer [image tiles | text tiles] (wf_attn_cross2_fwd; bit-identical to the two launches, WF_CROSS_FUSED=0 keeps those)
@@ -715,7 +736,7 @@ class WanTransformer3DModel:
             # ---- FFN (model.py:311-313) ----
             self._ln(x, emod[4], emod[3], hbuf, cfg.eps, plus_one=True)
             gemm(hbuf, W[p + "ffn.0.w"], W[p + "ffn.0.b"], ffh, EPI_BF16_GELU)
-            gemm(ffh, W[p + "ffn.2.w"], W[p + "ffn.2.b"], x, EPI_RESID, gate=emod[5])
+            gemm(ffh[:, :cfg.ffn_dim], W[p + "ffn.2.w"], W[p + "ffn.2.b"], x, EPI_RESID, gate=emod[5])
 
         # ---- head (model.py:337-347) + unpatchify (:584-607) ----
         hm = _buf("hm", (2, d), f32)
