@@ -8,7 +8,7 @@ python bench.py --workload longcat --distill --steps 5 --no-cpu-baseline > gpuru
 python tools/longcat_bench.py --refine > gpurun_out/r3/w_longcat_refine.txt 2>&1; tail -5 gpurun_out/r3/w_longcat_refine.txt
 python - <<'PY'
 import json
-for n in ("k_c3_bench","k_longcat_bench","k_longcat_distill_bench"):
+for n in ("w_c3_bench","w_longcat_bench","w_longcat_distill_bench"):
     try:
         d=json.load(open(f"gpurun_out/r3/{n}.json")); print(n, round(d["value"],4), d.get("guided_step_ms"), d.get("plain_step_ms"), d.get("roofline",{}).get("achieved"), d.get("job50_steps_per_s"), d.get("job16_steps_per_s"))
     except Exception as e: print(n, "ERR", e)
