@@ -60,6 +60,84 @@ __device__ __forceinline__ size_t out_pixel(const ConvArgs& a, long m) {
   return ((size_t)t * a.oH + (size_t)(a.osy * y + a.ooy)) * a.oW + (size_t)(a.osx * x + a.oox);
 }
 
+// Epilogue of the implicit-GEMM kernels (k_conv, k_conv_pp): wave tile 3 x 2 MFMA tiles, lane = pixel l31 of each 32-pixel block, 4
+// consecutive output channels per (i, g).  The twelve bias quads of the lane are loaded in ONE batch (tested and loaded per store group
+// they were 24 L2 round trips waited one at a time -- on the small-K layers these kernels serve that was a large part of the tile), and
+// the optional operands (residual, fp32 / bf16 output, the time-split destination) are tile-uniform, so the store loop is instantiated per
+// combination and dispatched once (run-time tests inside the loop are ~4 scalar branches per store group: tools/isa_audit.py).
+template <int R, int F, int H, int TS, class OutPixel>
+__device__ __forceinline__ void conv_store_wave_tile(const ConvArgs& a, const f32x16 (&acc)[3][2], long m_first, long M, int n0, int l31, int hi,
+                                                     OutPixel out_pixel_of) {
+  // R / F / H / TS: 0 absent, 1 present, 2 decide at run time
+  const bool has_resid = R == 2 ? a.resid != nullptr : R == 1;
+  const bool has_f32 = F == 2 ? a.out_f32 != nullptr : F == 1;
+  const bool has_bf16 = H == 2 ? a.out_bf16 != nullptr : H == 1;
+  const bool tsplit = TS == 2 ? a.tsplit != 0 : TS == 1;
+  f32x4 bq[3][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bq[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (a.bias) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bq[i][g] = *reinterpret_cast<const f32x4*>(a.bias + min(n0 + i * 32 + 8 * g + 4 * hi, a.Cout - 4));
+  }
+  const int chalf = a.Cout >> 1;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const long m = m_first + j * 32 + l31;
+    if (m >= M) continue;
+    const long hw = (long)a.Ho * a.Wo;
+    const long tt = tsplit ? m / hw : 0, pix = tsplit ? m - tt * hw : 0;
+    const size_t opix = tsplit ? 0 : out_pixel_of(m);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = n0 + i * 32 + 8 * g + 4 * hi;
+        if (__builtin_expect(co >= a.Cout, 0)) continue;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q] + bq[i][g][q];
+        size_t o;
+        if (tsplit) {
+          const int half = co >= chalf ? 1 : 0;
+          o = ((size_t)(1 + 2 * tt + half) * hw + pix) * chalf + (co - half * chalf);
+        } else {
+          o = opix * a.Cout + co;
+        }
+        if (has_resid) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(a.resid + o);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += rr[q];
+        }
+        if (has_f32) {
+          f32x4 ov = {v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(a.out_f32 + o) = ov;
+        }
+        if (has_bf16) {
+          u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(a.out_bf16 + o) = pk;
+        }
+      }
+    }
+  }
+}
+template <class OutPixel>
+__device__ __forceinline__ void conv_store_dispatch(const ConvArgs& a, const f32x16 (&acc)[3][2], long m_first, long M, int n0, int l31, int hi,
+                                                    OutPixel out_pixel_of) {
+  if (a.out_f32 && !a.out_bf16 && !a.tsplit) {
+    if (a.resid)
+      conv_store_wave_tile<1, 1, 0, 0>(a, acc, m_first, M, n0, l31, hi, out_pixel_of);
+    else
+      conv_store_wave_tile<0, 1, 0, 0>(a, acc, m_first, M, n0, l31, hi, out_pixel_of);
+  } else {
+    conv_store_wave_tile<2, 2, 2, 2>(a, acc, m_first, M, n0, l31, hi, out_pixel_of);
+  }
+}
+
 __global__ __launch_bounds__(CNT, 2) void k_conv(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -183,50 +261,7 @@ __global__ __launch_bounds__(CNT, 2) void k_conv(ConvArgs a) {
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------------------------
-  const int chalf = a.Cout >> 1;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const long m = m0 + wid * 64 + j * 32 + l31;
-    if (m >= M) continue;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = n0 + i * 32 + 8 * g + 4 * hi;
-        if (co >= a.Cout) continue;
-        float v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q];
-        if (a.bias) {
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + co);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] += bb[q];
-        }
-        size_t o;
-        if (a.tsplit) {
-          const long hw = (long)a.Ho * a.Wo;
-          const long t = m / hw, pix = m - t * hw;
-          const int half = co >= chalf ? 1 : 0;
-          o = ((size_t)(1 + 2 * t + half) * hw + pix) * chalf + (co - half * chalf);
-        } else {
-          o = out_pixel(a, m) * a.Cout + co;
-        }
-        if (a.resid) {
-          const f32x4 rr = *reinterpret_cast<const f32x4*>(a.resid + o);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] += rr[q];
-        }
-        if (a.out_f32) {
-          f32x4 ov = {v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(a.out_f32 + o) = ov;
-        }
-        if (a.out_bf16) {
-          u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(a.out_bf16 + o) = pk;
-        }
-      }
-    }
-  }
+  conv_store_dispatch(a, acc, m0 + wid * 64, M, n0, l31, hi, [&](long m) { return out_pixel(a, m); });
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -474,41 +509,7 @@ __global__ __launch_bounds__(QT, 2) void k_conv_pp(ConvPPArgs pa) {
   }
 
   // ---- epilogue (as k_conv) ---------------------------------------------------------------------------------------------------
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const long m = m0 + wid * 64 + j * 32 + l31;
-    if (m >= M) continue;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = n0 + i * 32 + 8 * g + 4 * hi;
-        if (co >= a.Cout) continue;
-        float v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q];
-        if (a.bias) {
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + co);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] += bb[q];
-        }
-        const size_t o = out_pixel(a, m) * a.Cout + co;
-        if (a.resid) {
-          const f32x4 rr = *reinterpret_cast<const f32x4*>(a.resid + o);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] += rr[q];
-        }
-        if (a.out_f32) {
-          f32x4 ov = {v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(a.out_f32 + o) = ov;
-        }
-        if (a.out_bf16) {
-          u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(a.out_bf16 + o) = pk;
-        }
-      }
-    }
-  }
+  conv_store_dispatch(a, acc, m0 + wid * 64, M, n0, l31, hi, [&](long m) { return out_pixel(a, m); });
 }
 
 // ------------------------------------------------------------------------------------------------------------------
