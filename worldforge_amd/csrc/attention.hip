@@ -246,18 +246,31 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
   int st_tile = 0, st_left = tiles_per_seg - in0;  // tile number (in the split), tiles left in its segment
   uint32_t st_base = wu * 4096;                    // LDS byte offset of this wave's pieces in the ring slot of the staged tile
   int e_stage = 0, e_mask = 0;                     // KIND 3: list entry of the tile being staged / of the tile whose scores come next
+  // KIND 3: the list entries are read ONE SELECTION AHEAD (e_pref: the un-waited load of the entry the next stage_next will need) and the
+  // entry of the tile whose scores come next is remembered from when that tile was staged (e_q: entries of tiles t+1, t+2, t+3) -- a
+  // load that is used right away is waited for with vmcnt(0), which also waits for every LDS-DMA piece in flight: two such waits per
+  // tile were ~a quarter of the block-sparse loop (tools/isa_audit.py: "loads waited singly")
+  int e_pref = 0, e_q[3] = {0, 0, 0};
+  const int n_entries = KIND == 3 ? ntiles / tpe : 1;
+  auto entry_index = [&](int tile) { return min(tpe == 2 ? (tile >> 1) : tile, n_entries - 1); };
   if constexpr (KIND == 3) {
     e_stage = __builtin_amdgcn_readfirstlane(bsa[0]);
     st_off = (size_t)(e_stage >> a.bsa_shift) * tpe * tile_bytes;
+    e_q[0] = e_q[1] = e_q[2] = e_stage;
+    e_pref = bsa[entry_index(1)];
   }
   auto stage_next = [&]() {  // select tile st_tile + 1.  Branch-free on purpose: the same bookkeeping with a rarely-taken branch for the
     ++st_tile;               // segment / end-of-split cases (3 scalar instructions + s_cbranch in the common case) measured 22 cycles per tile SLOWER
     const bool live = st_tile < ntiles;
     if constexpr (KIND == 3) {
       if (live) {
-        if ((st_tile & (tpe - 1)) == 0) e_stage = __builtin_amdgcn_readfirstlane(bsa[tpe == 2 ? (st_tile >> 1) : st_tile]);
+        e_stage = __builtin_amdgcn_readfirstlane(e_pref);  // = bsa[entry_index(st_tile)], loaded one selection ago
         st_off = ((size_t)(e_stage >> a.bsa_shift) * tpe + (st_tile & (tpe - 1))) * tile_bytes;
       }
+      e_pref = bsa[entry_index(st_tile + 1)];  // unconditional (clamped): consumed by the next selection
+      e_q[0] = e_q[1];
+      e_q[1] = e_q[2];
+      e_q[2] = e_stage;
       st_base = st_base + BUF_BYTES >= (uint32_t)(NBUF * BUF_BYTES) ? st_base + BUF_BYTES - NBUF * BUF_BYTES : st_base + BUF_BYTES;
       return;
     }
@@ -580,10 +593,7 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
 #endif
       if constexpr (g == 0) {
         stage_next();  // tile t + 3 (or trash): scalar bookkeeping, in the shadow of the first MFMA
-        if constexpr (KIND == 3) {  // the entry of tile t + 1 (its scores are produced in this tile and masked at gap 51)
-          const int tn = t + 1 < ntiles ? t + 1 : t;
-          e_mask = __builtin_amdgcn_readfirstlane(bsa[tpe == 2 ? (tn >> 1) : tn]);
-        }
+        if constexpr (KIND == 3) e_mask = e_q[0];  // the entry of tile t + 1 (its scores are produced in this tile and masked at gap 51)
       }
 #if WF_ATTN_DMA_PLACE == 0
       if constexpr (g >= 2 && g < 32 && (g & 3) == 2) stage_piece_c(std::integral_constant<int, ((g - 2) >> 2)>{});
