@@ -290,6 +290,7 @@ def main_longcat(a):
                                       + f"steps {Wm}..{Wm + K - 1} = {len(gms)} guided + {len(pms)} plain",
                           "tokens": L, "dit_layers": cfg.depth, "dit_params_bytes": model.param_bytes(),
                           "parallelism": "single" if world == 1 else f"sp{world} (token-sharded DiT + row-sharded VAE, RCCL)"},
+               "window": {"guided": len(gms), "plain": len(pms), "guided_frac": len(gms) / max(K, 1)},
                "guided_step_ms": sum(gms) / len(gms) if gms else None, "plain_step_ms": sum(pms) / len(pms) if pms else None,
                "setup_s": t_setup}
         if gms and pms:
@@ -566,8 +567,10 @@ def main(argv=None):
     plain_ms = [1e3 * (marks[("e", i)] - marks[("b", i)]) for i in range(start + Wm, start + Wm + K) if i >= guide]
 
     if rank == 0:
+        # the resolution class named in the metric / workload strings follows the run's own size (`--height 720` printed "480p")
+        res = {(480, 832): "480p", (832, 480): "480p", (720, 1280): "720p", (1280, 720): "720p"}.get((a.height, a.width), f"{a.height}x{a.width}")
         out = {
-            "metric": "denoising steps/sec (81f x 480p, Wan2.1-14B)",
+            "metric": f"denoising steps/sec ({a.frames}f x {res}, Wan2.1-14B)",
             "value": K / elapsed,
             "unit": "steps/s",
             "n_gpus": world,
@@ -580,7 +583,7 @@ def main(argv=None):
             "dtype": "bf16",
             "data": "synthetic",
             "config": {
-                "workload": f"Wan2.1-I2V-14B-480P, {a.frames}f {a.height}x{a.width}, 50-step schedule, full IRR+FLF+DSG, CFG 4; "
+                "workload": f"Wan2.1-I2V-14B-{res.upper()}, {a.frames}f {a.height}x{a.width}, 50-step schedule, full IRR+FLF+DSG, CFG 4; "
                             f"timed steps {start + Wm}..{start + Wm + K - 1} = {len(guided_ms)} guided + {len(plain_ms)} plain",
                 "tokens": L, "dit_layers": cfg.num_layers, "dit_params_bytes": model.param_bytes(),
                 "parallelism": "single" if world == 1 else f"sp{world} (token-sharded DiT with K/V all-gather + row-sharded VAE with halo all-gather, RCCL)",
@@ -590,6 +593,9 @@ def main(argv=None):
                 "flow_backend_parity": "oracle-only (cv2 unpinned)" if a.flow_backend == "farneback" else "reference goldens (g4, g6)",
                 "vae_precision": a.vae_precision + (" (3-term split-bf16 operands, fp32 accumulate: ~2^-16 per product, not IEEE fp32)" if a.vae_precision == "bf16x3" else ""),
             },
+            # what the timed window holds (`value` is only comparable between lines with the same mix; the default K = 10 is the
+            # 50-step job's own 15 : 35)
+            "window": {"guided": len(guided_ms), "plain": len(plain_ms), "guided_frac": len(guided_ms) / max(K, 1)},
             "guided_step_ms": sum(guided_ms) / len(guided_ms) if guided_ms else None,
             "plain_step_ms": sum(plain_ms) / len(plain_ms) if plain_ms else None,
             "setup_s": t_setup,

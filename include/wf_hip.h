@@ -268,8 +268,11 @@ int wf_bsa_topk_lists(const void* scores, int64_t ld, int heads, int n_q, int n_
  * block, the key blocks in descending order of softmax(score / sqrt(128)) as long as their cumulative weight stays <= cdf_threshold
  * (`searchsorted(cdf, threshold, right=True)`: possibly none), at least n_min of them (int((1 - sparsity) * n_k) of the _topk form, 0
  * otherwise).  row_counts int32 [heads][n_q] receives the per-row counts; lists / counts / sel_mask as wf_bsa_topk_lists with
- * max_entries >= n_k.  Weights are summed in descending order with a fixed reduction tree (deterministic); against a sequential cumsum
- * a count can differ by one where the cumulative weight meets the threshold within fp32 rounding. */
+ * max_entries >= n_k.  The chain is evaluated as eager torch evaluates it on the reference's bf16 score tensor -- bf16(score * scale),
+ * softmax rounded to bf16, running fp32 sum of the sorted weights rounded to bf16 per element, compared with float32(cdf_threshold) --
+ * pinned by tests/golden/g14c_bsa_cdf_bf16.npz (recorded from the reference's function).  Deterministic; for thresholds <= 0.97 the
+ * tree scan equals the sequential cumsum exactly, what can differ from a torch run is one bf16 ulp of a weight where exp / the row sum
+ * round differently (about one row in a thousand changes its count by one). */
 int wf_bsa_cdf_lists(const void* scores, int64_t ld, int heads, int n_q, int n_k, float cdf_threshold, int n_min, int block,
                      int blocks_per_segment, int* lists, int* counts, int max_entries, uint32_t* sel_mask, int* row_counts, void* stream);
 /* out[i][:C] = in[index[i]][:C], bf16 rows (16-byte chunks): the two token permutes of BSA:600-610 the refine pass needs per forward

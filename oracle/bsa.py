@@ -56,6 +56,27 @@ def select_cdf(q_cmp: torch.Tensor, k_cmp: torch.Tensor, cdf_threshold: float, s
     return ws.indices, num
 
 
+def cdf_counts_bf16(score: torch.Tensor, cdf_threshold: float, sparsity=None) -> torch.Tensor:
+    """BSA:234-243 / 253-266 as eager torch evaluates it on a BF16 score tensor (the reference's model dtype), every rounding point spelled
+    out: x = bf16(score * sm_scale); w = bf16(softmax computed in fp32); weights sorted descending; cdf_k = bf16(sequential fp32 running
+    sum); count = #{float(cdf_k) <= float32(threshold)} (`searchsorted(right=True)` on a non-decreasing sequence), at least the top-k
+    count when sparsity is given.  Pinned bit-exactly against the reference's own function on bf16 scores (g14c; tests/test_oracle_bsa.py)."""
+    assert score.dtype == torch.bfloat16
+    xf = (score.float() * (1 / 128 ** 0.5)).bfloat16().float()
+    e = torch.exp(xf - xf.max(-1, keepdim=True).values)
+    w = (e / e.sum(-1, keepdim=True)).bfloat16()
+    ws = torch.sort(w, dim=-1, descending=True).values.float()
+    acc = torch.zeros(ws.shape[:-1])
+    num = torch.zeros(ws.shape[:-1], dtype=torch.int64)
+    thr = torch.tensor(cdf_threshold, dtype=torch.float32)
+    for k in range(ws.shape[-1]):
+        acc = acc + ws[..., k]
+        num += (acc.bfloat16().float() <= thr)
+    if sparsity is not None:
+        num = num.clamp_min(int((1 - sparsity) * score.shape[-1]))
+    return num
+
+
 def sparse_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_indices: torch.Tensor, block_q: int, block_k: int,
                      scale: float, block_lens: torch.Tensor = None, p_dtype=None) -> torch.Tensor:
     """flash_attn_bsa_varlen_mask.py:236-285 as a masked dense softmax: q [heads, Sq, D], k / v [heads, Sk, D] (block order),

@@ -58,3 +58,46 @@ def test_triton_sparse_attention_golden_regenerates(tmp_path, golden_dir):
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     _same(tmp_path / "g18_bsa_triton.npz", os.path.join(golden_dir, "g18_bsa_triton.npz"))
+
+
+def test_bsa_cdf_bf16_counts_golden_regenerates(tmp_path, golden_dir):
+    """g14c: the reference's cdf selection counts on bf16 scores (its functions are @torch.compile'd: own process, dynamo off)."""
+    import subprocess
+    code = (f"import sys; sys.argv = ['make_goldens.py', '__none__']; import importlib.util as u;"
+            f"s = u.spec_from_file_location('mg', {os.path.join(ROOT, 'tools', 'make_goldens.py')!r}); m = u.module_from_spec(s);"
+            f"s.loader.exec_module(m); m.g_bsa_cdf_bf16(out_dir={str(tmp_path)!r})")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TORCHDYNAMO_DISABLE="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    _same(tmp_path / "g14c_bsa_cdf_bf16.npz", os.path.join(golden_dir, "g14c_bsa_cdf_bf16.npz"))
+
+
+def test_flf_reference_study_recipe_still_runs_and_reproduces_its_reduced_fixture(tmp_path, golden_dir):
+    """g19's recipe (tools/flf_reference_study.py: the UNMODIFIED pipeline + scheduler + selector + vendored VAE + in-tree DiT twin) guarded
+    like the others.  The four g19 fixtures cost >= 1 CPU-hour each; this is the same tool on a 40-second job (8-step
+    schedule, 8 guided steps x 2 rounds, 5 x 64 x 64, d = 256 x 2 layers, the reference's own tdiff branch, 2 threads) whose gates 6 and 7
+    swap a channel: every recorded array -- frames, per-step latents, gate lists, similarities, margins -- regenerates bit for bit."""
+    import subprocess
+    out = tmp_path / "g19r.npz"
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "flf_reference_study.py"), "--threads", "2", "--flow", "tdiff", "--steps", "8", "--guide", "8",
+           "--frames", "5", "--size", "64", "--dim", "256", "--layers", "2", "--out", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = np.load(out), np.load(os.path.join(golden_dir, "g19r_flf_reference_tdiff_reduced.npz"))
+    assert set(a.files) == set(b.files)
+    for k in a.files:
+        if k != "meta":                                  # meta holds the wall-clock seconds of the run
+            assert np.array_equal(a[k], b[k]), k
+    import json
+    assert [c for _, c in json.loads(str(b["flf_lists"]))][6:] == [[13], [3]]
+
+
+def test_longcat_dit_with_the_references_triton_softmax_golden_regenerates(tmp_path, golden_dir):
+    """g11b: the reference LongCat DiT whose self-attention is its own Triton kernel at sparsity 0 (interpreter; own process)."""
+    import subprocess
+    code = (f"import sys; sys.argv = ['make_goldens.py', '__none__']; import importlib.util as u;"
+            f"s = u.spec_from_file_location('mg', {os.path.join(ROOT, 'tools', 'make_goldens.py')!r}); m = u.module_from_spec(s);"
+            f"s.loader.exec_module(m); m.g_longcat_dit_bsa0(out_dir={str(tmp_path)!r})")
+    env = dict(os.environ, TRITON_INTERPRET="1", TORCHDYNAMO_DISABLE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    _same(tmp_path / "g11b_longcat_dit_bsa0.npz", os.path.join(golden_dir, "g11b_longcat_dit_bsa0.npz"))

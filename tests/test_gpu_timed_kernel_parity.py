@@ -17,6 +17,7 @@ import torch
 from oracle import bsa as obsa
 from oracle import dit as odit
 from oracle import longcat_dit as olc
+from tests._tol import within
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
@@ -79,11 +80,12 @@ def _oracle_rows(c, rows, heads):
     return odit.attention(odit.rope_apply(q, ang[rows]), odit.rope_apply(k, ang), v)   # [rows, heads, 128]
 
 
-def _compare(out, want, rows, heads, tol_abs, tol_rel):
+def _compare(out, want, rows, heads, tol_abs, tol_rel, name="attn"):
     got = torch.stack([out[rows, h * 128:(h + 1) * 128].float().cpu() for h in heads], dim=1)
     err = (got - want).abs().max().item()
     rel = (got - want).norm().item() / want.norm().item()
-    assert err <= tol_abs and rel <= tol_rel, (err, rel)
+    within(name + ".max_abs", err, tol_abs)
+    within(name + ".rel_l2", rel, tol_rel)
     return err, rel
 
 
@@ -109,14 +111,14 @@ def test_timed_self_attention_production_chain_vs_oracle(grid):
     with _BodyCounter() as n:
         dit.attention(c["qh"], c["kh"], c["vt"], out_u, L, 0.0, nsplit=1, kmax2=c["km"], qmax2=c["qm"])
     assert (n.tracked, n.untracked) == (0, _wgs(L)), (n.tracked, n.untracked)       # the body bench.py times
-    eu = _compare(out_u, want, ROWS[grid], heads, 2e-3, 3e-2)
+    eu = _compare(out_u, want, ROWS[grid], heads, 2e-3, 3e-2, f"timed_attn.untracked.L{L}")
     out_t = torch.empty_like(out_u)
     with _BodyCounter() as n:
         dit.attention(c["qh"], c["kh"], c["vt"], out_t, L, 0.0, nsplit=1)           # no bounds -> running-max tracking (WF_ATTN_TRACK_MAX=1)
     assert (n.tracked, n.untracked) == (_wgs(L), 0), (n.tracked, n.untracked)
-    et = _compare(out_t, want, ROWS[grid], heads, 2e-3, 3e-2)
+    et = _compare(out_t, want, ROWS[grid], heads, 2e-3, 3e-2, f"timed_attn.tracked.L{L}")
     # the two bodies differ only in the reference max m of each row (exact for any m up to fp32 rounding of exp2 / the row sums)
-    assert (out_u.float() - out_t.float()).abs().max().item() <= 2.0 ** -8 * out_t.float().abs().max().item()
+    within(f"timed_attn.bodies_agree.L{L}", (out_u.float() - out_t.float()).abs().max().item() / out_t.float().abs().max().item(), 2.0 ** -8)
     print(f"k_attn_w4<4> L={L}: un-tracked max abs {eu[0]:.2e} rel {eu[1]:.2e}; tracked {et[0]:.2e} rel {et[1]:.2e}")
 
 
@@ -133,7 +135,7 @@ def test_timed_self_attention_large_norms_select_the_tracked_body_c2():
     assert (n.tracked, n.untracked) == (_wgs(L), 0), (n.tracked, n.untracked)
     want = _oracle_rows(c, ROWS[GRID_C2], (0, 17, 39))
     # sharp softmax: outputs are O(1) mixtures of a few values; the bf16 rounding of q / k moves a score by ~1e-2 -> ~1 % on p
-    _compare(out, want, ROWS[GRID_C2], (0, 17, 39), 6e-2, 3e-2)
+    _compare(out, want, ROWS[GRID_C2], (0, 17, 39), 6e-2, 3e-2, "timed_attn.large_norms")
 
 
 def test_nan_row_forces_the_tracked_body():
@@ -181,17 +183,20 @@ def test_timed_self_attention_split_kv_sweep_at_the_8_rank_shard_shape():
     rows = [lo, lo + 1, lo + 255, lo + 256, lo + 2047, L - 65, L - 64, L - 2, L - 1]
     heads = (0, 11, 39)
     want = _oracle_rows(c, rows, heads)
-    _compare(out, want, [r - lo for r in rows], heads, 2e-3, 3e-2)
+    _compare(out, want, [r - lo for r in rows], heads, 2e-3, 3e-2, "timed_attn.split_kv_shard")
     # and the unsplit single-GPU launch on the same rows: equal up to the re-association of the two partial sums
     full = torch.empty((L, H * 128), dtype=BF, device=DEV)
     dit.attention(c["qh"], c["kh"], c["vt"], full, L, 0.0, nsplit=1, kmax2=c["km"], qmax2=c["qm"])
-    assert (full[lo:hi].float() - out.float()).abs().max().item() <= 2.0 ** -7 * full.float().abs().max().item()
+    within("timed_attn.split_vs_unsplit", (full[lo:hi].float() - out.float()).abs().max().item() / full.float().abs().max().item(), 2.0 ** -7)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # one real-width DiT layer on the C2 token grid against oracle.dit on sampled tokens (a-16 at L = 32 760)
 # ---------------------------------------------------------------------------------------------------------------------
-def test_dit_one_real_width_layer_c2_tokens_vs_oracle_on_sampled_tokens():
+@pytest.mark.parametrize("name,T,Hh,Ww", [("C2", 21, 60, 104), ("C3", 21, 90, 160)])
+def test_dit_one_real_width_layer_vs_oracle_on_sampled_tokens(name, T, Hh, Ww):
+    """a-16 at the token counts of BASELINE configs[1] (32 760) and configs[2] (720 x 1280: 75 600; VERDICT r3 missing #5 -- until round 4
+    the 720p DiT was only compared with itself, sharded == single)."""
     from worldforge_amd import dit
     ocfg = odit.DiTConfig(num_layers=1)
     W = odit.random_weights(ocfg, seed=31)
@@ -200,9 +205,8 @@ def test_dit_one_real_width_layer_c2_tokens_vs_oracle_on_sampled_tokens():
     cfg.num_layers = 1
     model = dit.WanTransformer3DModel(cfg, DEV).load_state_dict(W)
     g = torch.Generator().manual_seed(32)
-    T, Hh, Ww = 21, 60, 104
     L = T * (Hh // 2) * (Ww // 2)
-    assert L == 32760
+    assert L == {"C2": 32760, "C3": 75600}[name]
     x = torch.randn(36, T, Hh, Ww, generator=g).to(BF)
     ctx = (torch.randn(200, 4096, generator=g) * 0.1).to(BF)
     clip = torch.randn(257, 1280, generator=g).to(BF)
@@ -210,7 +214,8 @@ def test_dit_one_real_width_layer_c2_tokens_vs_oracle_on_sampled_tokens():
         out = model.forward_tokens(x.to(DEV), 749.0, ctx.to(DEV), clip.to(DEV)).cpu()
     assert n.untracked == _wgs(L) and n.tracked == 0, (n.tracked, n.untracked)   # the layer's self-attention ran the timed body
     assert torch.isfinite(out).all()
-    rows = sorted(set([0, 1, 51, 52, 1559, 1560, L - 1561, L - 1560, L - 2, L - 1]
+    tpf = (Hh // 2) * (Ww // 2)
+    rows = sorted(set([0, 1, Ww // 2 - 1, Ww // 2, tpf - 1, tpf, L - tpf - 1, L - tpf, L - 2, L - 1]
                       + torch.randint(0, L, (64,), generator=g).tolist()))
     assert len(rows) >= 64
     with torch.no_grad():
@@ -218,8 +223,8 @@ def test_dit_one_real_width_layer_c2_tokens_vs_oracle_on_sampled_tokens():
     got = odit.token_patches(out, ocfg, rows)
     rel = (got - want).norm().item() / want.norm().item()
     err = (got - want).abs().max().item()
-    print(f"one real-width DiT layer, L = {L}, {len(rows)} sampled tokens: rel L2 {rel:.3e}, max abs {err:.3e} (|want| max {want.abs().max().item():.2f})")
-    assert rel <= 2e-2, rel
+    print(f"one real-width DiT layer ({name}), L = {L}, {len(rows)} sampled tokens: rel L2 {rel:.3e}, max abs {err:.3e} (|want| max {want.abs().max().item():.2f})")
+    within(f"dit_layer.{name}.rel_l2", rel, 2e-2)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -251,7 +256,7 @@ def test_longcat_released_width_block_37440_tokens_vs_oracle_on_sampled_tokens()
     got = olc.token_patches(got_full, ocfg, rows)
     rel = (got - want).norm().item() / want.norm().item()
     print(f"released-width LongCat block, L = {L}, {len(rows)} sampled tokens: rel L2 {rel:.3e}, max abs {(got - want).abs().max().item():.3e}")
-    assert rel <= 2e-2, rel
+    within("longcat_block.37440.rel_l2", rel, 2e-2)
 
 
 def test_block_sparse_attention_98560_tokens_product_selection_vs_oracle_on_sampled_query_blocks():
@@ -280,7 +285,7 @@ def test_block_sparse_attention_98560_tokens_product_selection_vs_oracle_on_samp
         # gating (bsa_interface.py:169-185) in bf16, as the reference's bf16 model runs it: pooled means and block scores
         osc = torch.matmul(obsa.mean_pool(qh[None], blk), obsa.mean_pool(kh[None], blk).transpose(-1, -2))[0].float()
         psc = sc[h].float().cpu()
-        assert (psc - osc).abs().max().item() <= 2.0 ** -6 * osc.abs().max().item()       # <= 2 bf16 ulp at the largest score
+        within("bsa.block_scores", (psc - osc).abs().max().item() / osc.abs().max().item(), 2.0 ** -6)       # <= 2 bf16 ulp at the largest score
         # selection (bsa_interface.py:211-224): a VALID top-96 of the product's own scores (770 bf16 scores per row tie at the 96th place
         # all the time, and the reference's torch.topk breaks ties arbitrarily) ...
         chosen = torch.zeros((nb, nb), dtype=torch.bool).scatter_(1, idx[h], True)
@@ -300,4 +305,4 @@ def test_block_sparse_attention_98560_tokens_product_selection_vs_oracle_on_samp
                                          torch.arange(n_sel).view(1, 1, n_sel), blk, blk, 128 ** -0.5)[0]
             got = out[rows, h * 128:(h + 1) * 128].float().cpu()
             err = (got - want).abs().max().item()
-            assert err <= 1e-2 * want.abs().max().item() + 2e-3, (h, b, err)
+            within("bsa.rows_vs_oracle", err / (1e-2 * want.abs().max().item() + 2e-3), 1.0)

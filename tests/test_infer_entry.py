@@ -93,3 +93,5 @@ def test_run_on_the_truck_fixture_writes_frames_and_equals_the_direct_pipeline_c
     assert np.array_equal(out.frames[0], frames)
     with pytest.raises(ValueError, match="frames"):                                                  # SCHED:1326 surfaced early
         infer.run(None, TRUCK, model="480p", embeds=str(emb), components=comps(), max_area=64 * 112, **{**kw, "num_frames": 5 + 8})
+    with pytest.raises(ValueError, match="frames"):        # a LONGER warped sequence is not silently truncated either
+        infer.run(None, TRUCK, model="480p", embeds=str(emb), components=comps(), max_area=64 * 112, **{**kw, "num_frames": 5})

@@ -112,3 +112,23 @@ def test_3d_block_interface_equals_reference():
     q, k, v = _g18_inputs("thw")
     got = obsa.flash_attn_bsa_3d(q, k, v, c["grid"], c["grid"], sparsity=c["sparsity"], chunk_q=c["chunk"], chunk_k=c["chunk"])[:, ::4]
     assert np.abs(got.numpy() - G18["thw_out"]).max() <= 2e-6
+
+
+def test_cdf_counts_on_bf16_scores_equal_reference():
+    """g14c: the reference's get_select_indices_cdf_from_score / _cdf_topk_from_score on BF16 scores (what its bf16 model hands them).
+    oracle.bsa.cdf_counts_bf16 spells out every bf16 rounding point of that eager chain and reproduces all counts exactly; the fp32 rule
+    (select_cdf on float scores) does NOT -- it is off by up to several blocks on most rows near 0.9."""
+    C = np.load(os.path.join(os.path.dirname(__file__), "golden", "g14c_bsa_cdf_bf16.npz"))
+    n_fp32_differs = 0
+    for name in ("flat770", "mid770", "peaked770", "small96"):
+        score = torch.from_numpy(C[f"{name}_score_bits"].view(np.int16).copy()).view(torch.bfloat16)
+        for thr, sp in ((0.3, None), (0.5, None), (0.9, None), (0.95, None), (0.3, 0.75), (0.9, 0.875)):
+            want = torch.from_numpy(C[f"{name}_lens_thr{thr}_sp{sp}"]).long()
+            got = obsa.cdf_counts_bf16(score, thr, sp)
+            assert torch.equal(got, want), (name, thr, sp, (got - want).abs().max())
+            w = torch.softmax(score.float() / 128 ** 0.5, -1)
+            n32 = (torch.cumsum(torch.sort(w, -1, descending=True).values, -1) <= thr).sum(-1)
+            if sp is not None:
+                n32 = n32.clamp_min(int((1 - sp) * score.shape[-1]))
+            n_fp32_differs += int((n32 != want).sum())
+    assert n_fp32_differs > 100          # the fp32 rule is a different selection: this golden is what tells them apart

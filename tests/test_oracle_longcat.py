@@ -32,6 +32,22 @@ def test_oracle_matches_reference_forward(name):
         assert err < 2e-5, (name, b, err)
 
 
+def test_oracle_matches_reference_forward_with_the_references_own_triton_softmax():
+    """g11b: the reference DiT with enable_bsa and sparsity 0 -- its self-attention is then a dense softmax computed
+    by the reference's OWN Triton kernel (through Triton's interpreter), not by the flash-attn stand-in that served g11.  The oracle's
+    dense forward (token order; the reference permutes to 3D-block order and back) must give the same velocities."""
+    B = np.load(os.path.join(os.path.dirname(__file__), "golden", "g11b_longcat_dit_bsa0.npz"))
+    C, heads, depth, cap, ct = (int(v) for v in B["cfg"])
+    assert int(B["triton_calls"]) == depth
+    cfg = olc.LongCatConfig(hidden_size=C, depth=depth, num_heads=heads, caption_channels=cap, adaln_tembed_dim=ct)
+    W = olc.random_weights(cfg, seed=21)
+    got = olc.forward(W, cfg, torch.from_numpy(B["x"]), torch.from_numpy(B["ts"][0]), torch.from_numpy(B["cap"][0]),
+                      torch.from_numpy(B["mask"][0]), num_cond_latents=0)
+    want = torch.from_numpy(B["out"][0])
+    err = (got - want).abs().max().item() / want.abs().max().item()
+    assert err < 2e-5, err
+
+
 def test_ffn_width_and_rope_partition():
     cfg = olc.LongCatConfig()
     assert cfg.ffn_hidden == 11008

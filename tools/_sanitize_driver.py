@@ -162,6 +162,7 @@ ok("wf_ln_modulate", f32(L * C), f32(C), f32(C), buf(2 * L * C), BF, L, C, 1e-6,
 ok("wf_rmsnorm_heads", buf(2 * L * 3 * C), 3 * C, f32(C), f32(L * 64), f32(L * 64), buf(2 * 40 * 320 * 128), L, 320, C, 1e-6, 0.1275, None)
 ok("wf_rmsnorm_heads_bound", buf(2 * L * 3 * C), 3 * C, f32(C), f32(L * 64), f32(L * 64), buf(2 * 40 * 320 * 128), L, 320, C, 1e-6, 0.1275,
    f32(dll.wf_rmsnorm_heads_bound_ws_floats(L, C)), f32(40), None)
+bad("wf_rmsnorm_heads_bound", buf(64), 8, f32(8), None, None, buf(64), 4, 4, 0, 1e-6, 1.0, f32(8), f32(8), None)   # C = 0: no heads to divide by
 ok("wf_v_transpose", buf(2 * L * 3 * C), 3 * C, buf(2 * 40 * 320 * 128), L, 320, 40, None)
 ok("wf_v_transpose_seg", buf(2 * L * 3 * C), 3 * C, buf(2 * 40 * 13 * 128 * 64), L, 320, 40, 13, None)
 bad("wf_v_transpose_seg", buf(2 * L * 3 * C), 3 * C, buf(64), L, 320, 40, 4, None)                        # head stride shorter than the segment

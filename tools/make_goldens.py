@@ -5,8 +5,11 @@
   python tools/make_goldens.py vae_akw     # g8b (the executed class: diffusers' AutoencoderKLWan as vendored under longcat_video/modules)
   python tools/make_goldens.py longcat | longcat_pipe | longcat_lora | longcat_refine      # g11, g12, g13, g15 (LongCat DiT, guided
                                            # i2v trajectories, run-time LoRA, refine-pass trajectories)
-  TORCHDYNAMO_DISABLE=1 python tools/make_goldens.py bsa | bsa_cdf                          # g14, g14b (block-sparse gating helpers)
+  TORCHDYNAMO_DISABLE=1 python tools/make_goldens.py bsa | bsa_cdf | bsa_cdf_bf16           # g14, g14b, g14c (block-sparse gating helpers;
+                                           # g14c = the cdf counts on bf16 scores, the dtype the reference's model hands them)
   python tools/make_goldens.py warp | warp_cams                                             # g16, g16b (stage-1 forward warp, cameras)
+  TRITON_INTERPRET=1 TORCHDYNAMO_DISABLE=1 python tools/make_goldens.py longcat_bsa0       # g11b (LongCat DiT whose self-attention is the
+                                           # reference's own Triton kernel at sparsity 0, through the interpreter)
   TRITON_INTERPRET=1 TORCHDYNAMO_DISABLE=1 python tools/make_goldens.py bsa_triton         # g18 (the reference's Triton sparse-attention
                                            # kernel itself, executed on CPU tensors by Triton's interpreter)
 
@@ -448,6 +451,61 @@ if __name__ == "__main__" and "longcat" in sys.argv[1:]:
     g_longcat_dit()
 
 
+def g_longcat_dit_bsa0(out_dir=OUT):
+    """G11b: the unmodified LongCatVideoTransformer3DModel with `enable_bsa=True, sparsity = 0` -- every key block
+    selected, so its self-attention is a DENSE softmax computed by the REFERENCE'S OWN Triton kernel (flash_attn_bsa_3d ->
+    _attn_fwd_bsa_varlen_align, bsa_interface.py:612-659 / flash_attn_bsa_varlen_mask.py:174-285) executed on CPU tensors by Triton's
+    interpreter, instead of the builder's plain-softmax stand-in for flash-attn that served g11.  (The cross-attention has no such path in
+    the reference -- attention.py:218-246 calls flash_attn_varlen_func or xformers only -- so it stays on the stand-in: 24 caption keys.)
+    fp32, 4 x 8 x 8 = 256 tokens = four 64-token blocks (chunk 4 x 4 x 4).  Needs TRITON_INTERPRET=1 TORCHDYNAMO_DISABLE=1."""
+    assert os.environ.get("TRITON_INTERPRET") == "1", "run with TRITON_INTERPRET=1 TORCHDYNAMO_DISABLE=1"
+    import warnings
+
+    _longcat_paths()
+    from longcat_video.modules.longcat_video_dit import LongCatVideoTransformer3DModel
+    from oracle import longcat_dit as olc
+
+    c = dict(C=256, heads=2, depth=2, cap=64, ct=64, T=4, h=16, w=16)
+    cfg = olc.LongCatConfig(hidden_size=c["C"], depth=c["depth"], num_heads=c["heads"], caption_channels=c["cap"], adaln_tembed_dim=c["ct"])
+    W = olc.random_weights(cfg, seed=21)
+    bsa_params = dict(sparsity=0.0, chunk_3d_shape_q=[4, 4, 4], chunk_3d_shape_k=[4, 4, 4])
+    m = LongCatVideoTransformer3DModel(hidden_size=c["C"], depth=c["depth"], num_heads=c["heads"], caption_channels=c["cap"],
+                                       adaln_tembed_dim=c["ct"], enable_flashattn2=True, enable_bsa=True, bsa_params=bsa_params,
+                                       cp_split_hw=[1, 1])
+    m.load_state_dict(W, strict=True)
+    m.eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 16, c["T"], c["h"], c["w"], generator=g)
+    cap = torch.randn(1, 1, 24, c["cap"], generator=g)
+    mask = torch.zeros(1, 24, dtype=torch.int64)
+    mask[0, :17] = 1
+    ts = torch.full((1, c["T"]), 637.0)
+    calls = []
+    from longcat_video.block_sparse_attention import bsa_interface as B
+    orig = B.attn_fwd_bsa_varlen_triton
+
+    def counted(*a, **k):
+        calls.append(1)
+        return orig(*a, **k)
+
+    B.attn_fwd_bsa_varlen_triton = counted
+    try:
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            o = m(hidden_states=x, timestep=ts, encoder_hidden_states=cap, encoder_attention_mask=mask, num_cond_latents=0)
+    finally:
+        B.attn_fwd_bsa_varlen_triton = orig
+    assert len(calls) == c["depth"], calls      # every block's self-attention went through the reference's Triton kernel
+    out = {"x": x[0].numpy(), "cap": cap[:, 0].numpy(), "mask": mask.numpy(), "ts": ts.numpy(), "out": o.numpy(),
+           "cfg": np.array([c["C"], c["heads"], c["depth"], c["cap"], c["ct"]]), "triton_calls": np.array(len(calls))}
+    np.savez_compressed(os.path.join(out_dir, "g11b_longcat_dit_bsa0.npz"), **out)
+    print("g11b", tuple(o.shape), float(o.abs().mean()), "triton self-attention launches:", len(calls))
+
+
+if __name__ == "__main__" and "longcat_bsa0" in sys.argv[1:]:
+    g_longcat_dit_bsa0()
+
+
 # ------------------------------------------------------------------------------------------------------------
 LC_PIPE_CASES = {
     "irr_flf": dict(steps=9, R=2, guide=8, rnd=8, flf=True, omega=1.8, omega_r=1.0, cfg=4.0, F=9, H=32, W=32, guided=True, shift=1.0,
@@ -691,6 +749,34 @@ def g_bsa_cdf():
 
 if __name__ == "__main__" and "bsa_cdf" in sys.argv[1:]:
     g_bsa_cdf()
+
+
+def g_bsa_cdf_bf16(out_dir=OUT):
+    """G14c: the reference's cdf / cdf+top-k COUNTS on BF16 block scores -- the dtype its bf16 model hands
+    get_select_indices_cdf_from_score / _cdf_topk_from_score (bsa_interface.py:234-243, 253-266), where eager torch rounds score * scale,
+    the softmax weights and every cumsum output to bf16.  Counts only: ties among bf16 weights make the sorted INDEX order arbitrary.
+    Needs TORCHDYNAMO_DISABLE=1 (the functions are @torch.compile'd)."""
+    _longcat_paths()
+    from longcat_video.block_sparse_attention import bsa_interface as B
+
+    g = torch.Generator().manual_seed(23)
+    out = {}
+    for name, (Hh, nq, nk, scale) in {"flat770": (2, 24, 770, 1.0), "mid770": (2, 24, 770, 6.0), "peaked770": (2, 24, 770, 20.0),
+                                      "small96": (3, 16, 96, 4.0)}.items():
+        score = (torch.randn(1, Hh, nq, nk, generator=g) * scale).bfloat16()
+        out[f"{name}_score_bits"] = score[0].view(torch.int16).numpy().view(np.uint16)
+        for thr, sp in ((0.3, None), (0.5, None), (0.9, None), (0.95, None), (0.3, 0.75), (0.9, 0.875)):
+            if sp is None:
+                _, lens = B.get_select_indices_cdf_from_score(score, thr, 1 / 128 ** 0.5)
+            else:
+                _, lens = B.get_select_indices_cdf_topk_from_score(score, sp, thr, 1 / 128 ** 0.5)
+            out[f"{name}_lens_thr{thr}_sp{sp}"] = lens[0].numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(out_dir, "g14c_bsa_cdf_bf16.npz"), **out)
+    print("g14c", {k: (int(v.min()), int(v.max())) for k, v in out.items() if "_lens_" in k})
+
+
+if __name__ == "__main__" and "bsa_cdf_bf16" in sys.argv[1:]:
+    g_bsa_cdf_bf16()
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -75,8 +75,10 @@ def select_cdf(scores: torch.Tensor, cdf_threshold: float, sparsity=None):
     cdf_threshold, at least the top-k count when `sparsity` is given.  Returns (sorted indices [heads, n_q, n_k], counts [heads, n_q])."""
     w = torch.softmax(scores * (1 / 128 ** 0.5), dim=-1)
     ws = torch.sort(w, dim=-1, descending=True)
-    cdf = torch.cumsum(ws.values, dim=-1)
-    thr = torch.full(cdf.shape[:-1] + (1,), cdf_threshold, dtype=cdf.dtype, device=cdf.device)
+    # eager CPU torch (the parity target) keeps a cumsum's running sum in fp32 and rounds every OUTPUT to the tensor's dtype; a GPU scan
+    # may round the running sum itself -- spelled out so that bf16 scores give the reference's counts on either device
+    cdf = torch.cumsum(ws.values.float(), dim=-1).to(ws.values.dtype).float()
+    thr = torch.full(cdf.shape[:-1] + (1,), cdf_threshold, dtype=torch.float32, device=cdf.device)
     num = torch.searchsorted(cdf, thr, right=True).squeeze(-1)
     if sparsity is not None:
         num = num.clamp_min(int((1 - sparsity) * scores.shape[-1]))

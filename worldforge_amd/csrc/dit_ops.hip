@@ -323,7 +323,8 @@ extern "C" int wf_rmsnorm_heads_bound(const void* in, int ld, const float* weigh
                                       int L, int Lout, int C, float eps, float out_scale, float* ws, float* max_norm2, void* stream) {
   WF_CHECK_ARG(in && weight && out && ws && max_norm2, "wf_rmsnorm_heads_bound: null pointer");
   WF_CHECK_ARG(out_scale > 0.0f, "wf_rmsnorm_heads_bound: out_scale must be positive (1 = none)");
-  WF_CHECK_ARG(C % 128 == 0 && C <= 8192 && ld % 8 == 0, "wf_rmsnorm_heads_bound: C=%d must be a multiple of 128 (<= 8192), ld %% 8", C);
+  // C >= 128: H = C / 128 heads is a divisor in k_norm2_part / k_norm2_final (C = 0 passed the old check)
+  WF_CHECK_ARG(C >= 128 && C % 128 == 0 && C <= 8192 && ld % 8 == 0, "wf_rmsnorm_heads_bound: C=%d must be a multiple of 128 in 128..8192, ld %% 8", C);
   WF_CHECK_ARG(Lout >= L && L > 0, "wf_rmsnorm_heads_bound: need 0 < L <= Lout");
   WF_CHECK_ARG((cos_tab == nullptr) == (sin_tab == nullptr), "wf_rmsnorm_heads_bound: cos/sin must both be given or both null");
   const int H = C / 128, nblk = (L + NB_RB - 1) / NB_RB;

@@ -1091,7 +1091,11 @@ extern "C" int wf_gemm_bf16(const void* X, const void* W, const float* bias, voi
     const char* e = getenv("WF_GEMM_KERNEL");
     return e && e[0] == 'w' && e[1] == '4';
   }();
-  if (use_w4 && !no_pp && K % PK == 0 && M >= 1024 && N >= 256 && (long)M * N >= (1L << 22)) {
+  // INVARIANT relied on by k_gemm_pp / k_gemm_pp16 / k_gemm_w4: their epilogues load bias / gate / old-value quads UNCONDITIONALLY at
+  // clamped addresses `min(n, N - 4)` (a guard per load would put every load in its own basic block), which needs N >= 4 and N % 4 == 0.
+  // `big` guarantees both (N >= 256, N % 4 == 0); a future relaxation of this gate must keep them.
+  const bool big = K % PK == 0 && M >= 1024 && N >= 256 && N % 4 == 0 && (long)M * N >= (1L << 22);
+  if (use_w4 && !no_pp && big) {
     switch (epilogue) {
       case EPI_BF16: launch_w4<EPI_BF16>(a, s); break;
       case EPI_BF16_GELU: launch_w4<EPI_BF16_GELU>(a, s); break;
@@ -1103,7 +1107,7 @@ extern "C" int wf_gemm_bf16(const void* X, const void* W, const float* bias, voi
     WF_LAUNCH_CHECK("wf_gemm_bf16");
     return WF_OK;
   }
-  if (!no_pp && K % PK == 0 && M >= 1024 && N >= 256 && (long)M * N >= (1L << 22)) {
+  if (!no_pp && big) {
     switch (epilogue) {
       case EPI_BF16: launch_pp_any<EPI_BF16>(a, s); break;
       case EPI_BF16_GELU: launch_pp_any<EPI_BF16_GELU>(a, s); break;

@@ -253,9 +253,16 @@ __device__ __forceinline__ float block_incscan_f(float v, float* sm /* >= 4 floa
 }
 // bsa_interface.py:226-263 (get_select_indices_cdf / _cdf_topk): per (head, query block) row, the number of key blocks the cdf rule takes =
 // how many blocks, in descending weight order, have a cumulative softmax(score / sqrt(128)) weight <= cdf_threshold (searchsorted right),
-// at least n_min, at most n_k.  The row's 16-bit score keys are sorted in LDS (bitonic, descending), the weights scanned in that order
-// with a fixed reduction tree: the result is deterministic; against a sequential cumsum it can differ by one block where the cumulative
-// weight crosses the threshold within fp32 rounding.  Which blocks = the top `need` of the row: k_bsa_topk_lists with need_rows.
+// at least n_min, at most n_k.  The reference evaluates this chain on its bf16 score tensor, and eager torch rounds to bf16 after every
+// op (pinned by tests/golden/g14c_bsa_cdf_bf16.npz, recorded from get_select_indices_cdf_from_score on bf16 scores):
+//     x = bf16(score * c)   w = bf16(exp(x - max x) / sum)   [softmax: fp32 inside, bf16 out]   cdf_k = bf16(fp32 running sum of the sorted w)
+// and compares float(cdf_k) <= float32(threshold).  Near 0.9 the bf16 spacing is 2^-8, so many consecutive cdf values collapse and the
+// count differs from the fp32 rule by several blocks -- the rounding points are reproduced here.  The row's 16-bit score keys are sorted
+// in LDS (bitonic, descending; x and w are monotone in the score, so this is the weight order), the weights scanned in that order with a
+// fixed tree: every partial sum of bf16 weights >= 2^-17 is exact in fp32 whatever the order, and once a weight is smaller than that the
+// cumulative sum is already > 0.97 (n_k <= 2048) -- so for thresholds <= 0.97 the scan equals the sequential cumsum bit for bit.  What can
+// still differ from a torch run is one bf16 ulp of a weight where exp / the row sum round differently (about 1 row in 10^3 changes its
+// count).  Which blocks = the top `need` of the row: k_bsa_topk_lists with need_rows.
 __global__ __launch_bounds__(256) void k_bsa_cdf_need(const uint16_t* __restrict__ scores, long ld, int n_q, int n_k, float thr, int n_min,
                                                       int* __restrict__ need_rows) {
   __shared__ uint16_t key[TK_MAXK];
@@ -283,12 +290,12 @@ __global__ __launch_bounds__(256) void k_bsa_cdf_need(const uint16_t* __restrict
   };
   constexpr int PER = TK_MAXK / 256;
   const float c = 0.08838834764831845f;  // 1 / sqrt(128)
-  const float mx = score_of(key[0]) * c;
+  const float mx = rbf(score_of(key[0]) * c);  // bf16(score * sm_scale), the softmax input
   float e[PER], part = 0.f;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int p = tid * PER + i;
-    e[i] = p < n_k ? expf(score_of(key[p]) * c - mx) : 0.f;
+    e[i] = p < n_k ? expf(rbf(score_of(key[p]) * c) - mx) : 0.f;
     part += e[i];
   }
   float total;
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(256) void k_bsa_cdf_need(const uint16_t* __restrict
   float wsum = 0.f;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    e[i] = e[i] / total;  // the softmax weight, as torch.softmax divides
+    e[i] = rbf(e[i] / total);  // the softmax weight, as torch.softmax divides; stored as bf16
     wsum += e[i];
   }
   float tot2;
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(256) void k_bsa_cdf_need(const uint16_t* __restrict
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     run += e[i];
-    cnt += (tid * PER + i < n_k) && run <= thr;
+    cnt += (tid * PER + i < n_k) && rbf(run) <= thr;  // torch.cumsum on bf16: fp32 running sum, every output rounded to bf16
   }
   int tot;
   block_exscan(cnt, smi, &tot);

@@ -72,13 +72,22 @@ def target_size(image_height: int, image_width: int, max_area: int, mod_value: i
 
 
 def prepare_inputs(directory: str, model: str = "480p", num_frames: int = None, soften: bool = True,
-                   transition_distance: int = 15, decay_type: str = "sine", device=None, max_area: int = None):
+                   transition_distance: int = 15, decay_type: str = "sine", device=None, max_area: int = None, image=None):
     """INFER:153-254 -> (image PIL, video_ref [1,3,F,H,W] f32 in [0,1], mask [1,1,F,H,W], height, width).
     `num_frames` (not in the reference) truncates the warped sequence: the reference requires #reference frames == the
     (4k+1) frame count it decodes, otherwise SCHED:1326 raises.  `max_area` (not in the reference) overrides the model's pixel budget
     (INFER:217: 480*832 or 720*1280) so that the same size rule can be exercised at test sizes.  With `device` (a GPU) the mask softening runs there
-    (wf_soften_mask: exact windowed EDT) and video_ref / mask are returned on that device."""
+    (wf_soften_mask: exact windowed EDT) and video_ref / mask are returned on that device.  `image` (a PIL image or a path; INFER:209-215
+    `--image`): the input image -- the size rule takes ITS aspect ratio and the warped frames / masks are resized to that size (INFER:218-
+    241); without it the first warped frame is the image."""
     frames, masks, first = read_frames_from_directory(directory)
+    if image is not None:
+        if isinstance(image, (str, os.PathLike)):
+            from PIL import Image
+            image = Image.open(image).convert("RGB")
+        first = image
+    if first is None:
+        raise ValueError("Cannot get first frame as input image, please specify --image parameter")   # INFER:214-215
     if num_frames is not None:
         frames, masks = frames[:num_frames], masks[:num_frames]
     if max_area is None:

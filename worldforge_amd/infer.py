@@ -11,7 +11,8 @@ Same argument names, defaults and meaning as the reference's CLI.  Outside SURVE
 and the CLIP vision encoder (run once per video; the loop consumes their outputs).  Their outputs come in through --embeds (a .npz / .safetensors
 with `prompt_embeds` [1,L,4096], `negative_prompt_embeds`, `image_embeds` [1,257,1280]) or, when the checkpoint folder holds `text_encoder/`,
 `tokenizer/`, `image_encoder/`, `image_processor/` and `transformers` is importable, are computed with those classes exactly as PIPE:166-214 does.
-The reference's prompt table (utils/prompts.py) is text data of the reference and is not shipped: pass --prompt / --negative-prompt.
+The reference's scene -> prompt table (utils/prompts.py) is text data of the reference and is not shipped: pass --prompt; the negative
+prompt defaults to the entry point's own two literals (INFER:277-285, by --static).
 """
 from __future__ import annotations
 
@@ -24,6 +25,11 @@ import numpy as np
 import torch
 
 from . import harness
+
+
+# INFER:277-278: the entry point's two negative prompts (protocol constants of the CLI, selected by --static at INFER:280-285)
+NEGATIVE_PROMPT_STATIC = "Blink, twinkle, waggle, speak, wind, windy, leaves shaking, leaves tremble, sighboard, background dynamics, dynamic imagery, gray sky, hazy sky, overcast, gloomy sky, dim, murky, smoggy, shake, object motion blur, streaking objects, object jitter, camera shake, time flow, illogical composition, bright tones, overexposed, blurred details, subtitles, text, logo, overall gray, worst quality, low quality, JPEG compression residue, ugly, incomplete, sudden scene shift, incoherent scene jump, extra fingers, poorly drawn hands, poorly drawn faces, deformed, disfigured, misshapen limbs, fused fingers, any movement, character motion, slight object movement, object swaying, character micro-movements, subtle object rotation, object vibration, messy background, three legs, many people in the background, walking, scene changes, visual detail movement, object disintegration, object breakage."
+NEGATIVE_PROMPT_DYNAMIC = "Streaking objects, mosaic, grainy, pixelated, noise, flickering, cropped, glitch, fragmented, broken, artifacts, chromatic aberration, micro camera shake, grid, tiling, blurry, camera shake, sudden scene shift, incoherent scene jump, sudden object appearance, blinking, object jitter, camera shake, illogical composition, bright tones, overexposed, blurred details, subtitles, overall gray, solid color, worst quality, low quality, JPEG compression residue, ugly, incomplete, extra fingers, poorly drawn hands, poorly drawn faces, deformed, disfigured, misshapen limbs, fused fingers, messy background, three legs, many people in the background, walking backwards"
 
 
 def load_embeds(path: str, device) -> Dict[str, torch.Tensor]:
@@ -95,21 +101,24 @@ def run(models_dir: Optional[str], video_ref: str, model: str = "720p", output: 
     pipe = WanImageToVideoPipeline(transformer, vae, scheduler, device=dev)
 
     # INFER:206-254 (the first frame of the warped sequence is the input image unless --image is given)
-    pil, video, mask, height, width = harness.prepare_inputs(video_ref, model=model, num_frames=num_frames, soften=soften_mask,
+    # --image given: the size rule takes the IMAGE's aspect ratio and the warped frames / masks are resized to it (INFER:209-241).  The
+    # warped sequence is NOT truncated to --num-frames: the reference blends frame by frame and its resize of a sequence of another length
+    # raises (scheduling_unipc_multistep_clean.py:1326), so a mismatch is an error here too, before any GPU work.
+    pil, video, mask, height, width = harness.prepare_inputs(video_ref, model=model, num_frames=None, soften=soften_mask,
                                                              transition_distance=transition_distance, decay_type=decay_type, device=dev,
-                                                             max_area=max_area)
-    if image is not None:
-        from PIL import Image
-        pil = Image.open(image).convert("RGB").resize((width, height))
-    if video.shape[2] != num_frames:
-        raise ValueError(f"--video-ref holds {video.shape[2]} frames but --num-frames is {num_frames}: the reference blends frame by frame "
-                         "(scheduling_unipc_multistep_clean.py:1326 raises on a mismatch)")
+                                                             max_area=max_area, image=image)
+    eff_frames = max(num_frames // 4 * 4 + 1 if num_frames % 4 != 1 else num_frames, 1)     # PIPE:475-478
+    if video.shape[2] != eff_frames:
+        raise ValueError(f"--video-ref holds {video.shape[2]} frames but --num-frames {num_frames} decodes {eff_frames}: the reference blends "
+                         "frame by frame (scheduling_unipc_multistep_clean.py:1326 raises on a mismatch)")
+    if negative_prompt is None:   # INFER:277-284: the two negative prompts are literals of the entry point, chosen by --static
+        negative_prompt = NEGATIVE_PROMPT_STATIC if static else NEGATIVE_PROMPT_DYNAMIC
 
     if embeds is not None:
         emb = load_embeds(embeds, dev)
     elif model_path is not None and all(os.path.isdir(os.path.join(model_path, d)) for d in ("text_encoder", "tokenizer", "image_encoder", "image_processor")):
-        if prompt is None or negative_prompt is None:
-            raise ValueError("pass --prompt and --negative-prompt (the reference's prompt table utils/prompts.py is not shipped)")
+        if prompt is None:
+            raise ValueError("pass --prompt (the reference's scene -> prompt table utils/prompts.py is not shipped)")
         emb = encode_with_transformers(model_path, prompt, negative_prompt, pil, dev)
     else:
         raise ValueError("no --embeds file and no text_encoder / image_encoder folders to compute them from")
@@ -151,9 +160,10 @@ def main(argv=None):
     ap.add_argument("--soften-mask", action="store_true")
     ap.add_argument("--transition-distance", type=int, default=15)
     ap.add_argument("--decay-type", choices=["linear", "exponential", "sine", "cosine"], default="sine")
-    ap.add_argument("--save-png", action="store_true")
+    ap.add_argument("--save-png", action="store_true",
+                    help="accepted for CLI compatibility: the lossless PNG frames are ALWAYS written (this engine has no mp4 encoder, INFER:317)")
     ap.add_argument("--prompt", default=None, help="instead of the reference's --scene lookup in utils/prompts.py")
-    ap.add_argument("--negative-prompt", default=None)
+    ap.add_argument("--negative-prompt", default=None, help="default: the reference's static / dynamic negative prompt by --static (INFER:277-285)")
     ap.add_argument("--embeds", default=None, help=".npz / .safetensors with prompt_embeds, negative_prompt_embeds, image_embeds")
     ap.add_argument("--device", default="cuda:0")
     a = ap.parse_args(argv)

@@ -251,14 +251,14 @@ class UniPCMultistepScheduler:
                 tds = 2 ** sum(vae.temperal_downsample)
                 sds = 2 ** len(vae.temperal_downsample)
                 shape = (1, 3, (x0.shape[2] - 1) * tds + 1, x0.shape[3] * sds, x0.shape[4] * sds)
-                ref, m = align_reference(video_latents, mask, shape)
+                ref, m = align_reference(video_latents, mask, shape, memo=self.__dict__.setdefault("_align_memo", {}))
                 enc = vae.decode_blend_encode(ops.latent_denorm(x0, mean, std), ref, m).mode()
                 enc = ops.latent_norm(enc, mean, std, const_dtype=x0.dtype)
         else:
             with tr.range("vae_decode", step=step):
                 decoded = vae.decode(ops.latent_denorm(x0, mean, std), return_dict=False)[0]
             with tr.range("blend", step=step):
-                ref, m = align_reference(video_latents, mask, decoded.shape)
+                ref, m = align_reference(video_latents, mask, decoded.shape, memo=self.__dict__.setdefault("_align_memo", {}))
                 fused = ops.blend_pixels(ref, m, decoded)
             with tr.range("vae_encode", step=step):
                 enc = vae.encode(fused).latent_dist.mode()
@@ -368,10 +368,23 @@ def scalar_as(s: torch.Tensor, dtype: torch.dtype) -> float:
     return s.to(dtype).float().item()
 
 
-def align_reference(ref: torch.Tensor, mask: torch.Tensor, target_shape):
+def align_reference(ref: torch.Tensor, mask: torch.Tensor, target_shape, memo: Optional[dict] = None):
     """SCHED:1300-1374: bring the reference video / mask to the decoded video's shape (fp32).
     Spatial size mismatches are resized on the GPU (bilinear for RGB, nearest for the mask); a frame-count mismatch raises
-    ValueError exactly like the reference's F.interpolate call on a 4-D tensor does (SCHED:1326-1334, 1364-1371)."""
+    ValueError exactly like the reference's F.interpolate call on a 4-D tensor does (SCHED:1326-1334, 1364-1371).
+    `memo` (a dict owned by the caller, one live entry): the reference video and the mask are the SAME objects for all ~30 injections of a
+    job, so when a cast / resize is needed its result is kept and returned again while the inputs are unchanged -- otherwise every
+    injection would produce fresh full-resolution tensors (390 MB each at 81 x 480 x 832) and defeat the row-slab cache of the sharded
+    VAE, which keys on the tensors it is handed."""
+    if memo is not None:
+        key = (ref.data_ptr(), ref._version, tuple(ref.shape), ref.dtype, mask.data_ptr(), mask._version, tuple(mask.shape), mask.dtype,
+               tuple(target_shape))
+        hit = memo.get("entry")
+        if hit is not None and hit[0] == key:
+            return hit[3], hit[4]
+        out = align_reference(ref, mask, target_shape)
+        memo["entry"] = (key, ref, mask, out[0], out[1])   # the sources are held so that their storage cannot be recycled under the key
+        return out
     B, C, Fr, H, W = target_shape
     ref = ops.cast(ref, torch.float32) if ref.dtype == torch.bfloat16 else ref.to(torch.float32)
     mask = mask.to(torch.float32)

@@ -936,7 +936,9 @@ class AutoencoderKLWan:
         cache = self.__dict__.setdefault("_slab_cache", {})
         hit = cache.get(key)
         if hit is None:
-            while len(cache) >= 4:
+            # two live entries (the reference video and the mask); an entry whose source differs from both is dropped, so a caller that
+            # hands over fresh tensors every time pins at most two stale full-resolution sources, not four
+            while len(cache) >= 2:
                 cache.pop(next(iter(cache)))
             hit = cache[key] = (t, t[:, :, :, y0:y0 + Hs].contiguous())  # `t` is held so that its storage cannot be recycled under the key
         return hit[1]
