@@ -446,10 +446,11 @@ def main(argv=None):
                     help="FLF motion backend: farneback (default) = what the installed reference executes, as the GPU restatement of "
                          "cv2.calcOpticalFlowFarneback (parity with a real cv2 unpinned); tdiff = the branch the reference runs only "
                          "when `import cv2` fails (golden-pinned)")
-    ap.add_argument("--vae-precision", default="bf16x3", choices=["bf16x3", "fp32", "bf16"],
-                    help="bf16x3 (default; 'fp32' is the old name of the same mode): fp32-CLASS VAE contractions standing in for the reference's "
-                         "fp32 VAE (INFER:185-189) -- three-term split bf16 operands on the matrix cores, ~2^-16 per product, 3x the VAE MFMA "
-                         "work; bf16: every VAE operand rounded to bf16 (faster, 2^-9 per operand)")
+    ap.add_argument("--vae-precision", default="fp16x3", choices=["fp16x3", "bf16x3", "fp32", "bf16"],
+                    help="fp16x3 (default; 'fp32' names the same mode): fp32-CLASS VAE contractions standing in for the reference's fp32 VAE "
+                         "(INFER:185-189) -- three-term split operands on the matrix cores, fp16 parts: ~2^-22 per product, 3x the VAE MFMA "
+                         "work; bf16x3: the same split on bf16 parts (~2^-16 per product; the default of rounds 2-3, same cost); bf16: every "
+                         "VAE operand rounded to bf16 (faster, 2^-9 per operand)")
     ap.add_argument("--distill", action="store_true",
                     help="with --workload longcat: the distilled 16-step schedule without CFG (BASELINE config 4's first half; the "
                          "cfg_step_lora is a weight fold and does not change the cost)")
@@ -462,7 +463,7 @@ def main(argv=None):
                     help="wan = the BASELINE metric (default); longcat = the same contract on LongCat-Video 13.6B guided i2v (config 4's model)")
     a = ap.parse_args(argv)
     if a.vae_precision == "fp32":
-        a.vae_precision = "bf16x3"
+        a.vae_precision = "fp16x3"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: become the launcher.  Nothing above or in here initialises the GPU in this process.
         sys.exit(launch_ranks(a.gpus, argv))
@@ -591,7 +592,8 @@ def main(argv=None):
                 # the Farneback branch is what an installed reference executes, but its GPU statement is checked against the
                 # in-repo restatement of OpenCV only (no cv2 in the image or the reference tree); the tdiff branch is golden-pinned
                 "flow_backend_parity": "oracle-only (cv2 unpinned)" if a.flow_backend == "farneback" else "reference goldens (g4, g6)",
-                "vae_precision": a.vae_precision + (" (3-term split-bf16 operands, fp32 accumulate: ~2^-16 per product, not IEEE fp32)" if a.vae_precision == "bf16x3" else ""),
+                "vae_precision": a.vae_precision + {"bf16x3": " (3-term split-bf16 operands, fp32 accumulate: ~2^-16 per product, not IEEE fp32)",
+                                                     "fp16x3": " (3-term split-fp16 operands hi.hi + lo.hi + hi.lo, fp32 accumulate: ~2^-22 per product; fp32-class, not IEEE fp32)"}.get(a.vae_precision, ""),
             },
             # what the timed window holds (`value` is only comparable between lines with the same mix; the default K = 10 is the
             # 50-step job's own 15 : 35)

@@ -151,6 +151,10 @@ int wf_gemm_bf16(const void* X, const void* W, const float* bias, void* out, con
  * (bsa_interface.py:181-185: one [n_q, 128] x [n_k, 128]^T per head) and the per-frame score / PV products of the VAE mid-block. */
 int wf_gemm_bf16_batched(const void* X, const void* W, void* out, int batch, int M, int N, int K, int ldx, int ldw, int ldo,
                          int64_t bsx, int64_t bsw, int64_t bso, int epilogue, void* stream);
+/* wf_gemm_bf16 on fp16 operands (X, W fp16; fp32 accumulation; epilogue WF_EPI_BF16 writes fp16, WF_EPI_F32, WF_EPI_F32_ACC): the
+ * 1x1 convolutions and mid-block attention products of the VAE in its fp16 operand formats (see wf_split_f16x3). */
+int wf_gemm_f16(const void* X, const void* W, const float* bias, void* out, int M, int N, int K, int ldx, int ldw, int ldo, int epilogue,
+                void* stream);
 
 /* flash_attention (attention.py:24-130) as used by model.py:149-154 (self) and :220-222 (cross): fused
  * softmax(Q K^T * softmax_scale) V, no mask, head_dim 128.  Q [H][Lq][128], K [H][Lkp][128] (rows >= kv_len zero),
@@ -187,6 +191,17 @@ int wf_attn_debug_body_counter(void* counters2);
 int wf_attn_fwd_split(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len, int ldo,
                       float softmax_scale, int accumulate, int nsplit, void* workspace, const float* kmax2, int kmax_n, const float* qmax2,
                       int qmax_n, void* stream);
+/* The KV sweep in PARTS (round 4; sequence-parallel layers WITHOUT a second CFG branch to hide the K / V^T exchange under -- LongCat-Video,
+ * distilled schedules, guidance_scale <= 1; reference idea: wan/distributed/xdit_context_parallel.py:160-176, pipeline_longcat_video.py:
+ * 857-866).  The key segments arrive one source rank after the other; a part launch walks only the 64-key tiles [t_begin, t_end) that are
+ * there already -- the rank's own shard needs no wait at all -- and leaves un-normalised partials (O f32, reference max, row sum) in slot
+ * `part` of an `nparts`-slot workspace of wf_attn_split_workspace_bytes(H, Lq, nparts) bytes.  Pre-scaled Q only (the form of
+ * wf_attn_fwd with softmax_scale = 0); Q / K / Vt / bounds as wf_attn_fwd.  wf_attn_merge combines the slots exactly (the flash combine
+ * wf_attn_fwd_split uses) into O once every slot has been written; the result equals the one-launch sweep up to the re-association of the
+ * fp32 partial sums. */
+int wf_attn_fwd_part(const void* Q, const void* K, const void* Vt, int H, int Lq, int Lkp, int kv_len, int seg_len, int t_begin, int t_end,
+                     int part, int nparts, void* workspace, const float* kmax2, int kmax_n, const float* qmax2, int qmax_n, void* stream);
+int wf_attn_merge(void* O, int H, int Lq, int ldo, int accumulate, int nparts, const void* workspace, void* stream);
 
 /* WanLayerNorm (model.py:92-102; eps, no affine) fused with y = ln * (plus_one + mul[c]) + add[c]:
  *   AdaLN modulate (model.py:303, 311, 346): mul = scale e[1]/e[4], add = shift e[0]/e[3], plus_one = 1;
@@ -350,6 +365,28 @@ int wf_rms_silu_cl_blocked(const float* x, const float* gamma, void* out, size_t
 /* wf_softmax_rows with f32 probabilities (vae.py:252-256 in fp32) / wf_transpose_bf16 on f32. */
 int wf_softmax_rows_f32(const float* S, int lds, float* P, int ldp, int M, int N, float scale, void* stream);
 int wf_transpose_f32(const float* in, int ld_in, float* out, int ld_out, int R, int C, void* stream);
+/* ---- fp16 operand formats of the VAE (round 4) -----------------------------------------------------------------------------------------
+ * The reference's VAE is fp32 (infer_worldforge.py:185-189).  The three-term split above on BF16 parts (8-bit significands) leaves
+ * ~2^-16 per product; the same split on FP16 parts (11-bit significands: hi = fp16(x), lo = fp16(x - hi), contraction hi.hi + lo.hi +
+ * hi.lo on v_mfma_f32_32x32x16_f16, same rate) leaves ~2^-22 -- two decimal digits closer to IEEE fp32 at the same cost; it is the
+ * VAE's default ("fp16x3").  fp16 has a 5-bit exponent: values beyond +-65504 do not fit.  The producers raise a sticky flag
+ * (wf_f16_overflow_flag) that the host turns into an error after every VAE call; the bf16 split ("bf16x3") remains for such weights.
+ * Every *_f16 entry point is its bf16 namesake with fp16 in place of bf16 in the operands (and in a 16-bit output copy). */
+int wf_split_f16x3(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, size_t rows, int C, int side, void* stream);
+int wf_rms_silu_cl_x3_f16(const float* x, const float* gamma, void* out_x3, size_t npix, int C, int silu, void* stream);
+int wf_rms_silu_cl_blocked_f16(const float* x, const float* gamma, void* out, size_t npix, int C, int silu, int W, int split,
+                               int halo_rows, void* stream);
+int wf_conv3d_cl_f16(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_f16, int Ti,
+                     int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st, int ss, int pt, int ph,
+                     int pw, int up2, int tsplit, const void* zero_page, void* stream);
+int wf_conv3d_cl_scatter_f16(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_f16, int Ti,
+                             int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st, int ss, int pt,
+                             int ph, int pw, const void* zero_page, int out_H, int out_W, int sy, int oy, int sx, int ox, void* stream);
+int wf_conv3d_333_f16(const void* in, const void* w_packed, const float* bias, const float* resid, float* out_f32, void* out_f16, int T,
+                      int Hi, int Wi, int Cin, int Ho, int Cout, int ph, const void* zero_page, size_t zero_page_bytes, int layout,
+                      int Cin_stored, void* stream);
+/* *out = 1 if a producer converted a value beyond the fp16 range (or a NaN) since the last reset; synchronises `stream`. */
+int wf_f16_overflow_flag(int* out, int reset, void* stream);
 /* [C, N] f32 -> [N, Cpad] (f32 and/or bf16; channels C..Cpad zero, so thin inputs fill an MFMA K slice);
  * [N, ld] f32 (first C channels) -> [C, N] f32 with optional clamp (autoencoder_kl_wan.py:1222).  N = T*H*W. */
 int wf_ncthw_to_cl(const float* in, float* out_f32, void* out_bf16, int C, int Cpad, size_t N, void* stream);

@@ -54,12 +54,12 @@ def test_self_attention_c2_sampled_rows_vs_oracle_and_normalisation():
         got = out[rows, h * 128:(h + 1) * 128].float().cpu()
         err = (got - want).abs().max().item()
         # outputs are O(1/sqrt(L)) averages of unit normals: |o| ~ 0.02; P is rounded to bf16 before P.V (as flash_attention)
-        within("fullsize.attn_c2.max_abs", err, 2e-3)
+        within("fullsize.attn_c2.max_abs", err, 2e-4)   # measured 1.0e-4
     # normalisation: with V = 1 every output is sum(p)/sum(p) = 1 up to the bf16 rounding of P (whole tensor)
     vt.fill_(1.0)
     dit.attention(q, k, vt, out, L, 1.0 / math.sqrt(128.0))
     dev = (out.float() - 1.0).abs().max().item()
-    within("fullsize.attn_c2.ones", dev, 2.0 ** -7)
+    within("fullsize.attn_c2.ones", dev, 2.0 ** -9)   # measured 0 (exactly 1.0 everywhere); half a bf16 ulp allowed
     # scale invariance of the key padding: garbage in the padded key rows must not leak (mask by kv_len)
     k[:, L:] = 1e4
     out2 = torch.empty_like(out)
@@ -85,7 +85,8 @@ def test_gemm_c2_sampled_rows_and_exact_linearity(N, K, epi):
     if epi == 1:
         want = torch.nn.functional.gelu(want, approximate="tanh")
     got = out[rows].float().cpu()
-    tol = 3e-5 * math.sqrt(K) if epi == 2 else 2.0 ** -8 * max(1.0, want.abs().max().item())
+    # bf16 outputs: one bf16 ulp of the largest output (measured 0.76 of it); fp32 outputs: measured 4.6e-6 at K = 13 824 (fp32 accumulation order)
+    tol = 8e-8 * math.sqrt(K) if epi == 2 else 2.0 ** -8 * max(1.0, want.abs().max().item())
     within(f"fullsize.gemm.epi{epi}", (got - want).abs().max().item() / tol, 1.0)
     if epi != 1:
         # power-of-two linearity is exact in bf16 / fp32 (no bias): the whole [M, N] output, every tile and edge
@@ -137,7 +138,7 @@ def test_conv3d_c2_sampled_pixels_borders_and_exact_linearity():
                         continue
                     acc += (wf[:, :, dt, dy, dx].double() @ x[tt, yy, xc].float().cpu().double())
         got = of[t, y, xx].cpu().double()
-        within("fullsize.conv_c2.max_abs", (got - acc).abs().max().item(), 2e-4)
+        within("fullsize.conv_c2.max_abs", (got - acc).abs().max().item(), 2.1e-6)   # measured 1.04e-6
     o1 = torch.empty_like(of)
     run(x, None, o1)
     x.mul_(2.0)
@@ -164,7 +165,7 @@ def test_blend_and_latent_ops_c2_equal_oracle_on_the_whole_tensor():
     want = oinject.dsg(a, b, 4.0)
     have = ops.dsg(a.to(DEV), b.to(DEV), 4.0).cpu()
     # the three global sums are reduced in a different (fixed) order than torch's: <= 1 bf16 ulp on values at a rounding boundary
-    within("fullsize.dsg", (have.float() - want.float()).abs().max().item() / want.float().abs().max().item(), 2.0 ** -7)
+    within("fullsize.dsg", (have.float() - want.float()).abs().max().item() / want.float().abs().max().item(), 1.1e-3)   # measured 5.6e-4
     assert (have != want).float().mean().item() < 5e-3
 
 
@@ -218,8 +219,8 @@ def test_dit_c2_tokens_sharded_and_lockstep_forwards_match_single_rank():
                 assert torch.equal(res[r][1], ref_b), (P, r)
             else:
                 assert torch.equal(res[r][0], res[0][0]) and torch.equal(res[r][1], res[0][1])   # all ranks agree exactly
-                within(f"fullsize.dit_split_kv.P{P}.a", (res[r][0] - ref_a).abs().max().item() / ref_a.abs().max().item(), 2e-2)
-                within(f"fullsize.dit_split_kv.P{P}.b", (res[r][1] - ref_b).abs().max().item() / ref_a.abs().max().item(), 2e-2)
+                within(f"fullsize.dit_split_kv.P{P}.a", (res[r][0] - ref_a).abs().max().item() / ref_a.abs().max().item(), 3.5e-3)   # measured 1.78e-3 / 1.75e-3
+                within(f"fullsize.dit_split_kv.P{P}.b", (res[r][1] - ref_b).abs().max().item() / ref_a.abs().max().item(), 3.5e-3)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -287,4 +288,4 @@ def test_dit_full_width_two_layers_vs_oracle():
     rel = (out - orc).norm().item() / orc.norm().item()
     print(f"full-width DiT (2 layers, L = {T * (Hh // 2) * (Ww // 2)}): rel L2 vs oracle {rel:.3e}, max abs {(out - orc).abs().max().item():.3e}")
     assert torch.isfinite(out).all()
-    within("fullsize.dit_2layers.rel_l2", rel, 2e-2)
+    within("fullsize.dit_2layers.rel_l2", rel, 4.7e-3)   # measured 2.33e-3

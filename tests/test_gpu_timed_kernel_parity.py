@@ -111,14 +111,16 @@ def test_timed_self_attention_production_chain_vs_oracle(grid):
     with _BodyCounter() as n:
         dit.attention(c["qh"], c["kh"], c["vt"], out_u, L, 0.0, nsplit=1, kmax2=c["km"], qmax2=c["qm"])
     assert (n.tracked, n.untracked) == (0, _wgs(L)), (n.tracked, n.untracked)       # the body bench.py times
-    eu = _compare(out_u, want, ROWS[grid], heads, 2e-3, 3e-2, f"timed_attn.untracked.L{L}")
+    # bars at <= 2x the error measured on an MI355X (profiles/r4_tolerances.txt): max abs 2.5e-4 / 1.3e-4, rel L2 4.9e-3 / 5.2e-3 at C2 / C3
+    tol_abs = 5e-4 if grid == GRID_C2 else 2.6e-4
+    eu = _compare(out_u, want, ROWS[grid], heads, tol_abs, 1e-2, f"timed_attn.untracked.L{L}")
     out_t = torch.empty_like(out_u)
     with _BodyCounter() as n:
         dit.attention(c["qh"], c["kh"], c["vt"], out_t, L, 0.0, nsplit=1)           # no bounds -> running-max tracking (WF_ATTN_TRACK_MAX=1)
     assert (n.tracked, n.untracked) == (_wgs(L), 0), (n.tracked, n.untracked)
-    et = _compare(out_t, want, ROWS[grid], heads, 2e-3, 3e-2, f"timed_attn.tracked.L{L}")
+    et = _compare(out_t, want, ROWS[grid], heads, tol_abs, 1e-2, f"timed_attn.tracked.L{L}")
     # the two bodies differ only in the reference max m of each row (exact for any m up to fp32 rounding of exp2 / the row sums)
-    within(f"timed_attn.bodies_agree.L{L}", (out_u.float() - out_t.float()).abs().max().item() / out_t.float().abs().max().item(), 2.0 ** -8)
+    within(f"timed_attn.bodies_agree.L{L}", (out_u.float() - out_t.float()).abs().max().item() / out_t.float().abs().max().item(), 2.0 ** -10)   # measured: identical (no rescale ever fires on unit-variance data); the bar allows a quarter of a bf16 ulp
     print(f"k_attn_w4<4> L={L}: un-tracked max abs {eu[0]:.2e} rel {eu[1]:.2e}; tracked {et[0]:.2e} rel {et[1]:.2e}")
 
 
@@ -135,7 +137,7 @@ def test_timed_self_attention_large_norms_select_the_tracked_body_c2():
     assert (n.tracked, n.untracked) == (_wgs(L), 0), (n.tracked, n.untracked)
     want = _oracle_rows(c, ROWS[GRID_C2], (0, 17, 39))
     # sharp softmax: outputs are O(1) mixtures of a few values; the bf16 rounding of q / k moves a score by ~1e-2 -> ~1 % on p
-    _compare(out, want, ROWS[GRID_C2], (0, 17, 39), 6e-2, 3e-2, "timed_attn.large_norms")
+    _compare(out, want, ROWS[GRID_C2], (0, 17, 39), 6e-2, 2.6e-2, "timed_attn.large_norms")   # measured 5.1e-2 / 1.3e-2
 
 
 def test_nan_row_forces_the_tracked_body():
@@ -183,11 +185,11 @@ def test_timed_self_attention_split_kv_sweep_at_the_8_rank_shard_shape():
     rows = [lo, lo + 1, lo + 255, lo + 256, lo + 2047, L - 65, L - 64, L - 2, L - 1]
     heads = (0, 11, 39)
     want = _oracle_rows(c, rows, heads)
-    _compare(out, want, [r - lo for r in rows], heads, 2e-3, 3e-2, "timed_attn.split_kv_shard")
+    _compare(out, want, [r - lo for r in rows], heads, 4e-4, 1e-2, "timed_attn.split_kv_shard")   # measured 2.0e-4 / 5.2e-3
     # and the unsplit single-GPU launch on the same rows: equal up to the re-association of the two partial sums
     full = torch.empty((L, H * 128), dtype=BF, device=DEV)
     dit.attention(c["qh"], c["kh"], c["vt"], full, L, 0.0, nsplit=1, kmax2=c["km"], qmax2=c["qm"])
-    within("timed_attn.split_vs_unsplit", (full[lo:hi].float() - out.float()).abs().max().item() / full.float().abs().max().item(), 2.0 ** -7)
+    within("timed_attn.split_vs_unsplit", (full[lo:hi].float() - out.float()).abs().max().item() / full.float().abs().max().item(), 7e-3)   # measured 3.4e-3
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -224,7 +226,7 @@ def test_dit_one_real_width_layer_vs_oracle_on_sampled_tokens(name, T, Hh, Ww):
     rel = (got - want).norm().item() / want.norm().item()
     err = (got - want).abs().max().item()
     print(f"one real-width DiT layer ({name}), L = {L}, {len(rows)} sampled tokens: rel L2 {rel:.3e}, max abs {err:.3e} (|want| max {want.abs().max().item():.2f})")
-    within(f"dit_layer.{name}.rel_l2", rel, 2e-2)
+    within(f"dit_layer.{name}.rel_l2", rel, 4.4e-3)   # measured 2.30e-3 (C2), 2.24e-3 (C3)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -256,7 +258,7 @@ def test_longcat_released_width_block_37440_tokens_vs_oracle_on_sampled_tokens()
     got = olc.token_patches(got_full, ocfg, rows)
     rel = (got - want).norm().item() / want.norm().item()
     print(f"released-width LongCat block, L = {L}, {len(rows)} sampled tokens: rel L2 {rel:.3e}, max abs {(got - want).abs().max().item():.3e}")
-    within("longcat_block.37440.rel_l2", rel, 2e-2)
+    within("longcat_block.37440.rel_l2", rel, 7.2e-3)   # measured 3.61e-3
 
 
 def test_block_sparse_attention_98560_tokens_product_selection_vs_oracle_on_sampled_query_blocks():
@@ -285,7 +287,7 @@ def test_block_sparse_attention_98560_tokens_product_selection_vs_oracle_on_samp
         # gating (bsa_interface.py:169-185) in bf16, as the reference's bf16 model runs it: pooled means and block scores
         osc = torch.matmul(obsa.mean_pool(qh[None], blk), obsa.mean_pool(kh[None], blk).transpose(-1, -2))[0].float()
         psc = sc[h].float().cpu()
-        within("bsa.block_scores", (psc - osc).abs().max().item() / osc.abs().max().item(), 2.0 ** -6)       # <= 2 bf16 ulp at the largest score
+        within("bsa.block_scores", (psc - osc).abs().max().item() / osc.abs().max().item(), 1.7e-3)       # measured 8.4e-4 (a fraction of a bf16 ulp at the largest score)
         # selection (bsa_interface.py:211-224): a VALID top-96 of the product's own scores (770 bf16 scores per row tie at the 96th place
         # all the time, and the reference's torch.topk breaks ties arbitrarily) ...
         chosen = torch.zeros((nb, nb), dtype=torch.bool).scatter_(1, idx[h], True)
@@ -305,4 +307,4 @@ def test_block_sparse_attention_98560_tokens_product_selection_vs_oracle_on_samp
                                          torch.arange(n_sel).view(1, 1, n_sel), blk, blk, 128 ** -0.5)[0]
             got = out[rows, h * 128:(h + 1) * 128].float().cpu()
             err = (got - want).abs().max().item()
-            within("bsa.rows_vs_oracle", err / (1e-2 * want.abs().max().item() + 2e-3), 1.0)
+            within("bsa.rows_vs_oracle", err / (1e-2 * want.abs().max().item() + 2e-3), 0.2)   # measured 0.099 of the bf16-P bar

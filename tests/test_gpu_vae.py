@@ -245,7 +245,63 @@ def test_row_sharded_vae_equals_unsharded(P, H, model):
 @pytest.fixture(scope="module")
 def model_fp32():
     from worldforge_amd.vae import AutoencoderKLWan
-    return AutoencoderKLWan(DEV, precision="fp32").load_state_dict(ovae.random_weights(seed=5))
+    m = AutoencoderKLWan(DEV, precision="fp32").load_state_dict(ovae.random_weights(seed=5))
+    assert m.precision == "fp16x3" and m.f16 and m.x3      # "fp32" names the fp32-class default: fp16 three-term operands since round 4
+    return m
+
+
+@pytest.fixture(scope="module")
+def model_bf16x3():
+    from worldforge_amd.vae import AutoencoderKLWan
+    return AutoencoderKLWan(DEV, precision="bf16x3").load_state_dict(ovae.random_weights(seed=5))
+
+
+@pytest.mark.parametrize("side", [0, 1])
+def test_split_f16x3_reconstructs_fp32(side):
+    """fp16 parts: hi + lo reproduces x to 2^-22 relative while lo is a normal fp16 number, and to the fp16 subnormal quantum 2^-24
+    absolutely below that; same layouts as the bf16 split."""
+    from worldforge_amd import _ffi, ops
+    g = torch.Generator().manual_seed(11)
+    rows, C, ld = 37, 96, 128
+    src = (torch.randn(rows, ld, generator=g) * torch.logspace(-3, 3, rows).unsqueeze(1)).to(DEV)
+    dst = torch.empty(rows, 3 * C, dtype=torch.float16, device=DEV)
+    _ffi.call("wf_split_f16x3", src.data_ptr(), ld, dst.data_ptr(), 3 * C, rows, C, side, ops.stream())
+    x = src[:, :C]
+    hi = x.to(torch.float16)
+    lo = (x - hi.float()).to(torch.float16)
+    want = torch.cat([hi, lo, hi] if side == 0 else [hi, hi, lo], dim=1)
+    assert torch.equal(dst, want)
+    err = ((hi.float() + lo.float()) - x).abs()
+    assert bool((err <= torch.maximum(2.0 ** -22 * x.abs(), torch.tensor(2.0 ** -25, device=DEV))).all())
+
+
+def test_f16_range_flag_is_raised_and_reported():
+    """fp16 cannot hold |x| > 65504: the split raises the sticky device flag and the VAE turns it into an error (never a silent inf)."""
+    import ctypes
+    from worldforge_amd import _ffi, ops
+    from worldforge_amd.vae import AutoencoderKLWan
+    flag = ctypes.c_int(-1)
+    _ffi.call("wf_f16_overflow_flag", ctypes.byref(flag), 1, ops.stream())
+    src = torch.ones(4, 32, device=DEV)
+    dst = torch.empty(4, 96, dtype=torch.float16, device=DEV)
+    _ffi.call("wf_split_f16x3", src.data_ptr(), 32, dst.data_ptr(), 96, 4, 32, 0, ops.stream())
+    _ffi.call("wf_f16_overflow_flag", ctypes.byref(flag), 1, ops.stream())
+    assert flag.value == 0
+    src[2, 5] = 7.0e4
+    _ffi.call("wf_split_f16x3", src.data_ptr(), 32, dst.data_ptr(), 96, 4, 32, 0, ops.stream())
+    _ffi.call("wf_f16_overflow_flag", ctypes.byref(flag), 0, ops.stream())
+    assert flag.value == 1
+    m = AutoencoderKLWan(DEV, precision="fp16x3")
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        m._check_range("test")                      # reads and resets
+    _ffi.call("wf_f16_overflow_flag", ctypes.byref(flag), 1, ops.stream())
+    assert flag.value == 0
+    with pytest.raises(ValueError, match="fp16 range"):
+        w = ovae.random_weights(seed=5)
+        k = next(k for k in w if k.endswith("residual.2.weight"))
+        w[k] = w[k].clone()
+        w[k].view(-1)[0] = 1.0e5
+        AutoencoderKLWan(DEV, precision="fp16x3").load_state_dict(w)
 
 
 @pytest.mark.parametrize("side", [0, 1])
@@ -265,21 +321,31 @@ def test_split_bf16x3_reconstructs_fp32(side):
     assert ((hi.float() + lo.float()) - x).abs().max().item() <= 2.0 ** -16 * x.abs().max().item()
 
 
+# bars per fp32-class mode: (rel L2 of mu / dec, max abs on pixels in [-1, 1]) against the fp32 goldens
+# (measured on MI355X, profiles/r4_tolerances.txt: fp16x3 4.2e-6 / 6.0e-6 / 1.6e-5 -- the level at which two fp32 implementations of the same
+# network differ by accumulation order; bf16x3 1.9e-5 / 2.2e-5 / 5.2e-5; the bars sit at <= 2x)
+FP32_CLASS_BARS = {"bf16x3": (4.4e-5, 1.04e-4), "fp16x3": (1.2e-5, 3.2e-5)}
+
+
+@pytest.mark.parametrize("mode", ["fp16x3", "bf16x3"])
 @pytest.mark.parametrize("name", CASES)
-def test_fp32_mode_encode_decode_vs_twin_goldens(name, model_fp32, golden_dir):
-    """The fp32-class VAE against the fp32 twin goldens.  Tolerance (stated): 2e-4 relative L2, 1e-3 max abs on pixels in [-1, 1]
-    (75x tighter than the bf16-operand mode): what is left is the dropped lo.lo term, fp32 accumulation order and __expf-class
-    transcendental error."""
+def test_fp32_mode_encode_decode_vs_twin_goldens(name, mode, model_fp32, model_bf16x3, golden_dir):
+    """The fp32-class VAE against the fp32 twin goldens, both operand splits: fp16 parts (default: ~2^-22 per product) and bf16 parts
+    (~2^-16).  What is left: the dropped lo.lo term, fp32 accumulation order and the transcendental error of SiLU / softmax."""
+    from tests._tol import within
+    model = model_fp32 if mode == "fp16x3" else model_bf16x3
     g = np.load(os.path.join(golden_dir, "g8_vae.npz"))
     x, z = torch.from_numpy(g[f"{name}_x"]), torch.from_numpy(g[f"{name}_z"])
-    mu = model_fp32.encode(x.to(DEV)).latent_dist.mode().cpu()
-    dec = model_fp32.decode(z.to(DEV), return_dict=False)[0].cpu()
+    mu = model.encode(x.to(DEV)).latent_dist.mode().cpu()
+    dec = model.decode(z.to(DEV), return_dict=False)[0].cpu()
     mu_ref, dec_ref = torch.from_numpy(g[f"{name}_mu"]), torch.from_numpy(g[f"{name}_dec"])
     e_mu, e_dec = _rel(mu, mu_ref), _rel(dec, dec_ref)
-    print(f"[fp32 {name}] rel L2: mu {e_mu:.3e} dec {e_dec:.3e}; max abs: mu {(mu - mu_ref).abs().max():.3e} "
+    print(f"[{mode} {name}] rel L2: mu {e_mu:.3e} dec {e_dec:.3e}; max abs: mu {(mu - mu_ref).abs().max():.3e} "
           f"dec {(dec - dec_ref).abs().max():.3e}")
-    assert e_mu <= 2e-4 and e_dec <= 2e-4
-    assert (dec - dec_ref).abs().max().item() <= 1e-3
+    tol_rel, tol_abs = FP32_CLASS_BARS[mode]
+    within(f"vae.{mode}.mu.rel_l2", e_mu, tol_rel)
+    within(f"vae.{mode}.dec.rel_l2", e_dec, tol_rel)
+    within(f"vae.{mode}.dec.max_abs", (dec - dec_ref).abs().max().item(), tol_abs)
 
 
 @pytest.mark.parametrize("P,H", [(2, 64), (4, 64), (8, 96)])   # (8, 96): the low-resolution stage in 4 row groups of 2 ranks each
@@ -323,7 +389,7 @@ def test_diffusers_layout_checkpoint_loads_and_matches_executed_class(name, gold
     assert set(sd) == set(shapes)
     os.makedirs(tmp_path / "vae")
     save_file(sd, str(tmp_path / "vae" / "diffusion_pytorch_model.safetensors"))
-    for precision, tol_rel, tol_abs in (("bf16", 1.5e-2, 6e-2), ("fp32", 2e-4, 1e-3)):
+    for precision, tol_rel, tol_abs in (("bf16", 1.5e-2, 6e-2), ("fp32",) + FP32_CLASS_BARS["fp16x3"], ("bf16x3",) + FP32_CLASS_BARS["bf16x3"]):
         m = AutoencoderKLWan.from_pretrained(str(tmp_path), device=DEV, precision=precision)
         mu = m.encode(torch.from_numpy(g[f"{name}_x"]).to(DEV)).latent_dist.mode().cpu()
         dec = m.decode(torch.from_numpy(g[f"{name}_z"]).to(DEV), return_dict=False)[0].cpu()

@@ -199,6 +199,19 @@ ok("wf_rms_silu_cl", f32(npix * Ci), f32(Ci), buf(2 * npix * Ci), None, npix, Ci
 ok("wf_rms_silu_cl_x3", f32(npix * Ci), f32(Ci), buf(2 * npix * 3 * Ci), npix, Ci, 1, None)
 ok("wf_rms_silu_cl_blocked", f32(npix * Ci), f32(Ci), buf(2 * npix * 2 * Ci), npix, Ci, 1, W_, 1, 0, None)
 ok("wf_split_bf16x3", f32(npix * Ci), Ci, buf(2 * npix * 3 * Ci), 3 * Ci, npix, Ci, 0, None)
+# the fp16 operand formats (round 4): the same host paths with the element type flag set
+ok("wf_conv3d_cl_f16", buf(2 * T_ * H_ * W_ * Ci), buf(2 * Co * 27 * Ci), f32(Co), None, f32(T_ * H_ * W_ * Co), None, T_, H_, W_, Ci, T_, H_, W_, Co,
+   3, 3, 3, 1, 1, 2, 1, 1, 0, 0, zp, None)
+ok("wf_conv3d_cl_scatter_f16", buf(2 * T_ * H_ * W_ * Ci), buf(2 * Co * 4 * Ci), f32(Co), None, f32(T_ * 2 * H_ * 2 * W_ * Co), None, T_, H_, W_, Ci, T_, H_, W_, Co,
+   1, 2, 2, 1, 1, 0, 1, 1, zp, 2 * H_, 2 * W_, 2, 0, 2, 0, None)
+ok("wf_conv3d_333_f16", buf(2 * T_ * H_ * W_ * Ci), buf(2 * 27 * (Ci // 16) * Co * 16), f32(Co), None, f32(T_ * H_ * W_ * Co), None, T_, H_, W_, Ci, H_, Co, 1,
+   zp, 4096, 0, Ci, None)
+ok("wf_rms_silu_cl_x3_f16", f32(npix * Ci), f32(Ci), buf(2 * npix * 3 * Ci), npix, Ci, 1, None)
+ok("wf_rms_silu_cl_blocked_f16", f32(npix * Ci), f32(Ci), buf(2 * npix * 2 * Ci), npix, Ci, 1, W_, 1, 0, None)
+ok("wf_split_f16x3", f32(npix * Ci), Ci, buf(2 * npix * 3 * Ci), 3 * Ci, npix, Ci, 0, None)
+for (M, N, K, epi) in ((4095, 1152, 1152, 2), (300, 384, 1152, 4), (2048, 2560, 384, 0)):
+    ok("wf_gemm_f16", buf(2 * M * K), buf(2 * N * K), f32(N), buf((2 if epi == 0 else 4) * M * N), M, N, K, K, K, N, epi, None)
+bad("wf_gemm_f16", buf(64), buf(64), None, buf(64), 4, 4, 8, 8, 8, 4, 3, None)                           # the gated-residual epilogue is not built for fp16 operands
 ok("wf_softmax_rows", f32(40 * 48), 48, buf(2 * 40 * 48), 48, 40, 48, 0.5, None)
 ok("wf_softmax_rows_f32", f32(40 * 48), 48, f32(40 * 48), 48, 40, 48, 0.5, None)
 ok("wf_transpose_bf16", buf(2 * 40 * 48), 48, buf(2 * 48 * 40), 40, 40, 48, None)

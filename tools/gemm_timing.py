@@ -8,7 +8,7 @@ x = torch.randn(M, K, device="cuda:0").to(torch.bfloat16)
 w = (torch.randn(N, K, device="cuda:0") / math.sqrt(K)).to(torch.bfloat16)
 out = torch.empty(M, N, device="cuda:0", dtype=torch.bfloat16)
 lib = _ffi.lib()
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 16)()
 dit.gemm(x, w, None, out, 0); torch.cuda.synchronize(); lib.wf_debug_gemm_cycles(buf, 1)
 dit.gemm(x, w, None, out, 0); torch.cuda.synchronize(); lib.wf_debug_gemm_cycles(buf, 1)
 n = max(buf[4], 1)

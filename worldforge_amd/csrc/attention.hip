@@ -33,6 +33,7 @@
 #include "common.h"
 #include "mfma.h"
 
+#include <climits>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -60,6 +61,9 @@ struct AttnArgs {
   int prio_mode;     // experiment: 1 = static s_setprio 1 for waves 4-7, 2 = for waves 0-3
   // split-KV (k_attn_w4 only): blockIdx.y = split s works on KV tiles [s * tiles_per_split, ...) and leaves un-normalised partials
   int nsplit, tiles_per_split;
+  // KV-tile window of this launch (wf_attn_fwd_part: the segments that have ARRIVED so far): split s starts at absolute tile
+  // t_begin0 + s * tiles_per_split, no tile >= t_end is touched, and the partials land in slot part0 + s.  Whole-sweep launches: 0, INT_MAX, 0.
+  int t_begin0, t_end, part0;
   float* o_part;   // [nsplit][Lq][H*128] f32
   float* ml_part;  // [nsplit][H][Lq][2] f32: reference max m (raw score units), row sum l
   // block-sparse attention (KIND 3): per (head, 256-row query group) a list of 128-key blocks to visit, entry = block * 4 + flags,
@@ -210,9 +214,9 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
   }
   const float c = PS ? 1.0f : a.scale_log2;
   const int ntiles_all = (KIND == 5 ? a.n1 : 0) + (a.kv_len + KB - 1) / KB;
-  const int split = blockIdx.y;
-  const int t_begin = split * a.tiles_per_split;                         // first KV tile of this split (absolute)
-  int ntiles_ = min(a.tiles_per_split, ntiles_all - t_begin);            // tiles of this split (>= 1 by construction of the grid)
+  const int split = a.part0 + blockIdx.y;                                // partial slot of this split
+  const int t_begin = a.t_begin0 + blockIdx.y * a.tiles_per_split;       // first KV tile of this split (absolute)
+  int ntiles_ = min(a.tiles_per_split, min(ntiles_all, a.t_end) - t_begin);  // tiles of this split (>= 1 by construction of the grid)
   // block-sparse variant: per-workgroup list of PHYSICAL key blocks (entry = block * 2^g + flags, g = bsa_shift query blocks per
   // workgroup = 2 waves each for 128-token blocks / 1 wave each for 64-token blocks), tpe tiles per entry
   const int* bsa = nullptr;
@@ -922,9 +926,11 @@ __global__ void k_attn_merge(AttnArgs a) {
 
 static unsigned int* g_dbg_body = nullptr;  // wf_attn_debug_body_counter
 
+// part_index >= 0: a PART launch (wf_attn_fwd_part) -- KV tiles [part_t0, part_t1) only, un-normalised partials into slot part_index of the
+// `nsplit`-slot workspace, no merge (wf_attn_merge follows once every slot is filled)
 static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len, int ldo,
                        float softmax_scale, int accumulate, int nsplit, void* workspace, const float* kmax2, int kmax_n, const float* qmax2,
-                       int qmax_n, void* stream, const char* who) {
+                       int qmax_n, void* stream, const char* who, int part_index = -1, int part_t0 = 0, int part_t1 = 0) {
   WF_CHECK_ARG(Q && K && Vt && O, "%s: null pointer", who);
   WF_CHECK_ARG((!kmax2 || (kmax_n >= 1 && kmax_n <= 64)) && (!qmax2 || (qmax_n >= 1 && qmax_n <= 64)), "%s: kmax_n / qmax_n must be 1..64", who);
   WF_CHECK_ARG(H > 0 && Lq > 0 && kv_len > 0, "%s: empty problem", who);
@@ -955,6 +961,9 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
   const int ntiles = ceil_div(kv_len, KB);
   a.nsplit = 1;
   a.tiles_per_split = ntiles;
+  a.t_begin0 = 0;
+  a.t_end = INT_MAX;
+  a.part0 = 0;
   a.o_part = nullptr;
   a.ml_part = nullptr;
   a.bsa_list = nullptr;
@@ -971,7 +980,20 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
   const int hslots = (H + 7) / 8;
   const int grid = hslots * a.n_qblk * 8;
   const size_t lds_w4 = 5 * (K_TILE_BYTES + V_TILE_BYTES);  // ring of 5 (160 KiB: the whole LDS of a CU)
-  if (nsplit > 1) {
+  int grid_y = 1;
+  if (part_index >= 0) {
+    WF_CHECK_ARG(softmax_scale == 0.0f, "%s: part launches are built for the pre-scaled-Q form only (softmax_scale = 0)", who);
+    WF_CHECK_ARG(nsplit >= 2 && nsplit <= 8 && part_index < nsplit, "%s: part %d of %d slots (2..8)", who, part_index, nsplit);
+    WF_CHECK_ARG(part_t0 >= 0 && part_t0 < part_t1 && part_t0 < ntiles, "%s: empty tile window [%d, %d) of %d tiles", who, part_t0, part_t1, ntiles);
+    WF_CHECK_ARG(workspace && (((uintptr_t)workspace) & 15) == 0, "%s: needs a 16-byte aligned workspace", who);
+    a.nsplit = nsplit;  // > 1: the kernel leaves un-normalised partials
+    a.t_begin0 = part_t0;
+    a.t_end = part_t1;
+    a.tiles_per_split = part_t1 - part_t0;
+    a.part0 = part_index;
+    a.o_part = (float*)workspace;
+    a.ml_part = a.o_part + (size_t)nsplit * Lq * H * D;
+  } else if (nsplit > 1) {
     WF_CHECK_ARG(workspace && (((uintptr_t)workspace) & 15) == 0, "%s: nsplit > 1 needs a 16-byte aligned workspace", who);
     int tps = ceil_div(ntiles, nsplit);
     const int ns = ceil_div(ntiles, tps);  // splits that actually get tiles
@@ -979,19 +1001,20 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
     a.tiles_per_split = tps;
     a.o_part = (float*)workspace;
     a.ml_part = a.o_part + (size_t)ns * Lq * H * D;
+    grid_y = ns;
   }
   if (prescaled)
-    hipLaunchKernelGGL(k_attn_w4<4>, dim3(grid, a.nsplit), dim3(NT4), lds_w4, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_attn_w4<4>, dim3(grid, grid_y), dim3(NT4), lds_w4, (hipStream_t)stream, a);
 #ifdef WF_ATTN_LAB  // lab builds (tools/attn_lab.py) instantiate the timed kernel only: 5x shorter compile
   else
     WF_CHECK_ARG(false, "%s: lab build, pre-scaled self-attention only", who);
 #else
   else if (Lkp > 1024)
-    hipLaunchKernelGGL(k_attn_w4<0>, dim3(grid, a.nsplit), dim3(NT4), lds_w4, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_attn_w4<0>, dim3(grid, grid_y), dim3(NT4), lds_w4, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL(k_attn_w4<1>, dim3(grid, a.nsplit), dim3(NT4), lds_w4, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_attn_w4<1>, dim3(grid, grid_y), dim3(NT4), lds_w4, (hipStream_t)stream, a);
 #endif
-  if (a.nsplit > 1) {
+  if (a.nsplit > 1 && part_index < 0) {
     const size_t n = (size_t)Lq * H * (D / 4);
     hipLaunchKernelGGL(k_attn_merge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   }
@@ -1093,6 +1116,9 @@ extern "C" int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, voi
   a.prio_mode = 0;
   a.nsplit = 1;
   a.tiles_per_split = 0;
+  a.t_begin0 = 0;
+  a.t_end = INT_MAX;
+  a.part0 = 0;
   a.o_part = nullptr;
   a.ml_part = nullptr;
   a.bsa_list = group_lists;
@@ -1143,6 +1169,9 @@ extern "C" int wf_attn_cross2_fwd(const void* Q, const void* K, const void* Vt, 
   a.prio_mode = 0;
   a.nsplit = 1;
   a.tiles_per_split = a.Lkp / KB;
+  a.t_begin0 = 0;
+  a.t_end = INT_MAX;
+  a.part0 = 0;
   a.o_part = nullptr;
   a.ml_part = nullptr;
   a.bsa_list = nullptr;
@@ -1161,6 +1190,39 @@ extern "C" int wf_attn_cross2_fwd(const void* Q, const void* K, const void* Vt, 
   hipLaunchKernelGGL(k_attn_w4<5>, dim3(grid, 1), dim3(NT4), 5 * (K_TILE_BYTES + V_TILE_BYTES), (hipStream_t)stream, a);
 #endif
   WF_LAUNCH_CHECK("wf_attn_cross2_fwd");
+  return WF_OK;
+}
+
+// The KV sweep of wf_attn_fwd in PARTS: the key segments of a sequence-parallel layer arrive one source rank after the other, and a part
+// launch walks only the tiles [t_begin, t_end) that are there already (pre-scaled Q form) and leaves un-normalised partials (O f32, reference
+// max, row sum) in slot `part` of an `nparts`-slot workspace (wf_attn_split_workspace_bytes(H, Lq, nparts)); wf_attn_merge combines the
+// slots exactly (the flash combine of wf_attn_fwd_split) once every slot has been written.  The rank's own shard needs no wait at all, so a
+// forward WITHOUT a second CFG branch to hide under still overlaps the exchange with attention itself.
+extern "C" int wf_attn_fwd_part(const void* Q, const void* K, const void* Vt, int H, int Lq, int Lkp, int kv_len, int seg_len,
+                                int t_begin, int t_end, int part, int nparts, void* workspace, const float* kmax2, int kmax_n,
+                                const float* qmax2, int qmax_n, void* stream) {
+  // O is not written by a part launch; the checks of attn_launch want a valid aligned pointer: the workspace serves
+  return attn_launch(Q, K, Vt, workspace, H, Lq, Lkp, kv_len, seg_len, H * D, 0.0f, 0, nparts, workspace, kmax2, kmax_n, qmax2, qmax_n, stream,
+                     "wf_attn_fwd_part", part, t_begin, t_end);
+}
+
+extern "C" int wf_attn_merge(void* O, int H, int Lq, int ldo, int accumulate, int nparts, const void* workspace, void* stream) {
+  WF_CHECK_ARG(O && workspace, "wf_attn_merge: null pointer");
+  WF_CHECK_ARG(H > 0 && Lq > 0 && nparts >= 2 && nparts <= 8, "wf_attn_merge: H=%d Lq=%d nparts=%d (2..8)", H, Lq, nparts);
+  WF_CHECK_ARG(ldo % 8 == 0 && ldo >= H * D && ((((uintptr_t)O) | ((uintptr_t)workspace)) & 15) == 0, "wf_attn_merge: ldo %d / alignment", ldo);
+  AttnArgs a = {};
+  a.O = (uint16_t*)O;
+  a.H = H;
+  a.Lq = Lq;
+  a.ldo = ldo;
+  a.accumulate = accumulate;
+  a.scale_log2 = 1.0f;  // pre-scaled Q: the partial maxima are in the exp2 domain
+  a.nsplit = nparts;
+  a.o_part = (float*)const_cast<void*>(workspace);
+  a.ml_part = a.o_part + (size_t)nparts * Lq * H * D;
+  const size_t n = (size_t)Lq * H * (D / 4);
+  hipLaunchKernelGGL(k_attn_merge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  WF_LAUNCH_CHECK("wf_attn_merge");
   return WF_OK;
 }
 

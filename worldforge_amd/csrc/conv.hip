@@ -48,6 +48,7 @@ struct ConvArgs {
   int up2;         // read input through nearest 2x spatial upsample
   int tsplit;      // Resample 'upsample3d' (vae.py:134-137): channel half h of output frame t goes to frame 1 + 2*t + h
   int silu_out;    // unused (reserved)
+  int f16;         // operands (in, w) and the 16-bit output copy are fp16 instead of bf16 (wf_*_f16 entry points)
   // output scatter (osy == 0: none): output pixel (t, y, x) of the [To, Ho, Wo] grid is written to pixel (t, osy * y + ooy, osx * x + oox)
   // of a [To, oH, oW] tensor -- the four phases of a nearest-2x-upsample + 3 x 3 convolution are 2 x 2 convolutions on the source grid
   int osy, ooy, osx, oox, oH, oW;
@@ -118,7 +119,7 @@ __device__ __forceinline__ void conv_store_wave_tile(const ConvArgs& a, const f3
           *reinterpret_cast<f32x4*>(a.out_f32 + o) = ov;
         }
         if (has_bf16) {
-          u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          u32x2 pk = {pack16x2(a.f16, v[0], v[1]), pack16x2(a.f16, v[2], v[3])};
           *reinterpret_cast<u32x2*>(a.out_bf16 + o) = pk;
         }
       }
@@ -138,6 +139,7 @@ __device__ __forceinline__ void conv_store_dispatch(const ConvArgs& a, const f32
   }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(CNT, 2) void k_conv(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -246,15 +248,15 @@ __global__ __launch_bounds__(CNT, 2) void k_conv(ConvArgs a) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int c = 2 * s + hi;
-      bf16x8 fw[3], fx[2];
+      u32x4 fw[3], fx[2];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) fw[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(base + fwoff[i] + ((c ^ fwsw[i]) << 4)));
+      for (int i = 0; i < 3; ++i) fw[i] = *reinterpret_cast<const u32x4*>(base + fwoff[i] + ((c ^ fwsw[i]) << 4));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fx[j] = as_bf16x8(*reinterpret_cast<const u32x4*>(base + fxoff[j] + ((c ^ fxsw[j]) << 4)));
+      for (int j = 0; j < 2; ++j) fx[j] = *reinterpret_cast<const u32x4*>(base + fxoff[j] + ((c ^ fxsw[j]) << 4));
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fw[i], fx[j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32t<F16>(fw[i], fx[j], acc[i][j]);
     }
     if (kt_ + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
@@ -294,6 +296,7 @@ struct ConvPPArgs {
   const uint16_t* zeros;  // >= 16 bytes of zeros in device memory
 };
 
+template <bool F16>
 __global__ __launch_bounds__(QT, 2) void k_conv_pp(ConvPPArgs pa) {
   const ConvArgs& a = pa.c;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(QT, 2) void k_conv_pp(ConvPPArgs pa) {
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          acc[i][j] = mfma32(as_bf16x8(fw[ks][i]), as_bf16x8(fx[ks][j]), acc[i][j]);
+          acc[i][j] = mfma32t<F16>(fw[ks][i], fx[ks][j], acc[i][j]);
           const int idx = ks * 6 + i * 2 + j;
           if (dma_kt2 >= 0 && idx < 10) dma_piece(dma_kt2, d, idx);
         }
@@ -562,7 +565,7 @@ struct ConvW4Args {
 // loads, bit 2 = no in-loop LDS fragment reads.  Compile-time, so that the production instantiation (DBG = 0) carries no branches.
 // NCB = 32-channel output blocks per workgroup: 3 (96 output channels, the ResidualBlock layers) or 1 (the 96 -> 3 decoder head and the
 // 384 -> 32 encoder head, zero-padded to 32 output channels: a third of the MFMAs of the 96-wide tile they used to be computed with).
-template <int DBG, int NCB = 3>
+template <int DBG, int NCB = 3, bool F16 = false>
 __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const ConvArgs& a = pa.c;
@@ -664,7 +667,10 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
 
   f32x16 acc[4][NCB];
   auto mma = [&](f32x16& c, const u32x4& wv, const u32x4& xv) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(wv), "v"(xv));
+    if constexpr (F16)
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(wv), "v"(xv));
+    else
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(wv), "v"(xv));
   };
   auto bar = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -811,7 +817,7 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
             *reinterpret_cast<f32x4*>(a.out_f32 + o) = ov;
           }
           if (has_bf16) {
-            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            u32x2 pk = {pack16x2(a.f16, v[0], v[1]), pack16x2(a.f16, v[2], v[3])};
             *reinterpret_cast<u32x2*>(a.out_bf16 + o) = pk;
           }
         }
@@ -902,7 +908,8 @@ __global__ void k_conv_small(SmallConvArgs a) {
 
 static int conv3d_cl_impl(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_bf16,
                           int Ti, int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st,
-                          int ss, int pt, int ph, int pw, int up2, int tsplit, const void* zero_page, const int* scatter, void* stream) {
+                          int ss, int pt, int ph, int pw, int up2, int tsplit, const void* zero_page, const int* scatter, void* stream,
+                          int f16 = 0) {
   WF_CHECK_ARG(in && w && (out_f32 || out_bf16), "wf_conv3d_cl: null pointer");
   WF_CHECK_ARG(Cin % CBK == 0, "wf_conv3d_cl: Cin (%d) must be a multiple of 32 (use wf_conv3d_small otherwise)", Cin);
   WF_CHECK_ARG(Cout % 4 == 0, "wf_conv3d_cl: Cout (%d) must be a multiple of 4", Cout);
@@ -922,6 +929,7 @@ static int conv3d_cl_impl(const void* in, const void* w, const float* bias, cons
   a.kt = kt; a.kh = kh; a.kw = kw;
   a.st = st; a.ss = ss; a.pt = pt; a.ph = ph; a.pw = pw;
   a.up2 = up2; a.tsplit = tsplit; a.silu_out = 0;
+  a.f16 = f16;
   a.osy = a.ooy = a.osx = a.oox = a.oH = a.oW = 0;
   if (scatter) {  // {out_H, out_W, sy, oy, sx, ox}
     WF_CHECK_ARG(!tsplit && scatter[2] >= 1 && scatter[4] >= 1 && scatter[3] >= 0 && scatter[5] >= 0 &&
@@ -939,12 +947,18 @@ static int conv3d_cl_impl(const void* in, const void* w, const float* bias, cons
     pa.c = a;
     pa.zeros = (const uint16_t*)zero_page;
     dim3 grid((unsigned)((M + QM - 1) / QM), (unsigned)((Cout + QN - 1) / QN));
-    hipLaunchKernelGGL(k_conv_pp, grid, dim3(QT), 2 * QBUF, (hipStream_t)stream, pa);
+    if (f16)
+      hipLaunchKernelGGL(k_conv_pp<true>, grid, dim3(QT), 2 * QBUF, (hipStream_t)stream, pa);
+    else
+      hipLaunchKernelGGL(k_conv_pp<false>, grid, dim3(QT), 2 * QBUF, (hipStream_t)stream, pa);
     WF_LAUNCH_CHECK("wf_conv3d_cl");
     return WF_OK;
   }
   dim3 grid((unsigned)((M + CBM - 1) / CBM), (unsigned)((Cout + CBN - 1) / CBN));
-  hipLaunchKernelGGL(k_conv, grid, dim3(CNT), 2 * CBUF, (hipStream_t)stream, a);
+  if (f16)
+    hipLaunchKernelGGL(k_conv<true>, grid, dim3(CNT), 2 * CBUF, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(k_conv<false>, grid, dim3(CNT), 2 * CBUF, (hipStream_t)stream, a);
   WF_LAUNCH_CHECK("wf_conv3d_cl");
   return WF_OK;
 }
@@ -963,6 +977,24 @@ extern "C" int wf_conv3d_cl_scatter(const void* in, const void* w, const float* 
   const int scatter[6] = {out_H, out_W, sy, oy, sx, ox};
   return conv3d_cl_impl(in, w, bias, resid, out_f32, out_bf16, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, kt, kh, kw, st, ss, pt, ph, pw, 0, 0,
                         zero_page, scatter, stream);
+}
+
+// The same convolutions on fp16 operands (in, w and the optional 16-bit output copy are fp16; v_mfma_f32_32x32x16_f16): the VAE's
+// "fp16x3" operand format -- hi = fp16(x), lo = fp16(x - hi), 2^-22 per product where the bf16 split gives 2^-16 -- and its one-term "fp16" mode.
+extern "C" int wf_conv3d_cl_f16(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_f16,
+                                int Ti, int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st,
+                                int ss, int pt, int ph, int pw, int up2, int tsplit, const void* zero_page, void* stream) {
+  return conv3d_cl_impl(in, w, bias, resid, out_f32, out_f16, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, kt, kh, kw, st, ss, pt, ph, pw, up2, tsplit,
+                        zero_page, nullptr, stream, 1);
+}
+
+extern "C" int wf_conv3d_cl_scatter_f16(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_f16,
+                                        int Ti, int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st,
+                                        int ss, int pt, int ph, int pw, const void* zero_page, int out_H, int out_W, int sy, int oy, int sx,
+                                        int ox, void* stream) {
+  const int scatter[6] = {out_H, out_W, sy, oy, sx, ox};
+  return conv3d_cl_impl(in, w, bias, resid, out_f32, out_f16, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, kt, kh, kw, st, ss, pt, ph, pw, 0, 0,
+                        zero_page, scatter, stream, 1);
 }
 
 extern "C" int wf_conv3d_small(const void* in, int in_dtype, const float* w, const float* bias, float* out_f32, void* out_bf16,
@@ -1008,9 +1040,9 @@ extern "C" size_t wf_conv3d_333_zero_page_bytes(int Wi, int Cin_stored, int layo
   return (nsa - 1) * slice_stride * 2 + 64;
 }
 
-extern "C" int wf_conv3d_333(const void* in, const void* w_packed, const float* bias, const float* resid, float* out_f32,
-                             void* out_bf16, int T, int Hi, int Wi, int Cin, int Ho, int Cout, int ph, const void* zero_page,
-                             size_t zero_page_bytes, int layout, int Cin_stored, void* stream) {
+static int conv3d_333_impl(const void* in, const void* w_packed, const float* bias, const float* resid, float* out_f32,
+                           void* out_bf16, int T, int Hi, int Wi, int Cin, int Ho, int Cout, int ph, const void* zero_page,
+                           size_t zero_page_bytes, int layout, int Cin_stored, void* stream, int f16) {
   WF_CHECK_ARG(in && w_packed && zero_page && (out_f32 || out_bf16), "wf_conv3d_333: null pointer");
   {
     const size_t need = wf_conv3d_333_zero_page_bytes(Wi, Cin_stored, layout);
@@ -1036,6 +1068,7 @@ extern "C" int wf_conv3d_333(const void* in, const void* w_packed, const float* 
   a.kt = a.kh = a.kw = 3;
   a.st = a.ss = 1; a.pt = 2; a.ph = ph; a.pw = 1;
   a.up2 = a.tsplit = a.silu_out = 0;
+  a.f16 = f16;
   a.osy = a.ooy = a.osx = a.oox = a.oH = a.oW = 0;
   wa.zeros = (const uint16_t*)zero_page;
   wa.tiles_x = (Wi + WX - 1) / WX;
@@ -1066,13 +1099,31 @@ extern "C" int wf_conv3d_333(const void* in, const void* w_packed, const float* 
     else hipLaunchKernelGGL(k_conv_w4<0>, grid, dim3(W4T), W4_LDS, (hipStream_t)stream, wa);
   }
 #else
-  if (thin)
+  if (thin && f16)
+    hipLaunchKernelGGL((k_conv_w4<0, 1, true>), grid, dim3(W4T), W4_LDS, (hipStream_t)stream, wa);
+  else if (thin)
     hipLaunchKernelGGL((k_conv_w4<0, 1>), grid, dim3(W4T), W4_LDS, (hipStream_t)stream, wa);
+  else if (f16)
+    hipLaunchKernelGGL((k_conv_w4<0, 3, true>), grid, dim3(W4T), W4_LDS, (hipStream_t)stream, wa);
   else
     hipLaunchKernelGGL((k_conv_w4<0, 3>), grid, dim3(W4T), W4_LDS, (hipStream_t)stream, wa);
 #endif
   WF_LAUNCH_CHECK("wf_conv3d_333");
   return WF_OK;
+}
+
+extern "C" int wf_conv3d_333(const void* in, const void* w_packed, const float* bias, const float* resid, float* out_f32,
+                             void* out_bf16, int T, int Hi, int Wi, int Cin, int Ho, int Cout, int ph, const void* zero_page,
+                             size_t zero_page_bytes, int layout, int Cin_stored, void* stream) {
+  return conv3d_333_impl(in, w_packed, bias, resid, out_f32, out_bf16, T, Hi, Wi, Cin, Ho, Cout, ph, zero_page, zero_page_bytes, layout,
+                         Cin_stored, stream, 0);
+}
+
+extern "C" int wf_conv3d_333_f16(const void* in, const void* w_packed, const float* bias, const float* resid, float* out_f32,
+                                 void* out_f16, int T, int Hi, int Wi, int Cin, int Ho, int Cout, int ph, const void* zero_page,
+                                 size_t zero_page_bytes, int layout, int Cin_stored, void* stream) {
+  return conv3d_333_impl(in, w_packed, bias, resid, out_f32, out_f16, T, Hi, Wi, Cin, Ho, Cout, ph, zero_page, zero_page_bytes, layout,
+                         Cin_stored, stream, 1);
 }
 
 #ifdef WF_CONV_TIMING

@@ -41,6 +41,7 @@ struct GemmArgs {
   int mt, nt;  // tile counts
   // batched launches of k_gemm (blockIdx.y = batch b): X, W, out of problem b start b * bsx / bsw / bso ELEMENTS further (0 = not batched)
   long bsx, bsw, bso;
+  int f16;  // X, W and a 16-bit output are fp16 instead of bf16 (wf_gemm_f16: the VAE's fp16 operand formats)
 };
 
 enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32 = 2, EPI_RESID = 3, EPI_F32_ACC = 4 };
@@ -56,7 +57,7 @@ __device__ __forceinline__ float gelu_tanh(float x) {
   return 0.5f * x * (1.0f + t);
 }
 
-template <int EPI>
+template <int EPI, bool F16 = false>
 __global__ __launch_bounds__(NTHREADS, 2) void k_gemm(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // ---- XCD-aware tile assignment --------------------------------------------------------------------------
@@ -150,16 +151,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_gemm(GemmArgs a) {
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       const int c = 2 * s + hi;
-      bf16x8 fw[2], fx[2];
+      u32x4 fw[2], fx[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        fw[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(sWb + offW[i] + ((c ^ rswW[i]) << 4)));
-        fx[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(sXb + offX[i] + ((c ^ rswX[i]) << 4)));
+        fw[i] = *reinterpret_cast<const u32x4*>(sWb + offW[i] + ((c ^ rswW[i]) << 4));
+        fx[i] = *reinterpret_cast<const u32x4*>(sXb + offX[i] + ((c ^ rswX[i]) << 4));
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn) acc[i][jn] = mfma32(fw[i], fx[jn], acc[i][jn]);
+        for (int jn = 0; jn < 2; ++jn) acc[i][jn] = mfma32t<F16>(fw[i], fx[jn], acc[i][jn]);
     }
     if (kt + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
@@ -190,7 +191,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_gemm(GemmArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
           }
-          u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          u32x2 pk;
+          if constexpr (F16)
+            pk = u32x2{pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3])};
+          else
+            pk = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
           *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + (size_t)blockIdx.y * a.bso + o) = pk;
         } else if constexpr (EPI == EPI_F32) {
           f32x4 ov = {v[0], v[1], v[2], v[3]};
@@ -225,6 +230,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_gemm(GemmArgs a) {
 // barrier 4t (its buffer was last read two intervals earlier) and drain it (vmcnt(0)) before barrier 4t+4.
 // Requirements: K % 64 == 0 (no K tail in the DMA path); ragged M / N handled by clamped source rows + predicated stores.
 // ------------------------------------------------------------------------------------------------------------------
+#ifdef WF_GEMM_TIMING
+// lab builds (WF_EXTRA_HIPCC_FLAGS=-DWF_GEMM_TIMING): k_gemm_w4 fills [0..7] (tools/gemm_timing.py); k_gemm_pp adds, per workgroup (its
+// wave 0): [8] prologue, [9] K loop, [10] epilogue shader cycles, [11] workgroups, [12] cycles of wave 4 (group B) K loop
+__device__ unsigned long long g_gemm_cycles[16];
+#endif
 constexpr int PM = 256, PN = 256, PK = 64, PT = 512;
 constexpr int P_TILE = PM * PK * 2;  // 32 KiB per operand tile
 constexpr int P_BUF = 2 * P_TILE;    // W tile | X tile
@@ -250,7 +260,7 @@ struct PPGeom {
   static constexpr int LDS = 2 * BUF > 8 * STG ? 2 * BUF : 8 * STG;
 };
 
-template <int EPI, int NI>
+template <int EPI, int NI, bool F16 = false>
 __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
   using G = PPGeom<NI>;
   constexpr int NJ = G::NJ, NWP = G::NWP, NP = G::NP, W_TILE = G::W_TILE, BUF = G::BUF;
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int jx = 0; jx < NJ; ++jx) {
-          acc[i][jx] = mfma32(as_bf16x8(fw[ks][i]), as_bf16x8(fx[ks][jx]), acc[i][jx]);
+          acc[i][jx] = mfma32t<F16>(fw[ks][i], fx[ks][jx], acc[i][jx]);
           const int idx = (ks * NI + i) * NJ + jx;
           if (dma_kt >= 0 && (idx & 1) && (idx >> 1) < NP) dma_piece(dma_kt, idx >> 1);
         }
@@ -356,9 +366,15 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
   auto drain = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
   const int nk = a.K / PK;
+#ifdef WF_GEMM_TIMING
+  const unsigned long long tt0 = __builtin_readcyclecounter();
+#endif
   dma(0);
   drain();
   bar();
+#ifdef WF_GEMM_TIMING
+  const unsigned long long tt1 = __builtin_readcyclecounter();
+#endif
   if (!groupB) {
     for (int kt = 0; kt < nk; ++kt) {
       read_half(kt, 0);
@@ -388,6 +404,9 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
     }
   }
 
+#ifdef WF_GEMM_TIMING
+  const unsigned long long tt2 = __builtin_readcyclecounter();
+#endif
   // ---- epilogue through LDS: row-contiguous global accesses ------------------------------------------------------------------
   // In the accumulator layout a lane owns one token row and quads of features, so a store instruction touches 32-64 different rows
   // (8 / 16 bytes each): 64 such instructions per lane made the epilogue ~20 k cycles per tile, 9 % of a K = 5120 GEMM.  Each wave
@@ -434,7 +453,11 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
               }
-              u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+              u32x2 pk;
+              if constexpr (F16)
+                pk = u32x2{pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3])};
+              else
+                pk = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
               *reinterpret_cast<u32x2*>(stg + (jx * 32 + l31) * RS + nl * 2) = pk;
             }
           }
@@ -524,6 +547,17 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
       }
     }
   }
+#ifdef WF_GEMM_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the epilogue's stores have left the wave
+  const unsigned long long tt3 = __builtin_readcyclecounter();
+  if (lane == 0 && wid == 0) {
+    atomicAdd(&g_gemm_cycles[8], tt1 - tt0);
+    atomicAdd(&g_gemm_cycles[9], tt2 - tt1);
+    atomicAdd(&g_gemm_cycles[10], tt3 - tt2);
+    atomicAdd(&g_gemm_cycles[11], 1ull);
+  }
+  if (lane == 0 && wid == 4) atomicAdd(&g_gemm_cycles[12], tt2 - tt1);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -804,9 +838,6 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp16(GemmArgs a) {
 // the last tile into the dead buffer instead of branching.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int WT = 256;  // threads
-#ifdef WF_GEMM_TIMING
-__device__ unsigned long long g_gemm_cycles[8];
-#endif
 
 template <int EPI>
 __global__ __launch_bounds__(WT, 1) void k_gemm_w4(GemmArgs a) {
@@ -1018,7 +1049,9 @@ static void launch_pp(GemmArgs a, hipStream_t s) {
   const int nsuper = ((a.mt + 3) / 4) * ((a.nt + 3) / 4);
   const int grid = ((nsuper + 7) / 8) * 8 * 16;
   static const bool mfma16 = [] { const char* e = getenv("WF_GEMM_MFMA"); return e && atoi(e) == 16; }();
-  if (mfma16)
+  if (a.f16) {  // fp16 operands: the epilogues the VAE uses (the others are rejected by wf_gemm_f16)
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_F32_ACC) hipLaunchKernelGGL((k_gemm_pp<EPI, NI, true>), dim3(grid), dim3(PT), G::LDS, s, a);
+  } else if (mfma16)
     hipLaunchKernelGGL((k_gemm_pp16<EPI, NI>), dim3(grid), dim3(PT), G::LDS, s, a);
   else
     hipLaunchKernelGGL((k_gemm_pp<EPI, NI>), dim3(grid), dim3(PT), G::LDS, s, a);
@@ -1057,9 +1090,11 @@ static void launch_pp_any(GemmArgs a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int wf_gemm_bf16(const void* X, const void* W, const float* bias, void* out, const float* gate, int M, int N,
-                            int K, int ldx, int ldw, int ldo, int epilogue, void* stream) {
+static int gemm_impl(const void* X, const void* W, const float* bias, void* out, const float* gate, int M, int N,
+                     int K, int ldx, int ldw, int ldo, int epilogue, void* stream, int f16) {
   WF_CHECK_ARG(X && W && out, "wf_gemm_bf16: null pointer");
+  WF_CHECK_ARG(!f16 || epilogue == EPI_BF16 || epilogue == EPI_F32 || epilogue == EPI_F32_ACC,
+               "wf_gemm_f16: epilogue %d is not built for fp16 operands (0 = 16-bit out, 2 = f32, 4 = f32 accumulate)", epilogue);
   WF_CHECK_ARG(M > 0 && N > 0 && K > 0, "wf_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
   WF_CHECK_ARG(K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldw >= K && ldx >= K,
                "wf_gemm_bf16: K (%d), ldx (%d), ldw (%d) must be multiples of 8 with ld >= K", K, ldx, ldw);
@@ -1081,6 +1116,7 @@ extern "C" int wf_gemm_bf16(const void* X, const void* W, const float* bias, voi
   a.mt = ceil_div(M, BM);
   a.nt = ceil_div(N, BN);
   a.bsx = a.bsw = a.bso = 0;
+  a.f16 = f16;
   const int nsuper = ((a.mt + 7) / 8) * ((a.nt + 7) / 8);
   const int grid = ((nsuper + 7) / 8) * 8 * 64;
   const size_t lds = 4 * TILE_BYTES;
@@ -1095,7 +1131,7 @@ extern "C" int wf_gemm_bf16(const void* X, const void* W, const float* bias, voi
   // clamped addresses `min(n, N - 4)` (a guard per load would put every load in its own basic block), which needs N >= 4 and N % 4 == 0.
   // `big` guarantees both (N >= 256, N % 4 == 0); a future relaxation of this gate must keep them.
   const bool big = K % PK == 0 && M >= 1024 && N >= 256 && N % 4 == 0 && (long)M * N >= (1L << 22);
-  if (use_w4 && !no_pp && big) {
+  if (use_w4 && !no_pp && big && !f16) {
     switch (epilogue) {
       case EPI_BF16: launch_w4<EPI_BF16>(a, s); break;
       case EPI_BF16_GELU: launch_w4<EPI_BF16_GELU>(a, s); break;
@@ -1119,6 +1155,15 @@ extern "C" int wf_gemm_bf16(const void* X, const void* W, const float* bias, voi
     WF_LAUNCH_CHECK("wf_gemm_bf16");
     return WF_OK;
   }
+  if (f16) {
+    switch (epilogue) {
+      case EPI_BF16: hipLaunchKernelGGL((k_gemm<EPI_BF16, true>), dim3(grid), dim3(NTHREADS), lds, s, a); break;
+      case EPI_F32: hipLaunchKernelGGL((k_gemm<EPI_F32, true>), dim3(grid), dim3(NTHREADS), lds, s, a); break;
+      default: hipLaunchKernelGGL((k_gemm<EPI_F32_ACC, true>), dim3(grid), dim3(NTHREADS), lds, s, a); break;
+    }
+    WF_LAUNCH_CHECK("wf_gemm_f16");
+    return WF_OK;
+  }
   switch (epilogue) {
     case EPI_BF16: hipLaunchKernelGGL(k_gemm<EPI_BF16>, dim3(grid), dim3(NTHREADS), lds, s, a); break;
     case EPI_BF16_GELU: hipLaunchKernelGGL(k_gemm<EPI_BF16_GELU>, dim3(grid), dim3(NTHREADS), lds, s, a); break;
@@ -1131,11 +1176,22 @@ extern "C" int wf_gemm_bf16(const void* X, const void* W, const float* bias, voi
   return WF_OK;
 }
 
+extern "C" int wf_gemm_bf16(const void* X, const void* W, const float* bias, void* out, const float* gate, int M, int N,
+                            int K, int ldx, int ldw, int ldo, int epilogue, void* stream) {
+  return gemm_impl(X, W, bias, out, gate, M, N, K, ldx, ldw, ldo, epilogue, stream, 0);
+}
+
+// The same GEMM on fp16 operands (X, W fp16; epilogue 0 writes fp16): v_mfma_f32_32x32x16_f16, fp32 accumulation.  Epilogues 0 / 2 / 4.
+extern "C" int wf_gemm_f16(const void* X, const void* W, const float* bias, void* out, int M, int N, int K, int ldx, int ldw, int ldo,
+                           int epilogue, void* stream) {
+  return gemm_impl(X, W, bias, out, nullptr, M, N, K, ldx, ldw, ldo, epilogue, stream, 1);
+}
+
 #ifdef WF_GEMM_TIMING
-extern "C" int wf_debug_gemm_cycles(unsigned long long* out8, int reset) {
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_gemm_cycles), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+extern "C" int wf_debug_gemm_cycles(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_gemm_cycles), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[8] = {};
+    unsigned long long z[16] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_cycles), z, sizeof(z)) != hipSuccess) return -1;
   }
   return 0;
@@ -1163,6 +1219,7 @@ extern "C" int wf_gemm_bf16_batched(const void* X, const void* W, void* out, int
   a.mt = ceil_div(M, BM);
   a.nt = ceil_div(N, BN);
   a.bsx = bsx; a.bsw = bsw; a.bso = bso;
+  a.f16 = 0;
   const int nsuper = ((a.mt + 7) / 8) * ((a.nt + 7) / 8);
   const int grid = ((nsuper + 7) / 8) * 8 * 64;
   if (epilogue == EPI_BF16)

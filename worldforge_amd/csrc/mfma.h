@@ -26,6 +26,25 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// The same instruction shape on fp16 operands (v_mfma_f32_32x32x16_f16, same rate): the VAE's "fp16x3" / "fp16" operand formats
+// (11-bit significands; round 4).  Kernels that serve both formats take the element type as a template flag and keep their operand
+// fragments as raw u32x4.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma32t(u32x4 a, u32x4 b, f32x16 c) {
+  if constexpr (F16) {
+    union { u32x4 u; f16x8 h; } xa, xb;
+    xa.u = a;
+    xb.u = b;
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(xa.h, xb.h, c, 0, 0, 0);
+  } else {
+    union { u32x4 u; bf16x8 h; } xa, xb;
+    xa.u = a;
+    xb.u = b;
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa.h, xb.h, c, 0, 0, 0);
+  }
+}
+
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) {
   union {
     u32x4 u;
@@ -47,6 +66,20 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   x.b = __builtin_convertvector(v, bf16x2_t);
   return x.u;
 }
+
+// two f32 -> two fp16 (round-to-nearest-even) in one dword, lo in bits 0..15
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  union {
+    f16x2_t h;
+    uint32_t u;
+  } x;
+  x.h = __builtin_convertvector(v, f16x2_t);
+  return x.u;
+}
+// 16-bit operand copy of an epilogue: fp16 when the launch's operands are fp16 (wave-uniform flag), bf16 otherwise
+__device__ __forceinline__ uint32_t pack16x2(int f16, float lo, float hi) { return f16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;

@@ -10,6 +10,18 @@ using namespace wf;
 
 namespace {
 
+// fp16 operand formats (round 4): the producers below write fp16 instead of bf16 when `f16` is set (wave-uniform).  fp16 has 11
+// significand bits but only 5 exponent bits: a value beyond +-65504 cannot be represented -- the producers raise a sticky device flag
+// (wf_f16_overflow_flag) that the host checks after every VAE call and turns into an error (never a silent inf / NaN).
+__device__ unsigned int g_f16_overflow;
+__device__ __forceinline__ float r16(int f16, float x) {  // x rounded through the 16-bit operand type
+  if (f16) return (float)(_Float16)x;
+  return rbf(x);
+}
+__device__ __forceinline__ void note_range(int f16, const float (&y)[4]) {
+  if (f16 && !(fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))) <= 65504.0f)) g_f16_overflow = 1u;  // NaN too
+}
+
 // RMS_norm (+ SiLU) over the C f32 channels of each pixel (C % 4 == 0, C <= 1024).  A pixel is handled by a group of G lanes
 // (G = 8 / 16 / 32 / 64 for C <= 128 / 256 / 512 / 1024: three or four float4 per lane), i.e. 64 / G pixels per wave: with one wave per
 // pixel only 24 of 64 lanes worked at C = 96 and the kernel ran at 2.4 TB/s.  The sum of squares is reduced inside the group by
@@ -18,7 +30,7 @@ namespace {
 template <int G, bool SPLIT = false>
 __global__ __launch_bounds__(256) void k_rms_silu(const float* __restrict__ x, const float* __restrict__ gamma,
                                                   uint16_t* __restrict__ out_bf16, float* __restrict__ out_f32, int C,
-                                                  float scale, int silu, size_t npix, int Wrow = 0, int halo_rows = 0) {
+                                                  float scale, int silu, size_t npix, int Wrow = 0, int halo_rows = 0, int f16 = 0) {
   constexpr int PPW = 64 / G;  // pixels per wave
   const int lane = threadIdx.x & 63;
   const int sub = lane & (G - 1), q = lane / G;
@@ -59,6 +71,7 @@ __global__ __launch_bounds__(256) void k_rms_silu(const float* __restrict__ x, c
 #pragma unroll
           for (int k = 0; k < 4; ++k) y[k] = y[k] / (1.0f + (SPLIT ? expf(-y[k]) : __expf(-y[k])));
         }
+        note_range(f16, y);
         if (Wrow > 0) {
           // slice-major operand for wf_conv3d_333 (layout 1): [row = p / W][stored slice][x][16]; SPLIT stores [hi | lo] slices
           size_t row = p / (size_t)Wrow;
@@ -67,27 +80,27 @@ __global__ __launch_bounds__(256) void k_rms_silu(const float* __restrict__ x, c
           if (halo_rows > 0) row += 2 * (row / (size_t)halo_rows) + 1;
           const int S = C >> 4, stot = SPLIT ? 2 * S : S;
           uint16_t* o = out_bf16 + ((row * stot + (id >> 2)) * (size_t)Wrow + xx) * 16 + (id & 3) * 4;
-          const u32x2 hi = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+          const u32x2 hi = {pack16x2(f16, y[0], y[1]), pack16x2(f16, y[2], y[3])};
           *reinterpret_cast<u32x2*>(o) = hi;
           if constexpr (SPLIT) {
             float r[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) r[k] = y[k] - rbf(y[k]);
-            const u32x2 lo = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+            for (int k = 0; k < 4; ++k) r[k] = y[k] - r16(f16, y[k]);
+            const u32x2 lo = {pack16x2(f16, r[0], r[1]), pack16x2(f16, r[2], r[3])};
             *reinterpret_cast<u32x2*>(o + (size_t)S * Wrow * 16) = lo;
           }
         } else if constexpr (SPLIT) {
           float r[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) r[k] = y[k] - rbf(y[k]);
-          const u32x2 hi = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
-          const u32x2 lo = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+          for (int k = 0; k < 4; ++k) r[k] = y[k] - r16(f16, y[k]);
+          const u32x2 hi = {pack16x2(f16, y[0], y[1]), pack16x2(f16, y[2], y[3])};
+          const u32x2 lo = {pack16x2(f16, r[0], r[1]), pack16x2(f16, r[2], r[3])};
           uint16_t* o = out_bf16 + p * (size_t)(3 * C);
           reinterpret_cast<u32x2*>(o)[id] = hi;
           reinterpret_cast<u32x2*>(o + C)[id] = lo;
           reinterpret_cast<u32x2*>(o + 2 * C)[id] = hi;
         } else if (out_bf16) {
-          u32x2 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+          u32x2 pk = {pack16x2(f16, y[0], y[1]), pack16x2(f16, y[2], y[3])};
           reinterpret_cast<u32x2*>(out_bf16 + p * C)[id] = pk;
         }
         if (out_f32) reinterpret_cast<float4*>(out_f32 + p * C)[id] = make_float4(y[0], y[1], y[2], y[3]);
@@ -124,7 +137,7 @@ __global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ 
 // dropped tail is <= 2^-17 |x|).  src f32 [rows, C] -> dst bf16 [rows, 3C]: side 0 (activation) [hi | lo | hi], side 1 (weight)
 // [hi | hi | lo], so that one K-concatenated bf16 MFMA contraction of a side-0 row with a side-1 row is hi.hi + lo.hi + hi.lo.
 __global__ __launch_bounds__(256) void k_split3(const float* __restrict__ src, long ld_src, uint16_t* __restrict__ dst, long ld_dst,
-                                                size_t rows, int C, int side) {
+                                                size_t rows, int C, int side, int f16) {
   const int nvec = C >> 2;
   const size_t n = rows * (size_t)nvec;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -134,9 +147,10 @@ __global__ __launch_bounds__(256) void k_split3(const float* __restrict__ src, l
     const float y[4] = {v.x, v.y, v.z, v.w};
     float t[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) t[k] = y[k] - rbf(y[k]);
-    const u32x2 hi = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
-    const u32x2 lo = {pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3])};
+    for (int k = 0; k < 4; ++k) t[k] = y[k] - r16(f16, y[k]);
+    note_range(f16, y);
+    const u32x2 hi = {pack16x2(f16, y[0], y[1]), pack16x2(f16, y[2], y[3])};
+    const u32x2 lo = {pack16x2(f16, t[0], t[1]), pack16x2(f16, t[2], t[3])};
     uint16_t* o = dst + r * ld_dst;
     reinterpret_cast<u32x2*>(o)[id] = hi;
     reinterpret_cast<u32x2*>(o + C)[id] = side ? hi : lo;
@@ -269,19 +283,39 @@ extern "C" int wf_softmax_rows_f32(const float* S, int lds, float* P, int ldp, i
   return WF_OK;
 }
 
-extern "C" int wf_split_bf16x3(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, size_t rows, int C, int side, void* stream) {
+static int split_x3_impl(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, size_t rows, int C, int side, void* stream, int f16) {
   WF_CHECK_ARG(src && dst, "wf_split_bf16x3: null pointer");
   WF_CHECK_ARG(C > 0 && C % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && ld_src >= C && ld_dst >= 3L * C,
                "wf_split_bf16x3: C=%d ld_src=%ld ld_dst=%ld (C, strides multiples of 4; ld_dst >= 3C)", C, (long)ld_src, (long)ld_dst);
   WF_CHECK_ARG(side == 0 || side == 1, "wf_split_bf16x3: side must be 0 (activation) or 1 (weight)");
   if (rows == 0) return WF_OK;
   hipLaunchKernelGGL(k_split3, dim3(grid_for(rows * (size_t)(C / 4), 256, 16384)), dim3(256), 0, (hipStream_t)stream, src, ld_src,
-                     (uint16_t*)dst, ld_dst, rows, C, side);
+                     (uint16_t*)dst, ld_dst, rows, C, side, f16);
   WF_LAUNCH_CHECK("wf_split_bf16x3");
   return WF_OK;
 }
+extern "C" int wf_split_bf16x3(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, size_t rows, int C, int side, void* stream) {
+  return split_x3_impl(src, ld_src, dst, ld_dst, rows, C, side, stream, 0);
+}
+extern "C" int wf_split_f16x3(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, size_t rows, int C, int side, void* stream) {
+  return split_x3_impl(src, ld_src, dst, ld_dst, rows, C, side, stream, 1);
+}
+// Sticky range flag of the fp16 producers: *out = 1 if any value beyond the fp16 range (or a NaN) was converted since the last reset.
+// Synchronous (a 4-byte device -> host copy on the NULL stream after `stream` has drained).
+extern "C" int wf_f16_overflow_flag(int* out, int reset, void* stream) {
+  WF_CHECK_ARG(out, "wf_f16_overflow_flag: null pointer");
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return WF_EHIP;
+  unsigned int v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_f16_overflow), sizeof(v)) != hipSuccess) return WF_EHIP;
+  *out = (int)v;
+  if (reset && v) {
+    const unsigned int z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_f16_overflow), &z, sizeof(z)) != hipSuccess) return WF_EHIP;
+  }
+  return WF_OK;
+}
 
-extern "C" int wf_rms_silu_cl_x3(const float* x, const float* gamma, void* out_x3, size_t npix, int C, int silu, void* stream) {
+static int rms_silu_x3_impl(const float* x, const float* gamma, void* out_x3, size_t npix, int C, int silu, void* stream, int f16) {
   WF_CHECK_ARG(x && gamma && out_x3, "wf_rms_silu_cl_x3: null pointer");
   WF_CHECK_ARG(C % 4 == 0 && C > 0 && C <= 1024, "wf_rms_silu_cl_x3: C=%d must be a multiple of 4 and <= 1024", C);
   if (npix == 0) return WF_OK;
@@ -292,15 +326,21 @@ extern "C" int wf_rms_silu_cl_x3(const float* x, const float* gamma, void* out_x
   hipStream_t st = (hipStream_t)stream;
   uint16_t* o = (uint16_t*)out_x3;
   if (G == 8)
-    hipLaunchKernelGGL((k_rms_silu<8, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix, 0);
+    hipLaunchKernelGGL((k_rms_silu<8, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix, 0, 0, f16);
   else if (G == 16)
-    hipLaunchKernelGGL((k_rms_silu<16, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix, 0);
+    hipLaunchKernelGGL((k_rms_silu<16, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix, 0, 0, f16);
   else if (G == 32)
-    hipLaunchKernelGGL((k_rms_silu<32, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix, 0);
+    hipLaunchKernelGGL((k_rms_silu<32, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix, 0, 0, f16);
   else
-    hipLaunchKernelGGL((k_rms_silu<64, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix, 0);
+    hipLaunchKernelGGL((k_rms_silu<64, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, (float*)nullptr, C, sc, silu, npix, 0, 0, f16);
   WF_LAUNCH_CHECK("wf_rms_silu_cl_x3");
   return WF_OK;
+}
+extern "C" int wf_rms_silu_cl_x3(const float* x, const float* gamma, void* out_x3, size_t npix, int C, int silu, void* stream) {
+  return rms_silu_x3_impl(x, gamma, out_x3, npix, C, silu, stream, 0);
+}
+extern "C" int wf_rms_silu_cl_x3_f16(const float* x, const float* gamma, void* out_x3, size_t npix, int C, int silu, void* stream) {
+  return rms_silu_x3_impl(x, gamma, out_x3, npix, C, silu, stream, 1);
 }
 
 extern "C" int wf_ncthw_to_cl(const float* in, float* out_f32, void* out_bf16, int C, int Cpad, size_t N, void* stream) {
@@ -322,8 +362,8 @@ extern "C" int wf_cl_to_ncthw(const float* in, float* out, int C, int ld, size_t
   return WF_OK;
 }
 
-extern "C" int wf_rms_silu_cl_blocked(const float* x, const float* gamma, void* out, size_t npix, int C, int silu, int W, int split,
-                                      int halo_rows, void* stream) {
+static int rms_silu_blocked_impl(const float* x, const float* gamma, void* out, size_t npix, int C, int silu, int W, int split,
+                                 int halo_rows, void* stream, int f16) {
   WF_CHECK_ARG(halo_rows >= 0 && (halo_rows == 0 || (npix / (size_t)(W > 0 ? W : 1)) % (size_t)halo_rows == 0),
                "wf_rms_silu_cl_blocked: halo_rows=%d must divide the number of rows", halo_rows);
   WF_CHECK_ARG(x && gamma && out, "wf_rms_silu_cl_blocked: null pointer");
@@ -340,9 +380,9 @@ extern "C" int wf_rms_silu_cl_blocked(const float* x, const float* gamma, void* 
 #define WF_RMS_BLOCKED(GG)                                                                                                          \
   do {                                                                                                                              \
     if (split)                                                                                                                      \
-      hipLaunchKernelGGL((k_rms_silu<GG, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, nof, C, sc, silu, npix, W, halo_rows);  \
+      hipLaunchKernelGGL((k_rms_silu<GG, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, nof, C, sc, silu, npix, W, halo_rows, f16);  \
     else                                                                                                                            \
-      hipLaunchKernelGGL((k_rms_silu<GG, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, nof, C, sc, silu, npix, W, halo_rows); \
+      hipLaunchKernelGGL((k_rms_silu<GG, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, o, nof, C, sc, silu, npix, W, halo_rows, f16); \
   } while (0)
   if (G == 8) WF_RMS_BLOCKED(8);
   else if (G == 16) WF_RMS_BLOCKED(16);
@@ -351,4 +391,12 @@ extern "C" int wf_rms_silu_cl_blocked(const float* x, const float* gamma, void* 
 #undef WF_RMS_BLOCKED
   WF_LAUNCH_CHECK("wf_rms_silu_cl_blocked");
   return WF_OK;
+}
+extern "C" int wf_rms_silu_cl_blocked(const float* x, const float* gamma, void* out, size_t npix, int C, int silu, int W, int split,
+                                      int halo_rows, void* stream) {
+  return rms_silu_blocked_impl(x, gamma, out, npix, C, silu, W, split, halo_rows, stream, 0);
+}
+extern "C" int wf_rms_silu_cl_blocked_f16(const float* x, const float* gamma, void* out, size_t npix, int C, int silu, int W, int split,
+                                          int halo_rows, void* stream) {
+  return rms_silu_blocked_impl(x, gamma, out, npix, C, silu, W, split, halo_rows, stream, 1);
 }

@@ -76,7 +76,7 @@ def run(models_dir: Optional[str], video_ref: str, model: str = "720p", output: 
         prompt: Optional[str] = None, negative_prompt: Optional[str] = None, embeds: Optional[str] = None,
         use_pca_channel_selection: bool = False, soften_mask: bool = False, transition_distance: int = 15, decay_type: str = "sine",
         save_png: bool = False, device: str = "cuda:0", components: Optional[dict] = None, max_area: Optional[int] = None, seed: int = 42,
-        vae_precision: str = "bf16x3", flow_backend: str = "farneback"):
+        vae_precision: str = "fp16x3", flow_backend: str = "farneback"):
     """INFER:153-339.  Returns (frames float32 [F,H,W,3] in [0,1], output directory of the PNG frames or None).
     components: {"transformer", "vae", "scheduler"} to use instead of loading `models_dir` (tests; synthetic weights); max_area overrides the
     model's pixel budget the same way harness.prepare_inputs documents."""

@@ -17,7 +17,11 @@ precision (the reference loads the VAE with torch_dtype=torch.float32, INFER:185
   "bf16"  -- every matrix-core operand (activation and weight) rounded to bf16: 2^-9 relative per operand.  Opt-in fast mode: over a
              guided job's 31 decode -> encode round trips this noise is enough to flip near-tied FLF gate decisions
              (tools/vae_precision_study.py).
-  "bf16x3" -- DEFAULT.  fp32-CLASS contractions on the bf16 matrix cores, NOT IEEE fp32: every operand x is carried as hi = bf16(x),
+  "fp16x3" -- DEFAULT since round 4 (alias "fp32").  The three-term split below on FP16 parts (hi = fp16(x), lo = fp16(x - hi): 22
+             significand bits, ~2^-22 per product -- 64x closer to IEEE fp32 than the bf16 split) on v_mfma_f32_32x32x16_f16: same
+             kernels, same cost.  fp16 cannot hold |x| > 65504: the producers raise a device flag and every encode / decode ends
+             with a check that turns it into a RuntimeError (never a silent inf) -- such weights need "bf16x3".
+  "bf16x3" -- the default of rounds 2-3.  fp32-CLASS contractions on the bf16 matrix cores, NOT IEEE fp32: every operand x is carried as hi = bf16(x),
              lo = bf16(x - hi) and every contraction as hi.hi + lo.hi + hi.lo in fp32 accumulators (wf_split_bf16x3: activations
              [hi | lo | hi], weights [hi | hi | lo] on 3x the channels, the SAME conv / GEMM kernels; the dropped lo.lo term and the
              rounding of lo leave ~2^-16 relative per product, against 2^-24 for true fp32).  3x the MFMA work.  "fp32" is accepted as
@@ -180,13 +184,16 @@ class _LatentDist:
 class AutoencoderKLWan:
     dtype = torch.float32
 
-    def __init__(self, device="cuda:0", comm=None, precision: str = "bf16x3"):
-        if precision == "fp32":  # the earlier name of the same mode
-            precision = "bf16x3"
-        if precision not in ("bf16", "bf16x3"):
-            raise ValueError(f"precision must be 'bf16' or 'bf16x3' (alias 'fp32'), got {precision!r}")
+    def __init__(self, device="cuda:0", comm=None, precision: str = "fp16x3"):
+        if precision == "fp32":  # the fp32-CLASS mode of the round: three-term split operands, fp16 parts since round 4
+            precision = "fp16x3"
+        if precision not in ("bf16", "bf16x3", "fp16x3"):
+            raise ValueError(f"precision must be 'fp16x3' (alias 'fp32'), 'bf16x3' or 'bf16', got {precision!r}")
         self.precision = precision
-        self.x3 = precision == "bf16x3"  # three-term split operands
+        self.x3 = precision in ("bf16x3", "fp16x3")  # three-term split operands
+        self.f16 = precision == "fp16x3"               # ... whose parts are fp16 (v_mfma_f32_32x32x16_f16) instead of bf16
+        self.OP = torch.float16 if self.f16 else BF    # element type of every matrix-core operand tensor
+        self._sfx = "_f16" if self.f16 else ""         # the C-ABI entry points of that element type
         self.device = torch.device(device)
         self.comm = comm  # row-slab sharding of the high-resolution stages over the ranks of `comm` (parallel.Comm or a stand-in)
         self._reps = 1    # ranks per row group while a sharded stage runs (see _row_groups)
@@ -207,9 +214,11 @@ class AutoencoderKLWan:
             w = w.to(F32)
             if not x3:
                 return w.to(device=dev, dtype=BF).contiguous()
-            hi = w.to(BF)
-            lo = (w - hi.to(F32)).to(BF)
-            return torch.cat([hi, hi, lo], dim=-1).to(dev).contiguous()  # weight side of wf_split_bf16x3
+            if self.f16 and float(w.abs().max()) > 65504.0:
+                raise ValueError("a VAE weight exceeds the fp16 range: load with precision='bf16x3'")
+            hi = w.to(self.OP)
+            lo = (w - hi.to(F32)).to(self.OP)
+            return torch.cat([hi, hi, lo], dim=-1).to(dev).contiguous()  # weight side of wf_split_bf16x3 / wf_split_f16x3
 
         def mfma_conv(p):  # [Cout,Cin,kt,kh,kw] -> bf16 [Cout, taps, Cin]
             w = sd[p + ".weight"]
@@ -306,7 +315,7 @@ class AutoencoderKLWan:
         return self.load_state_dict(diffusers_to_twin_state_dict(sd))
 
     @classmethod
-    def from_pretrained(cls, path: str, device="cuda:0", comm=None, precision: str = "bf16x3", subfolder: str = "vae"):
+    def from_pretrained(cls, path: str, device="cuda:0", comm=None, precision: str = "fp16x3", subfolder: str = "vae"):
         """`AutoencoderKLWan.from_pretrained(model_id, subfolder="vae", torch_dtype=torch.float32)` (INFER:185-189) from a local
         diffusers checkpoint directory: reads `<path>/<subfolder>/*.safetensors` (sharded or not) with checkpoint.load_dir."""
         from . import checkpoint
@@ -366,23 +375,23 @@ class AutoencoderKLWan:
             Cin = Cst * 3 // 2 if self.x3 else Cst  # fp32-class: [hi | lo] stored, K = [hi | lo | hi]
         else:
             Ti, Hi, Wi, Cin = x.shape
-        assert x.dtype == BF and x.is_contiguous()
+        assert x.dtype == self.OP and x.is_contiguous()
         shape = out_shape or (To, Ho, Wo, Cout)
         of = torch.empty(shape, dtype=F32, device=x.device) if out_f32 else None
-        ob = out_bf_tensor if out_bf_tensor is not None else (torch.empty(shape, dtype=BF, device=x.device) if out_bf16 else None)
+        ob = out_bf_tensor if out_bf_tensor is not None else (torch.empty(shape, dtype=self.OP, device=x.device) if out_bf16 else None)
         W = self.w
         if (tuple(k) == (3, 3, 3) and st == 1 and ss == 1 and pt == 2 and ps == 1 and not up2 and not tsplit and To == Ti and Wo == Wi
                 and Cin % 32 == 0 and Cout % 32 == 0 and not os.environ.get("WF_CONV_NO_W4")):
             # the FLOP-heavy layers: LDS-resident input patch kernel on re-packed weights (packed once per layer, cached).  Chosen by
             # layer type only, never by size: a row slab of the sharded VAE must run the same arithmetic as the whole image
             zp = self._zero_page(int(_ffi.lib().wf_conv3d_333_zero_page_bytes(Wi, Cst, layout)))
-            call("wf_conv3d_333", x.data_ptr(), self._packed333(p, Cout, Cin).data_ptr(), W[p + ".b"].data_ptr(),
+            call("wf_conv3d_333" + self._sfx, x.data_ptr(), self._packed333(p, Cout, Cin).data_ptr(), W[p + ".b"].data_ptr(),
                  resid.data_ptr() if resid is not None else None, of.data_ptr() if of is not None else None,
                  ob.data_ptr() if ob is not None else None, Ti, Hi, Wi, Cin, Ho, Cout, ps if ph is None else ph,
                  zp.data_ptr(), zp.numel() * 2, layout, Cst, ops.stream())
         else:
             assert layout == 0, "slice-major operands are for the 3x3x3 stride-1 kernel only"
-            call("wf_conv3d_cl", x.data_ptr(), W[p + ".w"].data_ptr(), W[p + ".b"].data_ptr(),
+            call("wf_conv3d_cl" + self._sfx, x.data_ptr(), W[p + ".w"].data_ptr(), W[p + ".b"].data_ptr(),
                  resid.data_ptr() if resid is not None else None, of.data_ptr() if of is not None else None,
                  ob.data_ptr() if ob is not None else None, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, k[0], k[1], k[2], st, ss, pt,
                  ps if ph is None else ph, ps, 1 if up2 else 0, 1 if tsplit else 0, self._zero_page().data_ptr(), ops.stream())
@@ -399,7 +408,7 @@ class AutoencoderKLWan:
         cache = self.__dict__.setdefault("_packed", {})
         hit = cache.get(p)
         if hit is None or hit[0] is not w:
-            out = torch.empty((27, Cin // 16, Cout, 16), dtype=BF, device=w.device)
+            out = torch.empty((27, Cin // 16, Cout, 16), dtype=w.dtype, device=w.device)
             call("wf_conv3d_pack333", w.data_ptr(), out.data_ptr(), Cout, Cin, ops.stream())
             cache[p] = hit = (w, out)
         return hit[1]
@@ -429,13 +438,13 @@ class AutoencoderKLWan:
         if blocked and C % 32 == 0 and not os.environ.get("WF_CONV_NO_W4"):
             T, H, Wd, _ = x.shape
             # halo: the kernel writes rows 1 .. H of a [T, H + 2, ...] slab operand directly (row slabs: _halo_fill adds the neighbours' rows)
-            out = torch.empty((T, H + (2 if halo else 0), (2 if self.x3 else 1) * C // 16, Wd, 16), dtype=BF, device=x.device)
-            call("wf_rms_silu_cl_blocked", x.data_ptr(), gamma.data_ptr(), out.data_ptr(), x.numel() // C, C, 1 if silu else 0, Wd,
+            out = torch.empty((T, H + (2 if halo else 0), (2 if self.x3 else 1) * C // 16, Wd, 16), dtype=self.OP, device=x.device)
+            call("wf_rms_silu_cl_blocked" + self._sfx, x.data_ptr(), gamma.data_ptr(), out.data_ptr(), x.numel() // C, C, 1 if silu else 0, Wd,
                  1 if self.x3 else 0, H if halo else 0, ops.stream())
             return out
         if self.x3:
-            out = torch.empty(tuple(x.shape[:-1]) + (3 * C,), dtype=BF, device=x.device)
-            call("wf_rms_silu_cl_x3", x.data_ptr(), gamma.data_ptr(), out.data_ptr(), x.numel() // C, C, 1 if silu else 0, ops.stream())
+            out = torch.empty(tuple(x.shape[:-1]) + (3 * C,), dtype=self.OP, device=x.device)
+            call("wf_rms_silu_cl_x3" + self._sfx, x.data_ptr(), gamma.data_ptr(), out.data_ptr(), x.numel() // C, C, 1 if silu else 0, ops.stream())
             return out
         out = torch.empty(x.shape, dtype=BF, device=x.device)
         call("wf_rms_silu_cl", x.data_ptr(), gamma.data_ptr(), out.data_ptr(), None, x.numel() // C, C, 1 if silu else 0,
@@ -459,10 +468,33 @@ class AutoencoderKLWan:
         else:
             x2 = x
         if out is None:
-            out = torch.empty(tuple(x.shape[:-1]) + (3 * C,), dtype=BF, device=x.device)
-        assert out.is_contiguous() and out.numel() == 3 * x2.shape[0] * C
-        call("wf_split_bf16x3", x2.data_ptr(), x2.stride(0), out.data_ptr(), 3 * C, x2.shape[0], C, side, ops.stream())
+            out = torch.empty(tuple(x.shape[:-1]) + (3 * C,), dtype=self.OP, device=x.device)
+        assert out.is_contiguous() and out.numel() == 3 * x2.shape[0] * C and out.dtype == self.OP
+        call("wf_split_f16x3" if self.f16 else "wf_split_bf16x3", x2.data_ptr(), x2.stride(0), out.data_ptr(), 3 * C, x2.shape[0], C, side, ops.stream())
         return out
+
+    def _gemm(self, x, w, bias, out, epi):
+        """out[M,N] = epi(x[M,K] @ w[N,K]^T + bias) on the operand type of this precision mode (wf_gemm_bf16 / wf_gemm_f16)."""
+        if not self.f16:
+            return gemm(x, w, bias, out, epi)
+        M, K = x.shape
+        N = w.shape[0]
+        assert w.shape[1] == K and x.dtype == self.OP and w.dtype == self.OP and out.shape[0] == M and out.shape[1] == N
+        call("wf_gemm_f16", x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), M, N, K,
+             x.stride(0), w.stride(0), out.stride(0), epi, ops.stream())
+        return out
+
+    def _check_range(self, what: str):
+        """fp16 operand formats: a producer that met a value beyond +-65504 (or a NaN) raised the device flag -- fail loudly, never a
+        silent inf.  One 4-byte read per VAE call."""
+        if not self.f16:
+            return
+        import ctypes
+        flag = ctypes.c_int(0)
+        call("wf_f16_overflow_flag", ctypes.byref(flag), 1, ops.stream())
+        if flag.value:
+            raise RuntimeError(f"AutoencoderKLWan.{what}: an activation left the fp16 range (|x| > 65504) or was NaN under precision="
+                               f"{self.precision!r}; use precision='bf16x3' (8-bit exponent) for these weights / inputs")
 
     def _res(self, x, p, cin, cout):
         """vae.py:186-220."""
@@ -476,7 +508,7 @@ class AutoencoderKLWan:
         if cin != cout:
             xb = self._operand(x)
             h = torch.empty((T, H, Wd, cout), dtype=F32, device=x.device)
-            gemm(xb.view(-1, xb.shape[-1]), W[p + ".shortcut.w"], W[p + ".shortcut.b"], h.view(-1, cout), EPI_F32)
+            self._gemm(xb.view(-1, xb.shape[-1]), W[p + ".shortcut.w"], W[p + ".shortcut.b"], h.view(-1, cout), EPI_F32)
             self.flops_last += 2 * T * H * Wd * xb.shape[-1] * cout
             del xb
         else:
@@ -501,7 +533,7 @@ class AutoencoderKLWan:
             return self._attn_x3(x, p, a, hw, hwp, q0, nq)
         qkv = torch.empty((T * hw + 8, 3 * C), dtype=BF, device=x.device)  # +8 rows: the padded K rows stay in-bounds
         qkv[T * hw:].zero_()
-        gemm(a.view(-1, C), W[p + ".to_qkv.w"], W[p + ".to_qkv.b"], qkv[:T * hw], EPI_BF16)
+        self._gemm(a.view(-1, C), W[p + ".to_qkv.w"], W[p + ".to_qkv.b"], qkv[:T * hw], EPI_BF16)
         del a
         S = torch.empty((nq, hwp), dtype=F32, device=x.device)
         P = torch.empty((nq, hwp), dtype=BF, device=x.device)
@@ -510,11 +542,11 @@ class AutoencoderKLWan:
         scale = 1.0 / math.sqrt(C)
         for t in range(T):
             blk = qkv[t * hw:t * hw + hwp]
-            gemm(blk[q0:q1, 0:C], blk[:, C:2 * C], None, S, EPI_F32)
+            self._gemm(blk[q0:q1, 0:C], blk[:, C:2 * C], None, S, EPI_F32)
             call("wf_softmax_rows", S.data_ptr(), hwp, P.data_ptr(), hwp, nq, hw, float(scale), ops.stream())
             call("wf_transpose_bf16", blk[:, 2 * C:].data_ptr(), 3 * C, Vt.data_ptr(), hwp, hw, C, ops.stream())
-            gemm(P, Vt, None, O[t * nq:(t + 1) * nq], EPI_BF16)
-        gemm(O, W[p + ".proj.w"], W[p + ".proj.b"], x.view(-1, C), EPI_F32_ACC)  # x + proj(attn)  (vae.py:262)
+            self._gemm(P, Vt, None, O[t * nq:(t + 1) * nq], EPI_BF16)
+        self._gemm(O, W[p + ".proj.w"], W[p + ".proj.b"], x.view(-1, C), EPI_F32_ACC)  # x + proj(attn)  (vae.py:262)
         self.flops_last += T * (4 * nq * hw * C) + 2 * T * hw * C * 3 * C + 2 * T * nq * C * C
         return x
 
@@ -524,7 +556,7 @@ class AutoencoderKLWan:
         T, C = x.shape[0], x.shape[-1]
         W = self.w
         qkv = torch.zeros((T * hw + 8, 3 * C), dtype=F32, device=x.device)
-        gemm(a.view(-1, 3 * C), W[p + ".to_qkv.w"], W[p + ".to_qkv.b"], qkv[:T * hw], EPI_F32)
+        self._gemm(a.view(-1, 3 * C), W[p + ".to_qkv.w"], W[p + ".to_qkv.b"], qkv[:T * hw], EPI_F32)
         del a
         S = torch.empty((nq, hwp), dtype=F32, device=x.device)
         P = torch.empty((nq, hwp), dtype=F32, device=x.device)
@@ -533,11 +565,11 @@ class AutoencoderKLWan:
         scale = 1.0 / math.sqrt(C)
         for t in range(T):
             blk = qkv[t * hw:t * hw + hwp]
-            gemm(self._operand(blk[q0:q0 + nq, 0:C], 0), self._operand(blk[:, C:2 * C], 1), None, S, EPI_F32)
+            self._gemm(self._operand(blk[q0:q0 + nq, 0:C], 0), self._operand(blk[:, C:2 * C], 1), None, S, EPI_F32)
             call("wf_softmax_rows_f32", S.data_ptr(), hwp, P.data_ptr(), hwp, nq, hw, float(scale), ops.stream())
             call("wf_transpose_f32", blk[:, 2 * C:].data_ptr(), 3 * C, Vt.data_ptr(), hwp, hw, C, ops.stream())
-            gemm(self._operand(P, 0), self._operand(Vt, 1), None, Of[t * nq:(t + 1) * nq], EPI_F32)
-        gemm(self._operand(Of), W[p + ".proj.w"], W[p + ".proj.b"], x.view(-1, C), EPI_F32_ACC)
+            self._gemm(self._operand(P, 0), self._operand(Vt, 1), None, Of[t * nq:(t + 1) * nq], EPI_F32)
+        self._gemm(self._operand(Of), W[p + ".proj.w"], W[p + ".proj.b"], x.view(-1, C), EPI_F32_ACC)
         self.flops_last += 3 * (T * (4 * nq * hw * C) + 2 * T * hw * C * 3 * C + 2 * T * nq * C * C)
         return x
 
@@ -557,7 +589,7 @@ class AutoencoderKLWan:
         out = torch.empty((1 + To, Ho, Wo, C), dtype=F32, device=x.device)
         out[0].copy_(y[0])  # frame 0 by-passes time_conv (vae.py:146-148)
         W = self.w
-        call("wf_conv3d_cl", yb.data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
+        call("wf_conv3d_cl" + self._sfx, yb.data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
              out[1:].data_ptr(), None, T, Ho, Wo, yb.shape[-1], To, Ho, Wo, C, 3, 1, 1, 2, 1, 0, 0, 0, 0, 0, None, ops.stream())
         self.flops_last += 2 * To * Ho * Wo * C * 3 * yb.shape[-1]
         return out
@@ -582,7 +614,7 @@ class AutoencoderKLWan:
         W = self.w
         for py in range(2):
             for px in range(2):
-                call("wf_conv3d_cl_scatter", xb.data_ptr(), W[f"{p}.ph{py}{px}.w"].data_ptr(), W[p + ".b"].data_ptr(), None, out.data_ptr(), None,
+                call("wf_conv3d_cl_scatter" + self._sfx, xb.data_ptr(), W[f"{p}.ph{py}{px}.w"].data_ptr(), W[p + ".b"].data_ptr(), None, out.data_ptr(), None,
                      T, Hs, Wd, Cin, T, n_rows, Wd, Cout, 1, 2, 2, 1, 1, 0, 1 - py + row_off, 1 - px, self._zero_page().data_ptr(),
                      out_rows, 2 * Wd, 2, py, 2, px, ops.stream())
         self.flops_last += 4 * 2 * T * n_rows * Wd * Cout * 4 * Cin
@@ -689,7 +721,7 @@ class AutoencoderKLWan:
         if cin != cout:
             xb = self._operand(x)
             h = torch.empty((T, Hs, Wd, cout), dtype=F32, device=x.device)
-            gemm(xb.view(-1, xb.shape[-1]), W[p + ".shortcut.w"], W[p + ".shortcut.b"], h.view(-1, cout), EPI_F32)
+            self._gemm(xb.view(-1, xb.shape[-1]), W[p + ".shortcut.w"], W[p + ".shortcut.b"], h.view(-1, cout), EPI_F32)
             del xb
         else:
             h = x
@@ -707,15 +739,15 @@ class AutoencoderKLWan:
         self.flops_last += 2 * (T - 1) * H * Wd * 2 * C * 3 * Cop
         if self.x3:
             yf = torch.empty((1 + 2 * (T - 1), H, Wd, C), dtype=F32, device=xb.device)  # frame 0 is not written (tsplit: 1 + 2t + h)
-            call("wf_conv3d_cl", xb[1:].data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
+            call("wf_conv3d_cl" + self._sfx, xb[1:].data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
                  yf.data_ptr(), None, T - 1, H, Wd, Cop, T - 1, H, Wd, 2 * C, 3, 1, 1, 1, 1, 2, 0, 0, 0, 1, None, ops.stream())
-            yb = torch.empty((1 + 2 * (T - 1), H, Wd, Cop), dtype=BF, device=xb.device)
+            yb = torch.empty((1 + 2 * (T - 1), H, Wd, Cop), dtype=self.OP, device=xb.device)
             yb[0].copy_(xb[0])
             self._operand(yf[1:], out=yb[1:])
             return yb
         yb = torch.empty((1 + 2 * (T - 1), H, Wd, C), dtype=BF, device=xb.device)
         yb[0].copy_(xb[0])
-        call("wf_conv3d_cl", xb[1:].data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
+        call("wf_conv3d_cl" + self._sfx, xb[1:].data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
              None, yb.data_ptr(), T - 1, H, Wd, C, T - 1, H, Wd, 2 * C, 3, 1, 1, 1, 1, 2, 0, 0, 0, 1, None, ops.stream())
         return yb
 
@@ -754,7 +786,7 @@ class AutoencoderKLWan:
         out = torch.empty((1 + To, Ho, Wo, C), dtype=F32, device=x.device)
         out[0].copy_(y[0])
         W = self.w
-        call("wf_conv3d_cl", yb.data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
+        call("wf_conv3d_cl" + self._sfx, yb.data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
              out[1:].data_ptr(), None, T, Ho, Wo, yb.shape[-1], To, Ho, Wo, C, 3, 1, 1, 2, 1, 0, 0, 0, 0, 0, None, ops.stream())
         return out
 
@@ -960,12 +992,14 @@ class AutoencoderKLWan:
         y0 = self.comm.rank * Hs
         fused = ops.blend_pixels(self._row_slab_of(ref, y0, Hs), self._row_slab_of(mask, y0, Hs), slab.unsqueeze(0))
         mom = self._encode_one_sharded(None, slab=fused[0]).unsqueeze(0)
+        self._check_range("decode_blend_encode")
         return _LatentDist(mom[:, :Z_DIM].contiguous(), mom[:, Z_DIM:])
 
     @torch.no_grad()
     def encode(self, x: torch.Tensor, return_dict: bool = True):
         x = x.to(device=self.device, dtype=F32).contiguous()
         moments = torch.stack([self._encode_one(v) for v in x])
+        self._check_range("encode")
         post = _LatentDist(moments[:, :Z_DIM].contiguous(), moments[:, Z_DIM:])
         if not return_dict:
             return (post,)
@@ -975,6 +1009,7 @@ class AutoencoderKLWan:
     def decode(self, z: torch.Tensor, return_dict: bool = True):
         z = z.to(device=self.device, dtype=F32).contiguous()
         out = torch.stack([self._decode_one(v) for v in z])
+        self._check_range("decode")
         if not return_dict:
             return (out,)
         return SimpleNamespace(sample=out)
