@@ -213,6 +213,10 @@ def main_longcat(a):
 
     # WF_FORCE_COMM=1: a one-rank process group, so that a one-GPU box runs the sharded code path over RCCL itself (debug / CI aid)
     comm = parallel.init(world, rank, local_rank) if (world > 1 or os.environ.get("WF_FORCE_COMM")) else None
+    if a.as_rank_of > 1:   # one simulated rank of N on this GPU (parallel.LoopbackComm): the compute-bound ceiling of the N-GPU job
+        if world != 1:
+            raise SystemExit("bench.py: --as-rank-of is a one-process mode")
+        comm = parallel.LoopbackComm(a.as_rank_of, a.as_rank if a.as_rank >= 0 else a.as_rank_of // 2)
     cfg = LongCatConfig(depth=a.layers if a.layers != 40 else 48)
     frames = a.frames if a.frames != 81 else 93
     t0 = time.time()
@@ -251,6 +255,7 @@ def main_longcat(a):
             barrier()
             marks["t0"] = time.perf_counter()
             wdit.PROFILE_ATTN = []
+            wdit.PROFILE_COMM = [] if comm is not None else None
         torch.cuda.synchronize()
         marks[(phase[0], i)] = time.perf_counter()
         if phase == "end" and i == Wm + K - 1:
@@ -275,9 +280,22 @@ def main_longcat(a):
     wdit.PROFILE_ATTN = None
     torch.cuda.synchronize()
     attn_ms = [s.elapsed_time(e) for s, e in prof]
+    cprof = wdit.PROFILE_COMM or []
+    wdit.PROFILE_COMM = None
+    comm_ms = [wdit.comm_wait_ms(e) for e in cprof]
     T = (frames - 1) // 4 + 1
     tpf = (a.height // 16) * (a.width // 16)
     L = T * tpf
+    per_rank = None
+    if comm is not None:
+        # every rank's own figures: its noise-token self-attention time and how long its compute stream stalled per layer waiting for
+        # segments of the K / V^T exchange (the segmented exchange: only what has not arrived when the attention gets to it)
+        mine = torch.tensor([sum(attn_ms) / max(len(attn_ms), 1), sum(comm_ms) / max(len(comm_ms), 1), float(len(comm_ms))],
+                            dtype=torch.float64, device=device)
+        allr = torch.empty((comm.world, 3), dtype=torch.float64, device=device)
+        comm.all_gather(allr, mine)
+        per_rank = [{"rank": r, "attn_avg_ms": v[0], "comm_exposed_ms_per_layer": v[1], "layers_timed": int(v[2])}
+                    for r, v in enumerate(allr.cpu().tolist())]
     if rank == 0:
         gms = [1e3 * (marks[("e", i)] - marks[("s", i)]) for i in range(Wm, Wm + K) if i < guide]
         pms = [1e3 * (marks[("e", i)] - marks[("s", i)]) for i in range(Wm, Wm + K) if i >= guide]
@@ -293,12 +311,21 @@ def main_longcat(a):
                "window": {"guided": len(gms), "plain": len(pms), "guided_frac": len(gms) / max(K, 1)},
                "guided_step_ms": sum(gms) / len(gms) if gms else None, "plain_step_ms": sum(pms) / len(pms) if pms else None,
                "setup_s": t_setup}
+        if a.as_rank_of > 1:
+            out["metric"] += f" -- ONE simulated rank of {a.as_rank_of}: compute and local copies only, NOT a contract line"
+            out["simulated_rank_of"], out["simulated_rank"] = a.as_rank_of, comm.rank
+            out["config"]["parallelism"] = (f"rank {comm.rank} of sp{a.as_rank_of} on one GPU (parallel.LoopbackComm: collectives served from local "
+                                            "data); value = what the N-GPU job would reach if communication were free")
+            per_rank = per_rank[comm.rank:comm.rank + 1] if per_rank else per_rank
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+            out["exchange"] = "segmented (per-source broadcasts, own shard first)" if os.environ.get("WF_ATTN_SEGMENTED", "1") != "0" else "one all-gather per operand"
         if gms and pms:
             if a.distill:
                 out["job16_steps_per_s"] = 16.0 / ((6 * out["guided_step_ms"] + 10 * out["plain_step_ms"]) / 1e3)
             else:
                 out["job50_steps_per_s"] = 50.0 / ((20 * out["guided_step_ms"] + 30 * out["plain_step_ms"]) / 1e3)
-        if attn_ms and world == 1:
+        if attn_ms and world == 1 and a.as_rank_of <= 1:
             avg = sum(attn_ms) / len(attn_ms)
             flop = 4.0 * (L - tpf) * L * 128 * cfg.num_heads
             ach = flop / (avg * 1e-3) / 1e12
@@ -308,7 +335,7 @@ def main_longcat(a):
                                "traffic": None, "launches": len(attn_ms), "avg_launch_ms": avg, "flop_per_launch": flop}
         if cfg.depth != 48:
             out["invalid_reason"] = f"debug run with {cfg.depth} DiT blocks (the named model has 48)"
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and world == 1 and a.as_rank_of <= 1:
             cb = cpu_baseline_longcat()
             C, Hd = cfg.hidden_size, cfg.ffn_hidden
             fwd = cfg.depth * (2.0 * L * C * (6 * C + 3 * Hd) + 4.0 * L * L * C)
@@ -469,8 +496,6 @@ def main(argv=None):
         sys.exit(launch_ranks(a.gpus, argv))
     claim_stdout()
     if a.workload == "longcat":
-        if a.as_rank_of > 1:
-            raise SystemExit("bench.py: --as-rank-of is wired for --workload wan only")
         return main_longcat(a)
 
     rank, local_rank, world = rank_env(a)
@@ -549,7 +574,7 @@ def main(argv=None):
     attn_ms = [s.elapsed_time(e) for s, e in prof]
     cprof = wdit.PROFILE_COMM or []
     wdit.PROFILE_COMM = None
-    comm_ms = [s.elapsed_time(e) for s, e in cprof]
+    comm_ms = [wdit.comm_wait_ms(e) for e in cprof]
     T = (a.frames - 1) // 4 + 1
     L = T * (a.height // 16) * (a.width // 16)
     Lq = model.local_tokens(L)

@@ -170,6 +170,18 @@ class SimComm:
         self.all_gather(out, inp)
         return None
 
+    def exchange_segments_async(self, out):
+        """parallel.Comm.exchange_segments_async: slot `rank` of `out` is this rank's shard; the other slots come from their owners."""
+        sh = self.sh
+        sh["slots"][self.rank] = out[self.rank]
+        sh["bar"].wait()
+        for r in range(self.world):
+            if r != self.rank:
+                out[r].copy_(sh["slots"][r])
+        torch.cuda.current_stream().synchronize()
+        sh["bar"].wait()
+        return [None] * self.world
+
 
 def lora_state(cfg, seed=33, dim=8):
     """Synthetic LoRA state dict in the reference's naming (lora_utils.py:83-145): fused qkv with 3 up-blocks, kv_linear with 2,

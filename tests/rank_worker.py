@@ -42,8 +42,13 @@ def main():
     ref, ref_b = m0.forward_tokens(x, 500.0, ctx, clip).clone(), m0.forward_tokens(x, 500.0, ctx_b, clip).clone()
     m1 = dit.WanTransformer3DModel(cfg, dev, comm=comm)
     m1.w = m0.w
+    m1.segmented_exchange = False   # one all-gather per operand: the gathered tiles are the single-rank tiles
     got = m1.forward_tokens(x, 500.0, ctx, clip)
     assert torch.equal(got, ref), f"sharded DiT forward differs: {(got - ref).abs().max().item()}"
+    m1.segmented_exchange = True    # per-source broadcasts, own shard first, partial sweeps merged (real broadcasts, streams and events)
+    got = m1.forward_tokens(x, 500.0, ctx, clip)
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= (2e-2 if world > 1 else 0.0), f"segmented exchange: {err}"
     for _ in range(2):
         a, b = m1.forward_tokens_pair(x, 500.0, ctx, ctx_b, clip)
         assert torch.equal(a, ref) and torch.equal(b, ref_b), "lock-step CFG pair differs"

@@ -38,11 +38,16 @@ def _run_ranks(P, fn):
     return res
 
 
+@pytest.mark.parametrize("segmented", [False, True], ids=["one_event", "segmented"])
 @pytest.mark.parametrize("P,thw", [(2, (3, 16, 20)), (3, (5, 16, 24)), (4, (5, 16, 24)), (8, (5, 16, 24))])
-def test_token_sharded_dit_equals_single(P, thw):
+def test_token_sharded_dit_equals_single(P, thw, segmented):
     """Every rank must return the full velocity tensor of the single-rank forward.  The K tiles of the gathered
     [P, H, shard_len, 128] buffer coincide with the single-rank tiles (all shards but the last are full multiples of 64), so
-    the online softmax sees the same sequence of tiles: bit-identical."""
+    the online softmax sees the same sequence of tiles: bit-identical with the one-event all-gather.  With the SEGMENTED exchange
+    (round 4: per-source broadcasts, the attention walks its own shard first and the peers' as they arrive, partial results merged) the
+    fp32 partial sums are re-associated: equal to the split-KV class of tolerance, and every rank still returns the same tensor (each row
+    comes from its owner)."""
+    from tests._tol import within
     from worldforge_amd import dit
     cfg = dit.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
     T, Hh, Ww = thw
@@ -54,11 +59,17 @@ def test_token_sharded_dit_equals_single(P, thw):
     def rank_fn(comm):
         m = dit.WanTransformer3DModel(cfg, DEV, comm=comm)
         m.w = m0.w
+        m.segmented_exchange = segmented
         assert m.local_tokens(T * (Hh // 2) * (Ww // 2)) > 0
         return m.forward_tokens(x, 500.0, ctx, clip).clone()
 
-    for r, got in enumerate(_run_ranks(P, rank_fn)):
-        assert torch.equal(got, ref), (r, (got - ref).abs().max())
+    res = _run_ranks(P, rank_fn)
+    for r, got in enumerate(res):
+        if not segmented:
+            assert torch.equal(got, ref), (r, (got - ref).abs().max())
+        else:
+            assert torch.equal(got, res[0]), r
+            within(f"multirank.dit_segmented.P{P}", (got - ref).abs().max().item() / ref.abs().max().item(), 2e-2)
 
 
 @pytest.mark.parametrize("P", [2, 4])
@@ -168,8 +179,9 @@ def test_cfg_pair_lockstep_equals_two_sequential_forwards(P):
         assert torch.equal(b, ref_b), (r, (b - ref_b).abs().max())
 
 
+@pytest.mark.parametrize("segmented", [False, True], ids=["one_event", "segmented"])
 @pytest.mark.parametrize("P,thw,ncl", [(2, (3, 16, 20), 1), (3, (5, 16, 24), 1), (4, (5, 16, 24), 0), (8, (8, 16, 32), 2)])
-def test_token_sharded_longcat_dit_equals_single(P, thw, ncl):
+def test_token_sharded_longcat_dit_equals_single(P, thw, ncl, segmented):
     """LongCat DiT, sequence parallel: per-frame AdaLN selected by the global token index (row0), condition / noise split by global
     index (a shard may hold both kinds of rows, or only one), K / V^T shards all-gathered and consumed in place.  Every rank must
     return the single-rank velocity, bit for bit."""
@@ -189,10 +201,17 @@ def test_token_sharded_longcat_dit_equals_single(P, thw, ncl):
     def rank_fn(comm):
         m = LongCatVideoTransformer3DModel(LongCatConfig(**kw), DEV, comm=comm)
         m.w = m0.w
+        m.segmented_exchange = segmented
         return m.forward_tokens(x, ts, cap, mask, ncl).clone()
 
-    for r, got in enumerate(_run_ranks(P, rank_fn)):
-        assert torch.equal(got, ref), (r, (got - ref).abs().max())
+    from tests._tol import within
+    res = _run_ranks(P, rank_fn)
+    for r, got in enumerate(res):
+        if not segmented:   # the one-event all-gather: the gathered tiles are the single-rank tiles, bit for bit
+            assert torch.equal(got, ref), (r, (got - ref).abs().max())
+        else:               # segments walked own-first and merged: fp32 re-association of the partial sums (bf16 residual stream)
+            assert torch.equal(got, res[0]), r
+            within(f"multirank.longcat_segmented.P{P}", (got - ref).abs().max().item() / ref.abs().max().item(), 3e-2)
 
 
 @pytest.mark.parametrize("P", [2, 4])
@@ -220,6 +239,7 @@ def test_longcat_guided_sampler_on_sharded_dit_and_vae_equals_single(P):
     def run(comm):
         m = LongCatVideoTransformer3DModel(LongCatConfig(**kw), DEV, comm=comm)
         m.w = m0.w
+        m.segmented_exchange = False   # the bit-identical form of the exchange (the segmented one is compared with a tolerance above)
         v = AutoencoderKLWan(DEV, comm=comm)
         v.w = v0.w
         pipe = LongCatVideoPipeline(v, FlowMatchEulerDiscreteScheduler(shift=3.0), m, device=DEV)

@@ -62,6 +62,12 @@ def _worker(rank, world, port, L, H, ret):
     b = torch.full((3,), float(rank))
     comm.broadcast(b, src=0)
     ok &= float(b.sum()) == 0.0
+    # the segmented exchange (round 4): this rank's shard sits in its own slot, the peers' slots arrive by per-source broadcasts
+    k_seg = torch.full((world, H, plan.shard_len, 8), -7.0)
+    k_seg[rank] = k_loc
+    evs = comm.exchange_segments_async(k_seg)
+    ok &= len(evs) == world and all(e is None for e in evs)   # CPU: synchronous, nothing to wait for
+    ok &= torch.equal(k_seg, k_all)
     comm.barrier()
     ret[rank] = bool(ok)
     torch.distributed.destroy_process_group()
@@ -107,3 +113,31 @@ def test_loopback_comm_serves_collectives_locally():
     c.barrier()
     for name in ("all_gather", "all_gather_async", "broadcast", "barrier", "all_reduce_max"):
         assert hasattr(parallel.Comm, name) and hasattr(c, name)
+
+
+def test_segment_groups_own_shard_first_then_arrival_order():
+    """dit.segment_groups: the runs of consecutive physical key segments a rank walks -- its own shard first (no wait), then the peers in
+    source order (the order of the per-source broadcasts), never crossing the own shard, at most peer_groups + 2 runs, every segment once."""
+    from worldforge_amd.dit import segment_groups
+    assert segment_groups(8, 0) == [(0, 1), (1, 5), (5, 8)]
+    assert segment_groups(8, 3) == [(3, 4), (0, 3), (4, 8)]
+    assert segment_groups(8, 7) == [(7, 8), (0, 4), (4, 7)]
+    assert segment_groups(2, 1) == [(1, 2), (0, 1)]
+    assert segment_groups(4, 2, peer_groups=3) == [(2, 3), (0, 1), (1, 2), (3, 4)]
+    for P in (2, 3, 4, 8):
+        for r in range(P):
+            for g in (1, 2, 3):
+                runs = segment_groups(P, r, g)
+                assert runs[0] == (r, r + 1) and len(runs) <= g + 2 and len(runs) <= 8
+                segs = [s for a, b in runs for s in range(a, b)]
+                assert sorted(segs) == list(range(P))
+                assert all(not (a <= r < b) for a, b in runs[1:])
+
+
+def test_loopback_comm_serves_the_segmented_exchange():
+    from worldforge_amd import parallel
+    c = parallel.LoopbackComm(4, 2)
+    out = torch.zeros(4, 3, 5)
+    out[2] = torch.arange(15.0).view(3, 5)
+    evs = c.exchange_segments_async(out)
+    assert len(evs) == 4 and all(torch.equal(out[r], out[2]) for r in range(4))

@@ -12,7 +12,16 @@ three things no one-GPU box can show, and this probe measures them at PRODUCTION
   B  the self-attention launch of one rank's shard alone (k_attn_w4<4>, split KV sweep as dit.kv_splits decides);
   C  both at once (gather on the communication stream, attention on the compute stream): how much each slows the other -- RCCL's copy
      kernels need CUs, the attention kernel occupies every CU it runs on (160 KiB LDS, 512 registers per lane);
-  D  what the DiT itself sees: `comm_exposed_ms_per_layer` of a few lock-step layers (HIP events around the compute stream's wait).
+  D  what the DiT itself sees: `comm_exposed_ms_per_layer` of a few lock-step layers (HIP events around the compute stream's wait);
+  E  (round 4) the same for ONE forward on its own -- no second CFG branch to hide under: LongCat-Video, distilled schedules, guidance <= 1 --
+     with the one-event all-gather (only the Q projection overlaps) and with the SEGMENTED exchange (per-source broadcasts; the attention
+     walks its own shard at once and each later run of segments when its event fires: dit.attention_segmented);
+  F  the bare per-source broadcasts of that exchange against the all-gather of A.
+
+`--sweep` (launcher only): the whole probe once per RCCL setting -- NCCL_MAX_NCHANNELS in {4, 8, 16, 32} and NCCL_PROTO in {default, Simple,
+LL128} (the settings must be in the environment before the communicator exists, so every setting is a fresh set of rank processes) --
+and a table of A / C / D / E per setting: how many CUs RCCL's copy kernels take from the one-workgroup-per-CU attention / GEMM kernels is
+the thing no one-GPU box can show.
 
 It also reports what RCCL decided (channels, algorithm / protocol lines of NCCL_DEBUG=INFO with the INIT and TUNING subsystems).
 One JSON line on rank 0.  No data-path collective other than all-gather is used; the timing reduce is a max over ranks.
@@ -64,6 +73,39 @@ def rccl_log_summary(path):
     return out
 
 
+SWEEP = [{}] + [{"NCCL_MAX_NCHANNELS": str(c)} for c in (4, 8, 16, 32)] + [{"NCCL_PROTO": p} for p in ("Simple", "LL128")] \
+    + [{"NCCL_MAX_NCHANNELS": "8", "NCCL_PROTO": "Simple"}]
+
+
+def sweep(a, argv):
+    """One full probe per RCCL setting (fresh rank processes each: the variables are read when the communicator is created)."""
+    import subprocess
+    rows = []
+    for setting in SWEEP:
+        env = dict(os.environ, **setting)
+        for k in ("NCCL_MAX_NCHANNELS", "NCCL_PROTO", "NCCL_ALGO"):
+            if k not in setting:
+                env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, capture_output=True, text=True, timeout=3600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        name = " ".join(f"{k}={v}" for k, v in setting.items()) or "RCCL defaults"
+        if r.returncode != 0 or not line:
+            print(f"{name}: FAILED rc={r.returncode}\n{r.stderr[-1500:]}", flush=True)
+            continue
+        d = json.loads(line[-1])
+        rows.append((name, d))
+        print(json.dumps({"setting": name, **d}), flush=True)
+    f = lambda v, spec=".3f": "-" if v is None else format(v, spec)  # noqa: E731
+    print("\n| RCCL setting | channels | A all-gather ms | F broadcasts ms | A per-link GB/s | B attention ms | C attention under gather x | "
+          "D pair: exposed ms / layer | E single, one event: exposed | E single, segmented: exposed |\n|---|---|---|---|---|---|---|---|---|---|")
+    for name, d in rows:
+        print(f"| {name} | {(d.get('rccl') or {}).get('channels')} | {f(d['A_allgather_ms'])} | {f(d.get('F_broadcasts_ms'))} | "
+              f"{f(d['A_per_link_GBps_if_all_pairs'], '.1f')} | {f(d['B_attention_alone_ms'])} | {f(d['C_attention_slowdown'])} | "
+              f"{f(d['D_comm_exposed_ms_per_layer'])} | {f(d.get('E_single_one_event_exposed_ms_per_layer'))} | "
+              f"{f(d.get('E_single_segmented_exposed_ms_per_layer'))} |")
+    return 0 if rows else 1
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
@@ -71,7 +113,10 @@ def main(argv=None):
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--tokens", type=int, default=32760, help="L of the job (81 x 480 x 832 -> 32760; 720p -> 75600)")
     ap.add_argument("--layers", type=int, default=4, help="DiT layers of part D (real width)")
+    ap.add_argument("--sweep", action="store_true", help="launcher only: repeat the probe per RCCL channel count / protocol setting")
     a = ap.parse_args(argv)
+    if a.sweep and "WORLD_SIZE" not in os.environ:
+        sys.exit(sweep(a, [x for x in argv if x != "--sweep"]))
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         import bench
         logdir = tempfile.mkdtemp(prefix="wf_comm_probe_")
@@ -169,6 +214,7 @@ def main(argv=None):
         tc_attn.append(s.elapsed_time(e))
     # D: a few real-width lock-step layers
     exposed = layer_ms = None
+    single = {False: (0.0, 0.0), True: (0.0, 0.0)}
     if a.layers > 0:
         cfg = dit.DiTConfig.wan_i2v_14b()
         cfg.num_layers = a.layers
@@ -188,12 +234,38 @@ def main(argv=None):
             torch.cuda.synchronize()
             pair_ms = 1e3 * (time.perf_counter() - t0)
             prof, dit.PROFILE_COMM = dit.PROFILE_COMM, None
-            ex = [s.elapsed_time(e) for s, e in prof]
+            ex = [dit.comm_wait_ms(e) for e in prof]
             exposed = sum(ex) / max(len(ex), 1)
             layer_ms = pair_ms / (2 * a.layers)
-    mine = torch.tensor([_median(ta), _median(tb), _median(tc_attn), _median(tc_wall), exposed or 0.0, layer_ms or 0.0],
+            # E: ONE forward on its own, with the one-event all-gather and with the segmented exchange
+            for mode in (False, True):
+                model.segmented_exchange = mode
+                model.forward_tokens(x, 500.0, ctx_a, clip)   # warm
+                sync_all()
+                dit.PROFILE_COMM = []
+                t0 = time.perf_counter()
+                model.forward_tokens(x, 500.0, ctx_a, clip)
+                torch.cuda.synchronize()
+                one_ms = 1e3 * (time.perf_counter() - t0)
+                prof, dit.PROFILE_COMM = dit.PROFILE_COMM, None
+                ex = [dit.comm_wait_ms(e) for e in prof]
+                single[mode] = (sum(ex) / max(len(ex), 1), one_ms / a.layers)
+    # F: the bare per-source broadcasts (K and V^T: 2 P broadcasts) against the all-gather of A
+    tf = []
+    for _ in range(a.iters):
+        sync_all()
+        t0 = time.perf_counter()
+        e1 = comm.exchange_segments_async(k_all)
+        e2 = comm.exchange_segments_async(v_all)
+        for ev in (e1[-1], e2[-1]):
+            if ev is not None:
+                ev.synchronize()
+        torch.cuda.synchronize()
+        tf.append(1e3 * (time.perf_counter() - t0))
+    mine = torch.tensor([_median(ta), _median(tb), _median(tc_attn), _median(tc_wall), exposed or 0.0, layer_ms or 0.0,
+                         single[False][0], single[False][1], single[True][0], single[True][1], _median(tf)],
                         dtype=torch.float64, device=dev)
-    allr = torch.empty((world, 6), dtype=torch.float64, device=dev)
+    allr = torch.empty((world, 11), dtype=torch.float64, device=dev)
     comm.all_gather(allr, mine)
     if rank == 0:
         r = allr.cpu()
@@ -210,6 +282,11 @@ def main(argv=None):
                "D_layers": a.layers, "D_comm_exposed_ms_per_layer": worst[4] if exposed is not None else None,
                "D_layer_ms": worst[5] if layer_ms is not None else None,
                "D_exposed_frac_of_layer": (worst[4] / worst[5]) if exposed is not None and worst[5] > 0 else None,
+               "E_single_one_event_exposed_ms_per_layer": worst[6] if exposed is not None else None,
+               "E_single_one_event_layer_ms": worst[7] if exposed is not None else None,
+               "E_single_segmented_exposed_ms_per_layer": worst[8] if exposed is not None else None,
+               "E_single_segmented_layer_ms": worst[9] if exposed is not None else None,
+               "F_broadcasts_ms": worst[10],
                "per_rank": [{"rank": i, "allgather_ms": v[0], "attn_ms": v[1], "attn_under_gather_ms": v[2]} for i, v in enumerate(r.tolist())]}
         logdir = os.environ.get("WF_PROBE_LOGDIR")
         if logdir and os.path.isdir(logdir):

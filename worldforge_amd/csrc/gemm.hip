@@ -49,12 +49,14 @@ enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32 = 2, EPI_RESID = 3, EPI_F32_ACC 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
 __device__ __forceinline__ float gelu_tanh(float x) {
-  // nn.GELU(approximate='tanh') (model.py:272): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float u = k0 * (x + k1 * x * x * x);
-  float e = __expf(2.0f * u);
-  float t = 1.0f - 2.0f / (e + 1.0f);
-  return 0.5f * x * (1.0f + t);
+  // nn.GELU(approximate='tanh') (model.py:272): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).  0.5 (1 + tanh u) is the logistic
+  // function of 2u, so gelu = x / (1 + exp(-2u)) = x * rcp(1 + exp2(c x (1 + 0.044715 x^2))) with c = -2 sqrt(2/pi) log2(e): six VALU and
+  // two transcendentals per value where the textbook form took about twelve and two (round 4: the GELU was 13 k of the 22 k cycles of
+  // the FFN-up epilogue, profiles/r4_c_gemm_pp_cycles.md).  x -> +inf: exp2 -> 0, result x; x -> -inf: exp2 -> inf, rcp -> 0, result -0.
+  const float c = -2.0f * 0.7978845608028654f * 1.4426950408889634f, k1 = 0.044715f;
+  const float p = __builtin_fmaf(k1, x * x, 1.0f);
+  const float e = __builtin_amdgcn_exp2f((c * x) * p);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 template <int EPI, bool F16 = false>

@@ -85,7 +85,15 @@ def _pad_rows(t: torch.Tensor, rows: int) -> torch.Tensor:
 
 
 PROFILE_ATTN = None  # bench.py sets this to a list: (start, end) HIP events around every self-attention launch
-PROFILE_COMM = None  # bench.py (N > 1) sets this to a list: (start, end) HIP events around the compute stream's wait for a layer's K / V^T exchange
+PROFILE_COMM = None  # bench.py (N > 1) sets this to a list; per layer one (start, end) HIP event pair around the compute stream's wait for the
+                     # K / V^T exchange -- or, for a segmented exchange (attention_segmented), the LIST of such pairs of the layer
+
+
+def comm_wait_ms(entry) -> float:
+    """Exposed wait of one PROFILE_COMM entry in ms (after a device synchronise)."""
+    if isinstance(entry, list):
+        return sum(a.elapsed_time(b) for a, b in entry)
+    return entry[0].elapsed_time(entry[1])
 
 
 def kv_splits(H: int, Lq: int, kv_len: int, n_cu: int = 256) -> int:
@@ -142,6 +150,77 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1))
+    return out
+
+
+def segment_groups(P: int, rank: int, peer_groups: int = 2):
+    """The order in which rank `rank` of P walks the key segments of a sequence-parallel layer whose shards arrive by P broadcasts in
+    source order (parallel.Comm.exchange_segments_async): its OWN shard first (no wait), then the peers in arrival order, in at most
+    `peer_groups` + 1 runs of consecutive physical segments [a, b) that do not cross the own one.  -> [(a, b), ...]; a run is ready once
+    the event of source b - 1 has fired."""
+    per = max(1, -(-(P - 1) // max(1, peer_groups)))
+    runs = [(rank, rank + 1)]
+    for lo, hi in ((0, rank), (rank + 1, P)):
+        a = lo
+        while a < hi:
+            runs.append((a, min(a + per, hi)))
+            a = min(a + per, hi)
+    return runs
+
+
+def attention_segmented(q: torch.Tensor, k_all: torch.Tensor, vt_all: torch.Tensor, out: torch.Tensor, kv_len: int, rank: int,
+                        events, kmax_own: Optional[torch.Tensor], kmax_all: Optional[torch.Tensor], ev_kmax, qmax2: Optional[torch.Tensor],
+                        peer_groups: int = 2, profile: bool = False):
+    """Self-attention of one sequence-parallel layer in PARTS (wf_attn_fwd_part / wf_attn_merge; pre-scaled Q): k_all [P,H,S,128], vt_all
+    [P,H,S/64,128,64] whose slot `rank` is this rank's own shard and whose other slots are being filled by
+    exchange_segments_async -- `events` = (k events, v events), lists of P.  The own shard is walked at once, each later run of segments
+    (segment_groups) after the event of its last source; the exposed part of the exchange is what the compute stream still has to wait for
+    THEN (PROFILE_COMM records every wait).  Result = the one-launch sweep up to the re-association of the fp32 partial sums (the class of
+    the split KV sweep the 8-rank shards already use)."""
+    P, H, seg, _ = k_all.shape
+    Lq = q.shape[1]
+    assert vt_all.shape == (P, H, seg // 64, 128, 64) and q.shape[0] == H and seg % 64 == 0
+    runs = segment_groups(P, rank, peer_groups)
+    nparts, tps, ntiles = len(runs), seg // 64, -(-kv_len // 64)
+    assert 2 <= nparts <= 8, nparts
+    ws = ops._workspace("attn_split", (_ffi.lib().wf_attn_split_workspace_bytes(H, Lq, nparts) + 3) // 4, q.device)
+    prof = PROFILE_ATTN if profile else None
+    cprof = PROFILE_COMM
+    waits = []
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    cur = torch.cuda.current_stream()
+    for i, (a, b) in enumerate(runs):
+        kmx = kmax_own
+        if i > 0:
+            if cprof is not None:
+                cw0, cw1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                cw0.record()
+            for evs in events:
+                if evs[b - 1] is not None:
+                    cur.wait_event(evs[b - 1])
+            if ev_kmax is not None:
+                cur.wait_event(ev_kmax)
+                ev_kmax = None
+            if cprof is not None:
+                cw1.record()
+                waits.append((cw0, cw1))
+            kmx = kmax_all
+        t0, t1 = a * tps, min(b * tps, ntiles)
+        if t0 >= t1:  # a trailing shard that holds padding only
+            t1 = t0 + 1
+        kmp, kmn, qmp, qmn = None, 0, None, 0
+        if kmx is not None and qmax2 is not None:
+            kmp, kmn, qmp, qmn = kmx.data_ptr(), kmx.numel() // H, qmax2.data_ptr(), qmax2.numel() // H
+        call("wf_attn_fwd_part", q.data_ptr(), k_all.data_ptr(), vt_all.data_ptr(), H, Lq, P * seg, kv_len, seg, t0, t1, i, nparts,
+             ws.data_ptr(), kmp, kmn, qmp, qmn, ops.stream())
+    call("wf_attn_merge", out.data_ptr(), H, Lq, out.stride(0), 0, nparts, ws.data_ptr(), ops.stream())
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1))
+    if cprof is not None:
+        cprof.append(waits)   # one entry per layer: the list of (start, end) event pairs of its waits
     return out
 
 
@@ -492,7 +571,14 @@ class WanTransformer3DModel:
     def forward_tokens(self, x_in: torch.Tensor, t_value: float, text: torch.Tensor, img: torch.Tensor) -> torch.Tensor:
         """x_in [in_dim, T, h, w] bf16; text [<=512, text_dim]; img [n_img, img_dim] -> velocity [out_dim, T, h, w] f32."""
         out = [None]
-        for _ in self._forward_steps(x_in, t_value, text, img, "", out):
+        # one forward on its own has no second CFG branch to hide the K / V^T exchange under: the exchange runs as per-source broadcasts and
+        # the attention walks the segments as they arrive, its own shard first (attention_segmented; `segmented_exchange = False` or
+        # WF_ATTN_SEGMENTED=0: the one-event all-gather of the lock-step pair, bit-identical to one GPU up to 4 ranks)
+        seg = getattr(self, "segmented_exchange", None)
+        if seg is None:
+            seg = os.environ.get("WF_ATTN_SEGMENTED", "1") != "0"
+        seg = bool(seg) and self.comm is not None and self.comm.world > 1 and hasattr(self.comm, "exchange_segments_async")
+        for _ in self._forward_steps(x_in, t_value, text, img, "", out, segmented=seg):
             pass
         return out[0]
 
@@ -520,7 +606,7 @@ class WanTransformer3DModel:
                     live.remove(gen)
         return oa[0], ob[0]
 
-    def _forward_steps(self, x_in, t_value, text, img, tag, result):
+    def _forward_steps(self, x_in, t_value, text, img, tag, result, segmented=False):
         """Generator over one forward: yields once per layer, right after that layer's K / V^T exchange has been launched (the
         point where another forward can usefully take over the compute stream).  `tag` separates the workspaces of concurrent
         forwards; the velocity lands in result[0]."""
@@ -573,9 +659,12 @@ class WanTransformer3DModel:
         qm = _buf("qmax2", (H,), f32) if km is not None else None
         fused_bound = km is not None and os.environ.get("WF_NORM_BOUND_PASS", "0") != "1"
         if comm is not None:
-            kh_all = _buf("kh_all", (comm.world, H, Lp, 128), bf)
+            kh_all = _buf("kh_all", (comm.world, H, Lp, 128), bf, zero=True)
             vt_all = _buf("vt_all", (comm.world, H, Lp // 64, 128, 64), bf)
             km_all = _buf("kmax2_all", (comm.world, H), f32) if prescale else None
+            segmented = segmented and prescale and km is not None
+            if segmented:  # the producers write this rank's shard straight into its slot of the exchange buffers
+                kh, vt = kh_all[comm.rank], vt_all[comm.rank]
         ao = _buf("ao", (L, d), bf)
         qc = _buf("qc", (L, d), bf)
         ffh = _buf("ffh", (L, ffn_padded_features(cfg.ffn_dim)), bf)
@@ -662,8 +751,11 @@ class WanTransformer3DModel:
                 gemm(hbuf, W[p + "qkv.w"][d:], W[p + "qkv.b"][d:], qkv[:, d:], EPI_BF16)
                 self._heads(qkv, d, W[p + "self_attn.norm_k"], cos, sin, kh, L, bound=km if fused_bound else None)
                 self._vt(qkv, 2 * d, vt, L)
-                ev_k = comm.all_gather_async(kh_all, kh)
-                ev_v = comm.all_gather_async(vt_all, vt)
+                if segmented:
+                    evs_kv = (comm.exchange_segments_async(kh_all), comm.exchange_segments_async(vt_all))
+                else:
+                    ev_k = comm.all_gather_async(kh_all, kh)
+                    ev_v = comm.all_gather_async(vt_all, vt)
                 if km is not None:  # every shard's per-head max |k|^2 travels with it (40 floats per rank)
                     if not fused_bound:
                         head_max_norm2(kh, L, km)
@@ -673,19 +765,25 @@ class WanTransformer3DModel:
                 yield i
                 gemm(hbuf, W[p + "qkv.w"][:d], W[p + "qkv.b"][:d], qkv[:, :d], EPI_BF16)
                 self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L, out_scale=q_scale, bound=qm if fused_bound else None)
-                cprof = PROFILE_COMM
+                if segmented:
+                    if not fused_bound:
+                        head_max_norm2(qh, L, qm)
+                    attention_segmented(qh, kh_all, vt_all, ao, Lfull, comm.rank, evs_kv, km, km_all, ev_m, qm, profile=True,
+                                        peer_groups=int(os.environ.get("WF_ATTN_SEG_GROUPS", "2")))
+                cprof = PROFILE_COMM if not segmented else None
                 if cprof is not None:  # exposed communication = how long the compute stream stalls here
                     cw0, cw1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     cw0.record()
-                for ev in (ev_k, ev_v) + ((ev_m,) if km is not None else ()):
+                for ev in () if segmented else (ev_k, ev_v) + ((ev_m,) if km is not None else ()):
                     if ev is not None:
                         torch.cuda.current_stream().wait_event(ev)
                 if cprof is not None:
                     cw1.record()
                     cprof.append((cw0, cw1))
-                if km is not None and not fused_bound:  # this rank's own queries only
+                if km is not None and not fused_bound and not segmented:  # this rank's own queries only
                     head_max_norm2(qh, L, qm)
-                attention(qh, kh_all, vt_all, ao, Lfull, sa_scale, profile=True, kmax2=km_all if km is not None else None, qmax2=qm)
+                if not segmented:
+                    attention(qh, kh_all, vt_all, ao, Lfull, sa_scale, profile=True, kmax2=km_all if km is not None else None, qmax2=qm)
             gemm(ao, W[p + "self_attn.o.w"], W[p + "self_attn.o.b"], x, EPI_RESID, gate=emod[2])
             # ---- cross-attention (model.py:310, 202-229) ----
             self._ln(x, W[p + "norm3.w"], W[p + "norm3.b"], hbuf, cfg.eps, plus_one=False)

@@ -379,10 +379,22 @@ class LongCatVideoTransformer3DModel:
         km = _buf("kmax2", (H,), f32) if prescale and os.environ.get("WF_ATTN_TRACK_MAX", "0") != "1" else None
         qm_c = _buf("qmax2_c", (H,), f32) if km is not None else None
         qm_n = _buf("qmax2_n", (H,), f32) if km is not None else None
+        segmented = False
         if comm is not None:
-            kh_all = _buf("kh_all", (comm.world, H, Sp, 128), bf)
+            kh_all = _buf("kh_all", (comm.world, H, Sp, 128), bf, zero=True)
             vt_all = _buf("vt_all", (comm.world, H, Sp // 64, 128, 64), bf)
             km_all = _buf("kmax2_all", (comm.world, H), f32) if km is not None else None
+            # The samples of a LongCat batch run one after the other (and the distilled schedule has no CFG at all, pipeline_longcat_video.py:
+            # 857-866): there is no second branch to hide the K / V^T exchange under.  Dense layers therefore exchange by per-source
+            # broadcasts and the noise-token attention walks the segments as they arrive, this rank's own shard first
+            # (dit.attention_segmented; `segmented_exchange = False` / WF_ATTN_SEGMENTED=0: the one-event all-gather, bit-identical to
+            # one GPU up to 4 ranks).  The producers then write straight into this rank's slot of the exchange buffers.
+            seg_opt = getattr(self, "segmented_exchange", None)
+            if seg_opt is None:
+                seg_opt = os.environ.get("WF_ATTN_SEGMENTED", "1") != "0"
+            segmented = bool(seg_opt) and comm.world > 1 and not use_bsa and km is not None and hasattr(comm, "exchange_segments_async")
+            if segmented:
+                kh, vt = kh_all[comm.rank], vt_all[comm.rank]
         ao = _buf("ao", (L, C), bf)
         ys = _buf("ys", (L, C), bf)
         qc = _buf("qc", (L, C), bf)
@@ -473,7 +485,12 @@ class LongCatVideoTransformer3DModel:
                 kk, vv, kmx = kh, vt, km
                 if km is not None:  # zero rows past L do not raise a maximum: the whole (padded) shard is scanned
                     head_max_norm2(kh, Sp, km)
-                if comm is not None:
+                seg_evs = ev_km = None
+                if segmented:
+                    seg_evs = (comm.exchange_segments_async(kh_all), comm.exchange_segments_async(vt_all))
+                    ev_km = comm.all_gather_async(km_all, km)
+                    kk, vv, kmx = kh_all, vt_all, km_all
+                elif comm is not None:
                     evs = (comm.all_gather_async(kh_all, kh), comm.all_gather_async(vt_all, vt))
                     if km is not None:
                         evs = evs + (comm.all_gather_async(km_all, km),)
@@ -481,11 +498,22 @@ class LongCatVideoTransformer3DModel:
                         if ev is not None:
                             torch.cuda.current_stream().wait_event(ev)
                     kk, vv, kmx = kh_all, vt_all, (km_all if km is not None else None)
+                if segmented and L - nc > 0:
+                    # the noise queries first: their sweep is what the exchange hides under (the condition queries below need every event)
+                    from .dit import attention_segmented
+                    head_max_norm2(qh_n, L - nc, qm_n)
+                    attention_segmented(qh_n, kh_all, vt_all, ao[nc:], L_all, comm.rank, seg_evs, km, km_all, ev_km, qm_n, profile=True,
+                                        peer_groups=int(os.environ.get("WF_ATTN_SEG_GROUPS", "2")))
+                    ev_km = None
+                if segmented:
+                    for ev in (seg_evs[0][-1], seg_evs[1][-1], ev_km):
+                        if ev is not None:
+                            torch.cuda.current_stream().wait_event(ev)
                 if nc > 0:
                     if km is not None:
                         head_max_norm2(qh_c, nc, qm_c)
                     attention(qh_c, kk, vv, ao[:nc], nc_all, sa_scale, kmax2=kmx, qmax2=qm_c)  # condition tokens see condition tokens only (LCA:127-131)
-                if L - nc > 0:
+                if L - nc > 0 and not segmented:
                     if km is not None:
                         head_max_norm2(qh_n, L - nc, qm_n)
                     attention(qh_n, kk, vv, ao[nc:], L_all, sa_scale, profile=True, kmax2=kmx, qmax2=qm_n)  # noise tokens see everything (LCA:133-134)

@@ -91,6 +91,41 @@ class Comm:
         dist.broadcast(t, src=src, group=self.group)
         return t
 
+    def exchange_segments_async(self, out: torch.Tensor):
+        """out [P, ...]: slot `rank` already holds this rank's shard (its producer wrote it on the current stream); every other slot is
+        filled by a broadcast from its owner -- P broadcasts in SOURCE order (every rank must issue the same collective sequence) on the
+        communication stream, one event per source.  Where all_gather_async hands back ONE event for the whole exchange, the consumer can
+        here start on slot s as soon as event s has fired (stream order: events 0 .. s-1 have fired by then): the attention kernel walks
+        its own shard with no wait at all and the segments that have arrived while the rest is still in flight (dit.attention_segmented)
+        -- the overlap a forward without a second CFG branch has no other way to get.  Returns the list of P events (None on CPU)."""
+        assert out.shape[0] == self.world and out.is_contiguous()
+        gloo = dist.get_backend(self.group) == "gloo"
+
+        def bcast(src):
+            if gloo and out.is_cuda:  # debug configuration (ranks sharing one GPU over gloo): stage through the host
+                host = out[src].cpu()
+                dist.broadcast(host, src=src, group=self.group)
+                if src != self.rank:
+                    out[src].copy_(host)
+            else:
+                dist.broadcast(out[src], src=src, group=self.group)
+
+        if self.stream is None:
+            for src in range(self.world):
+                bcast(src)
+            return [None] * self.world
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        evs = []
+        with torch.cuda.stream(self.stream):
+            for src in range(self.world):
+                bcast(src)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+                evs.append(ev)
+        out.record_stream(self.stream)
+        return evs
+
     def barrier(self):
         dist.barrier(group=self.group)
 
@@ -116,6 +151,27 @@ class LoopbackComm:
         return out
 
     all_gather_async = Comm.all_gather_async
+
+    def exchange_segments_async(self, out: torch.Tensor):
+        """Every peer slot is a copy of this rank's own (one copy + one event per source on the communication stream, like the real one)."""
+        assert out.shape[0] == self.world and out.is_contiguous()
+        if self.stream is None:
+            for src in range(self.world):
+                if src != self.rank:
+                    out[src].copy_(out[self.rank])
+            return [None] * self.world
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        evs = []
+        with torch.cuda.stream(self.stream):
+            for src in range(self.world):
+                if src != self.rank:
+                    out[src].copy_(out[self.rank])
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+                evs.append(ev)
+        out.record_stream(self.stream)
+        return evs
 
     def broadcast(self, t: torch.Tensor, src: int = 0):
         return t
