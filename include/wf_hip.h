@@ -194,13 +194,15 @@ int wf_attn_fwd_split(const void* Q, const void* K, const void* Vt, void* O, int
 /* The KV sweep in PARTS (round 4; sequence-parallel layers WITHOUT a second CFG branch to hide the K / V^T exchange under -- LongCat-Video,
  * distilled schedules, guidance_scale <= 1; reference idea: wan/distributed/xdit_context_parallel.py:160-176, pipeline_longcat_video.py:
  * 857-866).  The key segments arrive one source rank after the other; a part launch walks only the 64-key tiles [t_begin, t_end) that are
- * there already -- the rank's own shard needs no wait at all -- and leaves un-normalised partials (O f32, reference max, row sum) in slot
- * `part` of an `nparts`-slot workspace of wf_attn_split_workspace_bytes(H, Lq, nparts) bytes.  Pre-scaled Q only (the form of
+ * there already -- the rank's own shard needs no wait at all -- and leaves un-normalised partials (O f32, reference max, row sum) in the
+ * slots `part` ... `part + inner_splits - 1` of an `nparts`-slot workspace of wf_attn_split_workspace_bytes(H, Lq, nparts) bytes
+ * (inner_splits >= 1 halves / thirds the window over blockIdx.y so that a short query shard fills whole rounds of workgroups).  Pre-scaled Q only (the form of
  * wf_attn_fwd with softmax_scale = 0); Q / K / Vt / bounds as wf_attn_fwd.  wf_attn_merge combines the slots exactly (the flash combine
  * wf_attn_fwd_split uses) into O once every slot has been written; the result equals the one-launch sweep up to the re-association of the
  * fp32 partial sums. */
 int wf_attn_fwd_part(const void* Q, const void* K, const void* Vt, int H, int Lq, int Lkp, int kv_len, int seg_len, int t_begin, int t_end,
-                     int part, int nparts, void* workspace, const float* kmax2, int kmax_n, const float* qmax2, int qmax_n, void* stream);
+                     int part, int inner_splits, int nparts, void* workspace, const float* kmax2, int kmax_n, const float* qmax2, int qmax_n,
+                     void* stream);
 int wf_attn_merge(void* O, int H, int Lq, int ldo, int accumulate, int nparts, const void* workspace, void* stream);
 
 /* WanLayerNorm (model.py:92-102; eps, no affine) fused with y = ln * (plus_one + mul[c]) + add[c]:

@@ -69,7 +69,7 @@ def test_token_sharded_dit_equals_single(P, thw, segmented):
             assert torch.equal(got, ref), (r, (got - ref).abs().max())
         else:
             assert torch.equal(got, res[0]), r
-            within(f"multirank.dit_segmented.P{P}", (got - ref).abs().max().item() / ref.abs().max().item(), 2e-2)
+            within(f"multirank.dit_segmented.P{P}", (got - ref).abs().max().item() / ref.abs().max().item(), 4.4e-3)   # measured 1.9e-3 ... 2.2e-3
 
 
 @pytest.mark.parametrize("P", [2, 4])
@@ -211,7 +211,7 @@ def test_token_sharded_longcat_dit_equals_single(P, thw, ncl, segmented):
             assert torch.equal(got, ref), (r, (got - ref).abs().max())
         else:               # segments walked own-first and merged: fp32 re-association of the partial sums (bf16 residual stream)
             assert torch.equal(got, res[0]), r
-            within(f"multirank.longcat_segmented.P{P}", (got - ref).abs().max().item() / ref.abs().max().item(), 3e-2)
+            within(f"multirank.longcat_segmented.P{P}", (got - ref).abs().max().item() / ref.abs().max().item(), 8e-3)   # measured 3.1e-3 ... 4.0e-3
 
 
 @pytest.mark.parametrize("P", [2, 4])

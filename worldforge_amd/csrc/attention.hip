@@ -930,7 +930,7 @@ static unsigned int* g_dbg_body = nullptr;  // wf_attn_debug_body_counter
 // `nsplit`-slot workspace, no merge (wf_attn_merge follows once every slot is filled)
 static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len, int ldo,
                        float softmax_scale, int accumulate, int nsplit, void* workspace, const float* kmax2, int kmax_n, const float* qmax2,
-                       int qmax_n, void* stream, const char* who, int part_index = -1, int part_t0 = 0, int part_t1 = 0) {
+                       int qmax_n, void* stream, const char* who, int part_index = -1, int part_t0 = 0, int part_t1 = 0, int part_inner = 1) {
   WF_CHECK_ARG(Q && K && Vt && O, "%s: null pointer", who);
   WF_CHECK_ARG((!kmax2 || (kmax_n >= 1 && kmax_n <= 64)) && (!qmax2 || (qmax_n >= 1 && qmax_n <= 64)), "%s: kmax_n / qmax_n must be 1..64", who);
   WF_CHECK_ARG(H > 0 && Lq > 0 && kv_len > 0, "%s: empty problem", who);
@@ -983,13 +983,18 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
   int grid_y = 1;
   if (part_index >= 0) {
     WF_CHECK_ARG(softmax_scale == 0.0f, "%s: part launches are built for the pre-scaled-Q form only (softmax_scale = 0)", who);
-    WF_CHECK_ARG(nsplit >= 2 && nsplit <= 8 && part_index < nsplit, "%s: part %d of %d slots (2..8)", who, part_index, nsplit);
     WF_CHECK_ARG(part_t0 >= 0 && part_t0 < part_t1 && part_t0 < ntiles, "%s: empty tile window [%d, %d) of %d tiles", who, part_t0, part_t1, ntiles);
+    const int t1 = part_t1 < ntiles ? part_t1 : ntiles;
+    // inner splits of the window (blockIdx.y): whole rounds of workgroups for short query shards, as wf_attn_fwd_split does for the whole sweep
+    const int tps = ceil_div(t1 - part_t0, part_inner < 1 ? 1 : part_inner);
+    grid_y = ceil_div(t1 - part_t0, tps);  // splits that actually get tiles
+    WF_CHECK_ARG(nsplit >= 2 && nsplit <= 8 && part_index + grid_y <= nsplit, "%s: slots %d..%d of %d (2..8)", who, part_index,
+                 part_index + grid_y - 1, nsplit);
     WF_CHECK_ARG(workspace && (((uintptr_t)workspace) & 15) == 0, "%s: needs a 16-byte aligned workspace", who);
     a.nsplit = nsplit;  // > 1: the kernel leaves un-normalised partials
     a.t_begin0 = part_t0;
-    a.t_end = part_t1;
-    a.tiles_per_split = part_t1 - part_t0;
+    a.t_end = t1;
+    a.tiles_per_split = tps;
     a.part0 = part_index;
     a.o_part = (float*)workspace;
     a.ml_part = a.o_part + (size_t)nsplit * Lq * H * D;
@@ -1199,11 +1204,11 @@ extern "C" int wf_attn_cross2_fwd(const void* Q, const void* K, const void* Vt, 
 // slots exactly (the flash combine of wf_attn_fwd_split) once every slot has been written.  The rank's own shard needs no wait at all, so a
 // forward WITHOUT a second CFG branch to hide under still overlaps the exchange with attention itself.
 extern "C" int wf_attn_fwd_part(const void* Q, const void* K, const void* Vt, int H, int Lq, int Lkp, int kv_len, int seg_len,
-                                int t_begin, int t_end, int part, int nparts, void* workspace, const float* kmax2, int kmax_n,
-                                const float* qmax2, int qmax_n, void* stream) {
+                                int t_begin, int t_end, int part, int inner_splits, int nparts, void* workspace, const float* kmax2,
+                                int kmax_n, const float* qmax2, int qmax_n, void* stream) {
   // O is not written by a part launch; the checks of attn_launch want a valid aligned pointer: the workspace serves
   return attn_launch(Q, K, Vt, workspace, H, Lq, Lkp, kv_len, seg_len, H * D, 0.0f, 0, nparts, workspace, kmax2, kmax_n, qmax2, qmax_n, stream,
-                     "wf_attn_fwd_part", part, t_begin, t_end);
+                     "wf_attn_fwd_part", part, t_begin, t_end, inner_splits);
 }
 
 extern "C" int wf_attn_merge(void* O, int H, int Lq, int ldo, int accumulate, int nparts, const void* workspace, void* stream) {

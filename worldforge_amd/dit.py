@@ -181,7 +181,18 @@ def attention_segmented(q: torch.Tensor, k_all: torch.Tensor, vt_all: torch.Tens
     Lq = q.shape[1]
     assert vt_all.shape == (P, H, seg // 64, 128, 64) and q.shape[0] == H and seg % 64 == 0
     runs = segment_groups(P, rank, peer_groups)
-    nparts, tps, ntiles = len(runs), seg // 64, -(-kv_len // 64)
+    tps, ntiles = seg // 64, -(-kv_len // 64)
+    # inner splits per run: a part launch of W = ceil(Lq / 256) * H workgroups takes ceil(W / 256) rounds -- 640 workgroups (one rank of 8)
+    # would idle a sixth of the chip in EVERY part; two inner splits make it five full rounds (the decision kv_splits takes for the whole sweep)
+    w = -(-Lq // 256) * H
+    inner = 2 if (w / 256.0) / -(-w // 256) < 0.92 and len(runs) * 2 <= 8 else 1
+    slots, nparts = [], 0
+    for (a, b) in runs:
+        n_t = min(b * tps, ntiles) - a * tps
+        k = max(1, min(inner, n_t // 8))
+        slots.append((nparts, k))
+        nparts += k
+    nparts = max(nparts, 2)
     assert 2 <= nparts <= 8, nparts
     ws = ops._workspace("attn_split", (_ffi.lib().wf_attn_split_workspace_bytes(H, Lq, nparts) + 3) // 4, q.device)
     prof = PROFILE_ATTN if profile else None
@@ -213,8 +224,8 @@ def attention_segmented(q: torch.Tensor, k_all: torch.Tensor, vt_all: torch.Tens
         kmp, kmn, qmp, qmn = None, 0, None, 0
         if kmx is not None and qmax2 is not None:
             kmp, kmn, qmp, qmn = kmx.data_ptr(), kmx.numel() // H, qmax2.data_ptr(), qmax2.numel() // H
-        call("wf_attn_fwd_part", q.data_ptr(), k_all.data_ptr(), vt_all.data_ptr(), H, Lq, P * seg, kv_len, seg, t0, t1, i, nparts,
-             ws.data_ptr(), kmp, kmn, qmp, qmn, ops.stream())
+        call("wf_attn_fwd_part", q.data_ptr(), k_all.data_ptr(), vt_all.data_ptr(), H, Lq, P * seg, kv_len, seg, t0, t1, slots[i][0],
+             slots[i][1], nparts, ws.data_ptr(), kmp, kmn, qmp, qmn, ops.stream())
     call("wf_attn_merge", out.data_ptr(), H, Lq, out.stride(0), 0, nparts, ws.data_ptr(), ops.stream())
     if prof is not None:
         ev1.record()
