@@ -69,7 +69,7 @@ def test_token_sharded_dit_equals_single(P, thw, segmented):
             assert torch.equal(got, ref), (r, (got - ref).abs().max())
         else:
             assert torch.equal(got, res[0]), r
-            within(f"multirank.dit_segmented.P{P}", (got - ref).abs().max().item() / ref.abs().max().item(), 4.4e-3)   # measured 1.9e-3 ... 2.2e-3
+            within(f"multirank.dit_segmented.P{P}", (got - ref).abs().max().item() / ref.abs().max().item(), 5.4e-3)   # measured 2.1e-3 ... 2.7e-3
 
 
 @pytest.mark.parametrize("P", [2, 4])
