@@ -7,20 +7,26 @@ the epilogue buy?).  Shader cycles of wave 0 of every workgroup (`-DWF_GEMM_TIMI
 import ctypes, math, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, "worldforge_amd", "_lib", "lab", "libwf_hip_gemmtiming.so")
+LABDIR = os.path.join(ROOT, "worldforge_amd", "_lib", "lab")
+LIB = os.path.join(LABDIR, "libwf_hip_gemmtiming.so")
+# ablations of the K loop (wrong results by construction: they price one ingredient in cycles, like tools/attn_lab.py does for the attention)
+VARIANTS = {"gemmtiming": [], "gemm_nodma": ["-DWF_GEMM_ABLATE=1"], "gemm_nophasebar": ["-DWF_GEMM_ABLATE=2"], "gemm_nolds": ["-DWF_GEMM_ABLATE=4"],
+            "gemm_noprio": ["-DWF_GEMM_ABLATE=8"], "gemm_mfma_only": ["-DWF_GEMM_ABLATE=7"]}
 
 
 def build():
     from worldforge_amd import build as wb
     wb.build(verbose=True)
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    os.makedirs(LABDIR, exist_ok=True)
     os.makedirs(os.path.join(wb.BUILD, "lab"), exist_ok=True)
     cc = wb.hipcc()
-    obj = os.path.join(wb.BUILD, "lab", "gemm_timing.o")
-    subprocess.run([cc] + wb.COMMON + ["-DWF_GEMM_TIMING", "-c", os.path.join(wb.CSRC, "gemm.hip"), "-o", obj], check=True)
     others = [os.path.join(wb.BUILD, s.replace(".hip", ".o")) for s in wb.SOURCES if s != "gemm.hip"]
-    subprocess.run([cc, "-shared", "-fPIC", f"--offload-arch={wb.ARCH}", "-o", LIB, obj] + others + ["-L/opt/rocm/lib", "-lamdhip64"], check=True)
-    print(LIB)
+    for name, flags in VARIANTS.items():
+        obj = os.path.join(wb.BUILD, "lab", f"{name}.o")
+        subprocess.run([cc] + wb.COMMON + ["-DWF_GEMM_TIMING"] + flags + ["-c", os.path.join(wb.CSRC, "gemm.hip"), "-o", obj], check=True)
+        lib = os.path.join(LABDIR, f"libwf_hip_{name}.so")
+        subprocess.run([cc, "-shared", "-fPIC", f"--offload-arch={wb.ARCH}", "-o", lib, obj] + others + ["-L/opt/rocm/lib", "-lamdhip64"], check=True)
+        print(lib)
 
 
 def child():
@@ -30,9 +36,10 @@ def child():
     buf = (ctypes.c_ulonglong * 16)()
     print("| shape M x N x K | epilogue | ms | TFLOP/s | tiles | prologue | K loop (group A / B) | epilogue | epilogue share | MFMA pipe cycles of the K loop | K-loop efficiency | clock GHz (busy cycles per CU / wall) |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|")
-    for P in (1, 8):
+    short = len(sys.argv) > 2 and sys.argv[2] == "short"
+    for P in ((1,) if short else (1, 8)):
         M = (32760 + P - 1) // P
-        for (N, K, epi, name) in ((15360, 5120, 0, "bf16"), (5120, 5120, 3, "x += gate * y"), (14080, 5120, 1, "bf16 + GELU"), (5120, 13824, 3, "x += gate * y")):
+        for (N, K, epi, name) in ((15360, 5120, 0, "bf16"),) if short else ((15360, 5120, 0, "bf16"), (5120, 5120, 3, "x += gate * y"), (14080, 5120, 1, "bf16 + GELU"), (5120, 13824, 3, "x += gate * y")):
             x = torch.randn(M, K, device="cuda").bfloat16()
             w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).bfloat16()
             b, g = torch.randn(N, device="cuda"), torch.randn(N, device="cuda")
@@ -69,5 +76,9 @@ if __name__ == "__main__":
         build()
     elif mode == "child":
         child()
+    elif mode == "ablate":   # K-loop cycles of every ablation variant on the QKV shape only
+        for name in VARIANTS:
+            print(f"\n== {name} {VARIANTS[name]}", flush=True)
+            subprocess.run([sys.executable, os.path.abspath(__file__), "child", "short"], env=dict(os.environ, WF_LIB=os.path.join(LABDIR, f"libwf_hip_{name}.so")), timeout=600)
     else:
         sys.exit(subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, WF_LIB=LIB)).returncode)

@@ -232,6 +232,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_gemm(GemmArgs a) {
 // barrier 4t (its buffer was last read two intervals earlier) and drain it (vmcnt(0)) before barrier 4t+4.
 // Requirements: K % 64 == 0 (no K tail in the DMA path); ragged M / N handled by clamped source rows + predicated stores.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef WF_GEMM_ABLATE
+#define WF_GEMM_ABLATE 0  // lab only (tools/gemm_pp_cycles.py, wrong results): 1 no LDS-DMA pieces in the K loop of k_gemm_pp, 2 only the K tile's
+#endif                    // last barrier (no phase hand-over barriers), 4 no LDS fragment reads in the loop, 8 no s_setprio around the MFMA phases
 #ifdef WF_GEMM_TIMING
 // lab builds (WF_EXTRA_HIPCC_FLAGS=-DWF_GEMM_TIMING): k_gemm_w4 fills [0..7] (tools/gemm_timing.py); k_gemm_pp adds, per workgroup (its
 // wave 0): [8] prologue, [9] K loop, [10] epilogue shader cycles, [11] workgroups, [12] cycles of wave 4 (group B) K loop
@@ -329,6 +332,7 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
   u32x4 fw[2][NI], fx[2][NJ];
   auto read_half = [&](int kt, int half) {
     const unsigned char* base = smem + (kt & 1) * BUF;
+    if ((WF_GEMM_ABLATE & 4) && kt > 0) return;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int c = ((2 * (2 * half + ks) + hi) ^ sw) << 4;
@@ -341,7 +345,8 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
   // 2*NI*NJ MFMAs on register operands; optionally the NP LDS-DMA pieces of tile `dma_kt` are issued in the gaps (one behind
   // every second MFMA: the MFMA pipe hides their issue cost, and the read phases stay pure LDS reads)
   auto mma_half = [&](int dma_kt) {
-    __builtin_amdgcn_s_setprio(1);  // the MFMA phase outranks the co-resident wave's LDS phase at the issue arbiter
+    if (WF_GEMM_ABLATE & 1) dma_kt = -1;
+    if (!(WF_GEMM_ABLATE & 8)) __builtin_amdgcn_s_setprio(1);  // the MFMA phase outranks the co-resident wave's LDS phase at the issue arbiter
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -377,14 +382,17 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
 #ifdef WF_GEMM_TIMING
   const unsigned long long tt1 = __builtin_readcyclecounter();
 #endif
+  auto pbar = [&]() {  // a phase hand-over barrier (lab: WF_GEMM_ABLATE & 2 drops them, keeping the K tile's buffer hand-over)
+    if (!(WF_GEMM_ABLATE & 2)) bar();
+  };
   if (!groupB) {
     for (int kt = 0; kt < nk; ++kt) {
       read_half(kt, 0);
-      bar();  // 4kt+1
+      pbar();  // 4kt+1
       mma_half(kt + 1 < nk ? kt + 1 : -1);  // DMA of tile kt+1 rides in the MFMA gaps (its buffer is free since barrier 4kt)
-      bar();  // 4kt+2
+      pbar();  // 4kt+2
       read_half(kt, 1);
-      bar();  // 4kt+3
+      pbar();  // 4kt+3
       mma_half(-1);
       drain();
       bar();  // 4kt+4
@@ -395,14 +403,14 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
     bar();  // 1
     for (int kt = 0; kt < nk; ++kt) {
       read_half(kt, 0);
-      bar();  // 4kt+2
+      pbar();  // 4kt+2
       mma_half(-1);
-      bar();  // 4kt+3
+      pbar();  // 4kt+3
       read_half(kt, 1);
       drain();
       bar();  // 4kt+4
       mma_half(kt + 2 < nk ? kt + 2 : -1);
-      bar();  // 4kt+5
+      pbar();  // 4kt+5
     }
   }
 
