@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 LABDIR = os.path.join(ROOT, "worldforge_amd", "_lib", "lab")
 LIB = os.path.join(LABDIR, "libwf_hip_gemmtiming.so")
 # ablations of the K loop (wrong results by construction: they price one ingredient in cycles, like tools/attn_lab.py does for the attention)
-VARIANTS = {"gemmtiming": [], "gemm_nodma": ["-DWF_GEMM_ABLATE=1"], "gemm_nophasebar": ["-DWF_GEMM_ABLATE=2"], "gemm_nolds": ["-DWF_GEMM_ABLATE=4"],
+VARIANTS = {"gemmtiming": [], "gemm_dma_in_mfma": ["-DWF_GEMM_DMA_PHASE=0"], "gemm_dma_in_read": ["-DWF_GEMM_DMA_PHASE=1"], "gemm_rsplit0": ["-DWF_GEMM_DMA_RSPLIT=0"], "gemm_rsplit3": ["-DWF_GEMM_DMA_RSPLIT=3"], "gemm_rsplit7": ["-DWF_GEMM_DMA_RSPLIT=7"], "gemm_rsplit9": ["-DWF_GEMM_DMA_RSPLIT=9"], "gemm_nodma": ["-DWF_GEMM_ABLATE=1"], "gemm_nophasebar": ["-DWF_GEMM_ABLATE=2"], "gemm_nolds": ["-DWF_GEMM_ABLATE=4"],
             "gemm_noprio": ["-DWF_GEMM_ABLATE=8"], "gemm_mfma_only": ["-DWF_GEMM_ABLATE=7"]}
 
 

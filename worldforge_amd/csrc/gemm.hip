@@ -235,6 +235,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_gemm(GemmArgs a) {
 #ifndef WF_GEMM_ABLATE
 #define WF_GEMM_ABLATE 0  // lab only (tools/gemm_pp_cycles.py, wrong results): 1 no LDS-DMA pieces in the K loop of k_gemm_pp, 2 only the K tile's
 #endif                    // last barrier (no phase hand-over barriers), 4 no LDS fragment reads in the loop, 8 no s_setprio around the MFMA phases
+#ifndef WF_GEMM_DMA_PHASE
+// k_gemm_pp, where / how a wave issues the LDS-DMA pieces of the next K tile.  0 = rounds 1-3: in the gaps of its MFMA phase through the
+// builtin (per piece a 64-bit VALU address add, three scalar instructions and a branch: ~60 issue cycles where an MFMA leaves ~12 free --
+// 42 pipe cycles lost per piece, 12.7 % of the K loop: profiles/r4_f_gemm_ablate.md).  1 = in the wave's own READ phase (lab negative: the
+// read phase then outlasts the partner's MFMA phase, K loop 84.5 -> 70 %).  2 = round 4: in the MFMA gaps in the saddr form of the attention
+// kernel (wave-uniform 64-bit base + constant 32-bit lane offset, M0 in one s_add with an immediate, no branch per piece).
+#define WF_GEMM_DMA_PHASE 2
+#endif
+#ifndef WF_GEMM_DMA_RSPLIT
+#define WF_GEMM_DMA_RSPLIT 5  // (PHASE 2) how many of a wave's 9 (8) pieces go to the tail of its first READ phase instead of the MFMA gaps (lab: 0 -> 89.2 %, 3 -> 90.8, 5 -> 92-93.5, 6 / 7 -> 92.4, 9 -> 86.6 % of the pipe)
+#endif
 #ifdef WF_GEMM_TIMING
 // lab builds (WF_EXTRA_HIPCC_FLAGS=-DWF_GEMM_TIMING): k_gemm_w4 fills [0..7] (tools/gemm_timing.py); k_gemm_pp adds, per workgroup (its
 // wave 0): [8] prologue, [9] K loop, [10] epilogue shader cycles, [11] workgroups, [12] cycles of wave 4 (group B) K loop
@@ -262,7 +273,7 @@ struct PPGeom {
   static constexpr int NWP = PNT / 64;                // 1 KiB W pieces per wave
   static constexpr int NP = NWP + 4;                  // LDS-DMA pieces per wave per K tile
   static constexpr int STG = NJ * 32 * 144;           // epilogue staging bytes per wave
-  static constexpr int LDS = 2 * BUF > 8 * STG ? 2 * BUF : 8 * STG;
+  static constexpr int LDS = (2 * BUF > 8 * STG ? 2 * BUF : 8 * STG) + 8 * 1024;  // + a 1 KiB dummy LDS-DMA target per wave (k_gemm_pp)
 };
 
 template <int EPI, int NI, bool F16 = false>
@@ -316,6 +327,31 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) dma_piece(kt, i);
   };
+#if WF_GEMM_DMA_PHASE == 2
+  // saddr form: per-lane BYTE offsets from a.W / a.X (constant over K; the launcher guarantees N * ldw * 2 and M * ldx * 2 < 4 GiB)
+  uint32_t voffW[NWP], voffX[4];
+#pragma unroll
+  for (int i = 0; i < NWP; ++i) voffW[i] = (uint32_t)(reinterpret_cast<const unsigned char*>(srcW[i]) - reinterpret_cast<const unsigned char*>(a.W));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) voffX[i] = (uint32_t)(reinterpret_cast<const unsigned char*>(srcX[i]) - reinterpret_cast<const unsigned char*>(a.X));
+  const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_offset(smem));
+  const int nk_ = a.K / PK;
+  // Past the last K tile the pieces are still issued (no branch in the MFMA stream, and ONE code path for the MFMA phase: two copies of it
+  // behind a branch made the register allocator spill accumulators): they re-read tile nk-1 into a wave-private 1 KiB dummy region behind the
+  // operand buffers (G::LDS reserves it), which nobody reads.
+  auto piece_s = [&](int i, int kt) {  // i is a constant after unrolling; kt may be >= nk
+    const bool live = kt < nk_;
+    const int ks_ = live ? kt : nk_ - 1;
+    const uint32_t buf = smem_base + (uint32_t)((kt & 1) * BUF);
+    const uint32_t dummy = smem_base + (uint32_t)(2 * BUF + wid * 1024);
+    if (i < NWP)
+      glds16_saddr(reinterpret_cast<const unsigned char*>(a.W) + (size_t)ks_ * (PK * 2), voffW[i],
+                   live ? buf + (uint32_t)((wid * NWP + i) * 1024) : dummy);
+    else
+      glds16_saddr(reinterpret_cast<const unsigned char*>(a.X) + (size_t)ks_ * (PK * 2), voffX[i - NWP],
+                   live ? buf + (uint32_t)(W_TILE + (wid * 4 + i - NWP) * 1024) : dummy);
+  };
+#endif
 
   // ---- fragment addressing ------------------------------------------------------------------------------------------------
   // every fragment row of a wave is its lane's row l31 plus a multiple of 32: one swizzle term serves all of them
@@ -344,6 +380,27 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
   };
   // 2*NI*NJ MFMAs on register operands; optionally the NP LDS-DMA pieces of tile `dma_kt` are issued in the gaps (one behind
   // every second MFMA: the MFMA pipe hides their issue cost, and the read phases stay pure LDS reads)
+#if WF_GEMM_DMA_PHASE == 2
+  // MFMA phase WITH the pieces of tile `kt_next` (compile-time: the caller branches ONCE per phase between this and the plain phase)
+  auto mma_half_dma = [&](int kt_next) {
+    if (!(WF_GEMM_ABLATE & 8)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int jx = 0; jx < NJ; ++jx) {
+          acc[i][jx] = mfma32t<F16>(fw[ks][i], fx[ks][jx], acc[i][jx]);
+          const int idx = (ks * NI + i) * NJ + jx;
+          constexpr int RS = WF_GEMM_DMA_RSPLIT < NP ? WF_GEMM_DMA_RSPLIT : NP;
+          if ((idx & 1) && (idx >> 1) < NP - RS && !(WF_GEMM_ABLATE & 1)) {
+            piece_s(RS + (idx >> 1), kt_next);
+            __builtin_amdgcn_sched_barrier(0);  // the piece stays in this gap
+          }
+        }
+    __builtin_amdgcn_s_setprio(0);
+  };
+#endif
   auto mma_half = [&](int dma_kt) {
     if (WF_GEMM_ABLATE & 1) dma_kt = -1;
     if (!(WF_GEMM_ABLATE & 8)) __builtin_amdgcn_s_setprio(1);  // the MFMA phase outranks the co-resident wave's LDS phase at the issue arbiter
@@ -385,6 +442,81 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
   auto pbar = [&]() {  // a phase hand-over barrier (lab: WF_GEMM_ABLATE & 2 drops them, keeping the K tile's buffer hand-over)
     if (!(WF_GEMM_ABLATE & 2)) bar();
   };
+#if WF_GEMM_DMA_PHASE == 1
+  // Round 4.  A wave in its MFMA phase has ~12 free issue cycles per MFMA; an LDS-DMA piece (M0 set-up, 64-bit address, the VMEM issue)
+  // needs ~60, so every piece placed between two MFMAs cost ~42 cycles of matrix pipe: 9 pieces x 8 waves = 12.7 % of the K loop
+  // (cycle-counted ablation, profiles/r4_f_gemm_ablate.md).  The partner wave on the same SIMD, meanwhile, sits in its READ phase: 14 LDS
+  // reads, then the hand-over barrier.  Each wave therefore stages ITS pieces of tile kt+1 at the tail of its own first read phase of tile
+  // kt -- group A in phase 1, group B in phase 2 -- where their issue time overlaps the other group's MFMA phase; the MFMA phases are
+  // pure MFMA streams.  Hazards: buffer (kt+1)&1 was last read before barrier 4kt (both groups' R1 of tile kt-1), and every wave drains
+  // its pieces before barrier 4kt+4, behind which tile kt+1 is first read.
+  if (!groupB) {
+    for (int kt = 0; kt < nk; ++kt) {
+      read_half(kt, 0);
+      if (kt + 1 < nk && !(WF_GEMM_ABLATE & 1)) dma(kt + 1);
+      pbar();  // 4kt+1
+      mma_half(-1);
+      pbar();  // 4kt+2
+      read_half(kt, 1);
+      pbar();  // 4kt+3
+      mma_half(-1);
+      drain();
+      bar();  // 4kt+4
+    }
+    bar();
+  } else {
+    bar();  // 1
+    for (int kt = 0; kt < nk; ++kt) {
+      read_half(kt, 0);
+      if (kt + 1 < nk && !(WF_GEMM_ABLATE & 1)) dma(kt + 1);
+      pbar();  // 4kt+2
+      mma_half(-1);
+      pbar();  // 4kt+3
+      read_half(kt, 1);
+      drain();
+      bar();  // 4kt+4
+      mma_half(-1);
+      pbar();  // 4kt+5
+    }
+  }
+#elif WF_GEMM_DMA_PHASE == 2
+  auto rphase_pieces = [&](int kt_next) {  // the first WF_GEMM_DMA_RSPLIT pieces, behind the read phase's LDS reads
+#pragma unroll
+    for (int i = 0; i < (WF_GEMM_DMA_RSPLIT < NP ? WF_GEMM_DMA_RSPLIT : NP); ++i)
+      if (!(WF_GEMM_ABLATE & 1)) piece_s(i, kt_next);
+  };
+  if (!groupB) {
+    for (int kt = 0; kt < nk; ++kt) {
+      read_half(kt, 0);
+      rphase_pieces(kt + 1);
+      pbar();  // 4kt+1
+      mma_half_dma(kt + 1);  // the pieces of tile kt+1 ride in the MFMA gaps (its buffer is free since barrier 4kt)
+      pbar();  // 4kt+2
+      read_half(kt, 1);
+      pbar();  // 4kt+3
+      mma_half(-1);
+      drain();
+      bar();  // 4kt+4
+    }
+    bar();
+  } else {
+    if (nk > 1) dma(1);
+    bar();  // 1
+    for (int kt = 0; kt < nk; ++kt) {
+      read_half(kt, 0);
+      if (kt > 0) rphase_pieces(kt + 1);  // group B's share of tile kt+1 that its previous MFMA phase (in phase 1) left over; tile 1 came whole from the prologue
+      pbar();  // 4kt+2
+      mma_half(-1);
+      pbar();  // 4kt+3
+      read_half(kt, 1);
+      drain();
+      bar();  // 4kt+4
+      mma_half_dma(kt + 2);
+      pbar();  // 4kt+5
+    }
+    drain();  // the dummy pieces of the last two phases
+  }
+#else
   if (!groupB) {
     for (int kt = 0; kt < nk; ++kt) {
       read_half(kt, 0);
@@ -413,6 +545,7 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
       pbar();  // 4kt+5
     }
   }
+#endif
 
 #ifdef WF_GEMM_TIMING
   const unsigned long long tt2 = __builtin_readcyclecounter();
@@ -1140,7 +1273,9 @@ static int gemm_impl(const void* X, const void* W, const float* bias, void* out,
   // INVARIANT relied on by k_gemm_pp / k_gemm_pp16 / k_gemm_w4: their epilogues load bias / gate / old-value quads UNCONDITIONALLY at
   // clamped addresses `min(n, N - 4)` (a guard per load would put every load in its own basic block), which needs N >= 4 and N % 4 == 0.
   // `big` guarantees both (N >= 256, N % 4 == 0); a future relaxation of this gate must keep them.
-  const bool big = K % PK == 0 && M >= 1024 && N >= 256 && N % 4 == 0 && (long)M * N >= (1L << 22);
+  // ... and the saddr LDS-DMA of k_gemm_pp addresses a row's bytes by a 32-bit offset from X / W
+  const bool big = K % PK == 0 && M >= 1024 && N >= 256 && N % 4 == 0 && (long)M * N >= (1L << 22) &&
+                   (size_t)M * ldx * 2 < (1ull << 32) && (size_t)N * ldw * 2 < (1ull << 32);
   if (use_w4 && !no_pp && big && !f16) {
     switch (epilogue) {
       case EPI_BF16: launch_w4<EPI_BF16>(a, s); break;
