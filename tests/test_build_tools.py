@@ -30,10 +30,10 @@ def test_attn_lab_variants_name_macros_the_kernel_source_knows():
 def test_gpurun_scripts_readme_lists_every_script():
     d = os.path.join(ROOT, "tools", "gpurun_scripts")
     readme = open(os.path.join(d, "README.md")).read()
-    ranges = [(a, b) for a, b in re.findall(r"`r3_(\w)\.sh` \.\.\. `r3_(\w)\.sh`", readme)]
+    ranges = [(r, a, b) for r, a, b in re.findall(r"`r(\d)_(\w)\.sh` \.\.\. `r\1_(\w)\.sh`", readme)]
     for f in sorted(os.listdir(d)):
         if not f.endswith(".sh"):
             continue
-        m = re.fullmatch(r"r3_(\w)\.sh", f)
-        in_range = bool(m) and any(a <= m.group(1) <= b for a, b in ranges)
+        m = re.fullmatch(r"r(\d)_(\w)\.sh", f)
+        in_range = bool(m) and any(r == m.group(1) and a <= m.group(2) <= b for r, a, b in ranges)
         assert f"`{f}`" in readme or in_range, f"{f} is not described in tools/gpurun_scripts/README.md"
