@@ -626,6 +626,13 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   decode(tile_begin, t, y0, x0);
   compute_psrc(t, y0, x0);
   const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_offset(smem));
+  auto dma_piece_c = [&](int cs, auto JC) {  // the same for a compile-time piece number (slice loop): M0 = uniform base + immediate
+    (void)&psrc;
+    constexpr int j = decltype(JC)::value;
+    const int acs = cs >= pa.nsa ? cs - pa.nsa : cs;
+    const uint16_t* src = psrc[j] + (size_t)acs * pa.slice_stride;
+    glds16_async_m0_imm<j * 1024>(src, smem_base + (uint32_t)((cs & 1) * PATCH_BUF) + (uint32_t)(wid * 16 * 1024));
+  };
   auto dma_piece = [&](int cs, int j) {  // piece j of the patch of K slice cs -> buffer cs & 1 (stored slice cs mod nsa)
     const int acs = cs >= pa.nsa ? cs - pa.nsa : cs;
     // ONE wave-uniform slice offset for every lane (a single 64-bit add per piece, no per-lane select): the lanes of out-of-range pixels
@@ -656,10 +663,17 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   // hand.  The LDS-DMA pieces are inline asm too, i.e. invisible to the compiler's s_waitcnt insertion: with compiler-managed weight
   // loads it emitted vmcnt(N) for N outstanding loads IT knew of, while the hardware counter also held the younger DMA pieces -- every
   // wait then drained loads issued barely one tap earlier and the MFMA stream stalled on L2 latency (43 instead of 32 cycles per MFMA).
-  auto wload = [&](u32x4& dst, int cs, int tap, int cb) {
-    const int csc = cs < ns ? cs : 0;  // past the last slice: slice 0 of the next tile (same weights)
-    const unsigned char* sb = wbase + (size_t)(tap * ns + csc) * wslice + cb * 1024;  // wave-uniform
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(aoff), "s"(sb) : "memory");
+  // Round 4: the address of the fragment of (slice, tap, cb) was recomputed per load -- (tap * ns + slice) * wslice as a 64-bit scalar
+  // multiply-add, 12 SALU per tap -- in a wave that is alone on its SIMD and has ~12 free issue cycles per MFMA (issue-slot lab, DESIGN
+  // section 4c).  The loads of a slice visit (slice, 2), (slice, 3) ... (slice, 26), (next slice, 0), (next slice, 1): a RUNNING uniform
+  // pointer `wp` advances by `tapstride` per tap (one 64-bit scalar add) and jumps to the next slice's tap 0 once per slice; the output
+  // block cb is an immediate offset of the load.
+  const size_t tapstride = (size_t)ns * wslice;  // bytes between two taps of one slice
+  const unsigned char* wp = wbase;              // -> (slice 0, tap 0)
+  auto wload_cur = [&](u32x4& dst, auto CBC) {
+    (void)&aoff, (void)&wp;
+    constexpr int cb = decltype(CBC)::value;
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(aoff), "s"(wp), "n"(cb * 1024) : "memory");
   };
   // VMEM issue order per tap t of a slice: W(t+2) x 3 (gaps 4..6), then D x 2 (gaps 8, 10; taps 0..7 only).  Before the MFMAs of tap t
   // its weights W(t) must have landed; younger than them are D(t-2), W(t+1), D(t-1): vmcnt = 3 + 2 [0 <= t-2 < 8] + 2 [0 <= t-1 < 8].
@@ -683,14 +697,29 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
     const unsigned char* base = smem + buf * PATCH_BUF + ((dt * PR + dy) * PC + dx) * 32;
     return *reinterpret_cast<const u32x4*>(base + boff[pb]);
   };
+  // the same read in the slice loop: the lane's address INCLUDING the buffer offset sits in a register for the whole slice (bslice) and
+  // the tap's patch offset (<= 46 528 B) is the ds_read's immediate -- the per-tap v_add_u32 per fragment is gone
+  uint32_t bslice[4];
+  auto bread_c = [&](auto TC, int pb) {
+    (void)&bslice;
+    constexpr int tap = decltype(TC)::value;
+    constexpr int dt = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(bslice[pb]), "n"(((dt * PR + dy) * PC + dx) * 32) : "memory");
+    return v;
+  };
 
   // prologue: patch of slice 0, weights of taps 0, 1, then the pixel fragments of tap 0
 #pragma unroll
   for (int j = 0; j < 16; ++j) dma_piece(0, j);
-#pragma unroll
-  for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) wload(af[tp][cb], 0, tp, cb);
+  for_const<2>([&](auto TP) {
+    (void)&af, (void)&wp, (void)&tapstride, (void)&wload_cur;
+    for_const<NCB>([&](auto CBC) {
+      (void)&af, (void)&wload_cur;
+      wload_cur(af[decltype(TP)::value][decltype(CBC)::value], CBC);
+    });
+    wp += tapstride;
+  });  // wp -> (slice 0, tap 2)
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCB) : "memory");  // the 16 pieces landed (the 2 NCB weight loads were issued after them)
   bar();
 #pragma unroll
@@ -726,10 +755,16 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
     }
     // next slice's patch; last slice: slice 0 of the next tile into buffer 0 (or a harmless re-stage when there is none)
     const int csn = cs + 1 < ns ? cs + 1 : (has_next ? 0 : cs);
+    // per-slice uniforms / registers of the round-4 address paths: where the weight pointer jumps to after tap 26's fragments (the next
+    // slice's tap 0; past the last slice: slice 0 of the next tile, same weights), and the fragment read addresses with the buffer folded in
+    const unsigned char* w_next = wbase + (size_t)(cs + 1 < ns ? cs + 1 : 0) * wslice;
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+      bslice[pb] = lds_offset(smem) + (uint32_t)(buf * PATCH_BUF) + boff[pb];
+      asm volatile("" : "+v"(bslice[pb]));  // one register each for the whole slice (not re-materialised per tap)
+    }
     for_const<27>([&](auto TC) {
       constexpr int tap = decltype(TC)::value;
-      constexpr int ntap = tap + 2 < 27 ? tap + 2 : tap + 2 - 27;
-      const int ncs = tap + 2 < 27 ? cs : cs + 1;  // == ns on the last slice: wload wraps it to slice 0 of the next tile
       if constexpr (!(DBG & 2)) {
         constexpr int nd = (DBG & 1) ? 0 : 2;  // LDS-DMA pieces per tap over taps 0..7
         constexpr int nwait = NCB + ((tap >= 2 && tap - 2 < 8) ? nd : 0) + ((tap >= 1 && tap - 1 < 8) ? nd : 0);
@@ -738,19 +773,32 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
         else
           asm volatile("s_waitcnt vmcnt(%1)" : "+v"(af[tap % 3][0]) : "n"(nwait));
       }
+      // this tap's four pixel fragments were read (inline asm: the compiler does not count them) in gaps 0..3 of the previous tap, >= 8
+      // MFMAs ago; tap 0's come from the compiler-managed reads behind the slice barrier
+      if constexpr (tap > 0 && !(DBG & 4))
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[tap & 1][0]), "+v"(bf[tap & 1][1]), "+v"(bf[tap & 1][2]), "+v"(bf[tap & 1][3]));
       // gap m of the tap: MFMA (pixel block m / NCB, output block m % NCB); in its shadow: gaps 0..3 the next tap's 4 pixel fragments, then
       // the NCB weight fragments two taps ahead (VMEM), then the 2 LDS-DMA pieces of the next slice's patch (VMEM, taps 0..7) -- the VMEM
       // issue ORDER (weights before pieces within a tap) is what the hand-counted waits above assume
       constexpr int M = 4 * NCB, WL0 = NCB == 3 ? 4 : 1, D0 = NCB == 3 ? 8 : 2, D1 = NCB == 3 ? 10 : 3;
       for_const<M>([&](auto MC) {
-        (void)&acc, (void)&af, (void)&bf;
+        (void)&acc, (void)&af, (void)&bf, (void)&wp, (void)&w_next, (void)&tapstride, (void)&bslice, (void)&psrc, (void)&wload_cur, (void)&bread_c,
+            (void)&dma_piece_c;
         constexpr int m = decltype(MC)::value;
         constexpr int cb = m % NCB, pb = m / NCB;
         mma(acc[pb][cb], af[tap % 3][cb], bf[tap & 1][pb]);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (m < 4 && tap < 26 && !(DBG & 4)) bf[(tap + 1) & 1][m] = bread(buf, tap + 1, m);  // next tap's pixel fragments
-        if constexpr (m >= WL0 && m < WL0 + NCB && !(DBG & 2)) wload(af[(tap + 2) % 3][m - WL0], ncs, ntap, m - WL0);  // weights two taps ahead
-        if constexpr ((m == D0 || m == D1) && tap < 8 && !(DBG & 1)) dma_piece(csn, 2 * tap + (m == D1 ? 1 : 0));
+        if constexpr (m < 4 && tap < 26 && !(DBG & 4)) bf[(tap + 1) & 1][m] = bread_c(std::integral_constant<int, tap + 1>{}, m);  // next tap's pixel fragments
+        if constexpr (m >= WL0 && m < WL0 + NCB && !(DBG & 2)) {  // weights two taps ahead, through the running pointer
+          wload_cur(af[(tap + 2) % 3][m - WL0], std::integral_constant<int, m - WL0>{});
+          if constexpr (m == WL0 + NCB - 1) {
+            if constexpr (tap == 24)
+              wp = w_next;       // tap 26's fragments were the slice's last: on to (next slice, tap 0)
+            else
+              wp += tapstride;
+          }
+        }
+        if constexpr ((m == D0 || m == D1) && tap < 8 && !(DBG & 1)) dma_piece_c(csn, std::integral_constant<int, 2 * tap + (m == D1 ? 1 : 0)>{});
         __builtin_amdgcn_sched_barrier(0);
       });
     });

@@ -273,7 +273,11 @@ struct PPGeom {
   static constexpr int NWP = PNT / 64;                // 1 KiB W pieces per wave
   static constexpr int NP = NWP + 4;                  // LDS-DMA pieces per wave per K tile
   static constexpr int STG = NJ * 32 * 144;           // epilogue staging bytes per wave
-  static constexpr int LDS = (2 * BUF > 8 * STG ? 2 * BUF : 8 * STG) + 8 * 1024;  // + a 1 KiB dummy LDS-DMA target per wave (k_gemm_pp)
+  // + a 1 KiB dummy LDS-DMA target per wave (k_gemm_pp) BEHIND both uses of the rest: for NI = 2 the epilogue staging (8 x 18 KiB) is
+  // larger than the operand buffers, and a dummy region at 2 * BUF lay inside wave 7's staging rows -- a group-B wave's last dummy pieces
+  // could land there after wave 7 had begun its epilogue (seen as a rare wrong tile when several streams shared the GPU)
+  static constexpr int DUMMY = 2 * BUF > 8 * STG ? 2 * BUF : 8 * STG;
+  static constexpr int LDS = DUMMY + 8 * 1024;
 };
 
 template <int EPI, int NI, bool F16 = false>
@@ -343,7 +347,8 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
     const bool live = kt < nk_;
     const int ks_ = live ? kt : nk_ - 1;
     const uint32_t buf = smem_base + (uint32_t)((kt & 1) * BUF);
-    const uint32_t dummy = smem_base + (uint32_t)(2 * BUF + wid * 1024);
+    static_assert(G::DUMMY >= 2 * BUF && G::DUMMY >= 8 * G::STG && G::LDS >= G::DUMMY + 8 * 1024, "the dummy LDS-DMA targets overlap live LDS");
+    const uint32_t dummy = smem_base + (uint32_t)(G::DUMMY + wid * 1024);
     if (i < NWP)
       glds16_saddr(reinterpret_cast<const unsigned char*>(a.W) + (size_t)ks_ * (PK * 2), voffW[i],
                    live ? buf + (uint32_t)((wid * NWP + i) * 1024) : dummy);

@@ -115,6 +115,18 @@ __device__ __forceinline__ void glds16_async_m0(const void* gsrc, uint32_t lds_w
       : "v"(gsrc), "s"(lds_wave_base_byte)
       : "memory", "m0");
 }
+// glds16_async_m0 with the piece's LDS offset as an immediate: M0 = wave-uniform base + IMM in ONE scalar instruction (the 16 per-piece
+// destinations of k_conv_w4 were 16 scalars the compiler kept spilled in VGPR lanes: a v_readlane + s_add per piece)
+template <int IMM>
+__device__ __forceinline__ void glds16_async_m0_imm(const void* gsrc, uint32_t lds_base_byte) {
+  asm volatile(
+      "s_add_u32 m0, %1, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, off"
+      :
+      : "v"(gsrc), "s"(lds_base_byte), "n"(IMM)
+      : "memory", "m0", "scc");
+}
 // LDS-DMA in the saddr form: wave-uniform 64-bit base in SGPRs + 32-bit per-lane byte offset -- no 64-bit VALU address arithmetic.
 // Inline asm like glds16_async (the caller owns the ordering: s_waitcnt vmcnt + barrier before anyone reads the destination).
 __device__ __forceinline__ void glds16_saddr(const void* base_uniform, uint32_t voff_bytes, uint32_t lds_wave_base_byte) {
