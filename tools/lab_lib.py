@@ -12,6 +12,9 @@ from worldforge_amd import build as B
 
 def main():
     name, swaps = sys.argv[1], dict(a.split("=") for a in sys.argv[2:])
+    extra = os.environ.get("WF_EXTRA_HIPCC_FLAGS", "").split()  # instrumentation flags apply to the swapped sources ONLY: the shared
+    for f in extra:                                               # objects (and libwf_hip.so) stay the plain build
+        B.COMMON.remove(f)
     B.build(verbose=False)
     cc = B.hipcc()
     out_dir = os.path.join(B.LIBDIR, "lab")
@@ -24,6 +27,8 @@ def main():
         for f in os.listdir(B.CSRC):  # a private copy of csrc with the swapped files
             shutil.copy(os.path.join(B.CSRC, f), os.path.join(tmp, f))
         for f, rev in swaps.items():
+            if rev == "WORK":  # the working-tree file, recompiled (with WF_EXTRA_HIPCC_FLAGS, e.g. -DWF_CONV_TIMING -DWF_CONV_ABLATE)
+                continue
             src = subprocess.run(["git", "show", f"{rev}:worldforge_amd/csrc/{f}"], cwd=B.ROOT, capture_output=True, check=True).stdout
             open(os.path.join(tmp, f), "wb").write(src)
         hdr_swapped = any(f.endswith(".h") for f in swaps)
@@ -31,7 +36,7 @@ def main():
         for s, flags in B.SOURCES.items():
             if s in swaps or (hdr_swapped and s in ("conv.hip", "gemm.hip", "attention.hip")):
                 obj = os.path.join(tmp, s.replace(".hip", ".o"))
-                subprocess.run([cc] + B.COMMON + flags + ["-c", os.path.join(tmp, s), "-o", obj], check=True)
+                subprocess.run([cc] + B.COMMON + extra + flags + ["-c", os.path.join(tmp, s), "-o", obj], check=True)
             else:
                 obj = os.path.join(B.BUILD, s.replace(".hip", ".o"))
             objs.append(obj)

@@ -521,6 +521,34 @@ __global__ __launch_bounds__(QT, 2) void k_conv_pp(ConvPPArgs pa) {
 // in: channels-last f32 or bf16; w: [taps][Cin][Cout] f32 (Cout fastest, so consecutive lanes read consecutive weights).
 // One thread per (pixel, co).
 // ------------------------------------------------------------------------------------------------------------------
+// Issue schedule of one tap of k_conv_w4's slice loop, shared by the code that emits it and the code that counts its waits.
+//   M = 4 NCB MFMAs per tap, MFMA m works on output block m / 4 and pixel block m % 4; the "gap" m is what follows MFMA m.
+//   weight fragment of block cb: reloaded in gap 4 cb + 3 (tap t loads tap t + 3), first used by MFMA 4 cb three taps later
+//   LDS-DMA pieces (taps 0..7, ND per tap), next tap's 4 pixel fragment reads: the remaining gaps, one memory instruction per gap
+template <int NCB, int DMA_ON, int W_ON>
+struct W4Sched {
+  static constexpr int M = 4 * NCB;
+  // which of the tap's two pieces (0 / 1) goes out in gap m, or -1
+  static constexpr int dma_at(int m) { return NCB == 3 ? (m == 5 ? 0 : m == 9 ? 1 : -1) : (m == 1 ? 0 : m == 2 ? 1 : -1); }
+  // which pixel fragment of the next tap is read in gap m, or -1
+  static constexpr int bread_at(int m) { return NCB == 3 ? (m < 3 ? m : m == 4 ? 3 : -1) : (m < 4 ? m : -1); }
+  static constexpr int wload_at(int m) { return (m & 3) == 3 ? m / 4 : -1; }  // block whose fragment is reloaded in gap m
+  // VMEM operations issued after the load of fragment (tap, cb) -- in gap 4 cb + 3 of tap - 3 -- and before MFMA 4 cb of `tap`.  Taps < 0
+  // are the previous slice's 24..26 (no pieces there); the prologue issues W(0..2, .) in the same order.
+  static constexpr int younger(int tap, int cb) {
+    int n = 0;
+    for (int tt = tap - 3; tt <= tap; ++tt)
+      for (int g = 0; g < M; ++g) {
+        const bool after_issue = tt > tap - 3 || g > 4 * cb + 3;
+        const bool before_use = tt < tap || g < 4 * cb;
+        if (!after_issue || !before_use) continue;
+        if (W_ON && wload_at(g) >= 0) ++n;
+        if (DMA_ON && dma_at(g) >= 0 && tt >= 0 && tt < 8) ++n;
+      }
+    return n;
+  }
+};
+
 // k_conv_w4: 3x3x3 causal convolution (stride 1) with the input patch resident in LDS, one wave per SIMD.
 //
 // The implicit-GEMM kernels above gather every (tap, channel-slice) operand tile from L2, so each input pixel crosses the
@@ -675,9 +703,12 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
     constexpr int cb = decltype(CBC)::value;
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(aoff), "s"(wp), "n"(cb * 1024) : "memory");
   };
-  // VMEM issue order per tap t of a slice: W(t+2) x 3 (gaps 4..6), then D x 2 (gaps 8, 10; taps 0..7 only).  Before the MFMAs of tap t
-  // its weights W(t) must have landed; younger than them are D(t-2), W(t+1), D(t-1): vmcnt = 3 + 2 [0 <= t-2 < 8] + 2 [0 <= t-1 < 8].
-  // (Loads return in order, so W(t) also waits for every older DMA piece -- those were issued >= 3 taps ~ 1200 cycles earlier.)
+  // Round 4, schedule of a tap (W4Sched below): the MFMAs of a tap run OUTPUT-BLOCK-major (m -> cb = m / 4, pb = m % 4), so the fragment of
+  // block cb is dead after gap 4 cb + 3 -- and is reloaded right there with the fragment of the tap THREE ahead (same ring slot: 27 = 9 x 3),
+  // first needed at MFMA 4 cb of that tap: 32 MFMAs ~ 1024 pipe cycles of flight for every fragment where the tap-major order (reload two
+  // taps ahead in gaps 4..6, one wait per tap) gave 20 -- with no more registers.  One hand-counted wait per fragment, just before its first
+  // MFMA; W4Sched counts the VMEM operations younger than the fragment from the issue order itself.
+  using SCH = W4Sched<NCB, (DBG & 1) ? 0 : 1, (DBG & 2) ? 0 : 1>;
 
   f32x16 acc[4][NCB];
   auto mma = [&](f32x16& c, const u32x4& wv, const u32x4& xv) {
@@ -691,7 +722,7 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
     __builtin_amdgcn_s_barrier();
   };
   u32x4 bf[2][4];  // pixel fragments: tap parity (27 taps: tap 26 and the next slice's tap 0 share slot 0, refilled behind the barrier)
-  u32x4 af[3][NCB];  // weight fragments: ring over taps, 2 ahead (27 = 9 x 3: the slot of a tap is tap % 3 in every slice)
+  u32x4 af[3][NCB];  // weight fragments: ring over taps (27 = 9 x 3: the slot of a tap is tap % 3 in every slice), each reloaded 3 taps ahead
   auto bread = [&](int buf, int tap, int pb) {
     const int dt = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
     const unsigned char* base = smem + buf * PATCH_BUF + ((dt * PR + dy) * PC + dx) * 32;
@@ -712,15 +743,15 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   // prologue: patch of slice 0, weights of taps 0, 1, then the pixel fragments of tap 0
 #pragma unroll
   for (int j = 0; j < 16; ++j) dma_piece(0, j);
-  for_const<2>([&](auto TP) {
+  for_const<3>([&](auto TP) {
     (void)&af, (void)&wp, (void)&tapstride, (void)&wload_cur;
     for_const<NCB>([&](auto CBC) {
       (void)&af, (void)&wload_cur;
       wload_cur(af[decltype(TP)::value][decltype(CBC)::value], CBC);
     });
     wp += tapstride;
-  });  // wp -> (slice 0, tap 2)
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCB) : "memory");  // the 16 pieces landed (the 2 NCB weight loads were issued after them)
+  });  // wp -> (slice 0, tap 3); issue order W(0,0) W(0,1) ... W(2,NCB-1) as in the steady state
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NCB) : "memory");  // the 16 pieces landed (the 3 NCB weight loads were issued after them)
   bar();
 #pragma unroll
   for (int pb = 0; pb < 4; ++pb) bf[0][pb] = bread(0, 0, pb);
@@ -765,47 +796,42 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
     }
     for_const<27>([&](auto TC) {
       constexpr int tap = decltype(TC)::value;
-      if constexpr (!(DBG & 2)) {
-        constexpr int nd = (DBG & 1) ? 0 : 2;  // LDS-DMA pieces per tap over taps 0..7
-        constexpr int nwait = NCB + ((tap >= 2 && tap - 2 < 8) ? nd : 0) + ((tap >= 1 && tap - 1 < 8) ? nd : 0);
-        if constexpr (NCB == 3)
-          asm volatile("s_waitcnt vmcnt(%3)" : "+v"(af[tap % 3][0]), "+v"(af[tap % 3][1]), "+v"(af[tap % 3][2]) : "n"(nwait));
-        else
-          asm volatile("s_waitcnt vmcnt(%1)" : "+v"(af[tap % 3][0]) : "n"(nwait));
-      }
-      // this tap's four pixel fragments were read (inline asm: the compiler does not count them) in gaps 0..3 of the previous tap, >= 8
+      // this tap's four pixel fragments were read (inline asm: the compiler does not count them) in the first gaps of the previous tap, >= 7
       // MFMAs ago; tap 0's come from the compiler-managed reads behind the slice barrier
       if constexpr (tap > 0 && !(DBG & 4))
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[tap & 1][0]), "+v"(bf[tap & 1][1]), "+v"(bf[tap & 1][2]), "+v"(bf[tap & 1][3]));
-      // gap m of the tap: MFMA (pixel block m / NCB, output block m % NCB); in its shadow: gaps 0..3 the next tap's 4 pixel fragments, then
-      // the NCB weight fragments two taps ahead (VMEM), then the 2 LDS-DMA pieces of the next slice's patch (VMEM, taps 0..7) -- the VMEM
-      // issue ORDER (weights before pieces within a tap) is what the hand-counted waits above assume
-      constexpr int M = 4 * NCB, WL0 = NCB == 3 ? 4 : 1, D0 = NCB == 3 ? 8 : 2, D1 = NCB == 3 ? 10 : 3;
+      // gap m of the tap: MFMA (output block m / 4, pixel block m % 4); in its shadow, per W4Sched: the next tap's 4 pixel fragments, the
+      // weight fragment of the block just finished for the tap three ahead (VMEM), the 2 LDS-DMA pieces of the next slice's patch (VMEM,
+      // taps 0..7) -- the VMEM issue ORDER is what the hand-counted waits assume
+      constexpr int M = SCH::M;
       for_const<M>([&](auto MC) {
         (void)&acc, (void)&af, (void)&bf, (void)&wp, (void)&w_next, (void)&tapstride, (void)&bslice, (void)&psrc, (void)&wload_cur, (void)&bread_c,
             (void)&dma_piece_c;
         constexpr int m = decltype(MC)::value;
-        constexpr int cb = m % NCB, pb = m / NCB;
+        constexpr int cb = m / 4, pb = m % 4;
+        if constexpr (pb == 0 && !(DBG & 2))  // first MFMA on this block's fragment: it was issued 3 taps ago, SCH counts what is younger
+          asm volatile("s_waitcnt vmcnt(%1)" : "+v"(af[tap % 3][cb]) : "n"(SCH::younger(tap, cb)));
         mma(acc[pb][cb], af[tap % 3][cb], bf[tap & 1][pb]);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (m < 4 && tap < 26 && !(DBG & 4)) bf[(tap + 1) & 1][m] = bread_c(std::integral_constant<int, tap + 1>{}, m);  // next tap's pixel fragments
-        if constexpr (m >= WL0 && m < WL0 + NCB && !(DBG & 2)) {  // weights two taps ahead, through the running pointer
-          wload_cur(af[(tap + 2) % 3][m - WL0], std::integral_constant<int, m - WL0>{});
-          if constexpr (m == WL0 + NCB - 1) {
-            if constexpr (tap == 24)
+        if constexpr (SCH::bread_at(m) >= 0 && tap < 26 && !(DBG & 4))  // next tap's pixel fragments
+          bf[(tap + 1) & 1][SCH::bread_at(m)] = bread_c(std::integral_constant<int, tap + 1>{}, SCH::bread_at(m));
+        if constexpr (pb == 3 && !(DBG & 2)) {  // block cb is done for this tap: its slot takes the fragment of the tap three ahead
+          wload_cur(af[tap % 3][cb], std::integral_constant<int, cb>{});
+          if constexpr (cb == NCB - 1) {
+            if constexpr (tap == 23)
               wp = w_next;       // tap 26's fragments were the slice's last: on to (next slice, tap 0)
             else
               wp += tapstride;
           }
         }
-        if constexpr ((m == D0 || m == D1) && tap < 8 && !(DBG & 1)) dma_piece_c(csn, std::integral_constant<int, 2 * tap + (m == D1 ? 1 : 0)>{});
+        if constexpr (SCH::dma_at(m) >= 0 && tap < 8 && !(DBG & 1)) dma_piece_c(csn, std::integral_constant<int, 2 * tap + SCH::dma_at(m)>{});
         __builtin_amdgcn_sched_barrier(0);
       });
     });
 #ifdef WF_CONV_TIMING
     const unsigned long long tw0 = __builtin_readcyclecounter();
 #endif
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCB) : "memory");  // patch of slice cs+1 landed (only the 2 NCB prefetched weight loads are younger)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NCB) : "memory");  // patch of slice cs+1 landed (only the 3 NCB prefetched weight loads are younger)
     bar();
 #ifdef WF_CONV_TIMING
     t_wait += __builtin_readcyclecounter() - tw0;
