@@ -19,12 +19,13 @@ for (T, H, W, C) in ((81, 480, 832, 96), (81, 240, 416, 192), (41, 120, 208, 384
         x = x.view(T, H, W, Cs // 16, 16).permute(0, 1, 3, 2, 4).contiguous()
     w = (torch.randn(C, 27, K, device="cuda:0") / math.sqrt(K * 27)).to(BF)
     out = torch.empty(T, H, W, C, device="cuda:0")
+    bias = torch.randn(C, device="cuda:0")  # bias + fp32 out = the epilogue every ResidualBlock conv of the VAE runs
     zp = torch.zeros(1 << 20, dtype=BF, device="cuda:0")
     wp = torch.empty((27, K // 16, C, 16), dtype=BF, device="cuda:0")
     _ffi.call("wf_conv3d_pack333", w.data_ptr(), wp.data_ptr(), C, K, ops.stream())
 
     def run():
-        _ffi.call("wf_conv3d_333", x.data_ptr(), wp.data_ptr(), None, None, out.data_ptr(), None, T, H, W, K, H, C, 1, zp.data_ptr(),
+        _ffi.call("wf_conv3d_333", x.data_ptr(), wp.data_ptr(), bias.data_ptr(), None, out.data_ptr(), None, T, H, W, K, H, C, 1, zp.data_ptr(),
                   zp.numel() * 2, LAYOUT, Cs, ops.stream())
     run(); torch.cuda.synchronize(); lib.wf_debug_conv_cycles(buf, 1); lib.wf_debug_conv_slices(sl)
     run(); torch.cuda.synchronize(); lib.wf_debug_conv_cycles(buf, 1); lib.wf_debug_conv_slices(sl)

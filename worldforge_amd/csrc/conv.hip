@@ -568,6 +568,9 @@ constexpr int PR = WY + 2, PC = WX + 2;
 constexpr int PATCH_PX = 3 * PR * PC;      // 1980 pixels of 32 B
 constexpr int PATCH_BUF = 64 * 1024;       // 64 pieces of 1 KiB (1980 * 32 B = 61.9 KiB, the tail of the last piece is padding)
 constexpr int W4_LDS = 2 * PATCH_BUF;
+#ifndef WF_CONV_DIRECT_STORE
+#define WF_CONV_DIRECT_STORE 0  // lab only: 1 = the epilogue of rounds 1-3 (stores straight from the accumulator layout)
+#endif
 
 #ifdef WF_CONV_TIMING
 __device__ unsigned long long g_conv_cycles[8];
@@ -858,6 +861,9 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
     const bool has_f32 = F == 2 ? a.out_f32 != nullptr : F == 1;
     const bool has_bf16 = H == 2 ? a.out_bf16 != nullptr : H == 1;
     const bool has_bias = BI == 2 ? a.bias != nullptr : BI == 1;
+    int lane_ = lane;  // opaque per tile (see store_tile_lds): no per-lane address of the epilogue lives across the slice loop
+    asm volatile("" : "+v"(lane_));
+    const int hi = lane_ >> 5, l31 = lane_ & 31;
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb) {
       const int y = y0 + 2 * wid + (pb >> 1), x = x0 + (pb & 1) * 32 + l31;
@@ -898,17 +904,108 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
       }
     }
   };
+  // Round 4: the common case (bias, fp32 out, optional residual) of the 96-channel block goes THROUGH LDS.  In the accumulator layout a lane
+  // owns one pixel and quads of channels: a store instruction's 64 lanes hit 64 different lines (lane stride = Cout * 4 B), the CU's address
+  // pipe takes them one line per cycle, and 4 waves x 48 stores x 64 = 12.3 k of the epilogue's 14.8-15.9 k cycles (7.5 % of a 96-wide x3 tile,
+  // profiles/r4_q_conv_cycles_ablation.txt).  Each wave stages one pixel block at a time (32 pixels x 96 channels, rows padded to 400 B: the
+  // transposing ds_write_b128 are conflict-free) in ITS OWN 16 KiB quarter of patch buffer 1 -- dead behind the last slice's barrier, and the
+  // only LDS-DMA writes that will land there are this wave's own pieces of the next tile's slice 1, later in its program order: no
+  // workgroup barrier -- and reads it back pixel-row-major: 16 B per lane, 24 lanes per pixel, 384 B runs (the whole 12 KiB when Cout = 96).
+  // Same arithmetic in the same order (acc + bias, then + residual): bit-identical.
+  auto store_tile_lds = [&](auto RC) {  // FULL tiles only (every pixel and channel of the block in range): no predicate anywhere
+    constexpr int R = decltype(RC)::value;
+    constexpr int ROW = 400;
+    unsigned char* stg = smem + PATCH_BUF + wid * (16 * 1024);
+    int lane_ = lane;  // opaque per tile: the per-chunk pixel / channel / offset values below are a few VALU each -- hoisted out of the tile loop
+    asm volatile("" : "+v"(lane_));  // as loop invariants they were 36 registers live across the slice loop (78 spills)
+    const int hi_ = lane_ >> 5, l31_ = lane_ & 31;
+    // row phase geometry: chunk c = 64 i + lane of a pixel block = pixel c / 24, channels 4 (c % 24) .. + 3.  64 = 16 (mod 24): the channel
+    // quad of step i depends on i % 3 only -- THREE bias quads per lane serve the whole tile (loaded once, one wait)
+    int pc[3], kc[3];
+    f32x4 bq[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int c = j * 64 + lane_;
+      pc[j] = c / 24;
+      kc[j] = c - 24 * pc[j];
+      bq[j] = *reinterpret_cast<const f32x4*>(a.bias + n0 + 4 * kc[j]);
+    }
+    // step i = 3 q + j: c = 192 q + (64 j + lane) -> pixel 8 q + pc[j], channel quad kc[j]
+    auto gofs = [&](int pb, int i) -> size_t {
+      const int y = y0 + 2 * wid + (pb >> 1), x = x0 + (pb & 1) * 32 + 8 * (i / 3) + pc[i % 3];
+      return (((size_t)t * a.Ho + y) * a.Wo + x) * a.Cout + n0 + 4 * kc[i % 3];
+    };
+    f32x4 rr[2][4];
+    auto resid_group = [&](int slot, int pb, int g4) {  // the 4 residual quads of steps 4 g4 .. 4 g4 + 3 of pixel block pb
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rr[slot][u] = *reinterpret_cast<const f32x4*>(a.resid + gofs(pb, 4 * g4 + u));
+    };
+    if constexpr (R) resid_group(0, 0, 0);
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        f32x16 av = acc[pb][cb];
+        asm volatile("" : "+v"(av));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v = {av[4 * g], av[4 * g + 1], av[4 * g + 2], av[4 * g + 3]};
+          *reinterpret_cast<f32x4*>(stg + l31_ * ROW + (cb * 32 + 8 * g + 4 * hi_) * 4) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one accumulator block (16 registers) at a time
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 3; ++g4) {  // four chunks per lane at a time; the NEXT group's residual quads are in flight meanwhile
+        const int slot = (pb * 3 + g4) & 1;
+        if constexpr (R) {
+          if (g4 < 2)
+            resid_group(slot ^ 1, pb, g4 + 1);
+          else if (pb < 3)
+            resid_group(slot ^ 1, pb + 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 lv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = 4 * g4 + u;
+          lv[u] = *reinterpret_cast<const f32x4*>(stg + (8 * (i / 3) + pc[i % 3]) * ROW + kc[i % 3] * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the four LDS reads as one batch (one wait), not read - wait - store four times
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = 4 * g4 + u;
+          f32x4 v = lv[u];
+          const f32x4 bb = bq[i % 3];
+          v = f32x4{v[0] + bb[0], v[1] + bb[1], v[2] + bb[2], v[3] + bb[3]};
+          if constexpr (R) {
+            const f32x4 r4 = rr[slot][u];
+            v = f32x4{v[0] + r4[0], v[1] + r4[1], v[2] + r4[2], v[3] + r4[3]};
+          }
+          *reinterpret_cast<f32x4*>(a.out_f32 + gofs(pb, i)) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
   {
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
     const bool common = a.bias && a.out_f32 && !a.out_bf16;  // every ResidualBlock conv of the VAE: bias, fp32 activations out
-    if (common && !a.resid)
-      store_tile(I0{}, I1{}, I0{}, I1{});
-    else if (common)
-      store_tile(I1{}, I1{}, I0{}, I1{});
-    else
-      store_tile(I2{}, I2{}, I2{}, I2{});
+    const bool full = y0 + WY <= a.Ho && x0 + WX <= a.Wo && n0 + 32 * NCB <= a.Cout;  // ragged edge tiles keep the direct stores
+    if (NCB == 3 && !WF_CONV_DIRECT_STORE && common && full) {
+      if (!a.resid)
+        store_tile_lds(I0{});
+      else
+        store_tile_lds(I1{});
+    } else {
+      if (common && !a.resid)
+        store_tile(I0{}, I1{}, I0{}, I1{});
+      else if (common)
+        store_tile(I1{}, I1{}, I0{}, I1{});
+      else
+        store_tile(I2{}, I2{}, I2{}, I2{});
+    }
   }
 #ifdef WF_CONV_TIMING
   t_main += tt1 - tt0;
