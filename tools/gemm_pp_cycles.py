@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 LABDIR = os.path.join(ROOT, "worldforge_amd", "_lib", "lab")
 LIB = os.path.join(LABDIR, "libwf_hip_gemmtiming.so")
 # ablations of the K loop (wrong results by construction: they price one ingredient in cycles, like tools/attn_lab.py does for the attention)
-VARIANTS = {"gemmtiming": [], "gemm_dma_in_mfma": ["-DWF_GEMM_DMA_PHASE=0"], "gemm_dma_in_read": ["-DWF_GEMM_DMA_PHASE=1"], "gemm_rsplit0": ["-DWF_GEMM_DMA_RSPLIT=0"], "gemm_rsplit3": ["-DWF_GEMM_DMA_RSPLIT=3"], "gemm_rsplit7": ["-DWF_GEMM_DMA_RSPLIT=7"], "gemm_rsplit9": ["-DWF_GEMM_DMA_RSPLIT=9"], "gemm_nodma": ["-DWF_GEMM_ABLATE=1"], "gemm_nophasebar": ["-DWF_GEMM_ABLATE=2"], "gemm_nolds": ["-DWF_GEMM_ABLATE=4"],
+VARIANTS = {"gemmtiming": [], "gemm_touch1": ["-DWF_GEMM_TOUCH=1"], "gemm_touch2": ["-DWF_GEMM_TOUCH=2"], "gemm_touch2_24": ["-DWF_GEMM_TOUCH=2", "-DWF_GEMM_TOUCH_AT=24"], "gemm_dma_in_mfma": ["-DWF_GEMM_DMA_PHASE=0"], "gemm_dma_in_read": ["-DWF_GEMM_DMA_PHASE=1"], "gemm_rsplit0": ["-DWF_GEMM_DMA_RSPLIT=0"], "gemm_rsplit3": ["-DWF_GEMM_DMA_RSPLIT=3"], "gemm_rsplit7": ["-DWF_GEMM_DMA_RSPLIT=7"], "gemm_rsplit9": ["-DWF_GEMM_DMA_RSPLIT=9"], "gemm_nodma": ["-DWF_GEMM_ABLATE=1"], "gemm_nophasebar": ["-DWF_GEMM_ABLATE=2"], "gemm_nolds": ["-DWF_GEMM_ABLATE=4"],
             "gemm_noprio": ["-DWF_GEMM_ABLATE=8"], "gemm_mfma_only": ["-DWF_GEMM_ABLATE=7"]}
 
 
@@ -21,7 +21,10 @@ def build():
     os.makedirs(os.path.join(wb.BUILD, "lab"), exist_ok=True)
     cc = wb.hipcc()
     others = [os.path.join(wb.BUILD, s.replace(".hip", ".o")) for s in wb.SOURCES if s != "gemm.hip"]
+    only = os.environ.get("VARIANTS")  # VARIANTS=a,b: build / run only these
     for name, flags in VARIANTS.items():
+        if only and name not in only.split(","):
+            continue
         obj = os.path.join(wb.BUILD, "lab", f"{name}.o")
         subprocess.run([cc] + wb.COMMON + ["-DWF_GEMM_TIMING"] + flags + ["-c", os.path.join(wb.CSRC, "gemm.hip"), "-o", obj], check=True)
         lib = os.path.join(LABDIR, f"libwf_hip_{name}.so")
@@ -37,7 +40,8 @@ def child():
     print("| shape M x N x K | epilogue | ms | TFLOP/s | tiles | prologue | K loop (group A / B) | epilogue | epilogue share | MFMA pipe cycles of the K loop | K-loop efficiency | clock GHz (busy cycles per CU / wall) |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|")
     short = len(sys.argv) > 2 and sys.argv[2] == "short"
-    for P in ((1,) if short else (1, 8)):
+    p1 = len(sys.argv) > 2 and sys.argv[2] == "p1"
+    for P in ((1,) if short or p1 else (1, 8)):
         M = (32760 + P - 1) // P
         for (N, K, epi, name) in ((15360, 5120, 0, "bf16"),) if short else ((15360, 5120, 0, "bf16"), (5120, 5120, 3, "x += gate * y"), (14080, 5120, 1, "bf16 + GELU"), (5120, 13824, 3, "x += gate * y")):
             x = torch.randn(M, K, device="cuda").bfloat16()
@@ -76,6 +80,10 @@ if __name__ == "__main__":
         build()
     elif mode == "child":
         child()
+    elif mode == "pick":     # the full shape table for the variants named in VARIANTS=a,b (e.g. the touch-prefetch experiment of the RMW epilogue)
+        for name in os.environ["VARIANTS"].split(","):
+            print(f"\n== {name} {VARIANTS[name]}", flush=True)
+            subprocess.run([sys.executable, os.path.abspath(__file__), "child", "p1"], env=dict(os.environ, WF_LIB=os.path.join(LABDIR, f"libwf_hip_{name}.so")), timeout=900)
     elif mode == "ablate":   # K-loop cycles of every ablation variant on the QKV shape only
         for name in VARIANTS:
             print(f"\n== {name} {VARIANTS[name]}", flush=True)

@@ -3,7 +3,7 @@
 #   gpurun --timeout 2400 -- 'bash tools/gpurun_scripts/final.sh'      -> gpurun_out/final/*
 mkdir -p gpurun_out/final
 R=$GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q -x 2>&1 | tail -8 > gpurun_out/final/pytest_gpu.log
+python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed|rror|^FAILED|^tests/" | tail -12 > gpurun_out/final/pytest_gpu.log
 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/final/smoke.log
 WF_FORCE_COMM=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 python bench.py --gpus 1 --no-cpu-baseline > gpurun_out/final/bench_rccl1.json 2> gpurun_out/final/bench_rccl1.err
