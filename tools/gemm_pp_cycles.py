@@ -84,6 +84,10 @@ if __name__ == "__main__":
         for name in os.environ["VARIANTS"].split(","):
             print(f"\n== {name} {VARIANTS[name]}", flush=True)
             subprocess.run([sys.executable, os.path.abspath(__file__), "child", "p1"], env=dict(os.environ, WF_LIB=os.path.join(LABDIR, f"libwf_hip_{name}.so")), timeout=900)
+    elif mode == "pick":     # the full shape table (1 GPU's token count) for the variants named in VARIANTS=a,b
+        for name in os.environ["VARIANTS"].split(","):
+            print(f"\n== {name} {VARIANTS[name]}", flush=True)
+            subprocess.run([sys.executable, os.path.abspath(__file__), "child", "p1"], env=dict(os.environ, WF_LIB=os.path.join(LABDIR, f"libwf_hip_{name}.so")), timeout=900)
     elif mode == "ablate":   # K-loop cycles of every ablation variant on the QKV shape only
         for name in VARIANTS:
             print(f"\n== {name} {VARIANTS[name]}", flush=True)

@@ -734,13 +734,13 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   // the same read in the slice loop: the lane's address INCLUDING the buffer offset sits in a register for the whole slice (bslice) and
   // the tap's patch offset (<= 46 528 B) is the ds_read's immediate -- the per-tap v_add_u32 per fragment is gone
   uint32_t bslice[4];
-  auto bread_c = [&](auto TC, int pb) {
+  // (the destination is the fragment register itself, by reference: a local result copied into it afterwards would be copied BEFORE the
+  // data arrives -- the compiler does not know that an inline-asm load completes later)
+  auto bread_c = [&](u32x4& dst, auto TC, int pb) {
     (void)&bslice;
     constexpr int tap = decltype(TC)::value;
     constexpr int dt = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-    u32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(bslice[pb]), "n"(((dt * PR + dy) * PC + dx) * 32) : "memory");
-    return v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(bslice[pb]), "n"(((dt * PR + dy) * PC + dx) * 32) : "memory");
   };
 
   // prologue: patch of slice 0, weights of taps 0, 1, then the pixel fragments of tap 0
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
         mma(acc[pb][cb], af[tap % 3][cb], bf[tap & 1][pb]);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (SCH::bread_at(m) >= 0 && tap < 26 && !(DBG & 4))  // next tap's pixel fragments
-          bf[(tap + 1) & 1][SCH::bread_at(m)] = bread_c(std::integral_constant<int, tap + 1>{}, SCH::bread_at(m));
+          bread_c(bf[(tap + 1) & 1][SCH::bread_at(m)], std::integral_constant<int, tap + 1>{}, SCH::bread_at(m));
         if constexpr (pb == 3 && !(DBG & 2)) {  // block cb is done for this tap: its slot takes the fragment of the tap three ahead
           wload_cur(af[tap % 3][cb], std::integral_constant<int, cb>{});
           if constexpr (cb == NCB - 1) {

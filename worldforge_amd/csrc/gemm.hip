@@ -243,15 +243,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_gemm(GemmArgs a) {
 // kernel (wave-uniform 64-bit base + constant 32-bit lane offset, M0 in one s_add with an immediate, no branch per piece).
 #define WF_GEMM_DMA_PHASE 2
 #endif
-// Read-modify-write epilogues (EPI_RESID, EPI_F32_ACC): touch the tile's old values -- one dword per 128-byte line and lane -- while the K loop
-// runs, so that the epilogue's loads find them in the memory-side cache instead of joining its stores in one HBM burst of all CUs.
-// 0 off; 1 = before the K loop; 2 = WF_GEMM_TOUCH_AT K tiles before its end.
-#ifndef WF_GEMM_TOUCH
-#define WF_GEMM_TOUCH 0
-#endif
-#ifndef WF_GEMM_TOUCH_AT
-#define WF_GEMM_TOUCH_AT 8
-#endif
 #ifndef WF_GEMM_DMA_RSPLIT
 #define WF_GEMM_DMA_RSPLIT 5  // (PHASE 2) how many of a wave's 9 (8) pieces go to the tail of its first READ phase instead of the MFMA gaps (lab: 0 -> 89.2 %, 3 -> 90.8, 5 -> 92-93.5, 6 / 7 -> 92.4, 9 -> 86.6 % of the pipe)
 #endif
@@ -442,19 +433,6 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
     __builtin_amdgcn_s_barrier();
   };
   auto drain = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-  auto touch_old = [&]() {  // this wave's NJ*32 rows x NI lines of the output tile: lane -> row, one load per line column; the value is never read
-    if constexpr (WF_GEMM_TOUCH && (EPI == EPI_RESID || EPI == EPI_F32_ACC)) {
-#pragma unroll
-      for (int r = 0; r < NJ * 32; r += 64)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const int m = min(m0 + wt0 + r + lane, a.M - 1), n = min(n0 + wf0 + i * 32, a.N - 4);
-          const float* pt = reinterpret_cast<const float*>(a.out) + (size_t)m * a.ldo + n;
-          uint32_t dummy;
-          asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"(pt) : "memory");
-        }
-    }
-  };
 
   const int nk = a.K / PK;
 #ifdef WF_GEMM_TIMING
@@ -463,7 +441,6 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
   dma(0);
   drain();
   bar();
-  if constexpr (WF_GEMM_TOUCH == 1) touch_old();
 #ifdef WF_GEMM_TIMING
   const unsigned long long tt1 = __builtin_readcyclecounter();
 #endif
@@ -517,9 +494,6 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
     for (int kt = 0; kt < nk; ++kt) {
       read_half(kt, 0);
       rphase_pieces(kt + 1);
-      if constexpr (WF_GEMM_TOUCH == 2) {
-        if (__builtin_expect(kt == nk - WF_GEMM_TOUCH_AT, 0)) touch_old();
-      }
       pbar();  // 4kt+1
       mma_half_dma(kt + 1);  // the pieces of tile kt+1 ride in the MFMA gaps (its buffer is free since barrier 4kt)
       pbar();  // 4kt+2
@@ -536,9 +510,6 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
     for (int kt = 0; kt < nk; ++kt) {
       read_half(kt, 0);
       if (kt > 0) rphase_pieces(kt + 1);  // group B's share of tile kt+1 that its previous MFMA phase (in phase 1) left over; tile 1 came whole from the prologue
-      if constexpr (WF_GEMM_TOUCH == 2) {
-        if (__builtin_expect(kt == nk - WF_GEMM_TOUCH_AT, 0)) touch_old();
-      }
       pbar();  // 4kt+2
       mma_half(-1);
       pbar();  // 4kt+3
