@@ -33,6 +33,15 @@ MFMA_PEAK_TFLOPS_BF16 = 2500.0  # dense, MI355X_MICROARCH.md
 ATTN_PMC_FILE = os.path.join(ROOT, "profiles", "attn_pmc_latest.json")
 
 
+
+def _transport() -> str:
+    """What the collectives of this run travel over: RCCL, or -- debug runs with every rank on one GPU -- gloo through the host."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo":
+        return "gloo through the host: DEBUG transport, timings meaningless"
+    return "RCCL"
+
+
 def attn_pmc_fields(kernel: str, L: int, heads: int, world: int, simulated: bool):
     """-> dict of roofline side fields, or all-None when the tracked PMC summary does not describe this launch."""
     none = {"traffic": None, "traffic_source": None, "mfma_util_pmc": None, "clock_ghz_pmc": None}
@@ -307,7 +316,7 @@ def main_longcat(a):
                                          "50-step schedule, IRR x3 + FLF + DSG + CFG-zero 4; timed ")
                                       + f"steps {Wm}..{Wm + K - 1} = {len(gms)} guided + {len(pms)} plain",
                           "tokens": L, "dit_layers": cfg.depth, "dit_params_bytes": model.param_bytes(),
-                          "parallelism": "single" if world == 1 else f"sp{world} (token-sharded DiT + row-sharded VAE, RCCL)"},
+                          "parallelism": "single" if world == 1 else f"sp{world} (token-sharded DiT + row-sharded VAE, {_transport()})"},
                "window": {"guided": len(gms), "plain": len(pms), "guided_frac": len(gms) / max(K, 1)},
                "guided_step_ms": sum(gms) / len(gms) if gms else None, "plain_step_ms": sum(pms) / len(pms) if pms else None,
                "setup_s": t_setup}
@@ -612,7 +621,7 @@ def main(argv=None):
                 "workload": f"Wan2.1-I2V-14B-{res.upper()}, {a.frames}f {a.height}x{a.width}, 50-step schedule, full IRR+FLF+DSG, CFG 4; "
                             f"timed steps {start + Wm}..{start + Wm + K - 1} = {len(guided_ms)} guided + {len(plain_ms)} plain",
                 "tokens": L, "dit_layers": cfg.num_layers, "dit_params_bytes": model.param_bytes(),
-                "parallelism": "single" if world == 1 else f"sp{world} (token-sharded DiT with K/V all-gather + row-sharded VAE with halo all-gather, RCCL)",
+                "parallelism": "single" if world == 1 else f"sp{world} (token-sharded DiT with K/V all-gather + row-sharded VAE with halo all-gather, {_transport()})",
                 "flow_backend": a.flow_backend,
                 # the Farneback branch is what an installed reference executes, but its GPU statement is checked against the
                 # in-repo restatement of OpenCV only (no cv2 in the image or the reference tree); the tdiff branch is golden-pinned
