@@ -35,6 +35,8 @@ VARIANTS = {
     # c_*: the same with light cycle counting (two s_memtime per workgroup): shader cycles per KV tile, independent of the clock the
     # power limit allows (removing work raises the clock, so TFLOP/s alone overstates what an ingredient costs)
     "c_base": ["-DWF_ATTN_TIMING=2"],
+    "c_pf2": ["-DWF_ATTN_TIMING=2", "-DWF_ATTN_PF4=2"],   # round 4: fragment ring depth 2 / 8 instead of 4 (is the flight of the LDS reads a limit?)
+    "c_pf8": ["-DWF_ATTN_TIMING=2", "-DWF_ATTN_PF4=8"],
     "c_valu": ["-DWF_ATTN_TIMING=2", "-DWF_ATTN_ABLATE=1"],
     "c_lds": ["-DWF_ATTN_TIMING=2", "-DWF_ATTN_ABLATE=4"],
     "c_dma": ["-DWF_ATTN_TIMING=2", "-DWF_ATTN_DMA_PLACE=9"],

@@ -449,7 +449,10 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
   //                  instruction before it; P fragment f is complete before gap 32 + 8 f, where its first MFMA sits
   //     gaps 52..63  row max of the NEW scores (v_max3 chains); the commit (+ rare rescale) follows the last gap
   //   LDS-DMA: the 8 pieces of tile t+3 in gaps 2, 6, ..., 30;  fragment rings are refilled across the phase / tile seams.
-  constexpr int PF4 = 4;
+#ifndef WF_ATTN_PF4
+#define WF_ATTN_PF4 4  // fragment ring depth of the tile loop (lab: 2 / 8; must divide 16)
+#endif
+  constexpr int PF4 = WF_ATTN_PF4;
   u32x4 ring[PF4];
 #if defined(WF_ATTN_TIMING) && WF_ATTN_TIMING != 2
   unsigned long long tacc[20] = {};
