@@ -1210,10 +1210,15 @@ static void launch_pp(GemmArgs a, hipStream_t s) {
 // accumulations over K in both.
 static int pp_wide(int M, int N) {
   if (N % 320 != 0) return 0;
+#ifdef WF_GEMM_LAB_TILE  // lab builds: read per call, so that one process can launch both tile widths (tools/gemm_dephase.py)
+  const char* e_ = getenv("WF_GEMM_TILE");
+  const int force = e_ ? atoi(e_) : 0;
+#else
   static const int force = [] {
     const char* e = getenv("WF_GEMM_TILE");
     return e ? atoi(e) : 0;
   }();
+#endif
   if (force == 256) return 0;
   if (force == 320) return 1;
   static const int n_cu = [] {
