@@ -131,6 +131,19 @@ def test_conv3d_333_vs_torch(cfg):
     err = (of.cpu() - want).abs().max().item()
     assert err <= 2e-3 * max(1.0, want.abs().max().item()), err
     assert (ob.float().cpu() - want).abs().max().item() <= 1e-2 * want.abs().max().item()
+    # the epilogue every ResidualBlock conv of the VAE runs (bias, fp32 out only, with / without the residual) goes through LDS on full tiles
+    # (round 4) where the call above stored straight from the accumulator layout: same bits
+    for rd_ in (rd, None):
+        of3 = torch.full_like(of, float("nan"))
+        _ffi.call("wf_conv3d_333", xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), rd_.data_ptr() if rd_ is not None else None, of3.data_ptr(), None,
+                  T, H, W, cin, Ho, cout, 0 if halo else 1, zp.data_ptr(), zp.numel() * 2, 0, cin, ops.stream())
+        if rd_ is not None:
+            assert torch.equal(of3, of)
+        else:             # without the residual: (acc + bias) alone -- compare with the same call through the direct-store form (bf16 copy requested)
+            of4, ob4 = torch.full_like(of, float("nan")), torch.empty_like(ob)
+            _ffi.call("wf_conv3d_333", xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), None, of4.data_ptr(), ob4.data_ptr(), T, H, W, cin, Ho, cout,
+                      0 if halo else 1, zp.data_ptr(), zp.numel() * 2, 0, cin, ops.stream())
+            assert torch.equal(of3, of4)
     # same arithmetic as the generic kernel: fp32 accumulation order differs only within the MFMA k-steps
     of2 = torch.empty_like(of)
     _ffi.call("wf_conv3d_cl", xd.data_ptr(), wk.data_ptr(), bd.data_ptr(), rd.data_ptr(), of2.data_ptr(), None, T, H, W, cin, T, Ho, W, cout,
