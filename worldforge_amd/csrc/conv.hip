@@ -915,7 +915,8 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
   auto store_tile_lds = [&](auto RC) {  // FULL tiles only (every pixel and channel of the block in range): no predicate anywhere
     constexpr int R = decltype(RC)::value;
     constexpr int ROW = 400;
-    unsigned char* stg = smem + PATCH_BUF + wid * (16 * 1024);
+    static_assert(32 * ROW <= PATCH_BUF / (W4T / 64), "a pixel block must fit the wave's own quarter of the patch buffer");
+    unsigned char* stg = smem + PATCH_BUF + wid * (PATCH_BUF / (W4T / 64));
     int lane_ = lane;  // opaque per tile: the per-chunk pixel / channel / offset values below are a few VALU each -- hoisted out of the tile loop
     asm volatile("" : "+v"(lane_));  // as loop invariants they were 36 registers live across the slice loop (78 spills)
     const int hi_ = lane_ >> 5, l31_ = lane_ & 31;
