@@ -155,6 +155,10 @@ int wf_gemm_bf16_batched(const void* X, const void* W, void* out, int batch, int
  * 1x1 convolutions and mid-block attention products of the VAE in its fp16 operand formats (see wf_split_f16x3). */
 int wf_gemm_f16(const void* X, const void* W, const float* bias, void* out, int M, int N, int K, int ldx, int ldw, int ldo, int epilogue,
                 void* stream);
+/* wf_gemm_bf16_batched on fp16 operands (WF_EPI_BF16 writes fp16): the per-frame P . V products of the VAE mid-block attention
+ * (vae.py:252-258) of all frames in one launch. */
+int wf_gemm_f16_batched(const void* X, const void* W, void* out, int batch, int M, int N, int K, int ldx, int ldw, int ldo, int64_t bsx,
+                        int64_t bsw, int64_t bso, int epilogue, void* stream);
 
 /* flash_attention (attention.py:24-130) as used by model.py:149-154 (self) and :220-222 (cross): fused
  * softmax(Q K^T * softmax_scale) V, no mask, head_dim 128.  Q [H][Lq][128], K [H][Lkp][128] (rows >= kv_len zero),

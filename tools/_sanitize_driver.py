@@ -129,6 +129,8 @@ bad("wf_gemm_bf16", buf(64), buf(64), None, buf(64), None, 4, 4, 4, 2, 4, 4, 0, 
 bad("wf_gemm_bf16", buf(64), buf(64), None, buf(64), None, 4, 4, 4, 4, 4, 4, 9, None)                    # unknown epilogue
 ok("wf_gemm_bf16_batched", buf(2 * 8 * 770 * 128), buf(2 * 8 * 776 * 128), buf(2 * 8 * 770 * 776), 8, 770, 776, 128, 128, 128, 776, 770 * 128,
    776 * 128, 770 * 776, 0, None)
+ok("wf_gemm_f16_batched", buf(2 * 3 * 130 * 64), buf(2 * 3 * 72 * 64), buf(4 * 3 * 130 * 72), 3, 130, 72, 64, 64, 64, 72, 130 * 64, 72 * 64, 130 * 72, 2, None)
+bad("wf_gemm_f16_batched", buf(64), buf(64), buf(64), 1, 4, 4, 8, 8, 8, 4, 0, 0, 0, 3, None)             # epilogue 3 is not built for the batched form
 # attention: dense, split (workspace), sparse
 H, Lq, Lkp = 8, 1000, 1024
 Q, K, V, O = buf(2 * H * Lq * 128), buf(2 * H * Lkp * 128), buf(2 * H * Lkp * 128), buf(2 * Lq * H * 128)

@@ -1355,15 +1355,15 @@ extern "C" int wf_debug_gemm_cycles(unsigned long long* out16, int reset) {
 
 // `batch` independent small GEMMs in ONE launch (blockIdx.y = problem): out_b[M,N] = X_b[M,K] . W_b[N,K]^T, problem b at X + b*bsx,
 // W + b*bsw, out + b*bso (elements).  The 128 x 128 register-staged kernel; epilogue EPI_BF16 or EPI_F32, no bias / gate.
-extern "C" int wf_gemm_bf16_batched(const void* X, const void* W, void* out, int batch, int M, int N, int K, int ldx, int ldw, int ldo,
-                                    int64_t bsx, int64_t bsw, int64_t bso, int epilogue, void* stream) {
+static int gemm_batched_impl(const void* X, const void* W, void* out, int batch, int M, int N, int K, int ldx, int ldw, int ldo, int64_t bsx,
+                             int64_t bsw, int64_t bso, int epilogue, void* stream, int f16) {
   WF_CHECK_ARG(X && W && out, "wf_gemm_bf16_batched: null pointer");
   WF_CHECK_ARG(batch > 0 && batch <= 65535 && M > 0 && N > 0 && K > 0, "wf_gemm_bf16_batched: empty problem batch=%d M=%d N=%d K=%d", batch, M, N, K);
   WF_CHECK_ARG(K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldw >= K && ldx >= K && bsx % 8 == 0 && bsw % 8 == 0,
                "wf_gemm_bf16_batched: K, ldx, ldw, bsx, bsw must be multiples of 8 with ld >= K");
   WF_CHECK_ARG(N % 4 == 0 && ldo % 4 == 0 && bso % 4 == 0, "wf_gemm_bf16_batched: N, ldo, bso must be multiples of 4");
   WF_CHECK_ARG((((uintptr_t)X | (uintptr_t)W | (uintptr_t)out) & 15) == 0, "wf_gemm_bf16_batched: pointers must be 16-byte aligned");
-  WF_CHECK_ARG(epilogue == EPI_BF16 || epilogue == EPI_F32, "wf_gemm_bf16_batched: epilogue must be 0 (bf16) or 2 (f32)");
+  WF_CHECK_ARG(epilogue == EPI_BF16 || epilogue == EPI_F32, "wf_gemm_bf16_batched: epilogue must be 0 (16-bit out) or 2 (f32)");
   GemmArgs a;
   a.X = (const uint16_t*)X;
   a.W = (const uint16_t*)W;
@@ -1374,13 +1374,34 @@ extern "C" int wf_gemm_bf16_batched(const void* X, const void* W, void* out, int
   a.mt = ceil_div(M, BM);
   a.nt = ceil_div(N, BN);
   a.bsx = bsx; a.bsw = bsw; a.bso = bso;
-  a.f16 = 0;
+  a.f16 = f16;
   const int nsuper = ((a.mt + 7) / 8) * ((a.nt + 7) / 8);
   const int grid = ((nsuper + 7) / 8) * 8 * 64;
-  if (epilogue == EPI_BF16)
-    hipLaunchKernelGGL(k_gemm<EPI_BF16>, dim3(grid, batch), dim3(NTHREADS), 4 * TILE_BYTES, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(k_gemm<EPI_F32>, dim3(grid, batch), dim3(NTHREADS), 4 * TILE_BYTES, (hipStream_t)stream, a);
+  const dim3 g(grid, batch), blk(NTHREADS);
+  hipStream_t s = (hipStream_t)stream;
+  if (f16) {
+    if (epilogue == EPI_BF16)
+      hipLaunchKernelGGL((k_gemm<EPI_BF16, true>), g, blk, 4 * TILE_BYTES, s, a);
+    else
+      hipLaunchKernelGGL((k_gemm<EPI_F32, true>), g, blk, 4 * TILE_BYTES, s, a);
+  } else {
+    if (epilogue == EPI_BF16)
+      hipLaunchKernelGGL(k_gemm<EPI_BF16>, g, blk, 4 * TILE_BYTES, s, a);
+    else
+      hipLaunchKernelGGL(k_gemm<EPI_F32>, g, blk, 4 * TILE_BYTES, s, a);
+  }
   WF_LAUNCH_CHECK("wf_gemm_bf16_batched");
   return WF_OK;
+}
+
+extern "C" int wf_gemm_bf16_batched(const void* X, const void* W, void* out, int batch, int M, int N, int K, int ldx, int ldw, int ldo,
+                                    int64_t bsx, int64_t bsw, int64_t bso, int epilogue, void* stream) {
+  return gemm_batched_impl(X, W, out, batch, M, N, K, ldx, ldw, ldo, bsx, bsw, bso, epilogue, stream, 0);
+}
+
+// wf_gemm_bf16_batched on fp16 operands (epilogue 0 writes fp16): the per-frame P.V products of the VAE mid-block attention in its fp16
+// three-term mode, all frames in one launch (each is 147 workgroups of the 128 x 128 kernel: alone it fills a fraction of the chip)
+extern "C" int wf_gemm_f16_batched(const void* X, const void* W, void* out, int batch, int M, int N, int K, int ldx, int ldw, int ldo,
+                                   int64_t bsx, int64_t bsw, int64_t bso, int epilogue, void* stream) {
+  return gemm_batched_impl(X, W, out, batch, M, N, K, ldx, ldw, ldo, bsx, bsw, bso, epilogue, stream, 1);
 }

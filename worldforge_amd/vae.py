@@ -563,12 +563,27 @@ class AutoencoderKLWan:
         Vt = torch.empty((C, hwp), dtype=F32, device=x.device)
         Of = torch.empty((T * nq, C), dtype=F32, device=x.device)
         scale = 1.0 / math.sqrt(C)
+        # The P . V product of a frame is nq x C x 3 hwp: ceil(nq / 128) x 3 workgroups of the 128 x 128 kernel -- 147 at 480p, 37 on a row group's
+        # query slab -- i.e. a fraction of the chip, 21 times in a row.  The three-term operands of ALL frames are therefore kept (4.9 GB at 480p)
+        # and the T products run as ONE batched launch; per frame the arithmetic is that of the single call (same kernel, same tiles).
+        batched = not os.environ.get("WF_VAE_ATTN_UNBATCHED")  # (debug switch: the per-frame launches of rounds 2-3)
+        if batched:
+            P3 = torch.empty((T, nq, 3 * hwp), dtype=self.OP, device=x.device)
+            V3 = torch.empty((T, C, 3 * hwp), dtype=self.OP, device=x.device)
         for t in range(T):
             blk = qkv[t * hw:t * hw + hwp]
             self._gemm(self._operand(blk[q0:q0 + nq, 0:C], 0), self._operand(blk[:, C:2 * C], 1), None, S, EPI_F32)
             call("wf_softmax_rows_f32", S.data_ptr(), hwp, P.data_ptr(), hwp, nq, hw, float(scale), ops.stream())
             call("wf_transpose_f32", blk[:, 2 * C:].data_ptr(), 3 * C, Vt.data_ptr(), hwp, hw, C, ops.stream())
-            self._gemm(self._operand(P, 0), self._operand(Vt, 1), None, Of[t * nq:(t + 1) * nq], EPI_F32)
+            if batched:
+                self._operand(P, 0, out=P3[t])
+                self._operand(Vt, 1, out=V3[t])
+            else:
+                self._gemm(self._operand(P, 0), self._operand(Vt, 1), None, Of[t * nq:(t + 1) * nq], EPI_F32)
+        if batched:
+            call("wf_gemm_f16_batched" if self.f16 else "wf_gemm_bf16_batched", P3.data_ptr(), V3.data_ptr(), Of.data_ptr(), T, nq, C, 3 * hwp, 3 * hwp, 3 * hwp, C, nq * 3 * hwp,
+                 C * 3 * hwp, nq * C, EPI_F32, ops.stream())
+            del P3, V3
         self._gemm(self._operand(Of), W[p + ".proj.w"], W[p + ".proj.b"], x.view(-1, C), EPI_F32_ACC)
         self.flops_last += 3 * (T * (4 * nq * hw * C) + 2 * T * hw * C * 3 * C + 2 * T * nq * C * C)
         return x
