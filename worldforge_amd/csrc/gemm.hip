@@ -42,6 +42,7 @@ struct GemmArgs {
   // batched launches of k_gemm (blockIdx.y = batch b): X, W, out of problem b start b * bsx / bsw / bso ELEMENTS further (0 = not batched)
   long bsx, bsw, bso;
   int f16;  // X, W and a 16-bit output are fp16 instead of bf16 (wf_gemm_f16: the VAE's fp16 operand formats)
+  int batch;  // gridDim.y of a batched launch (1 otherwise)
 };
 
 enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32 = 2, EPI_RESID = 3, EPI_F32_ACC = 4 };
@@ -285,6 +286,10 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
   using G = PPGeom<NI>;
   constexpr int NJ = G::NJ, NWP = G::NWP, NP = G::NP, W_TILE = G::W_TILE, BUF = G::BUF;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // batched launch (wf_gemm_*_batched): problem blockIdx.y starts bsx / bsw / bso ELEMENTS further (all zero, and gridDim.y = 1, otherwise)
+  a.X += (size_t)blockIdx.y * a.bsx;
+  a.W += (size_t)blockIdx.y * a.bsw;
+  a.out = reinterpret_cast<unsigned char*>(a.out) + (size_t)blockIdx.y * a.bso * ((EPI == EPI_BF16 || EPI == EPI_BF16_GELU) ? 2 : 4);
   // XCD-aware tile assignment (4 x 4 super-tiles of 256 x 256 tiles per XCD pass)
   const int smt = (a.mt + 3) >> 2, snt = (a.nt + 3) >> 2;
   const int nsuper = smt * snt;
@@ -1198,11 +1203,11 @@ static void launch_pp(GemmArgs a, hipStream_t s) {
   const int grid = ((nsuper + 7) / 8) * 8 * 16;
   static const bool mfma16 = [] { const char* e = getenv("WF_GEMM_MFMA"); return e && atoi(e) == 16; }();
   if (a.f16) {  // fp16 operands: the epilogues the VAE uses (the others are rejected by wf_gemm_f16)
-    if constexpr (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_F32_ACC) hipLaunchKernelGGL((k_gemm_pp<EPI, NI, true>), dim3(grid), dim3(PT), G::LDS, s, a);
-  } else if (mfma16)
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_F32_ACC) hipLaunchKernelGGL((k_gemm_pp<EPI, NI, true>), dim3(grid, a.batch), dim3(PT), G::LDS, s, a);
+  } else if (mfma16 && a.batch == 1)  // (the opt-in 16x16x32 form has no batch index)
     hipLaunchKernelGGL((k_gemm_pp16<EPI, NI>), dim3(grid), dim3(PT), G::LDS, s, a);
   else
-    hipLaunchKernelGGL((k_gemm_pp<EPI, NI>), dim3(grid), dim3(PT), G::LDS, s, a);
+    hipLaunchKernelGGL((k_gemm_pp<EPI, NI>), dim3(grid, a.batch), dim3(PT), G::LDS, s, a);
 }
 
 // 256- or 320-feature tiles: whichever leaves fewer idle workgroup slots in the last round of `n_cu` concurrent workgroups
@@ -1270,6 +1275,7 @@ static int gemm_impl(const void* X, const void* W, const float* bias, void* out,
   a.nt = ceil_div(N, BN);
   a.bsx = a.bsw = a.bso = 0;
   a.f16 = f16;
+  a.batch = 1;
   const int nsuper = ((a.mt + 7) / 8) * ((a.nt + 7) / 8);
   const int grid = ((nsuper + 7) / 8) * 8 * 64;
   const size_t lds = 4 * TILE_BYTES;
@@ -1375,10 +1381,24 @@ static int gemm_batched_impl(const void* X, const void* W, void* out, int batch,
   a.nt = ceil_div(N, BN);
   a.bsx = bsx; a.bsw = bsw; a.bso = bso;
   a.f16 = f16;
+  a.batch = batch;
+  hipStream_t s = (hipStream_t)stream;
+  // problems that are large TOGETHER (the VAE mid-block's P . V products: 6240 x 384 x 18 720 per frame, 21 frames) take the ping-pong kernel
+  // with the batch index on gridDim.y; the gate is gemm_impl's with the batch counted in
+  static const bool no_pp = getenv("WF_GEMM_NO_PP") != nullptr;
+  const bool big = K % PK == 0 && M >= 1024 && N >= 256 && N % 4 == 0 && (long)M * N * batch >= (1L << 22) &&
+                   (size_t)M * ldx * 2 < (1ull << 32) && (size_t)N * ldw * 2 < (1ull << 32);
+  if (big && !no_pp) {
+    if (epilogue == EPI_BF16)
+      launch_pp_any<EPI_BF16>(a, s);
+    else
+      launch_pp_any<EPI_F32>(a, s);
+    WF_LAUNCH_CHECK("wf_gemm_bf16_batched");
+    return WF_OK;
+  }
   const int nsuper = ((a.mt + 7) / 8) * ((a.nt + 7) / 8);
   const int grid = ((nsuper + 7) / 8) * 8 * 64;
   const dim3 g(grid, batch), blk(NTHREADS);
-  hipStream_t s = (hipStream_t)stream;
   if (f16) {
     if (epilogue == EPI_BF16)
       hipLaunchKernelGGL((k_gemm<EPI_BF16, true>), g, blk, 4 * TILE_BYTES, s, a);

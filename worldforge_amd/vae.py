@@ -522,7 +522,9 @@ class AutoencoderKLWan:
         row-group sharded low-resolution stage; per output element the arithmetic is that of the whole-frame call."""
         T, H, Wd, C = x.shape
         hw = H * Wd
-        hwp = (hw + 7) // 8 * 8  # K / N padding for the MFMA GEMMs; padded score columns are never read by the softmax
+        # K / N padding for the MFMA GEMMs; padded score columns are never read by the softmax and are written as zero probabilities.  The
+        # fp32-class path pads to 64 so that the batched P . V products (K = 3 hwp) qualify for the ping-pong GEMM (whole 64-wide K tiles)
+        hwp = (hw + 63) // 64 * 64 if self.x3 else (hw + 7) // 8 * 8
         W = self.w
         a = self._rms(x, W[p + ".norm.gamma"], silu=False)
         q0, q1 = (0, hw) if rows is None else (rows[0] * Wd, rows[1] * Wd)
@@ -555,7 +557,7 @@ class AutoencoderKLWan:
         are updated ([T, rows, W, C]: the whole frames, or the query-row slab); a: the normalised WHOLE frames."""
         T, C = x.shape[0], x.shape[-1]
         W = self.w
-        qkv = torch.zeros((T * hw + 8, 3 * C), dtype=F32, device=x.device)
+        qkv = torch.zeros((T * hw + 64, 3 * C), dtype=F32, device=x.device)  # + 64 rows: the last frame's padded K rows stay in-bounds
         self._gemm(a.view(-1, 3 * C), W[p + ".to_qkv.w"], W[p + ".to_qkv.b"], qkv[:T * hw], EPI_F32)
         del a
         S = torch.empty((nq, hwp), dtype=F32, device=x.device)
