@@ -81,6 +81,35 @@ def test_gemm_wide_tile_equals_small_tile_kernel(M, N, K, epi):
     assert _rel(full, ref.cpu()) <= (1e-2 if epi in (0, 1) else 2e-5 * math.sqrt(K) + 1e-5)
 
 
+@pytest.mark.parametrize("name,f16", [("wf_gemm_bf16_batched", False), ("wf_gemm_f16_batched", True)])
+@pytest.mark.parametrize("B,M,N,K,epi", [(8, 1560, 384, 1152, 2),    # large together: the ping-pong kernel with the batch index on gridDim.y (ragged M / N tiles)
+                                         (16, 1100, 264, 128, 0),    # the same with a 16-bit output
+                                         (4, 300, 72, 136, 2)])      # small problems (K not a multiple of 64): the 128 x 128 kernel
+def test_gemm_batched_equals_the_per_problem_calls(name, f16, B, M, N, K, epi):
+    """`batch` independent products in one launch (the VAE mid-block's P . V of all frames; the block scores of the sparse attention): whichever
+    kernel the batched call takes, problem b must equal -- bit for bit -- the single call on its operands, which takes the 128 x 128 kernel or the
+    ping-pong kernel by its OWN size (every output element is the same K-ordered MFMA accumulation in both)."""
+    from worldforge_amd import ops
+    from worldforge_amd._ffi import call
+    OP = torch.float16 if f16 else BF
+    x = _rand((B, M, K), 31).to(OP).to(DEV)
+    w = (_rand((B, N, K), 32) / math.sqrt(K)).to(OP).to(DEV)
+    dt = OP if epi == 0 else F32
+    out = torch.full((B, M, N), float("nan"), dtype=dt, device=DEV)
+    call(name, x.data_ptr(), w.data_ptr(), out.data_ptr(), B, M, N, K, K, K, N, M * K, N * K, M * N, epi, ops.stream())
+    single = "wf_gemm_f16" if f16 else "wf_gemm_bf16"
+    for b in range(B):
+        one = torch.full((M, N), float("nan"), dtype=dt, device=DEV)
+        if f16:
+            call(single, x[b].data_ptr(), w[b].data_ptr(), None, one.data_ptr(), M, N, K, K, K, N, epi, ops.stream())
+        else:
+            call(single, x[b].data_ptr(), w[b].data_ptr(), None, one.data_ptr(), None, M, N, K, K, K, N, epi, ops.stream())
+        assert torch.isfinite(one.float()).all()
+        assert torch.equal(out[b], one), (b, (out[b].float() - one.float()).abs().max())
+    ref = torch.einsum("bmk,bnk->bmn", x.float().cpu(), w.float().cpu())
+    assert _rel(out.cpu(), ref) <= (1e-2 if epi == 0 else 2e-5 * math.sqrt(K) + 1e-5)
+
+
 def test_gemm_strided_views_and_no_bias():
     from worldforge_amd import dit
     big = _rand((200, 512), 6).to(BF).to(DEV)
