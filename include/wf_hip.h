@@ -152,9 +152,10 @@ int wf_gemm_bf16(const void* X, const void* W, const float* bias, void* out, con
 int wf_gemm_bf16_batched(const void* X, const void* W, void* out, int batch, int M, int N, int K, int ldx, int ldw, int ldo,
                          int64_t bsx, int64_t bsw, int64_t bso, int epilogue, void* stream);
 /* wf_gemm_bf16 on fp16 operands (X, W fp16; fp32 accumulation; epilogue WF_EPI_BF16 writes fp16, WF_EPI_F32, WF_EPI_F32_ACC): the
- * 1x1 convolutions and mid-block attention products of the VAE in its fp16 operand formats (see wf_split_f16x3). */
+ * 1x1 convolutions and mid-block attention products of the VAE in its fp16 operand formats (see wf_split_f16x3).  acc_scale (round 5;
+ * 1 = none): out = epilogue(acc * acc_scale + bias) -- 2^-k for a weight operand stored scaled by 2^k (see "fp16 operand formats"). */
 int wf_gemm_f16(const void* X, const void* W, const float* bias, void* out, int M, int N, int K, int ldx, int ldw, int ldo, int epilogue,
-                void* stream);
+                float acc_scale, void* stream);
 /* wf_gemm_bf16_batched on fp16 operands (WF_EPI_BF16 writes fp16): the per-frame P . V products of the VAE mid-block attention
  * (vae.py:252-258) of all frames in one launch. */
 int wf_gemm_f16_batched(const void* X, const void* W, void* out, int batch, int M, int N, int K, int ldx, int ldw, int ldo, int64_t bsx,
@@ -167,9 +168,14 @@ int wf_gemm_f16_batched(const void* X, const void* W, void* out, int batch, int 
  * seg_len: Lkp for one contiguous K/V; with sequence parallelism K/V are the all-gathered per-rank shards [P][H][seg_len][128]
  * (seg_len % 64 == 0, Lkp = P*seg_len) and key index = seg*seg_len + row.
  * softmax_scale = 0: Q already carries softmax_scale * log2(e) (wf_rmsnorm_heads out_scale) -- the score accumulators then start
- * from -m instead of 0 and hold s - m directly, which takes one VALU instruction per score out of the softmax. */
-int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len, int ldo,
-                float softmax_scale, int accumulate, const float* kmax2, int kmax_n, const float* qmax2, int qmax_n, void* stream);
+ * from -m instead of 0 and hold s - m directly, which takes one VALU instruction per score out of the softmax.
+ * seg_stride_bytes (round 5): 0 = the dense [P][H][seg_len][128] form above; otherwise the bytes from one segment's head 0 to the next
+ * segment's head 0, the SAME for K and Vt -- each source rank's K shard, V^T shard and norm-bound vector then travel as ONE packed slot
+ * [K | V^T | bounds] of an exchange buffer (one collective and one event per source or per chunk; worldforge_amd/parallel.py KVExchange),
+ * K and Vt point into slot 0.  kmax_stride: floats between two kmax2 vectors (0 = H, contiguous). */
+int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len,
+                size_t seg_stride_bytes, int ldo, float softmax_scale, int accumulate, const float* kmax2, int kmax_n, int kmax_stride,
+                const float* qmax2, int qmax_n, void* stream);
 /* Per-head max over the rows of |x|^2: X bf16 [H][Lp][128] (rows >= L ignored) -> out f32 [H], which the caller zeroes first.
  * Computed for K and for the pre-scaled Q and handed to wf_attn_fwd (softmax_scale = 0 only) as kmax2 / qmax2 -- kmax_n / qmax_n such
  * vectors each, one per shard when the tensor is all-gathered -- it lets the kernel prove by Cauchy-Schwarz that no score of the head
@@ -192,9 +198,9 @@ int wf_attn_cross2_fwd(const void* Q, const void* K, const void* Vt, void* O, in
  * (wf_attn_fwd / wf_attn_fwd_split with softmax_scale = 0) adds 1 to counters2[0] if it ran the max-tracking body and to counters2[1]
  * if it ran the un-tracked one -- lets a parity test assert WHICH body it compared with the oracle.  Process-global, not thread-safe. */
 int wf_attn_debug_body_counter(void* counters2);
-int wf_attn_fwd_split(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len, int ldo,
-                      float softmax_scale, int accumulate, int nsplit, void* workspace, const float* kmax2, int kmax_n, const float* qmax2,
-                      int qmax_n, void* stream);
+int wf_attn_fwd_split(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len,
+                      size_t seg_stride_bytes, int ldo, float softmax_scale, int accumulate, int nsplit, void* workspace, const float* kmax2,
+                      int kmax_n, int kmax_stride, const float* qmax2, int qmax_n, void* stream);
 /* The KV sweep in PARTS (round 4; sequence-parallel layers WITHOUT a second CFG branch to hide the K / V^T exchange under -- LongCat-Video,
  * distilled schedules, guidance_scale <= 1; reference idea: wan/distributed/xdit_context_parallel.py:160-176, pipeline_longcat_video.py:
  * 857-866).  The key segments arrive one source rank after the other; a part launch walks only the 64-key tiles [t_begin, t_end) that are
@@ -203,10 +209,14 @@ int wf_attn_fwd_split(const void* Q, const void* K, const void* Vt, void* O, int
  * (inner_splits >= 1 halves / thirds the window over blockIdx.y so that a short query shard fills whole rounds of workgroups).  Pre-scaled Q only (the form of
  * wf_attn_fwd with softmax_scale = 0); Q / K / Vt / bounds as wf_attn_fwd.  wf_attn_merge combines the slots exactly (the flash combine
  * wf_attn_fwd_split uses) into O once every slot has been written; the result equals the one-launch sweep up to the re-association of the
- * fp32 partial sums. */
-int wf_attn_fwd_part(const void* Q, const void* K, const void* Vt, int H, int Lq, int Lkp, int kv_len, int seg_len, int t_begin, int t_end,
-                     int part, int inner_splits, int nparts, void* workspace, const float* kmax2, int kmax_n, const float* qmax2, int qmax_n,
-                     void* stream);
+ * fp32 partial sums.
+ * Round 5: nparts up to 12; an optional SECOND window [t_begin2, t_end2) in inner_splits2 splits (0 = none) behind the first -- the keys on
+ * the far side of a hole, i.e. of the rank's own segment, which an earlier part launch walked without waiting for the exchange: one launch
+ * then covers "every peer" of an all-gathered buffer (slots part ... part + splits of window 1 + splits of window 2 - 1; a window of n
+ * tiles in k splits fills ceil(n / ceil(n / k)) slots).  seg_stride_bytes / kmax_stride as wf_attn_fwd. */
+int wf_attn_fwd_part(const void* Q, const void* K, const void* Vt, int H, int Lq, int Lkp, int kv_len, int seg_len, size_t seg_stride_bytes,
+                     int t_begin, int t_end, int inner_splits, int t_begin2, int t_end2, int inner_splits2, int part, int nparts,
+                     void* workspace, const float* kmax2, int kmax_n, int kmax_stride, const float* qmax2, int qmax_n, void* stream);
 int wf_attn_merge(void* O, int H, int Lq, int ldo, int accumulate, int nparts, const void* workspace, void* stream);
 
 /* WanLayerNorm (model.py:92-102; eps, no affine) fused with y = ln * (plus_one + mul[c]) + add[c]:
@@ -376,23 +386,32 @@ int wf_transpose_f32(const float* in, int ld_in, float* out, int ld_out, int R, 
  * ~2^-16 per product; the same split on FP16 parts (11-bit significands: hi = fp16(x), lo = fp16(x - hi), contraction hi.hi + lo.hi +
  * hi.lo on v_mfma_f32_32x32x16_f16, same rate) leaves ~2^-22 -- two decimal digits closer to IEEE fp32 at the same cost; it is the
  * VAE's default ("fp16x3").  fp16 has a 5-bit exponent: values beyond +-65504 do not fit.  The producers raise a sticky flag
- * (wf_f16_overflow_flag) that the host turns into an error after every VAE call; the bf16 split ("bf16x3") remains for such weights.
- * Every *_f16 entry point is its bf16 namesake with fp16 in place of bf16 in the operands (and in a 16-bit output copy). */
+ * (wf_f16_overflow_flag) that the host turns into an error; the bf16 split ("bf16x3") remains for such weights.
+ * Every *_f16 entry point is its bf16 namesake with fp16 in place of bf16 in the operands (and in a 16-bit output copy).
+ * acc_scale (round 5): `lo = fp16(x - hi)` is an fp16 SUBNORMAL for |x| < 2^-3 (absolute floor 2^-25), so a weight of
+ * 0.02 was carried to ~2^-18 relative, not 2^-22.  The host therefore stores every weight matrix multiplied by an exact power of two 2^k
+ * (its largest magnitude lands in [2^13, 2^14): lo is a normal fp16 for every weight above 2^-17 of the layer's largest) and passes
+ * acc_scale = 2^-k: the kernels compute out = acc * acc_scale + bias (+ residual) -- exact, one fma in place of the add. */
 int wf_split_f16x3(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, size_t rows, int C, int side, void* stream);
 int wf_rms_silu_cl_x3_f16(const float* x, const float* gamma, void* out_x3, size_t npix, int C, int silu, void* stream);
 int wf_rms_silu_cl_blocked_f16(const float* x, const float* gamma, void* out, size_t npix, int C, int silu, int W, int split,
                                int halo_rows, void* stream);
 int wf_conv3d_cl_f16(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_f16, int Ti,
                      int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st, int ss, int pt, int ph,
-                     int pw, int up2, int tsplit, const void* zero_page, void* stream);
+                     int pw, int up2, int tsplit, const void* zero_page, float acc_scale, void* stream);
 int wf_conv3d_cl_scatter_f16(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_f16, int Ti,
                              int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st, int ss, int pt,
-                             int ph, int pw, const void* zero_page, int out_H, int out_W, int sy, int oy, int sx, int ox, void* stream);
+                             int ph, int pw, const void* zero_page, int out_H, int out_W, int sy, int oy, int sx, int ox, float acc_scale,
+                             void* stream);
 int wf_conv3d_333_f16(const void* in, const void* w_packed, const float* bias, const float* resid, float* out_f32, void* out_f16, int T,
                       int Hi, int Wi, int Cin, int Ho, int Cout, int ph, const void* zero_page, size_t zero_page_bytes, int layout,
-                      int Cin_stored, void* stream);
+                      int Cin_stored, float acc_scale, void* stream);
 /* *out = 1 if a producer converted a value beyond the fp16 range (or a NaN) since the last reset; synchronises `stream`. */
 int wf_f16_overflow_flag(int* out, int reset, void* stream);
+/* The same word copied asynchronously into page-locked host memory behind the work queued on `stream` so far: no synchronisation (the
+ * caller records an event behind the call and reads the word once it has fired) -- what AutoencoderKLWan.encode / decode use since
+ * round 5, so that a VAE call never stalls the host (SURVEY 8b "no hidden device syncs"). */
+int wf_f16_overflow_flag_async(int* pinned_host_out, void* stream);
 /* [C, N] f32 -> [N, Cpad] (f32 and/or bf16; channels C..Cpad zero, so thin inputs fill an MFMA K slice);
  * [N, ld] f32 (first C channels) -> [C, N] f32 with optional clamp (autoencoder_kl_wan.py:1222).  N = T*H*W. */
 int wf_ncthw_to_cl(const float* in, float* out_f32, void* out_bf16, int C, int Cpad, size_t N, void* stream);
@@ -443,6 +462,12 @@ int wf_points_render(const float* points, const float* features, const void* dro
 size_t wf_depth_edge_mask_workspace_bytes(int H, int W);
 int wf_depth_edge_mask(const float* depth, int H, int W, double edge_threshold, int edge_dilation, float jump_threshold, int neighbor_radius,
                        void* out_drop, void* workspace, void* stream);
+
+/* ---- measurement aid (bench.py `box_calib_tflops`) -------------------------------------------------------------------------------------
+ * One launch of a fixed register-only stream of v_mfma_f32_32x32x16_bf16 (256 workgroups x 4 waves, one per SIMD, 16 accumulator tiles per
+ * wave, iters x 16 MFMAs each): what THIS box sustains on the matrix pipe alone under its power limit.  src: 1 MiB of bf16 operand values
+ * (N(0,1): the rate depends on the data), sink: >= 4 bytes; *flop (host, may be NULL) receives the launch's flop count.  Asynchronous. */
+int wf_calib_mfma(const void* src, float* sink, int iters, double* flop, void* stream);
 
 #ifdef __cplusplus
 }

@@ -156,12 +156,24 @@ class SimComm:
     def __init__(self, world, rank, shared):
         self.world, self.rank, self.sh = world, rank, shared
 
+    def split(self, n_groups):
+        """parallel.Comm.split: contiguous sub-groups; the threads of a sub-group meet in their own shared slot table."""
+        import threading
+        per = self.world // n_groups
+        g = self.rank // per
+        sub_sh = self.sh.setdefault(("sub", n_groups, g), {"slots": [None] * per, "bar": threading.Barrier(per)})   # (atomic in CPython)
+        sub = SimComm(per, self.rank % per, sub_sh)
+        sub.group_index = g
+        return sub
+
     def all_gather(self, out, inp):
         sh = self.sh
         sh["slots"][self.rank] = inp
+        torch.cuda.current_stream().synchronize()   # the producers of `inp` ran on this thread's stream
         sh["bar"].wait()
         for r in range(self.world):
-            out[r].copy_(sh["slots"][r])
+            if r != self.rank or inp.data_ptr() != out[r].data_ptr():   # (in-place form of parallel.KVExchange: the own slot stays)
+                out[r].copy_(sh["slots"][r])
         torch.cuda.current_stream().synchronize()
         sh["bar"].wait()
         return out
@@ -170,8 +182,8 @@ class SimComm:
         self.all_gather(out, inp)
         return None
 
-    def exchange_segments_async(self, out):
-        """parallel.Comm.exchange_segments_async: slot `rank` of `out` is this rank's shard; the other slots come from their owners."""
+    def broadcast_slots_async(self, out):
+        """parallel.Comm.broadcast_slots_async: slot `rank` of `out` is this rank's data; the other slots come from their owners."""
         sh = self.sh
         sh["slots"][self.rank] = out[self.rank]
         sh["bar"].wait()

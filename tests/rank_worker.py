@@ -42,13 +42,20 @@ def main():
     ref, ref_b = m0.forward_tokens(x, 500.0, ctx, clip).clone(), m0.forward_tokens(x, 500.0, ctx_b, clip).clone()
     m1 = dit.WanTransformer3DModel(cfg, dev, comm=comm)
     m1.w = m0.w
-    m1.segmented_exchange = False   # one all-gather per operand: the gathered tiles are the single-rank tiles
+    from tests._tol import within
+    m1.exchange_mode = "gather"     # one in-place all-gather of the packed slots, one launch: the gathered tiles are the single-rank tiles
     got = m1.forward_tokens(x, 500.0, ctx, clip)
     assert torch.equal(got, ref), f"sharded DiT forward differs: {(got - ref).abs().max().item()}"
-    m1.segmented_exchange = True    # per-source broadcasts, own shard first, partial sweeps merged (real broadcasts, streams and events)
-    got = m1.forward_tokens(x, 500.0, ctx, clip)
-    err = (got - ref).abs().max().item() / ref.abs().max().item()
-    assert err <= (2e-2 if world > 1 else 0.0), f"segmented exchange: {err}"
+    # the own-first modes over REAL collectives, streams and events: G all-gathers / per-source broadcasts, partial sweeps merged (fp32
+    # re-association only: measured 2.1e-3 ... 2.7e-3 of max|ref| on this net by the simulated-rank tests; bar at 2x, tests/_tol.py policy)
+    for mode, chunks in (("chunked", 1), ("chunked", 2), ("bcast", 1)):
+        m1.exchange_mode, m1.exchange_chunks = mode, chunks
+        got = m1.forward_tokens(x, 500.0, ctx, clip)
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        if world > 1:
+            within(f"rank_worker.dit_{mode}{chunks}.P{world}", err, 5.4e-3)
+        else:
+            assert err <= 5.4e-3, f"{mode}: {err}"
     for _ in range(2):
         a, b = m1.forward_tokens_pair(x, 500.0, ctx, ctx_b, clip)
         assert torch.equal(a, ref) and torch.equal(b, ref_b), "lock-step CFG pair differs"

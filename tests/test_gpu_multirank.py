@@ -38,15 +38,20 @@ def _run_ranks(P, fn):
     return res
 
 
-@pytest.mark.parametrize("segmented", [False, True], ids=["one_event", "segmented"])
+EXCHANGES = [("gather", 1), ("chunked", 1), ("chunked", 2), ("chunked", 3), ("bcast", 1)]
+EXCHANGE_IDS = ["gather", "own_first_1_gather", "chunked2", "chunked3", "bcast"]
+
+
+@pytest.mark.parametrize("exchange", EXCHANGES, ids=EXCHANGE_IDS)
 @pytest.mark.parametrize("P,thw", [(2, (3, 16, 20)), (3, (5, 16, 24)), (4, (5, 16, 24)), (8, (5, 16, 24))])
-def test_token_sharded_dit_equals_single(P, thw, segmented):
-    """Every rank must return the full velocity tensor of the single-rank forward.  The K tiles of the gathered
-    [P, H, shard_len, 128] buffer coincide with the single-rank tiles (all shards but the last are full multiples of 64), so
-    the online softmax sees the same sequence of tiles: bit-identical with the one-event all-gather.  With the SEGMENTED exchange
-    (round 4: per-source broadcasts, the attention walks its own shard first and the peers' as they arrive, partial results merged) the
-    fp32 partial sums are re-associated: equal to the split-KV class of tolerance, and every rank still returns the same tensor (each row
-    comes from its owner)."""
+def test_token_sharded_dit_equals_single(P, thw, exchange):
+    """Every rank must return the full velocity tensor of the single-rank forward.  The K tiles of the gathered exchange buffer
+    ([P] packed slots [K | V^T | bounds], parallel.KVExchange) coincide with the single-rank tiles (all shards but the last are full
+    multiples of 64), so the online softmax sees the same sequence of tiles: bit-identical in mode "gather" (one all-gather, one
+    launch).  The OWN-FIRST modes (round 5: "chunked" = G all-gathers of the g-th 1/G of every rank's keys, "bcast" = per-source
+    broadcasts; the attention walks its own shard first and the peers' windows as they arrive, partial results merged) re-associate
+    the fp32 partial sums: equal to the split-KV class of tolerance, and every rank still returns the same tensor (each row comes
+    from its owner)."""
     from tests._tol import within
     from worldforge_amd import dit
     cfg = dit.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
@@ -59,17 +64,17 @@ def test_token_sharded_dit_equals_single(P, thw, segmented):
     def rank_fn(comm):
         m = dit.WanTransformer3DModel(cfg, DEV, comm=comm)
         m.w = m0.w
-        m.segmented_exchange = segmented
+        m.exchange_mode, m.exchange_chunks = exchange
         assert m.local_tokens(T * (Hh // 2) * (Ww // 2)) > 0
         return m.forward_tokens(x, 500.0, ctx, clip).clone()
 
     res = _run_ranks(P, rank_fn)
     for r, got in enumerate(res):
-        if not segmented:
+        if exchange[0] == "gather":
             assert torch.equal(got, ref), (r, (got - ref).abs().max())
         else:
             assert torch.equal(got, res[0]), r
-            within(f"multirank.dit_segmented.P{P}", (got - ref).abs().max().item() / ref.abs().max().item(), 5.4e-3)   # measured 2.1e-3 ... 2.7e-3
+            within(f"multirank.dit_{exchange[0]}{exchange[1]}.P{P}", (got - ref).abs().max().item() / ref.abs().max().item(), 5.4e-3)   # measured 2.1e-3 ... 2.7e-3
 
 
 @pytest.mark.parametrize("P", [2, 4])
@@ -102,6 +107,52 @@ def test_guided_sampler_on_sharded_dit_and_vae_equals_single(P):
         if comm is not None:
             assert v.can_shard(H // 8)
         pipe = WanImageToVideoPipeline(m, v, UniPCMultistepScheduler(flow_shift=3.0), device=DEV)
+        out = pipe(image=image, height=H, width=Wd, num_frames=Fr, num_inference_steps=4, guidance_scale=4.0,
+                   generator=torch.Generator().manual_seed(42), prompt_embeds=text, negative_prompt_embeds=neg, image_embeds=img,
+                   output_type="np", video_ref=ref, mask=mask, static=True, **kw)
+        return torch.from_numpy(out.frames).clone()
+
+    want = run(None)
+    assert torch.isfinite(want).all()
+    for r, got in enumerate(_run_ranks(P, run)):
+        assert torch.equal(got, want), (r, (got - want).abs().max())
+
+
+@pytest.mark.parametrize("P", [4, 8])
+def test_cfg_groups_by_sequence_shards_equals_single(P):
+    """SURVEY 8e "P = 8 = 2 x 4": the job's ranks split into two CFG groups (parallel.Comm.split(2)); group 0 runs the positive-prompt
+    forward, group 1 the negative one, each sequence-parallel over its P / 2 ranks; one all-gather over the whole job hands every rank
+    both velocities (pipeline.cfg_split); the VAE stays row-sharded over all P ranks.  With the one-event exchange inside a group every
+    rank must produce the single-GPU frames bit for bit."""
+    from worldforge_amd import dit
+    from worldforge_amd.pipeline import WanImageToVideoPipeline
+    from worldforge_amd.scheduler import UniPCMultistepScheduler
+    from worldforge_amd.vae import AutoencoderKLWan
+
+    cfg = dit.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64)
+    Fr, H, Wd = 9, 128, 160
+    g = torch.Generator().manual_seed(3)
+    image = torch.rand(3, H, Wd, generator=g)
+    ref = torch.rand(1, 3, Fr, H, Wd, generator=g)
+    mask = (torch.rand(1, 1, Fr, H, Wd, generator=g) > 0.3).float()
+    text, neg = _rand((1, 30, 64), 7).to(BF), _rand((1, 30, 64), 8).to(BF)
+    img = _rand((1, 257, 1280), 9).to(BF)
+    m0 = dit.WanTransformer3DModel(cfg, DEV).init_random(5)
+    v0 = AutoencoderKLWan(DEV).init_random(seed=1)
+    kw = dict(guided=True, resample_steps=2, guide_steps=3, omega=4.0, omega_resample=4.0, resample_round=3,
+              use_pca_channel_selection=True)
+
+    def run(world):
+        sub = world.split(2) if world is not None else None
+        m = dit.WanTransformer3DModel(cfg, DEV, comm=sub)
+        m.w = m0.w
+        m.exchange_mode = "gather"
+        v = AutoencoderKLWan(DEV, comm=world)
+        v.w = v0.w
+        pipe = WanImageToVideoPipeline(m, v, UniPCMultistepScheduler(flow_shift=3.0), device=DEV)
+        if world is not None:
+            assert (sub.world, sub.rank, sub.group_index) == (P // 2, world.rank % (P // 2), world.rank // (P // 2))
+            pipe.cfg_split = (world, sub.group_index)
         out = pipe(image=image, height=H, width=Wd, num_frames=Fr, num_inference_steps=4, guidance_scale=4.0,
                    generator=torch.Generator().manual_seed(42), prompt_embeds=text, negative_prompt_embeds=neg, image_embeds=img,
                    output_type="np", video_ref=ref, mask=mask, static=True, **kw)
@@ -179,12 +230,13 @@ def test_cfg_pair_lockstep_equals_two_sequential_forwards(P):
         assert torch.equal(b, ref_b), (r, (b - ref_b).abs().max())
 
 
-@pytest.mark.parametrize("segmented", [False, True], ids=["one_event", "segmented"])
+@pytest.mark.parametrize("exchange", EXCHANGES, ids=EXCHANGE_IDS)
 @pytest.mark.parametrize("P,thw,ncl", [(2, (3, 16, 20), 1), (3, (5, 16, 24), 1), (4, (5, 16, 24), 0), (8, (8, 16, 32), 2)])
-def test_token_sharded_longcat_dit_equals_single(P, thw, ncl, segmented):
+def test_token_sharded_longcat_dit_equals_single(P, thw, ncl, exchange):
     """LongCat DiT, sequence parallel: per-frame AdaLN selected by the global token index (row0), condition / noise split by global
-    index (a shard may hold both kinds of rows, or only one), K / V^T shards all-gathered and consumed in place.  Every rank must
-    return the single-rank velocity, bit for bit."""
+    index (a shard may hold both kinds of rows, or only one), K / V^T shards exchanged through the packed buffers and consumed in
+    place.  Mode "gather": every rank must return the single-rank velocity, bit for bit; the own-first modes: the same tensor on every
+    rank, within the re-association tolerance (the condition rows' key prefix is walked through the same chunk windows)."""
     from oracle import longcat_dit as olc
     from worldforge_amd.longcat_dit import LongCatConfig, LongCatVideoTransformer3DModel
     kw = dict(hidden_size=256, depth=2, num_heads=2, caption_channels=64, adaln_tembed_dim=64)
@@ -201,17 +253,47 @@ def test_token_sharded_longcat_dit_equals_single(P, thw, ncl, segmented):
     def rank_fn(comm):
         m = LongCatVideoTransformer3DModel(LongCatConfig(**kw), DEV, comm=comm)
         m.w = m0.w
-        m.segmented_exchange = segmented
+        m.exchange_mode, m.exchange_chunks = exchange
         return m.forward_tokens(x, ts, cap, mask, ncl).clone()
 
     from tests._tol import within
     res = _run_ranks(P, rank_fn)
     for r, got in enumerate(res):
-        if not segmented:   # the one-event all-gather: the gathered tiles are the single-rank tiles, bit for bit
+        if exchange[0] == "gather":   # one all-gather, one launch: the gathered tiles are the single-rank tiles, bit for bit
             assert torch.equal(got, ref), (r, (got - ref).abs().max())
-        else:               # segments walked own-first and merged: fp32 re-association of the partial sums (bf16 residual stream)
+        else:               # windows walked own-first and merged: fp32 re-association of the partial sums (bf16 residual stream)
             assert torch.equal(got, res[0]), r
-            within(f"multirank.longcat_segmented.P{P}", (got - ref).abs().max().item() / ref.abs().max().item(), 8e-3)   # measured 3.1e-3 ... 4.0e-3
+            within(f"multirank.longcat_{exchange[0]}{exchange[1]}.P{P}", (got - ref).abs().max().item() / ref.abs().max().item(), 8e-3)   # measured 3.1e-3 ... 4.0e-3
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_longcat_cfg_batch_lockstep_equals_sequential_samples(P):
+    """LongCat's CFG batch (pipeline_longcat_video.py:857-866: [negative, positive] on the batch axis) under sequence parallelism: the two
+    samples are advanced in lock-step, one block apart (forward_tokens_pair, round 5), each on its own buffers with the one-event
+    all-gather -- each sample must equal its own single-rank forward bit for bit, on every rank, also when called through __call__."""
+    from oracle import longcat_dit as olc
+    from worldforge_amd.longcat_dit import LongCatConfig, LongCatVideoTransformer3DModel
+    kw = dict(hidden_size=256, depth=3, num_heads=2, caption_channels=64, adaln_tembed_dim=64)
+    W = olc.random_weights(olc.LongCatConfig(**kw), seed=5)
+    T, Hh, Ww, ncl = 5, 16, 24, 1
+    xs = _rand((2, 16, T, Hh, Ww), 60).to(BF).to(DEV)
+    caps = _rand((2, 1, 30, 64), 61).to(BF).to(DEV)
+    masks = torch.zeros(2, 30, dtype=torch.int64)
+    masks[0, :21] = 1
+    masks[1, :9] = 1
+    tstep = torch.tensor([[0.0] * ncl + [500.0] * (T - ncl)] * 2)
+    m0 = LongCatVideoTransformer3DModel(LongCatConfig(**kw), DEV).load_state_dict(W)
+    ref = m0(xs, tstep, caps, masks, num_cond_latents=ncl).clone()
+    assert not torch.equal(ref[0], ref[1])
+
+    def rank_fn(comm):
+        m = LongCatVideoTransformer3DModel(LongCatConfig(**kw), DEV, comm=comm)
+        m.w = m0.w
+        assert m.pair_lockstep
+        return m(xs, tstep, caps, masks, num_cond_latents=ncl).clone()
+
+    for r, got in enumerate(_run_ranks(P, rank_fn)):
+        assert torch.equal(got, ref), (r, (got - ref).abs().max())
 
 
 @pytest.mark.parametrize("P", [2, 4])
@@ -239,7 +321,8 @@ def test_longcat_guided_sampler_on_sharded_dit_and_vae_equals_single(P):
     def run(comm):
         m = LongCatVideoTransformer3DModel(LongCatConfig(**kw), DEV, comm=comm)
         m.w = m0.w
-        m.segmented_exchange = False   # the bit-identical form of the exchange (the segmented one is compared with a tolerance above)
+        m.exchange_mode = "gather"   # the bit-identical form of the exchange (the own-first ones are compared with a tolerance above);
+        # the CFG batches of this job run as lock-step pairs (forward_tokens_pair), which always use it
         v = AutoencoderKLWan(DEV, comm=comm)
         v.w = v0.w
         pipe = LongCatVideoPipeline(v, FlowMatchEulerDiscreteScheduler(shift=3.0), m, device=DEV)

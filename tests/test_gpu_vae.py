@@ -305,16 +305,49 @@ def test_f16_range_flag_is_raised_and_reported():
     _ffi.call("wf_f16_overflow_flag", ctypes.byref(flag), 0, ops.stream())
     assert flag.value == 1
     m = AutoencoderKLWan(DEV, precision="fp16x3")
+    m._note_range("test")                           # what every encode / decode ends with: an asynchronous copy of the flag, no host sync
     with pytest.raises(RuntimeError, match="fp16 range"):
-        m._check_range("test")                      # reads and resets
+        m.check_range()                             # the explicit check point (schedulers / pipelines): reads and resets
     _ffi.call("wf_f16_overflow_flag", ctypes.byref(flag), 1, ops.stream())
     assert flag.value == 0
+    m._note_range("clean")
+    m.check_range()                                 # nothing raised since the reset
+    # a flag raised by one call surfaces at the NEXT VAE call even without an explicit check (once its copy has landed)
+    _ffi.call("wf_split_f16x3", src.data_ptr(), 32, dst.data_ptr(), 96, 4, 32, 0, ops.stream())
+    m._note_range("first")
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="AutoencoderKLWan.first"):
+        m._note_range("second")
+    _ffi.call("wf_f16_overflow_flag", ctypes.byref(flag), 1, ops.stream())
     with pytest.raises(ValueError, match="fp16 range"):
         w = ovae.random_weights(seed=5)
         k = next(k for k in w if k.endswith("residual.2.weight"))
         w[k] = w[k].clone()
         w[k].view(-1)[0] = 1.0e5
         AutoencoderKLWan(DEV, precision="fp16x3").load_state_dict(w)
+
+
+def test_vae_decode_returns_while_the_gpu_is_still_busy(model_fp32):
+    """No host synchronisation inside encode / decode (round 5: the fp16 range flag is copied asynchronously and checked later): with
+    ~100 ms of GEMMs queued in front, decode() and encode() must come back to the host before the GPU has reached their work."""
+    from worldforge_amd import dit
+    a = torch.randn(8192, 8192, device=DEV).to(torch.bfloat16)
+    out = torch.empty(8192, 8192, dtype=torch.bfloat16, device=DEV)
+    z = torch.randn(1, 16, 2, 8, 8, device=DEV)
+    video = torch.rand(1, 3, 5, 64, 64, device=DEV) * 2 - 1
+    model_fp32.decode(z, return_dict=False)          # warm (allocations, packed weights)
+    model_fp32.encode(video)
+    model_fp32.check_range()
+    torch.cuda.synchronize()
+    for _ in range(100):                             # ~1 ms each
+        dit.gemm(a, a, None, out, dit.EPI_BF16)
+    ev = torch.cuda.Event()
+    model_fp32.decode(z, return_dict=False)
+    model_fp32.encode(video)
+    ev.record()
+    assert not ev.query(), "encode / decode synchronised the host with the stream"
+    model_fp32.check_range()                         # the explicit check point does wait
+    assert ev.query()
 
 
 @pytest.mark.parametrize("side", [0, 1])

@@ -62,12 +62,44 @@ def _worker(rank, world, port, L, H, ret):
     b = torch.full((3,), float(rank))
     comm.broadcast(b, src=0)
     ok &= float(b.sum()) == 0.0
-    # the segmented exchange (round 4): this rank's shard sits in its own slot, the peers' slots arrive by per-source broadcasts
-    k_seg = torch.full((world, H, plan.shard_len, 8), -7.0)
-    k_seg[rank] = k_loc
-    evs = comm.exchange_segments_async(k_seg)
-    ok &= len(evs) == world and all(e is None for e in evs)   # CPU: synchronous, nothing to wait for
-    ok &= torch.equal(k_seg, k_all)
+    # the packed exchange (round 5, parallel.KVExchange): every rank writes its K shard, V^T shard and norm bounds into ITS slot of the
+    # exchange buffers (chunk by chunk) and the collectives fill the peers' slots in place -- one collective per layer ("gather"), per
+    # chunk ("chunked": chunk g = the g-th 1/G of every rank's keys) or per source ("bcast"), each carrying K AND V^T AND the bounds
+    import torch.distributed as dist
+    Hx, S = 2, plan.shard_len
+
+    def fill(r, g, ex):  # what rank r puts into chunk g: a function of (rank, chunk) only
+        sc = ex.chunk_len(g)
+        base = 100.0 * r + 10.0 * g
+        return (torch.full((Hx, sc, 128), base + 1), torch.full((Hx, sc // 64, 128, 64), base + 2), torch.full((Hx,), base + 3))
+
+    for mode, chunks, want_calls in (("gather", 1, [("all_gather", None)]), ("chunked", 2, [("all_gather", None)] * 2),
+                                     ("bcast", 1, [("broadcast", s) for s in range(world)])):
+        ex = parallel.KVExchange(comm, Hx, S, mode, chunks, device="cpu")
+        ok &= ex.collectives() == [(k, i if k == "all_gather" else s) for i, (k, s) in enumerate(want_calls)]
+        for g in range(ex.G):
+            kk, vv, mm = fill(rank, g, ex)
+            ex.own_k(g).copy_(kk.bfloat16())
+            ex.own_vt(g).copy_(vv.bfloat16())
+            ex.own_km(g).copy_(mm)
+        calls = []
+        real_ag, real_bc = dist.all_gather, dist.broadcast
+        dist.all_gather = lambda outs, inp, group=None: (calls.append(("all_gather", None, inp.numel())), real_ag(outs, inp, group=group))[1]
+        dist.broadcast = lambda t, src=0, group=None: (calls.append(("broadcast", src, t.numel())), real_bc(t, src=src, group=group))[1]
+        try:
+            evs = ex.launch()
+        finally:
+            dist.all_gather, dist.broadcast = real_ag, real_bc
+        # the issue order every rank must share, and ONE collective per chunk / source carrying the whole slot (K, V^T and bounds together)
+        ok &= [(k, s_) for k, s_, _ in calls] == want_calls
+        ok &= [n for _, _, n in calls] == [ex.bufs[g if mode == "chunked" else 0].shape[1] for g in range(len(calls))] if mode != "bcast" else \
+            all(n == ex.bufs[0].shape[1] for _, _, n in calls)
+        ok &= len(evs) == len(want_calls) and all(e is None for e in evs)   # CPU: synchronous, nothing to wait for
+        for r in range(world):
+            for g in range(ex.G):
+                kk, vv, mm = fill(r, g, ex)
+                ok &= torch.equal(ex.k[g][r].float(), kk) and torch.equal(ex.vt[g][r].float(), vv) and torch.equal(ex.km[g][r], mm)
+        ex.wait_all()
     comm.barrier()
     ret[rank] = bool(ok)
     torch.distributed.destroy_process_group()
@@ -79,6 +111,41 @@ def test_gloo_world2_gather_layout():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), 200, 3, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def _split_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from worldforge_amd import parallel
+    comm = parallel.init(world, rank, 0, backend="gloo")
+    sub = comm.split(2)   # CFG groups x sequence shards (2 x world / 2)
+    per = world // 2
+    ok = (sub.world, sub.rank, sub.group_index, sub.ranks) == (per, rank % per, rank // per, list(range(rank // per * per, rank // per * per + per)))
+    # collectives of a sub-group stay inside it; group-local source indices of the slot broadcasts map to the right global ranks
+    mine = torch.full((3,), float(rank))
+    out = torch.empty(per, 3)
+    sub.all_gather(out, mine)
+    ok &= out[:, 0].tolist() == [float(r) for r in sub.ranks]
+    ex = parallel.KVExchange(sub, 2, 64, "bcast", 1, device="cpu")
+    ex.own_k().fill_(float(rank))
+    ex.launch()
+    ok &= [float(ex.k[0][j].max()) for j in range(per)] == [float(r) for r in sub.ranks]
+    # ... while the whole job still gathers over everyone (the velocity exchange between the two CFG groups, pipeline.cfg_split)
+    allv = torch.empty(world, 3)
+    comm.all_gather(allv, mine)
+    ok &= allv[:, 0].tolist() == [float(r) for r in range(world)]
+    comm.barrier()
+    ret[rank] = bool(ok)
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gloo_world4_cfg_groups():
+    world = 4
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_split_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
 
 
@@ -116,9 +183,9 @@ def test_loopback_comm_serves_collectives_locally():
 
 
 def test_segment_groups_own_shard_first_then_arrival_order():
-    """dit.segment_groups: the runs of consecutive physical key segments a rank walks -- its own shard first (no wait), then the peers in
+    """parallel.segment_groups: the runs of consecutive physical key segments a rank walks -- its own shard first (no wait), then the peers in
     source order (the order of the per-source broadcasts), never crossing the own shard, at most peer_groups + 2 runs, every segment once."""
-    from worldforge_amd.dit import segment_groups
+    from worldforge_amd.parallel import segment_groups
     assert segment_groups(8, 0) == [(0, 1), (1, 5), (5, 8)]
     assert segment_groups(8, 3) == [(3, 4), (0, 3), (4, 8)]
     assert segment_groups(8, 7) == [(7, 8), (0, 4), (4, 7)]
@@ -134,10 +201,73 @@ def test_segment_groups_own_shard_first_then_arrival_order():
                 assert all(not (a <= r < b) for a, b in runs[1:])
 
 
-def test_loopback_comm_serves_the_segmented_exchange():
+class _NoComm:
+    def __init__(self, world, rank):
+        self.world, self.rank = world, rank
+
+
+def _slots(n, k):
+    tps = -(-n // k)
+    return -(-n // tps)
+
+
+@pytest.mark.parametrize("mode,chunks", [("chunked", 1), ("chunked", 2), ("chunked", 3), ("chunked", 4), ("bcast", 1)])
+def test_sweep_plan_covers_every_valid_key_once_own_shard_first(mode, chunks):
+    """parallel.sweep_plan (the part launches of an own-first sweep): for every rank, every valid 64-key tile of every chunk buffer is
+    walked exactly once; the rank's own windows come first and wait for nothing; a peer window waits for the event of ITS chunk (chunked:
+    event g = all-gather g) or of its LAST source (bcast) and reads the norm bounds of arrived slots only; the partial slots are
+    contiguous, at most 12; second windows lie behind the first (the hole is the own segment).  Also for key prefixes (LongCat's
+    condition rows see the first frames only)."""
+    from worldforge_amd.parallel import MAX_ATTN_PARTS, KVExchange, shard_plan, sweep_plan
+    for L, P in ((32760, 8), (32760, 4), (32760, 2), (4524, 3), (37440, 8), (1000, 8)):
+        plan = shard_plan(L, P)
+        for r in range(P):
+            ex = KVExchange(_NoComm(P, r), 2, plan.shard_len, mode, chunks, device="cpu")
+            assert sum(ex.chunk_len(g) for g in range(ex.G)) == plan.shard_len
+            for kv_len in (L, L // 9 + 1, plan.shard_len, 64):
+                for wgs in (640, 2560):
+                    steps, nparts = sweep_plan(ex, kv_len, wgs)
+                    assert 1 <= nparts <= MAX_ATTN_PARTS
+                    seen = {g: [] for g in range(ex.G)}
+                    slot, peers_started = 0, False
+                    for st in steps:
+                        g, (t0, t1, k1), w2 = st["chunk"], st["win"], st["win2"]
+                        tps = ex.chunk_len(g) // 64
+                        assert st["slot"] == slot and t0 < t1 and k1 >= 1
+                        slot += _slots(t1 - t0, k1)
+                        seen[g] += list(range(t0, t1))
+                        if w2:
+                            assert w2[0] >= t1 and w2[0] < w2[1] and (t1, w2[0]) == (r * tps, (r + 1) * tps)   # the hole is the own segment
+                            slot += _slots(w2[1] - w2[0], w2[2])
+                            seen[g] += list(range(w2[0], w2[1]))
+                        own = st["wait"] is None
+                        if own:
+                            assert not peers_started and t0 >= r * tps and t1 <= (r + 1) * tps and st["km"] == (r, 1)
+                        else:
+                            peers_started = True
+                            a, n = st["km"]
+                            segs = {t // tps for t in range(t0, t1)} | ({t // tps for t in range(w2[0], w2[1])} if w2 else set())
+                            assert r not in segs and segs <= set(range(a, a + n))
+                            if mode == "chunked":
+                                assert st["wait"] == g and (a, n) == (0, P)
+                            else:
+                                assert st["wait"] == max(segs) and a + n - 1 == st["wait"]   # only slots that have arrived by then
+                    assert slot == nparts
+                    for g in range(ex.G):
+                        valid = -(-ex.chunk_kv_len(kv_len, g) // 64)
+                        assert sorted(seen[g]) == list(range(valid)), (L, P, r, g, kv_len)
+                    assert sum(ex.chunk_kv_len(kv_len, g) for g in range(ex.G)) == min(kv_len, P * plan.shard_len)
+
+
+def test_loopback_comm_serves_the_packed_exchange():
     from worldforge_amd import parallel
     c = parallel.LoopbackComm(4, 2)
-    out = torch.zeros(4, 3, 5)
-    out[2] = torch.arange(15.0).view(3, 5)
-    evs = c.exchange_segments_async(out)
-    assert len(evs) == 4 and all(torch.equal(out[r], out[2]) for r in range(4))
+    for mode, chunks in (("gather", 1), ("chunked", 2), ("bcast", 1)):
+        ex = parallel.KVExchange(c, 2, 128, mode, chunks, device="cpu")
+        for g in range(ex.G):
+            ex.own_k(g).fill_(3.0 + g)
+            ex.own_km(g).fill_(7.0)
+        evs = ex.launch()
+        assert len(evs) == (4 if mode == "bcast" else ex.G)
+        for g in range(ex.G):
+            assert all(torch.equal(ex.bufs[g][r], ex.bufs[g][2]) for r in range(4)) and float(ex.km[g].min()) == 7.0

@@ -134,13 +134,29 @@ bad("wf_gemm_f16_batched", buf(64), buf(64), buf(64), 1, 4, 4, 8, 8, 8, 4, 0, 0,
 # attention: dense, split (workspace), sparse
 H, Lq, Lkp = 8, 1000, 1024
 Q, K, V, O = buf(2 * H * Lq * 128), buf(2 * H * Lkp * 128), buf(2 * H * Lkp * 128), buf(2 * Lq * H * 128)
-ok("wf_attn_fwd", Q, K, V, O, H, Lq, Lkp, 1000, Lkp, H * 128, 0.0884, 0, None, 0, None, 0, None)
-ok("wf_attn_fwd", Q, K, V, O, H, Lq, Lkp, 1000, 512, H * 128, 0.0, 1, f32(2 * H), 2, f32(H), 1, None)    # two gathered shards, pre-scaled Q
+ok("wf_attn_fwd", Q, K, V, O, H, Lq, Lkp, 1000, Lkp, 0, H * 128, 0.0884, 0, None, 0, 0, None, 0, None)
+ok("wf_attn_fwd", Q, K, V, O, H, Lq, Lkp, 1000, 512, 0, H * 128, 0.0, 1, f32(2 * H), 2, 0, f32(H), 1, None)    # two gathered shards, pre-scaled Q
 ws = buf(dll.wf_attn_split_workspace_bytes(H, Lq, 2))
-ok("wf_attn_fwd_split", Q, K, V, O, H, Lq, Lkp, 1000, Lkp, H * 128, 0.0, 0, 2, ws, f32(H), 1, f32(H), 1, None)
-bad("wf_attn_fwd", Q, K, V, O, H, Lq, 1000, 1000, 1000, H * 128, 0.0884, 0, None, 0, None, 0, None)      # Lkp not a multiple of 64
-bad("wf_attn_fwd_split", Q, K, V, O, H, Lq, Lkp, 1000, Lkp, H * 128, 0.0, 0, 2, None, None, 0, None, 0, None)   # split without workspace
-bad("wf_attn_fwd", Q + 2, K, V, O, H, Lq, Lkp, 1000, Lkp, H * 128, 0.0884, 0, None, 0, None, 0, None)    # misaligned Q
+ok("wf_attn_fwd_split", Q, K, V, O, H, Lq, Lkp, 1000, Lkp, 0, H * 128, 0.0, 0, 2, ws, f32(H), 1, 0, f32(H), 1, None)
+bad("wf_attn_fwd", Q, K, V, O, H, Lq, 1000, 1000, 1000, 0, H * 128, 0.0884, 0, None, 0, 0, None, 0, None)      # Lkp not a multiple of 64
+bad("wf_attn_fwd_split", Q, K, V, O, H, Lq, Lkp, 1000, Lkp, 0, H * 128, 0.0, 0, 2, None, None, 0, 0, None, 0, None)   # split without workspace
+bad("wf_attn_fwd", Q + 2, K, V, O, H, Lq, Lkp, 1000, Lkp, 0, H * 128, 0.0884, 0, None, 0, 0, None, 0, None)    # misaligned Q
+# packed exchange slots (parallel.KVExchange): 4 sources x [K | V^T | bounds], 256 keys each; own-first part launches + merge
+seg, P4 = 256, 4
+slot = 2 * (2 * H * seg * 128) + 256                      # bytes
+X = buf(P4 * slot)
+Kx, Vx, KMx = X, X + 2 * H * seg * 128, X + 4 * H * seg * 128
+ok("wf_attn_fwd", Q, Kx, Vx, O, H, Lq, P4 * seg, 1000, seg, slot, H * 128, 0.0, 0, KMx, P4, slot // 4, f32(H), 1, None)
+bad("wf_attn_fwd", Q, Kx, Vx, O, H, Lq, P4 * seg, 1000, seg, H * seg * 256 - 16, H * 128, 0.0, 0, None, 0, 0, None, 0, None)   # a slot shorter than its K shard
+bad("wf_attn_fwd", Q, Kx, Vx, O, H, Lq, P4 * seg, 1000, seg, slot, H * 128, 0.0, 0, KMx, P4, H - 1, f32(H), 1, None)  # bound vectors overlap
+ws6 = buf(dll.wf_attn_split_workspace_bytes(H, Lq, 4))
+ok("wf_attn_fwd_part", Q, Kx, Vx, H, Lq, P4 * seg, 1000, seg, slot, 4, 8, 1, 0, 0, 0, 0, 4, ws6, KMx + slot, 1, slot // 4, f32(H), 1, None)     # own segment 1
+ok("wf_attn_fwd_part", Q, Kx, Vx, H, Lq, P4 * seg, 1000, seg, slot, 0, 4, 1, 8, 16, 2, 1, 4, ws6, KMx, P4, slot // 4, f32(H), 1, None)          # peers: before + after in 1 + 2 splits
+ok("wf_attn_merge", O, H, Lq, H * 128, 0, 4, ws6, None)
+bad("wf_attn_fwd_part", Q, Kx, Vx, H, Lq, P4 * seg, 1000, seg, slot, 0, 4, 1, 2, 16, 2, 1, 4, ws6, None, 0, 0, None, 0, None)                  # second window overlaps the first
+bad("wf_attn_fwd_part", Q, Kx, Vx, H, Lq, P4 * seg, 1000, seg, slot, 0, 4, 1, 8, 16, 2, 2, 4, ws6, None, 0, 0, None, 0, None)                  # slots 2..4 of 4
+bad("wf_attn_fwd_part", Q, Kx, Vx, H, Lq, P4 * seg, 1000, seg, slot, 16, 20, 1, 0, 0, 0, 0, 4, ws6, None, 0, 0, None, 0, None)                 # window behind the last valid tile
+bad("wf_attn_merge", O, H, Lq, H * 128, 0, 13, ws6, None)                                                                                # more than 12 slots
 ok("wf_head_max_norm2", K, H, 1000, Lkp, f32(H), None)
 ok("wf_attn_cross2_fwd", Q, buf(2 * H * 832 * 128), buf(2 * H * 832 * 128), O, H, Lq, 320, 257, 512, 512, H * 128, 0.0884, None)
 bad("wf_attn_cross2_fwd", Q, K, V, O, H, Lq, 320, 200, 512, 512, H * 128, 0.0884, None)                  # context 1 leaves a whole tile empty
@@ -203,17 +219,19 @@ ok("wf_rms_silu_cl_blocked", f32(npix * Ci), f32(Ci), buf(2 * npix * 2 * Ci), np
 ok("wf_split_bf16x3", f32(npix * Ci), Ci, buf(2 * npix * 3 * Ci), 3 * Ci, npix, Ci, 0, None)
 # the fp16 operand formats (round 4): the same host paths with the element type flag set
 ok("wf_conv3d_cl_f16", buf(2 * T_ * H_ * W_ * Ci), buf(2 * Co * 27 * Ci), f32(Co), None, f32(T_ * H_ * W_ * Co), None, T_, H_, W_, Ci, T_, H_, W_, Co,
-   3, 3, 3, 1, 1, 2, 1, 1, 0, 0, zp, None)
+   3, 3, 3, 1, 1, 2, 1, 1, 0, 0, zp, 2.0 ** -14, None)
+bad("wf_conv3d_cl_f16", buf(2 * T_ * H_ * W_ * Ci), buf(2 * Co * 27 * Ci), f32(Co), None, f32(T_ * H_ * W_ * Co), None, T_, H_, W_, Ci, T_, H_, W_, Co,
+    3, 3, 3, 1, 1, 2, 1, 1, 0, 0, zp, 0.0, None)                                                          # acc_scale must be positive
 ok("wf_conv3d_cl_scatter_f16", buf(2 * T_ * H_ * W_ * Ci), buf(2 * Co * 4 * Ci), f32(Co), None, f32(T_ * 2 * H_ * 2 * W_ * Co), None, T_, H_, W_, Ci, T_, H_, W_, Co,
-   1, 2, 2, 1, 1, 0, 1, 1, zp, 2 * H_, 2 * W_, 2, 0, 2, 0, None)
+   1, 2, 2, 1, 1, 0, 1, 1, zp, 2 * H_, 2 * W_, 2, 0, 2, 0, 1.0, None)
 ok("wf_conv3d_333_f16", buf(2 * T_ * H_ * W_ * Ci), buf(2 * 27 * (Ci // 16) * Co * 16), f32(Co), None, f32(T_ * H_ * W_ * Co), None, T_, H_, W_, Ci, H_, Co, 1,
-   zp, 4096, 0, Ci, None)
+   zp, 4096, 0, Ci, 2.0 ** -17, None)
 ok("wf_rms_silu_cl_x3_f16", f32(npix * Ci), f32(Ci), buf(2 * npix * 3 * Ci), npix, Ci, 1, None)
 ok("wf_rms_silu_cl_blocked_f16", f32(npix * Ci), f32(Ci), buf(2 * npix * 2 * Ci), npix, Ci, 1, W_, 1, 0, None)
 ok("wf_split_f16x3", f32(npix * Ci), Ci, buf(2 * npix * 3 * Ci), 3 * Ci, npix, Ci, 0, None)
 for (M, N, K, epi) in ((4095, 1152, 1152, 2), (300, 384, 1152, 4), (2048, 2560, 384, 0)):
-    ok("wf_gemm_f16", buf(2 * M * K), buf(2 * N * K), f32(N), buf((2 if epi == 0 else 4) * M * N), M, N, K, K, K, N, epi, None)
-bad("wf_gemm_f16", buf(64), buf(64), None, buf(64), 4, 4, 8, 8, 8, 4, 3, None)                           # the gated-residual epilogue is not built for fp16 operands
+    ok("wf_gemm_f16", buf(2 * M * K), buf(2 * N * K), f32(N), buf((2 if epi == 0 else 4) * M * N), M, N, K, K, K, N, epi, 0.25, None)
+bad("wf_gemm_f16", buf(64), buf(64), None, buf(64), 4, 4, 8, 8, 8, 4, 3, 1.0, None)                           # the gated-residual epilogue is not built for fp16 operands
 ok("wf_softmax_rows", f32(40 * 48), 48, buf(2 * 40 * 48), 48, 40, 48, 0.5, None)
 ok("wf_softmax_rows_f32", f32(40 * 48), 48, f32(40 * 48), 48, 40, 48, 0.5, None)
 ok("wf_transpose_bf16", buf(2 * 40 * 48), 48, buf(2 * 48 * 40), 40, 40, 48, None)

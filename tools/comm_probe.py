@@ -13,10 +13,12 @@ three things no one-GPU box can show, and this probe measures them at PRODUCTION
   C  both at once (gather on the communication stream, attention on the compute stream): how much each slows the other -- RCCL's copy
      kernels need CUs, the attention kernel occupies every CU it runs on (160 KiB LDS, 512 registers per lane);
   D  what the DiT itself sees: `comm_exposed_ms_per_layer` of a few lock-step layers (HIP events around the compute stream's wait);
-  E  (round 4) the same for ONE forward on its own -- no second CFG branch to hide under: LongCat-Video, distilled schedules, guidance <= 1 --
-     with the one-event all-gather (only the Q projection overlaps) and with the SEGMENTED exchange (per-source broadcasts; the attention
-     walks its own shard at once and each later run of segments when its event fires: dit.attention_segmented);
-  F  the bare per-source broadcasts of that exchange against the all-gather of A.
+  E  the same for ONE forward on its own -- no second CFG branch to hide under: LongCat-Video, distilled schedules, guidance <= 1 -- in
+     every exchange mode of parallel.KVExchange (round 5): "gather" (one all-gather of the packed [K | V^T | bounds] slots, one launch: only
+     the Q projection overlaps), "chunked1/2/4" (G all-gathers, the attention walks its own shard at once and every peer's chunk g after
+     all-gather g), "bcast" (per-source broadcasts, own shard first, peers in arrival order): dit.attention_exchange;
+  F  the bare collectives of those modes on the packed buffers (all-gather, 2 / 4 chunk all-gathers, P broadcasts) against the two
+     all-gathers of A.
 
 `--sweep` (launcher only): the whole probe once per RCCL setting -- NCCL_MAX_NCHANNELS in {4, 8, 16, 32} and NCCL_PROTO in {default, Simple,
 LL128} (the settings must be in the environment before the communicator exists, so every setting is a fresh set of rank processes) --
@@ -96,13 +98,16 @@ def sweep(a, argv):
         rows.append((name, d))
         print(json.dumps({"setting": name, **d}), flush=True)
     f = lambda v, spec=".3f": "-" if v is None else format(v, spec)  # noqa: E731
-    print("\n| RCCL setting | channels | A all-gather ms | F broadcasts ms | A per-link GB/s | B attention ms | C attention under gather x | "
-          "D pair: exposed ms / layer | E single, one event: exposed | E single, segmented: exposed |\n|---|---|---|---|---|---|---|---|---|---|")
+    modes = ["gather1", "chunked1", "chunked2", "chunked4", "bcast1"]
+    print("\n| RCCL setting | channels | A all-gather ms | A per-link GB/s | B attention ms | C attention under gather x | "
+          "D pair: exposed ms / layer | " + " | ".join(f"F bare {m} ms" for m in modes) + " | "
+          + " | ".join(f"E single {m}: layer ms (exposed)" for m in modes) + " |\n|" + "---|" * (7 + 2 * len(modes)))
     for name, d in rows:
-        print(f"| {name} | {(d.get('rccl') or {}).get('channels')} | {f(d['A_allgather_ms'])} | {f(d.get('F_broadcasts_ms'))} | "
+        fb, es = d.get("F_bare_collectives_ms") or {}, d.get("E_single_forward") or {}
+        print(f"| {name} | {(d.get('rccl') or {}).get('channels')} | {f(d['A_allgather_ms'])} | "
               f"{f(d['A_per_link_GBps_if_all_pairs'], '.1f')} | {f(d['B_attention_alone_ms'])} | {f(d['C_attention_slowdown'])} | "
-              f"{f(d['D_comm_exposed_ms_per_layer'])} | {f(d.get('E_single_one_event_exposed_ms_per_layer'))} | "
-              f"{f(d.get('E_single_segmented_exposed_ms_per_layer'))} |")
+              f"{f(d['D_comm_exposed_ms_per_layer'])} | " + " | ".join(f(fb.get(m)) for m in modes) + " | "
+              + " | ".join(f"{f((es.get(m) or {}).get('layer_ms'))} ({f((es.get(m) or {}).get('exposed_ms_per_layer'))})" for m in modes) + " |")
     return 0 if rows else 1
 
 
@@ -214,7 +219,8 @@ def main(argv=None):
         tc_attn.append(s.elapsed_time(e))
     # D: a few real-width lock-step layers
     exposed = layer_ms = None
-    single = {False: (0.0, 0.0), True: (0.0, 0.0)}
+    MODES = [("gather", 1), ("chunked", 1), ("chunked", 2), ("chunked", 4), ("bcast", 1)]
+    single = {m: (0.0, 0.0) for m in MODES}
     if a.layers > 0:
         cfg = dit.DiTConfig.wan_i2v_14b()
         cfg.num_layers = a.layers
@@ -237,9 +243,9 @@ def main(argv=None):
             ex = [dit.comm_wait_ms(e) for e in prof]
             exposed = sum(ex) / max(len(ex), 1)
             layer_ms = pair_ms / (2 * a.layers)
-            # E: ONE forward on its own, with the one-event all-gather and with the segmented exchange
-            for mode in (False, True):
-                model.segmented_exchange = mode
+            # E: ONE forward on its own in every exchange mode
+            for mode in MODES:
+                model.exchange_mode, model.exchange_chunks = mode
                 model.forward_tokens(x, 500.0, ctx_a, clip)   # warm
                 sync_all()
                 dit.PROFILE_COMM = []
@@ -250,22 +256,26 @@ def main(argv=None):
                 prof, dit.PROFILE_COMM = dit.PROFILE_COMM, None
                 ex = [dit.comm_wait_ms(e) for e in prof]
                 single[mode] = (sum(ex) / max(len(ex), 1), one_ms / a.layers)
-    # F: the bare per-source broadcasts (K and V^T: 2 P broadcasts) against the all-gather of A
-    tf = []
-    for _ in range(a.iters):
-        sync_all()
-        t0 = time.perf_counter()
-        e1 = comm.exchange_segments_async(k_all)
-        e2 = comm.exchange_segments_async(v_all)
-        for ev in (e1[-1], e2[-1]):
-            if ev is not None:
-                ev.synchronize()
-        torch.cuda.synchronize()
-        tf.append(1e3 * (time.perf_counter() - t0))
-    mine = torch.tensor([_median(ta), _median(tb), _median(tc_attn), _median(tc_wall), exposed or 0.0, layer_ms or 0.0,
-                         single[False][0], single[False][1], single[True][0], single[True][1], _median(tf)],
+    # F: the bare collectives of every mode on the packed exchange buffers
+    tf = {}
+    for mode in MODES:
+        kvx = parallel.KVExchange(comm, H, S, mode[0], mode[1], dev)
+        ts = []
+        for _ in range(a.iters):
+            sync_all()
+            t0 = time.perf_counter()
+            evs = kvx.launch()
+            if evs[-1] is not None:
+                evs[-1].synchronize()
+            torch.cuda.synchronize()
+            ts.append(1e3 * (time.perf_counter() - t0))
+        tf[mode] = _median(ts)
+        del kvx
+    nm = len(MODES)
+    mine = torch.tensor([_median(ta), _median(tb), _median(tc_attn), _median(tc_wall), exposed or 0.0, layer_ms or 0.0]
+                        + [single[m][0] for m in MODES] + [single[m][1] for m in MODES] + [tf[m] for m in MODES],
                         dtype=torch.float64, device=dev)
-    allr = torch.empty((world, 11), dtype=torch.float64, device=dev)
+    allr = torch.empty((world, 6 + 3 * nm), dtype=torch.float64, device=dev)
     comm.all_gather(allr, mine)
     if rank == 0:
         r = allr.cpu()
@@ -282,11 +292,9 @@ def main(argv=None):
                "D_layers": a.layers, "D_comm_exposed_ms_per_layer": worst[4] if exposed is not None else None,
                "D_layer_ms": worst[5] if layer_ms is not None else None,
                "D_exposed_frac_of_layer": (worst[4] / worst[5]) if exposed is not None and worst[5] > 0 else None,
-               "E_single_one_event_exposed_ms_per_layer": worst[6] if exposed is not None else None,
-               "E_single_one_event_layer_ms": worst[7] if exposed is not None else None,
-               "E_single_segmented_exposed_ms_per_layer": worst[8] if exposed is not None else None,
-               "E_single_segmented_layer_ms": worst[9] if exposed is not None else None,
-               "F_broadcasts_ms": worst[10],
+               "E_single_forward": {f"{m}{c}": {"exposed_ms_per_layer": worst[6 + i] if exposed is not None else None,
+                                                "layer_ms": worst[6 + nm + i] if exposed is not None else None} for i, (m, c) in enumerate(MODES)},
+               "F_bare_collectives_ms": {f"{m}{c}": worst[6 + 2 * nm + i] for i, (m, c) in enumerate(MODES)},
                "per_rank": [{"rank": i, "allgather_ms": v[0], "attn_ms": v[1], "attn_under_gather_ms": v[2]} for i, v in enumerate(r.tolist())]}
         logdir = os.environ.get("WF_PROBE_LOGDIR")
         if logdir and os.path.isdir(logdir):

@@ -80,8 +80,8 @@ if __name__ == "__main__":
     for var in (0, 1, 2, 3, 4):
         for data in (0, 1):
             run(f"{names[var]}, {'N(0,1)' if data else 'zeros'}", [LAB, str(var), str(data), "4"])
-    for kern, env_k in (("ping-pong 320-wide tile (default)", {}), ("ping-pong 256-wide tile", {"WF_GEMM_TILE": "256"}),
-                        ("one wave per SIMD (k_gemm_w4)", {"WF_GEMM_KERNEL": "w4"})):
+    # (round 5: `k_gemm_w4` / `k_gemm_pp16` were removed from the library; WF_GEMM_TILE is read by lab builds only, -DWF_GEMM_LAB_TILE)
+    for kern, env_k in (("ping-pong 320-wide tile (default)", {}), ("ping-pong 256-wide tile (lab build)", {"WF_GEMM_TILE": "256"})):
         for data in ("zeros", "random"):
             env = dict(os.environ, DATA=data, SECONDS="6", **env_k)
             run(f"QKV GEMM 32760 x 15360 x 5120, {kern}, {'N(0,1)' if data == 'random' else 'zeros'}", [sys.executable, "-c", GEMM_CHILD], env=env, seconds=6.0)

@@ -39,6 +39,7 @@ SOURCES = {
     "warp.hip": ["-ffp-contract=off"],
     "crackfill.hip": ["-ffp-contract=off"],
     "pointrender.hip": ["-ffp-contract=off"],
+    "calib.hip": [],
 }
 
 

@@ -55,6 +55,10 @@ struct AttnArgs {
   uint16_t* O;
   int H, Lq, Lkp, kv_len, ldo;
   int seg_len;  // keys per K/V segment (= Lkp, or the per-rank shard length when K/V were all-gathered: [P][H][seg_len][128])
+  // bytes from a head's first tile in one segment to the same head's first tile in the next one, in K and in V^T alike: H * seg_len * 256
+  // for the dense [P][H][seg_len][128] form; larger when each source's K, V^T (and norm bounds) travel in ONE packed slot of an exchange
+  // buffer (parallel.KVExchange: [P][K | V^T | bounds])
+  size_t seg_stride;
   int n_qblk;
   float scale_log2;  // softmax_scale * log2(e)
   int accumulate;    // O += result (second cross-attention, model.py:227)
@@ -64,6 +68,9 @@ struct AttnArgs {
   // KV-tile window of this launch (wf_attn_fwd_part: the segments that have ARRIVED so far): split s starts at absolute tile
   // t_begin0 + s * tiles_per_split, no tile >= t_end is touched, and the partials land in slot part0 + s.  Whole-sweep launches: 0, INT_MAX, 0.
   int t_begin0, t_end, part0;
+  // optional SECOND window of a part launch (the keys on the far side of a hole -- the rank's own segment, walked earlier without a wait):
+  // splits s >= n_first work on tiles [t_begin2 + (s - n_first) * tiles_per_split2, ...) below t_end2.  Launches with one window: n_first = INT_MAX
+  int n_first, t_begin2, t_end2, tiles_per_split2;
   float* o_part;   // [nsplit][Lq][H*128] f32
   float* ml_part;  // [nsplit][H][Lq][2] f32: reference max m (raw score units), row sum l
   // block-sparse attention (KIND 3): per (head, 256-row query group) a list of 128-key blocks to visit, entry = block * 4 + flags,
@@ -77,6 +84,7 @@ struct AttnArgs {
   const float* kmax2;
   const float* qmax2;
   int kmax_n, qmax_n;
+  int kmax_stride;  // floats between two kmax2 vectors (H when they are contiguous; the packed exchange slots carry one vector each)
   // KIND 5 (two-context cross-attention, model.py:202-229): the key sequence is [n1 tiles of context 1 (kv_len1 valid keys) | the tiles of
   // context 2 (kv_len valid keys)]; the softmax is taken over each context separately and the two results are summed
   int kv_len1, n1;
@@ -138,6 +146,16 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BUF_BYTES = K_TILE_BYTES + V_TILE_BYTES;
   constexpr int NBUF = 5;  // ring of 5 tile buffers = the whole 160 KiB: lets the workgroup barrier run every SECOND tile
+  // The LDS of this kernel is ONE ring, nothing is overlaid on it (no epilogue staging: O leaves through registers); what the
+  // hand-placed LDS-DMA pieces and the barrier-every-second-tile schedule rely on (guarded, not just commented):
+  static_assert(NBUF * BUF_BYTES == 160 * 1024, "the ring is the whole LDS of a CU and the launch asks for exactly that (attn_launch: lds_w4)");
+  static_assert((NT4 / 64) * 4 * 1024 == K_TILE_BYTES && (NT4 / 64) * 4 * 1024 == V_TILE_BYTES,
+                "4 waves x (4 K + 4 V^T) pieces of 1 KiB (64 lanes x 16 B) cover a K tile and a V^T tile exactly: no piece may spill into the next ring slot");
+  static_assert(K_TILE_BYTES % 1024 == 0 && BUF_BYTES % 16 == 0, "piece granularity / ds_read_b128 alignment of the slots");
+  // tiles are staged 3 ahead of the one being consumed and the workgroup barrier runs once per TWO tiles: while a wave still reads tile t
+  // (and its K(t+1) head), the fastest wave may already stage tile t + 3 + 1 -- the slot being written must not be one of the slots
+  // t .. t + 1 still being read: needs at least 2 (being read) + 3 (staged ahead) slots
+  static_assert(NBUF >= 2 + 3, "ring too short for the 3-ahead staging with one barrier per two tiles");
 
   const int b = blockIdx.x;
   const int xcd = b & 7, j = b >> 3;
@@ -215,8 +233,10 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
   const float c = PS ? 1.0f : a.scale_log2;
   const int ntiles_all = (KIND == 5 ? a.n1 : 0) + (a.kv_len + KB - 1) / KB;
   const int split = a.part0 + blockIdx.y;                                // partial slot of this split
-  const int t_begin = a.t_begin0 + blockIdx.y * a.tiles_per_split;       // first KV tile of this split (absolute)
-  int ntiles_ = min(a.tiles_per_split, min(ntiles_all, a.t_end) - t_begin);  // tiles of this split (>= 1 by construction of the grid)
+  const bool win2 = (int)blockIdx.y >= a.n_first;                        // (scalar: blockIdx.y is uniform) second window of a part launch
+  const int tps_w = win2 ? a.tiles_per_split2 : a.tiles_per_split;
+  const int t_begin = win2 ? a.t_begin2 + ((int)blockIdx.y - a.n_first) * tps_w : a.t_begin0 + (int)blockIdx.y * tps_w;  // first KV tile of this split (absolute)
+  int ntiles_ = min(tps_w, min(ntiles_all, win2 ? a.t_end2 : a.t_end) - t_begin);  // tiles of this split (>= 1 by construction of the grid)
   // block-sparse variant: per-workgroup list of PHYSICAL key blocks (entry = block * 2^g + flags, g = bsa_shift query blocks per
   // workgroup = 2 waves each for 128-token blocks / 1 wave each for 64-token blocks), tpe tiles per entry
   const int* bsa = nullptr;
@@ -244,9 +264,9 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
   // instructions, no division.  Past the last tile the pieces are still issued (no branch in the MFMA stream): they re-read the last
   // tile into the next ring slots, whose tiles (ntiles-5 ... ntiles-3) are dead by then.
   const size_t tile_bytes = (size_t)(KB * D * 2);
-  const size_t seg_jump = (size_t)(a.H - 1) * tiles_per_seg * tile_bytes;  // to the next K/V segment of the same head (all-gathered shards)
+  const size_t seg_jump = a.seg_stride - (size_t)tiles_per_seg * tile_bytes;  // to the next K/V segment of the same head (all-gathered shards)
   const int seg0 = t_begin / tiles_per_seg, in0 = t_begin - seg0 * tiles_per_seg;
-  size_t st_off = ((size_t)(seg0 * a.H + head) * tiles_per_seg + in0) * tile_bytes;  // byte offset of the staged tile in K and in V^T
+  size_t st_off = (size_t)seg0 * a.seg_stride + ((size_t)head * tiles_per_seg + in0) * tile_bytes;  // byte offset of the staged tile in K and in V^T
   int st_tile = 0, st_left = tiles_per_seg - in0;  // tile number (in the split), tiles left in its segment
   uint32_t st_base = wu * 4096;                    // LDS byte offset of this wave's pieces in the ring slot of the staged tile
   int e_stage = 0, e_mask = 0;                     // KIND 3: list entry of the tile being staged / of the tile whose scores come next
@@ -872,7 +892,7 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
       const int head = ((b >> 3) / a.n_qblk) * 8 + (b & 7);
       if (head < a.H) {
         float kn2 = 0.f, qn2 = 0.f;
-        for (int i = 0; i < a.kmax_n; ++i) kn2 = fmaxf(kn2, a.kmax2[i * a.H + head]);
+        for (int i = 0; i < a.kmax_n; ++i) kn2 = fmaxf(kn2, a.kmax2[(size_t)i * a.kmax_stride + head]);
         for (int i = 0; i < a.qmax_n; ++i) qn2 = fmaxf(qn2, a.qmax2[i * a.H + head]);
         fast = qn2 * kn2 <= 2500.0f;  // B <= 50.  Non-finite rows: k_head_max_norm2 reports +inf for a row holding a NaN or an inf, and
                                       // inf * x is inf (or NaN for x = 0), for which `<=` is false -> the tracked body
@@ -931,15 +951,25 @@ static unsigned int* g_dbg_body = nullptr;  // wf_attn_debug_body_counter
 
 // part_index >= 0: a PART launch (wf_attn_fwd_part) -- KV tiles [part_t0, part_t1) only, un-normalised partials into slot part_index of the
 // `nsplit`-slot workspace, no merge (wf_attn_merge follows once every slot is filled)
+struct PartWindow {  // a part launch (wf_attn_fwd_part): KV tiles [t0, t1) in `inner` splits (+ optionally [t0b, t1b) in `inner_b`)
+  int index = -1, t0 = 0, t1 = 0, inner = 1, t0b = 0, t1b = 0, inner_b = 0;
+};
+constexpr int MAX_PARTS = 12;
+
 static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len, int ldo,
                        float softmax_scale, int accumulate, int nsplit, void* workspace, const float* kmax2, int kmax_n, const float* qmax2,
-                       int qmax_n, void* stream, const char* who, int part_index = -1, int part_t0 = 0, int part_t1 = 0, int part_inner = 1) {
+                       int qmax_n, void* stream, const char* who, size_t seg_stride = 0, int kmax_stride = 0, PartWindow pw = PartWindow()) {
+  const int part_index = pw.index, part_t0 = pw.t0, part_t1 = pw.t1, part_inner = pw.inner;
   WF_CHECK_ARG(Q && K && Vt && O, "%s: null pointer", who);
   WF_CHECK_ARG((!kmax2 || (kmax_n >= 1 && kmax_n <= 64)) && (!qmax2 || (qmax_n >= 1 && qmax_n <= 64)), "%s: kmax_n / qmax_n must be 1..64", who);
   WF_CHECK_ARG(H > 0 && Lq > 0 && kv_len > 0, "%s: empty problem", who);
   WF_CHECK_ARG(Lkp % KB == 0 && kv_len <= Lkp, "%s: Lkp (%d) must be a multiple of 64 and >= kv_len (%d)", who, Lkp, kv_len);
   WF_CHECK_ARG(seg_len > 0 && seg_len % KB == 0 && Lkp % seg_len == 0, "%s: seg_len (%d) must be a multiple of 64 dividing Lkp", who,
                seg_len);
+  const size_t dense_stride = (size_t)H * seg_len * D * 2;
+  WF_CHECK_ARG(seg_stride == 0 || (seg_stride >= dense_stride && seg_stride % 16 == 0),
+               "%s: seg_stride_bytes (%zu) must be 0 (dense) or a multiple of 16 >= H * seg_len * 256 = %zu", who, seg_stride, dense_stride);
+  WF_CHECK_ARG(kmax_stride == 0 || kmax_stride >= H, "%s: kmax_stride (%d) must be 0 (contiguous) or >= H", who, kmax_stride);
   WF_CHECK_ARG(ldo % 8 == 0 && ldo >= H * D, "%s: ldo %d must be a multiple of 8 (16-byte stores) and >= H * 128", who, ldo);
   WF_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O) & 15) == 0, "%s: 16-byte alignment", who);
   AttnArgs a;
@@ -952,21 +982,22 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
   a.Lkp = Lkp;
   a.kv_len = kv_len;
   a.seg_len = seg_len;
+  a.seg_stride = seg_stride ? seg_stride : dense_stride;
+  a.kmax_stride = kmax_stride ? kmax_stride : H;
   a.ldo = ldo;
   a.n_qblk = ceil_div(Lq, QB);
   const bool prescaled = softmax_scale == 0.0f;  // Q already carries softmax_scale * log2(e) (wf_rmsnorm_heads out_scale)
   a.scale_log2 = prescaled ? 1.0f : softmax_scale * 1.4426950408889634f;
   a.accumulate = accumulate;
-  {
-    const char* e = getenv("WF_ATTN_PRIO");
-    a.prio_mode = e ? atoi(e) : 0;
-  }
+  a.prio_mode = 0;
   const int ntiles = ceil_div(kv_len, KB);
   a.nsplit = 1;
   a.tiles_per_split = ntiles;
   a.t_begin0 = 0;
   a.t_end = INT_MAX;
   a.part0 = 0;
+  a.n_first = INT_MAX;
+  a.t_begin2 = a.t_end2 = a.tiles_per_split2 = 0;
   a.o_part = nullptr;
   a.ml_part = nullptr;
   a.bsa_list = nullptr;
@@ -991,8 +1022,19 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
     // inner splits of the window (blockIdx.y): whole rounds of workgroups for short query shards, as wf_attn_fwd_split does for the whole sweep
     const int tps = ceil_div(t1 - part_t0, part_inner < 1 ? 1 : part_inner);
     grid_y = ceil_div(t1 - part_t0, tps);  // splits that actually get tiles
-    WF_CHECK_ARG(nsplit >= 2 && nsplit <= 8 && part_index + grid_y <= nsplit, "%s: slots %d..%d of %d (2..8)", who, part_index,
-                 part_index + grid_y - 1, nsplit);
+    if (pw.inner_b > 0) {  // second window: the tiles beyond a hole (the own segment of the exchange buffer, walked by an earlier launch)
+      WF_CHECK_ARG(pw.t0b >= t1 && pw.t0b < pw.t1b && pw.t0b < ntiles, "%s: second tile window [%d, %d) must lie behind the first [%d, %d) and inside the %d tiles",
+                   who, pw.t0b, pw.t1b, part_t0, t1, ntiles);
+      const int t1b = pw.t1b < ntiles ? pw.t1b : ntiles;
+      const int tps_b = ceil_div(t1b - pw.t0b, pw.inner_b);
+      a.n_first = grid_y;
+      a.t_begin2 = pw.t0b;
+      a.t_end2 = t1b;
+      a.tiles_per_split2 = tps_b;
+      grid_y += ceil_div(t1b - pw.t0b, tps_b);
+    }
+    WF_CHECK_ARG(nsplit >= 2 && nsplit <= MAX_PARTS && part_index + grid_y <= nsplit, "%s: slots %d..%d of %d (2..%d)", who, part_index,
+                 part_index + grid_y - 1, nsplit, MAX_PARTS);
     WF_CHECK_ARG(workspace && (((uintptr_t)workspace) & 15) == 0, "%s: needs a 16-byte aligned workspace", who);
     a.nsplit = nsplit;  // > 1: the kernel leaves un-normalised partials
     a.t_begin0 = part_t0;
@@ -1031,10 +1073,10 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
 }
 
 extern "C" int wf_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len,
-                           int ldo, float softmax_scale, int accumulate, const float* kmax2, int kmax_n, const float* qmax2, int qmax_n,
-                           void* stream) {
+                           size_t seg_stride_bytes, int ldo, float softmax_scale, int accumulate, const float* kmax2, int kmax_n,
+                           int kmax_stride, const float* qmax2, int qmax_n, void* stream) {
   return attn_launch(Q, K, Vt, O, H, Lq, Lkp, kv_len, seg_len, ldo, softmax_scale, accumulate, 1, nullptr, kmax2, kmax_n, qmax2, qmax_n,
-                     stream, "wf_attn_fwd");
+                     stream, "wf_attn_fwd", seg_stride_bytes, kmax_stride);
 }
 
 // max over the rows of each head of |x|^2 (X bf16 [H][Lp][128], rows >= L ignored) -> out[h] (atomic max on the float bits: norms are
@@ -1124,6 +1166,10 @@ extern "C" int wf_attn_bsa_fwd(const void* Q, const void* K, const void* Vt, voi
   a.prio_mode = 0;
   a.nsplit = 1;
   a.tiles_per_split = 0;
+  a.seg_stride = (size_t)a.H * a.seg_len * D * 2;
+  a.kmax_stride = a.H;
+  a.n_first = INT_MAX;
+  a.t_begin2 = a.t_end2 = a.tiles_per_split2 = 0;
   a.t_begin0 = 0;
   a.t_end = INT_MAX;
   a.part0 = 0;
@@ -1177,6 +1223,10 @@ extern "C" int wf_attn_cross2_fwd(const void* Q, const void* K, const void* Vt, 
   a.prio_mode = 0;
   a.nsplit = 1;
   a.tiles_per_split = a.Lkp / KB;
+  a.seg_stride = (size_t)a.H * a.seg_len * D * 2;
+  a.kmax_stride = a.H;
+  a.n_first = INT_MAX;
+  a.t_begin2 = a.t_end2 = a.tiles_per_split2 = 0;
   a.t_begin0 = 0;
   a.t_end = INT_MAX;
   a.part0 = 0;
@@ -1207,16 +1257,26 @@ extern "C" int wf_attn_cross2_fwd(const void* Q, const void* K, const void* Vt, 
 // slots exactly (the flash combine of wf_attn_fwd_split) once every slot has been written.  The rank's own shard needs no wait at all, so a
 // forward WITHOUT a second CFG branch to hide under still overlaps the exchange with attention itself.
 extern "C" int wf_attn_fwd_part(const void* Q, const void* K, const void* Vt, int H, int Lq, int Lkp, int kv_len, int seg_len,
-                                int t_begin, int t_end, int part, int inner_splits, int nparts, void* workspace, const float* kmax2,
-                                int kmax_n, const float* qmax2, int qmax_n, void* stream) {
+                                size_t seg_stride_bytes, int t_begin, int t_end, int inner_splits, int t_begin2, int t_end2,
+                                int inner_splits2, int part, int nparts, void* workspace, const float* kmax2, int kmax_n, int kmax_stride,
+                                const float* qmax2, int qmax_n, void* stream) {
+  PartWindow pw;
+  pw.index = part;
+  pw.t0 = t_begin;
+  pw.t1 = t_end;
+  pw.inner = inner_splits;
+  pw.t0b = t_begin2;
+  pw.t1b = t_end2;
+  pw.inner_b = inner_splits2 > 0 && t_end2 > t_begin2 ? inner_splits2 : 0;
+  WF_CHECK_ARG(part >= 0, "wf_attn_fwd_part: part index %d", part);
   // O is not written by a part launch; the checks of attn_launch want a valid aligned pointer: the workspace serves
   return attn_launch(Q, K, Vt, workspace, H, Lq, Lkp, kv_len, seg_len, H * D, 0.0f, 0, nparts, workspace, kmax2, kmax_n, qmax2, qmax_n, stream,
-                     "wf_attn_fwd_part", part, t_begin, t_end, inner_splits);
+                     "wf_attn_fwd_part", seg_stride_bytes, kmax_stride, pw);
 }
 
 extern "C" int wf_attn_merge(void* O, int H, int Lq, int ldo, int accumulate, int nparts, const void* workspace, void* stream) {
   WF_CHECK_ARG(O && workspace, "wf_attn_merge: null pointer");
-  WF_CHECK_ARG(H > 0 && Lq > 0 && nparts >= 2 && nparts <= 8, "wf_attn_merge: H=%d Lq=%d nparts=%d (2..8)", H, Lq, nparts);
+  WF_CHECK_ARG(H > 0 && Lq > 0 && nparts >= 2 && nparts <= MAX_PARTS, "wf_attn_merge: H=%d Lq=%d nparts=%d (2..%d)", H, Lq, nparts, MAX_PARTS);
   WF_CHECK_ARG(ldo % 8 == 0 && ldo >= H * D && ((((uintptr_t)O) | ((uintptr_t)workspace)) & 15) == 0, "wf_attn_merge: ldo %d / alignment", ldo);
   AttnArgs a = {};
   a.O = (uint16_t*)O;
@@ -1245,11 +1305,11 @@ extern "C" size_t wf_attn_split_workspace_bytes(int H, int Lq, int nsplit) {
 }
 
 extern "C" int wf_attn_fwd_split(const void* Q, const void* K, const void* Vt, void* O, int H, int Lq, int Lkp, int kv_len, int seg_len,
-                                 int ldo, float softmax_scale, int accumulate, int nsplit, void* workspace, const float* kmax2, int kmax_n,
-                                 const float* qmax2, int qmax_n, void* stream) {
+                                 size_t seg_stride_bytes, int ldo, float softmax_scale, int accumulate, int nsplit, void* workspace,
+                                 const float* kmax2, int kmax_n, int kmax_stride, const float* qmax2, int qmax_n, void* stream) {
   WF_CHECK_ARG(nsplit >= 1 && nsplit <= 8, "wf_attn_fwd_split: nsplit %d out of range 1..8", nsplit);
   return attn_launch(Q, K, Vt, O, H, Lq, Lkp, kv_len, seg_len, ldo, softmax_scale, accumulate, nsplit, workspace, kmax2, kmax_n, qmax2,
-                     qmax_n, stream, "wf_attn_fwd_split");
+                     qmax_n, stream, "wf_attn_fwd_split", seg_stride_bytes, kmax_stride);
 }
 
 #ifdef WF_ATTN_TIMING

@@ -47,7 +47,7 @@ struct ConvArgs {
   int pt, ph, pw;  // temporal (front) / top / left zero padding (ph may be negative: input slab carries halo rows)
   int up2;         // read input through nearest 2x spatial upsample
   int tsplit;      // Resample 'upsample3d' (vae.py:134-137): channel half h of output frame t goes to frame 1 + 2*t + h
-  int silu_out;    // unused (reserved)
+  float acc_scale;  // out = acc * acc_scale + bias (+ residual): 2^-k when the fp16 weight operand was stored scaled by 2^k (see wf_conv3d_cl_f16); 1 otherwise
   int f16;         // operands (in, w) and the 16-bit output copy are fp16 instead of bf16 (wf_*_f16 entry points)
   // output scatter (osy == 0: none): output pixel (t, y, x) of the [To, Ho, Wo] grid is written to pixel (t, osy * y + ooy, osx * x + oox)
   // of a [To, oH, oW] tensor -- the four phases of a nearest-2x-upsample + 3 x 3 convolution are 2 x 2 convolutions on the source grid
@@ -101,7 +101,7 @@ __device__ __forceinline__ void conv_store_wave_tile(const ConvArgs& a, const f3
         if (__builtin_expect(co >= a.Cout, 0)) continue;
         float v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q] + bq[i][g][q];
+        for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q] * a.acc_scale + bq[i][g][q];  // (a power of two: exact, fused or not)
         size_t o;
         if (tsplit) {
           const int half = co >= chalf ? 1 : 0;
@@ -281,6 +281,10 @@ constexpr int QM = 512, QN = 96, QT = 512;
 constexpr int QX_BYTES = QM * 128;  // 64 KiB
 constexpr int QW_BYTES = QN * 128;  // 12 KiB
 constexpr int QBUF = QX_BYTES + QW_BYTES;
+// k_conv_pp: a double buffer of [512 pixels x 64 channels | 96 output channels x 64 channels]; no region is overlaid (direct epilogue stores)
+static_assert(2 * QBUF <= 160 * 1024, "k_conv_pp's double buffer must fit the LDS of a CU");
+static_assert(QX_BYTES == (QT / 64) * 8192, "8 waves x 8 KiB of pixel rows fill the activation half of a buffer exactly (xb = ... + wid * 8192)");
+static_assert(QW_BYTES % 1024 == 0, "weight rows are staged in 1 KiB LDS-DMA pieces");
 
 // select between two global pointers with two 32-bit v_cndmask (a ?: on pointers is lowered to exec-mask branches by hipcc
 // when one arm carries address arithmetic)
@@ -568,6 +572,14 @@ constexpr int PR = WY + 2, PC = WX + 2;
 constexpr int PATCH_PX = 3 * PR * PC;      // 1980 pixels of 32 B
 constexpr int PATCH_BUF = 64 * 1024;       // 64 pieces of 1 KiB (1980 * 32 B = 61.9 KiB, the tail of the last piece is padding)
 constexpr int W4_LDS = 2 * PATCH_BUF;
+// LDS regions of k_conv_w4 and what overlays them:
+//   [0, PATCH_BUF)              patch buffer 0: slices 0, 2, 4 ... of a tile
+//   [PATCH_BUF, 2 * PATCH_BUF)  patch buffer 1: slices 1, 3, 5 ...; the epilogue's per-wave staging quarters overlay it (store_tile_lds:
+//                               dead behind the last slice's barrier, and only the wave's OWN later pieces land in its quarter)
+static_assert(PATCH_PX * 32 <= PATCH_BUF, "a 16-channel slice of the (3 frames) x (8 + 2 rows) x (64 + 2 cols) patch must fit one patch buffer");
+static_assert(PATCH_BUF == (W4T / 64) * 16 * 1024, "4 waves x 16 LDS-DMA pieces of 1 KiB fill a patch buffer exactly (stage_piece: wid * 16 + j)");
+static_assert(W4_LDS <= 160 * 1024, "two patch buffers must fit the LDS of a CU");
+static_assert((PATCH_BUF / (W4T / 64)) % 1024 == 0, "a wave's epilogue staging quarter = the LDS range of its own 16 pieces: whole pieces");
 #ifndef WF_CONV_DIRECT_STORE
 #define WF_CONV_DIRECT_STORE 0  // lab only: 1 = the epilogue of rounds 1-3 (stores straight from the accumulator layout)
 #endif
@@ -880,7 +892,7 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
           if (__builtin_expect(co >= a.Cout, 0)) continue;
           float v[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = av[4 * g + q];
+          for (int q = 0; q < 4; ++q) v[q] = F16 ? av[4 * g + q] * a.acc_scale : av[4 * g + q];
           if (has_bias) {
             const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + co);
 #pragma unroll
@@ -977,7 +989,12 @@ __global__ __launch_bounds__(W4T, 1) void k_conv_w4(ConvW4Args pa) {
           const int i = 4 * g4 + u;
           f32x4 v = lv[u];
           const f32x4 bb = bq[i % 3];
-          v = f32x4{v[0] + bb[0], v[1] + bb[1], v[2] + bb[2], v[3] + bb[3]};
+          if constexpr (F16) {  // fp16 weight operands are stored scaled by a power of two (exact): one fma instead of the add
+            const float sc = a.acc_scale;
+            v = f32x4{v[0] * sc + bb[0], v[1] * sc + bb[1], v[2] * sc + bb[2], v[3] * sc + bb[3]};
+          } else {
+            v = f32x4{v[0] + bb[0], v[1] + bb[1], v[2] + bb[2], v[3] + bb[3]};
+          }
           if constexpr (R) {
             const f32x4 r4 = rr[slot][u];
             v = f32x4{v[0] + r4[0], v[1] + r4[1], v[2] + r4[2], v[3] + r4[3]};
@@ -1081,7 +1098,8 @@ __global__ void k_conv_small(SmallConvArgs a) {
 static int conv3d_cl_impl(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_bf16,
                           int Ti, int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st,
                           int ss, int pt, int ph, int pw, int up2, int tsplit, const void* zero_page, const int* scatter, void* stream,
-                          int f16 = 0) {
+                          int f16 = 0, float acc_scale = 1.0f) {
+  WF_CHECK_ARG(acc_scale > 0.0f && acc_scale < 3.0e38f, "wf_conv3d_cl: acc_scale must be a positive finite number (1 = none)");
   WF_CHECK_ARG(in && w && (out_f32 || out_bf16), "wf_conv3d_cl: null pointer");
   WF_CHECK_ARG(Cin % CBK == 0, "wf_conv3d_cl: Cin (%d) must be a multiple of 32 (use wf_conv3d_small otherwise)", Cin);
   WF_CHECK_ARG(Cout % 4 == 0, "wf_conv3d_cl: Cout (%d) must be a multiple of 4", Cout);
@@ -1100,7 +1118,7 @@ static int conv3d_cl_impl(const void* in, const void* w, const float* bias, cons
   a.To = To; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   a.kt = kt; a.kh = kh; a.kw = kw;
   a.st = st; a.ss = ss; a.pt = pt; a.ph = ph; a.pw = pw;
-  a.up2 = up2; a.tsplit = tsplit; a.silu_out = 0;
+  a.up2 = up2; a.tsplit = tsplit; a.acc_scale = acc_scale;
   a.f16 = f16;
   a.osy = a.ooy = a.osx = a.oox = a.oH = a.oW = 0;
   if (scatter) {  // {out_H, out_W, sy, oy, sx, ox}
@@ -1111,9 +1129,8 @@ static int conv3d_cl_impl(const void* in, const void* w, const float* bias, cons
   }
   // stride-1, no upsample / frame interleave, big enough to fill the chip: the 512-pixel ping-pong kernel (needs a zero page
   // for the out-of-range taps of its DMA gather and chunk-granular 32-bit offsets)
-  static const bool no_pp = getenv("WF_CONV_NO_PP") != nullptr;
   const long in_chunks = (long)Ti * Hi * Wi * (Cin / 8);
-  if (!no_pp && zero_page && st == 1 && ss == 1 && !up2 && !tsplit && kt <= 3 && kh <= 3 && kw <= 3 && M >= 64 * QM &&
+  if (zero_page && st == 1 && ss == 1 && !up2 && !tsplit && kt <= 3 && kh <= 3 && kw <= 3 && M >= 64 * QM &&
       in_chunks < (1L << 31) - (1L << 24) && (long)Cout * kt * kh * kw * (Cin / 8) < (1L << 31)) {
     ConvPPArgs pa;
     pa.c = a;
@@ -1155,18 +1172,18 @@ extern "C" int wf_conv3d_cl_scatter(const void* in, const void* w, const float* 
 // "fp16x3" operand format -- hi = fp16(x), lo = fp16(x - hi), 2^-22 per product where the bf16 split gives 2^-16 -- and its one-term "fp16" mode.
 extern "C" int wf_conv3d_cl_f16(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_f16,
                                 int Ti, int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st,
-                                int ss, int pt, int ph, int pw, int up2, int tsplit, const void* zero_page, void* stream) {
+                                int ss, int pt, int ph, int pw, int up2, int tsplit, const void* zero_page, float acc_scale, void* stream) {
   return conv3d_cl_impl(in, w, bias, resid, out_f32, out_f16, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, kt, kh, kw, st, ss, pt, ph, pw, up2, tsplit,
-                        zero_page, nullptr, stream, 1);
+                        zero_page, nullptr, stream, 1, acc_scale);
 }
 
 extern "C" int wf_conv3d_cl_scatter_f16(const void* in, const void* w, const float* bias, const float* resid, float* out_f32, void* out_f16,
                                         int Ti, int Hi, int Wi, int Cin, int To, int Ho, int Wo, int Cout, int kt, int kh, int kw, int st,
                                         int ss, int pt, int ph, int pw, const void* zero_page, int out_H, int out_W, int sy, int oy, int sx,
-                                        int ox, void* stream) {
+                                        int ox, float acc_scale, void* stream) {
   const int scatter[6] = {out_H, out_W, sy, oy, sx, ox};
   return conv3d_cl_impl(in, w, bias, resid, out_f32, out_f16, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, kt, kh, kw, st, ss, pt, ph, pw, 0, 0,
-                        zero_page, scatter, stream, 1);
+                        zero_page, scatter, stream, 1, acc_scale);
 }
 
 extern "C" int wf_conv3d_small(const void* in, int in_dtype, const float* w, const float* bias, float* out_f32, void* out_bf16,
@@ -1214,8 +1231,9 @@ extern "C" size_t wf_conv3d_333_zero_page_bytes(int Wi, int Cin_stored, int layo
 
 static int conv3d_333_impl(const void* in, const void* w_packed, const float* bias, const float* resid, float* out_f32,
                            void* out_bf16, int T, int Hi, int Wi, int Cin, int Ho, int Cout, int ph, const void* zero_page,
-                           size_t zero_page_bytes, int layout, int Cin_stored, void* stream, int f16) {
+                           size_t zero_page_bytes, int layout, int Cin_stored, void* stream, int f16, float acc_scale = 1.0f) {
   WF_CHECK_ARG(in && w_packed && zero_page && (out_f32 || out_bf16), "wf_conv3d_333: null pointer");
+  WF_CHECK_ARG(acc_scale > 0.0f && acc_scale < 3.0e38f, "wf_conv3d_333: acc_scale must be a positive finite number (1 = none)");
   {
     const size_t need = wf_conv3d_333_zero_page_bytes(Wi, Cin_stored, layout);
     WF_CHECK_ARG(zero_page_bytes >= need, "wf_conv3d_333: zero page of %zu bytes, this shape needs %zu (wf_conv3d_333_zero_page_bytes)",
@@ -1239,17 +1257,15 @@ static int conv3d_333_impl(const void* in, const void* w_packed, const float* bi
   a.To = T; a.Ho = Ho; a.Wo = Wi; a.Cout = Cout;
   a.kt = a.kh = a.kw = 3;
   a.st = a.ss = 1; a.pt = 2; a.ph = ph; a.pw = 1;
-  a.up2 = a.tsplit = a.silu_out = 0;
+  a.up2 = a.tsplit = 0;
+  a.acc_scale = acc_scale;
   a.f16 = f16;
   a.osy = a.ooy = a.osx = a.oox = a.oH = a.oW = 0;
   wa.zeros = (const uint16_t*)zero_page;
   wa.tiles_x = (Wi + WX - 1) / WX;
   wa.tiles_y = (Ho + WY - 1) / WY;
   wa.nsa = Cin_stored / 16;
-  {
-    static const int walk_env = [] { const char* e = getenv("WF_CONV_WALK"); return e ? atoi(e) : 1; }();  // default: XCD-cooperative (WF_CONV_WALK=0: contiguous chunks)
-    wa.walk = walk_env;
-  }
+  wa.walk = 1;  // XCD-cooperative tile walk (round 2: +14 % on the 96-wide layer over one contiguous chunk per workgroup, walk = 0)
 
   if (layout == 0) {
     wa.row_stride = (long)Wi * Cin_stored; wa.pix_stride = Cin_stored; wa.slice_stride = 16;
@@ -1293,9 +1309,9 @@ extern "C" int wf_conv3d_333(const void* in, const void* w_packed, const float* 
 
 extern "C" int wf_conv3d_333_f16(const void* in, const void* w_packed, const float* bias, const float* resid, float* out_f32,
                                  void* out_f16, int T, int Hi, int Wi, int Cin, int Ho, int Cout, int ph, const void* zero_page,
-                                 size_t zero_page_bytes, int layout, int Cin_stored, void* stream) {
+                                 size_t zero_page_bytes, int layout, int Cin_stored, float acc_scale, void* stream) {
   return conv3d_333_impl(in, w_packed, bias, resid, out_f32, out_f16, T, Hi, Wi, Cin, Ho, Cout, ph, zero_page, zero_page_bytes, layout,
-                         Cin_stored, stream, 1);
+                         Cin_stored, stream, 1, acc_scale);
 }
 
 #ifdef WF_CONV_TIMING

@@ -43,6 +43,7 @@ struct GemmArgs {
   long bsx, bsw, bso;
   int f16;  // X, W and a 16-bit output are fp16 instead of bf16 (wf_gemm_f16: the VAE's fp16 operand formats)
   int batch;  // gridDim.y of a batched launch (1 otherwise)
+  float acc_scale;  // F16 instantiations only: out = epilogue(acc * acc_scale + bias) -- 2^-k when the fp16 weight operand is stored scaled by 2^k
 };
 
 enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32 = 2, EPI_RESID = 3, EPI_F32_ACC = 4 };
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_gemm(GemmArgs a) {
         if (n >= a.N) continue;
         float v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = acc[i][jn][4 * g + q];
+        for (int q = 0; q < 4; ++q) v[q] = F16 ? acc[i][jn][4 * g + q] * a.acc_scale : acc[i][jn][4 * g + q];
         if (a.bias) {
           const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
 #pragma unroll
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
               const int n = n0 + wf0 + i0 * 32 + nl;
               float v[4];
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = acc[i][jx][4 * g + q] + bq[ii][g][q];
+              for (int q = 0; q < 4; ++q) v[q] = (F16 ? acc[i][jx][4 * g + q] * a.acc_scale : acc[i][jx][4 * g + q]) + bq[ii][g][q];
               if constexpr (EPI == EPI_BF16_GELU) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
@@ -651,8 +652,9 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int nl = 8 * g + 4 * hi;
-            f32x4 v = {acc[i][jx][4 * g + 0] + bq[g][0], acc[i][jx][4 * g + 1] + bq[g][1], acc[i][jx][4 * g + 2] + bq[g][2],
-                       acc[i][jx][4 * g + 3] + bq[g][3]};
+            const float sc = F16 ? a.acc_scale : 1.0f;  // (folds away in the bf16 instantiations)
+            f32x4 v = {acc[i][jx][4 * g + 0] * sc + bq[g][0], acc[i][jx][4 * g + 1] * sc + bq[g][1], acc[i][jx][4 * g + 2] * sc + bq[g][2],
+                       acc[i][jx][4 * g + 3] * sc + bq[g][3]};
             *reinterpret_cast<f32x4*>(stg + (jx * 32 + l31) * RS + nl * 4) = v;
           }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -714,485 +716,12 @@ __global__ __launch_bounds__(PT, 2) void k_gemm_pp(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// The same ping-pong kernel on v_mfma_f32_16x16x32_bf16 (round 3, opt-in: WF_GEMM_MFMA=16).  On N(0,1) operands every MFMA-bound kernel
-// of this engine runs at the socket's power limit, and a bare stream of 16x16x32 does 12-13 % more flops under that limit than one of
-// 32x32x16 (profiles/r3_gemm_energy.md: half the accumulator read-modify-write per flop).  Same tiles, same LDS images and DMA, same
-// operand bytes read from LDS per flop (that ratio belongs to the wave tile, not to the MFMA shape); a 64-wide K tile is two k steps of 32
-// instead of four of 16, so the fp32 accumulation ORDER over K differs from the 32x32x16 kernels (results equal up to fp32 rounding).
+// Removed in round 5 (superseded kernels kept alive behind environment switches): `k_gemm_pp16`, the same ping-pong
+// kernel on v_mfma_f32_16x16x32_bf16 (round 3, WF_GEMM_MFMA=16: +3 ... +5 % in isolated back-to-back launches, nothing in the model,
+// profiles/r3_i_gemm_mfma16.md), and `k_gemm_w4`, the one-wave-per-SIMD 256 x 256 tile with all 256 accumulators in AGPRs (round 2,
+// WF_GEMM_KERNEL=w4: a better K loop, the same 1200-1300 TFLOP/s, bench 0.234 vs 0.242).  Both are measured negatives documented in
+// DESIGN.md section 4; their source is in the history (last present at 57ab8ba).
 // ------------------------------------------------------------------------------------------------------------------
-template <int EPI, int NI>
-__global__ __launch_bounds__(PT, 2) void k_gemm_pp16(GemmArgs a) {
-  using G = PPGeom<NI>;
-  constexpr int NJ = G::NJ, NWP = G::NWP, NP = G::NP, W_TILE = G::W_TILE, BUF = G::BUF;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // XCD-aware tile assignment (4 x 4 super-tiles of 256 x 256 tiles per XCD pass)
-  const int smt = (a.mt + 3) >> 2, snt = (a.nt + 3) >> 2;
-  const int nsuper = smt * snt;
-  const int b = blockIdx.x;
-  const int xcd = b & 7, j = b >> 3;
-  const int gid = (j >> 4) * 8 + xcd;
-  if (gid >= nsuper) return;
-  const int within = j & 15;
-  const int tm = (gid / snt) * 4 + (within >> 2);
-  const int tn = (gid % snt) * 4 + (within & 3);
-  if (tm >= a.mt || tn >= a.nt) return;
-  const int m0 = tm * PM, n0 = tn * G::PNT;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, hi = lane >> 5;
-  const bool groupB = wid >= 4;
-  const int wfi = NJ == 4 ? (wid & 3) : (wid >> 2);  // wave index along features
-  const int wti = NJ == 4 ? (wid >> 2) : (wid & 3);  // wave index along tokens
-  const int wf0 = wfi * NI * 32, wt0 = wti * NJ * 32;  // wave tile origin inside the workgroup tile
-
-  // ---- LDS-DMA geometry: an operand tile = rows x 128 B = pieces of 1 KiB (8 rows); wave w moves pieces NWP*w.. of W and
-  // 4w..4w+3 of X.  lane -> (row = 8*piece + lane/8, slot = lane%8) receives source chunk slot ^ ((row >> 1) & 7).
-  const uint16_t* srcW[NWP];
-  const uint16_t* srcX[4];
-#pragma unroll
-  for (int i = 0; i < NWP; ++i) {
-    const int row = 8 * (wid * NWP + i) + (lane >> 3), slot = lane & 7;
-    srcW[i] = a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw + (slot ^ ((row >> 1) & 7)) * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 8 * (wid * 4 + i) + (lane >> 3), slot = lane & 7;
-    srcX[i] = a.X + (size_t)min(m0 + row, a.M - 1) * a.ldx + (slot ^ ((row >> 1) & 7)) * 8;
-  }
-  auto dma_piece = [&](int kt, int i) {  // i in 0..NP-1: W pieces first, then the 4 X pieces
-    unsigned char* base = smem + (kt & 1) * BUF;
-    if (i < NWP)
-      glds16(srcW[i] + (size_t)kt * PK, base + (wid * NWP + i) * 1024);
-    else
-      glds16(srcX[i - NWP] + (size_t)kt * PK, base + W_TILE + (wid * 4 + i - NWP) * 1024);
-  };
-  auto dma = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i) dma_piece(kt, i);
-  };
-
-  // ---- fragment addressing ------------------------------------------------------------------------------------------------
-  // 16 x 16 x 32 fragments: lane -> row (l & 15) of a 16-row tile, k-group (l >> 4) of the 32-wide k step; every fragment row is the lane's
-  // row l15 plus a multiple of 16, so one swizzle term serves all of them.  A "half" of a 64-wide K tile is ONE k step here.
-  constexpr int NA = 2 * NI, NB = 2 * NJ;  // 16-row feature tiles / 16-column token tiles per wave
-  const int l15 = lane & 15, kg = lane >> 4;
-  const int sw = (l15 >> 1) & 7;
-  const int offW = (wf0 + l15) * 128, offX = W_TILE + (wt0 + l15) * 128;
-  f32x4 acc[NA][NB];
-#pragma unroll
-  for (int i = 0; i < NA; ++i)
-#pragma unroll
-    for (int jx = 0; jx < NB; ++jx) acc[i][jx] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  u32x4 fw[NA], fx[NB];
-  auto read_half = [&](int kt, int half) {
-    const unsigned char* base = smem + (kt & 1) * BUF;
-    const int c = ((4 * half + kg) ^ sw) << 4;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) fw[i] = *reinterpret_cast<const u32x4*>(base + offW + i * 2048 + c);
-#pragma unroll
-    for (int jx = 0; jx < NB; ++jx) fx[jx] = *reinterpret_cast<const u32x4*>(base + offX + jx * 2048 + c);
-  };
-  // 2*NI*NJ MFMAs on register operands; optionally the NP LDS-DMA pieces of tile `dma_kt` are issued in the gaps (one behind
-  // every second MFMA: the MFMA pipe hides their issue cost, and the read phases stay pure LDS reads)
-  auto mma_half = [&](int dma_kt) {
-    __builtin_amdgcn_s_setprio(1);  // the MFMA phase outranks the co-resident wave's LDS phase at the issue arbiter
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-#pragma unroll
-      for (int jx = 0; jx < NB; ++jx) {
-        acc[i][jx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(fw[i]), as_bf16x8(fx[jx]), acc[i][jx], 0, 0, 0);
-        const int idx = i * NB + jx;
-        if (dma_kt >= 0 && (idx & 3) == 3 && (idx >> 2) < NP) dma_piece(dma_kt, idx >> 2);  // a piece behind every fourth (16-cycle) MFMA
-      }
-    if (dma_kt >= 0) {
-#pragma unroll
-      for (int q = 0; q < NP; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
-    }
-    __builtin_amdgcn_s_setprio(0);
-  };
-  auto bar = [&]() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  };
-  auto drain = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-
-  const int nk = a.K / PK;
-  dma(0);
-  drain();
-  bar();
-  if (!groupB) {
-    for (int kt = 0; kt < nk; ++kt) {
-      read_half(kt, 0);
-      bar();  // 4kt+1
-      mma_half(kt + 1 < nk ? kt + 1 : -1);  // DMA of tile kt+1 rides in the MFMA gaps (its buffer is free since barrier 4kt)
-      bar();  // 4kt+2
-      read_half(kt, 1);
-      bar();  // 4kt+3
-      mma_half(-1);
-      drain();
-      bar();  // 4kt+4
-    }
-    bar();
-  } else {
-    if (nk > 1) dma(1);
-    bar();  // 1
-    for (int kt = 0; kt < nk; ++kt) {
-      read_half(kt, 0);
-      bar();  // 4kt+2
-      mma_half(-1);
-      bar();  // 4kt+3
-      read_half(kt, 1);
-      drain();
-      bar();  // 4kt+4
-      mma_half(kt + 2 < nk ? kt + 2 : -1);
-      bar();  // 4kt+5
-    }
-  }
-
-  // ---- epilogue through LDS: row-contiguous global accesses ------------------------------------------------------------------
-  // In the accumulator layout a lane owns one token row and quads of features, so a store instruction touches 32-64 different rows
-  // (8 / 16 bytes each): 64 such instructions per lane made the epilogue ~20 k cycles per tile, 9 % of a K = 5120 GEMM.  Each wave
-  // therefore transposes its tile through a private LDS region (the operand buffers are free behind the last barrier) in passes of
-  // [NJ*32 tokens][128 B]  (64 bf16 features = two MFMA tiles, or 32 fp32 features = one; an odd last bf16 tile makes a 64-byte
-  // pass) and reads / writes global memory in whole rows of a pass.  Rows are padded by 16 B (144-byte stride) so that neither the
-  // column-wise writes nor the row-wise reads conflict.  No workgroup barrier: the region is wave-private.
-  {
-    constexpr int RS = 144;  // padded row stride in bytes
-    constexpr int ROWS = NJ * 32;
-    unsigned char* stg = smem + wid * G::STG;
-    if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
-#pragma unroll
-      for (int i0 = 0; i0 < NI; i0 += 2) {
-        const int nti = (NI - i0) >= 2 ? 2 : 1;  // feature tiles in this pass (compile-time after unrolling)
-#pragma unroll
-        for (int jx = 0; jx < NB; ++jx)
-#pragma unroll
-          for (int ia = 0; ia < 4; ++ia) {   // the 16-row feature tiles of this pass (2 per 32-feature tile)
-            if (ia >= 2 * nti) continue;
-            const int i = 2 * i0 + ia;
-            const int nl = ia * 16 + 4 * kg;  // feature within the pass: the lane's 4 consecutive features
-            const int n = n0 + wf0 + i0 * 32 + nl;
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = acc[i][jx][q];
-            if (a.bias && n < a.N) {
-              const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
-#pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] += bb[q];
-            }
-            if constexpr (EPI == EPI_BF16_GELU) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
-            }
-            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-            *reinterpret_cast<u32x2*>(stg + (jx * 16 + l15) * RS + nl * 2) = pk;
-          }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // row phase: 8 (4) lanes x 16 B per token row, 8 (16) rows per instruction
-        const int lpr = nti * 4;
-        const int lrow = lane / lpr, lch = lane % lpr;
-#pragma unroll
-        for (int r8 = 0; r8 < ROWS * nti / 16; ++r8) {
-          const int row = r8 * (64 / lpr) + lrow;
-          const int m = m0 + wt0 + row;
-          const int n = n0 + wf0 + i0 * 32 + lch * 8;
-          const u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * RS + lch * 16);
-          if (m < a.M && n < a.N) {  // N % 4 == 0: a chunk of 8 features may straddle the edge
-            uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
-            if (n + 8 <= a.N)
-              *reinterpret_cast<u32x4*>(op) = val;
-            else
-              *reinterpret_cast<u32x2*>(op) = u32x2{val[0], val[1]};
-          }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next pass overwrites the staging rows
-      }
-    } else {
-      const int lrow = lane >> 3, lch = lane & 7;  // row phase: 8 rows x 8 chunks of 16 B per instruction
-      // fp32 outputs: one pass of [NJ*32 tokens][32 features] f32 = 128 B per row for every feature tile
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-#pragma unroll
-        for (int jx = 0; jx < NB; ++jx)
-#pragma unroll
-          for (int ia = 0; ia < 2; ++ia) {
-            const int nl = ia * 16 + 4 * kg;
-            const int n = n0 + wf0 + i * 32 + nl;
-            f32x4 v = acc[2 * i + ia][jx];
-            if (a.bias && n < a.N) {
-              const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
-#pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] += bb[q];
-            }
-            *reinterpret_cast<f32x4*>(stg + (jx * 16 + l15) * RS + nl * 4) = v;
-          }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // Read-modify-write epilogues: ALL the old values of a chunk of rows are loaded before the first store.  Written as one loop
-        // (load, add, store per row) the compiler must keep every load behind the previous row's store -- it cannot know they do not
-        // alias -- and each row waited a full HBM round trip: 40 serialized round trips per wave and tile.  The gate row (the same
-        // features for every row of the pass) is loaded once per pass for the same reason.
-        const int n = n0 + wf0 + i * 32 + lch * 4;
-        f32x4 gg = {1.f, 1.f, 1.f, 1.f};
-        if constexpr (EPI == EPI_RESID) {
-          if (a.gate) gg = *reinterpret_cast<const f32x4*>(a.gate + min(n, a.N - 4));
-        }
-        constexpr int CH = 4;  // rows-of-8 per chunk: 4 x 16 B per lane in flight (8 spill: the accumulators of the later passes are still live)
-#pragma unroll
-        for (int c0 = 0; c0 < ROWS / 8; c0 += CH) {
-          f32x4 oldv[CH];
-          if constexpr (EPI != EPI_F32) {
-#pragma unroll
-            for (int r8 = 0; r8 < CH; ++r8) {  // unconditional, clamped: a guard per load would put each in its own block with its own wait
-              const int m = min(m0 + wt0 + (c0 + r8) * 8 + lrow, a.M - 1);
-              oldv[r8] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.out) + (size_t)m * a.ldo + min(n, a.N - 4));
-            }
-          }
-#pragma unroll
-          for (int r8 = 0; r8 < CH; ++r8) {
-            const int row = (c0 + r8) * 8 + lrow;
-            const int m = m0 + wt0 + row;
-            f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * RS + lch * 16);
-            if (m < a.M && n < a.N) {
-              float* po = reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n;
-              if constexpr (EPI == EPI_F32) {
-                *reinterpret_cast<f32x4*>(po) = v;
-              } else if constexpr (EPI == EPI_F32_ACC) {
-                const f32x4 old = oldv[r8];
-                *reinterpret_cast<f32x4*>(po) = f32x4{old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
-              } else {
-                const f32x4 old = oldv[r8];
-                *reinterpret_cast<f32x4*>(po) =
-                    f32x4{old[0] + v[0] * gg[0], old[1] + v[1] * gg[1], old[2] + v[2] * gg[2], old[3] + v[3] * gg[3]};
-              }
-            }
-          }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next pass overwrites the staging rows
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// One wave per SIMD variant: 256 x 256 tile, 4 waves (2 feature halves x 2 token halves), wave tile 128 features x 128 tokens =
-// 4 x 4 MFMA 32x32x16 tiles = 256 accumulator registers, ALL in AGPRs (inline-asm MFMAs: hipcc picks one accumulator form per
-// function and would otherwise shuttle them through v_accvgpr copies).  With two waves per SIMD (k_gemm_pp) the partner wave's LDS /
-// DMA / address instructions take issue slots from the MFMA wave; here one instruction stream carries 16 MFMAs per k-step with only
-// ~1.3 other instructions per MFMA (8 fragment reads + <= 6 LDS-DMA pieces per 16 MFMAs), all placed in the MFMA issue shadows, so
-// the matrix pipe is paced by itself.  Per K tile (BK = 64 = 4 k-steps): the fragments of k-step s+1 are read during the MFMAs of
-// k-step s; the LDS-DMA pieces of the NEXT tile are issued during k-steps 0-1, drained + workgroup barrier after k-step 2, so
-// that k-step 3 can already prefetch the next tile's first fragments (no MFMA waits on an LDS read after the barrier) and start
-// the pieces of the tile after next (its buffer was last read before that barrier).  Past the last K tile the pieces re-stage
-// the last tile into the dead buffer instead of branching.
-// ------------------------------------------------------------------------------------------------------------------
-constexpr int WT = 256;  // threads
-
-template <int EPI>
-__global__ __launch_bounds__(WT, 1) void k_gemm_w4(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int smt = (a.mt + 3) >> 2, snt = (a.nt + 3) >> 2;
-  const int nsuper = smt * snt;
-  const int b = blockIdx.x;
-  const int xcd = b & 7, j = b >> 3;
-  const int gid = (j >> 4) * 8 + xcd;
-  if (gid >= nsuper) return;
-  const int within = j & 15;
-  const int tm = (gid / snt) * 4 + (within >> 2);
-  const int tn = (gid % snt) * 4 + (within & 3);
-  if (tm >= a.mt || tn >= a.nt) return;
-  const int m0 = tm * PM, n0 = tn * PN;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int wf = wid & 1;   // feature half (128 features)
-  const int wm = wid >> 1;  // token half (128 tokens)
-
-  // LDS-DMA geometry (as k_gemm_pp): operand tile = 256 rows x 128 B = 32 pieces of 1 KiB; wave w moves pieces 8w..8w+7 of W and X
-  const uint16_t* src[16];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int piece = wid * 8 + i;
-    const int row = 8 * piece + (lane >> 3), slot = lane & 7;
-    const int ch = slot ^ ((row >> 1) & 7);
-    src[i] = a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw + ch * 8;
-    src[8 + i] = a.X + (size_t)min(m0 + row, a.M - 1) * a.ldx + ch * 8;
-  }
-  const int nk = a.K / PK;
-  auto dma_piece = [&](int kt, int i) {  // i in 0..15: W pieces 0..7, X pieces 0..7 of K tile kt (clamped: see header)
-    const int ks = kt < nk ? kt : nk - 1;
-    unsigned char* dst = smem + (kt & 1) * P_BUF + (i < 8 ? 0 : P_TILE) + wid * 8192 + (i & 7) * 1024;
-    glds16(src[i] + (size_t)ks * PK, dst);
-  };
-
-  int offW[4], swW[4], offX[4], swX[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wf * 128 + i * 32 + l31;
-    offW[i] = r * 128;
-    swW[i] = (r >> 1) & 7;
-    const int rx = wm * 128 + i * 32 + l31;
-    offX[i] = P_TILE + rx * 128;
-    swX[i] = (rx >> 1) & 7;
-  }
-  f32x16 acc[4][4];
-  u32x4 fw[2][4], fx[2][4];  // fragment double buffer: k-step parity
-  auto read_frag = [&](int kt, int ks, int which) {  // which 0..3 -> fw[.][which], 4..7 -> fx[.][which-4]
-    const unsigned char* base = smem + (kt & 1) * P_BUF;
-    const int c = 2 * ks + hi;
-    if (which < 4)
-      fw[ks & 1][which] = *reinterpret_cast<const u32x4*>(base + offW[which] + ((c ^ swW[which]) << 4));
-    else
-      fx[ks & 1][which - 4] = *reinterpret_cast<const u32x4*>(base + offX[which - 4] + ((c ^ swX[which - 4]) << 4));
-  };
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int jx = 0; jx < 4; ++jx) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][jx][r] = 0.f;
-      asm volatile("" : "+a"(acc[i][jx]));  // the accumulators enter the loop in AGPRs
-    }
-  auto mma = [&](f32x16& c, const u32x4& wv, const u32x4& xv) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(wv), "v"(xv));
-  };
-  auto bar = [&]() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  };
-
-#ifdef WF_GEMM_TIMING
-  const unsigned long long t_start = __builtin_readcyclecounter();
-#endif
-  // prologue: tile 0 whole, tile 1 pieces 0..7; tile 0 landed -> barrier -> fragments of (tile 0, k-step 0)
-#pragma unroll
-  for (int i = 0; i < 16; ++i) dma_piece(0, i);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) dma_piece(1, i);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  bar();
-#pragma unroll
-  for (int q = 0; q < 8; ++q) read_frag(0, 0, q);
-
-#ifdef WF_GEMM_TIMING
-  unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
-  const unsigned long long t_loop = tlast;
-#define GMARK(k) do { const unsigned long long n__ = __builtin_readcyclecounter(); tacc[k] += n__ - tlast; tlast = n__; } while (0)
-#else
-#define GMARK(k) do { } while (0)
-#endif
-  for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-      for (int idx = 0; idx < 16; ++idx) {
-        const int i = idx >> 2, jx = idx & 3;
-        mma(acc[i][jx], fw[ks & 1][i], fx[ks & 1][jx]);
-        __builtin_amdgcn_sched_barrier(0);
-        // fragments of the next k-step (of the next tile behind the barrier at the end of k-step 2): one read per two MFMAs
-        if ((idx & 1) == 0) {
-          if (ks < 3)
-            read_frag(kt, ks + 1, idx >> 1);
-          else
-            read_frag(kt + 1, 0, idx >> 1);  // past the last tile: reads a dead buffer, never used
-        }
-        // LDS-DMA: k-step 3 -> pieces 0..7 of tile kt+2 (its buffer is free since the barrier), k-step 0 -> pieces 8..15 of tile kt+1
-        if (idx & 1) {
-          const int s_ = idx >> 1;  // 0..7
-          if (ks == 0) dma_piece(kt + 1, 8 + s_);
-          if (ks == 3) dma_piece(kt + 2, s_);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (ks == 2) {
-        GMARK(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1 landed (its last pieces were issued during k-step 0)
-        GMARK(1);
-        bar();
-        GMARK(2);
-      }
-      if (ks == 3) GMARK(3);
-    }
-  }
-#ifdef WF_GEMM_TIMING
-  const unsigned long long t_end_loop = __builtin_readcyclecounter();
-#endif
-
-  // ---- epilogue: lane owns token row m and feature quads (as k_gemm) ------------------------------------------------------
-  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");  // asm MFMA write -> v_accvgpr_read
-#pragma unroll
-  for (int jx = 0; jx < 4; ++jx) {
-    const int m = m0 + wm * 128 + jx * 32 + l31;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f32x16 av = acc[i][jx];
-      asm volatile("" : "+v"(av));
-      if (m >= a.M) continue;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wf * 128 + i * 32 + 8 * g + 4 * hi;
-        if (n >= a.N) continue;
-        float v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = av[4 * g + q];
-        if (a.bias) {
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + n);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] += bb[q];
-        }
-        const size_t o = (size_t)m * a.ldo + n;
-        if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
-          if constexpr (EPI == EPI_BF16_GELU) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
-          }
-          u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + o) = pk;
-        } else if constexpr (EPI == EPI_F32) {
-          f32x4 ov = {v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + o) = ov;
-        } else if constexpr (EPI == EPI_F32_ACC) {
-          float* po = reinterpret_cast<float*>(a.out) + o;
-          f32x4 old = *reinterpret_cast<const f32x4*>(po);
-          f32x4 ov = {old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
-          *reinterpret_cast<f32x4*>(po) = ov;
-        } else {
-          float* po = reinterpret_cast<float*>(a.out) + o;
-          f32x4 old = *reinterpret_cast<const f32x4*>(po);
-          f32x4 gg = {1.f, 1.f, 1.f, 1.f};
-          if (a.gate) gg = *reinterpret_cast<const f32x4*>(a.gate + n);
-          f32x4 ov = {old[0] + v[0] * gg[0], old[1] + v[1] * gg[1], old[2] + v[2] * gg[2], old[3] + v[3] * gg[3]};
-          *reinterpret_cast<f32x4*>(po) = ov;
-        }
-      }
-    }
-  }
-#ifdef WF_GEMM_TIMING
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0 && wid == 0) {
-    const unsigned long long t_end = __builtin_readcyclecounter();
-    for (int q = 0; q < 4; ++q) atomicAdd(&g_gemm_cycles[q], tacc[q]);
-    atomicAdd(&g_gemm_cycles[4], (unsigned long long)nk);
-    atomicAdd(&g_gemm_cycles[5], t_loop - t_start);
-    atomicAdd(&g_gemm_cycles[6], t_end - t_end_loop);
-    atomicAdd(&g_gemm_cycles[7], 1ull);
-  }
-#endif
-}
-
-template <int EPI>
-static void launch_w4(GemmArgs a, hipStream_t s) {
-  a.mt = ceil_div(a.M, PM);
-  a.nt = ceil_div(a.N, PN);
-  const int nsuper = ((a.mt + 3) / 4) * ((a.nt + 3) / 4);
-  const int grid = ((nsuper + 7) / 8) * 8 * 16;
-  hipLaunchKernelGGL(k_gemm_w4<EPI>, dim3(grid), dim3(WT), 2 * P_BUF, s, a);
-}
 
 template <int EPI, int NI>
 static void launch_pp(GemmArgs a, hipStream_t s) {
@@ -1201,12 +730,9 @@ static void launch_pp(GemmArgs a, hipStream_t s) {
   a.nt = ceil_div(a.N, G::PNT);
   const int nsuper = ((a.mt + 3) / 4) * ((a.nt + 3) / 4);
   const int grid = ((nsuper + 7) / 8) * 8 * 16;
-  static const bool mfma16 = [] { const char* e = getenv("WF_GEMM_MFMA"); return e && atoi(e) == 16; }();
   if (a.f16) {  // fp16 operands: the epilogues the VAE uses (the others are rejected by wf_gemm_f16)
     if constexpr (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_F32_ACC) hipLaunchKernelGGL((k_gemm_pp<EPI, NI, true>), dim3(grid, a.batch), dim3(PT), G::LDS, s, a);
-  } else if (mfma16 && a.batch == 1)  // (the opt-in 16x16x32 form has no batch index)
-    hipLaunchKernelGGL((k_gemm_pp16<EPI, NI>), dim3(grid), dim3(PT), G::LDS, s, a);
-  else
+  } else
     hipLaunchKernelGGL((k_gemm_pp<EPI, NI>), dim3(grid, a.batch), dim3(PT), G::LDS, s, a);
 }
 
@@ -1215,14 +741,11 @@ static void launch_pp(GemmArgs a, hipStream_t s) {
 // accumulations over K in both.
 static int pp_wide(int M, int N) {
   if (N % 320 != 0) return 0;
-#ifdef WF_GEMM_LAB_TILE  // lab builds: read per call, so that one process can launch both tile widths (tools/gemm_dephase.py)
+#ifdef WF_GEMM_LAB_TILE  // lab builds only: WF_GEMM_TILE=256|320 read per call, so that one process can launch both tile widths (tools/gemm_dephase.py, gemm_tiles.py)
   const char* e_ = getenv("WF_GEMM_TILE");
   const int force = e_ ? atoi(e_) : 0;
 #else
-  static const int force = [] {
-    const char* e = getenv("WF_GEMM_TILE");
-    return e ? atoi(e) : 0;
-  }();
+  const int force = 0;
 #endif
   if (force == 256) return 0;
   if (force == 320) return 1;
@@ -1249,7 +772,8 @@ static void launch_pp_any(GemmArgs a, hipStream_t s) {
 }  // namespace
 
 static int gemm_impl(const void* X, const void* W, const float* bias, void* out, const float* gate, int M, int N,
-                     int K, int ldx, int ldw, int ldo, int epilogue, void* stream, int f16) {
+                     int K, int ldx, int ldw, int ldo, int epilogue, void* stream, int f16, float acc_scale = 1.0f) {
+  WF_CHECK_ARG(acc_scale > 0.0f && acc_scale < 3.0e38f, "wf_gemm_f16: acc_scale must be a positive finite number (1 = none)");
   WF_CHECK_ARG(X && W && out, "wf_gemm_bf16: null pointer");
   WF_CHECK_ARG(!f16 || epilogue == EPI_BF16 || epilogue == EPI_F32 || epilogue == EPI_F32_ACC,
                "wf_gemm_f16: epilogue %d is not built for fp16 operands (0 = 16-bit out, 2 = f32, 4 = f32 accumulate)", epilogue);
@@ -1276,35 +800,19 @@ static int gemm_impl(const void* X, const void* W, const float* bias, void* out,
   a.bsx = a.bsw = a.bso = 0;
   a.f16 = f16;
   a.batch = 1;
+  a.acc_scale = acc_scale;
   const int nsuper = ((a.mt + 7) / 8) * ((a.nt + 7) / 8);
   const int grid = ((nsuper + 7) / 8) * 8 * 64;
   const size_t lds = 4 * TILE_BYTES;
   hipStream_t s = (hipStream_t)stream;
   // large problems with a whole number of 64-wide K tiles take the 256x256 ping-pong kernel
-  static const bool no_pp = getenv("WF_GEMM_NO_PP") != nullptr;
-  static const bool use_w4 = [] {
-    const char* e = getenv("WF_GEMM_KERNEL");
-    return e && e[0] == 'w' && e[1] == '4';
-  }();
-  // INVARIANT relied on by k_gemm_pp / k_gemm_pp16 / k_gemm_w4: their epilogues load bias / gate / old-value quads UNCONDITIONALLY at
+  // INVARIANT relied on by k_gemm_pp: its epilogues load bias / gate / old-value quads UNCONDITIONALLY at
   // clamped addresses `min(n, N - 4)` (a guard per load would put every load in its own basic block), which needs N >= 4 and N % 4 == 0.
   // `big` guarantees both (N >= 256, N % 4 == 0); a future relaxation of this gate must keep them.
   // ... and the saddr LDS-DMA of k_gemm_pp addresses a row's bytes by a 32-bit offset from X / W
   const bool big = K % PK == 0 && M >= 1024 && N >= 256 && N % 4 == 0 && (long)M * N >= (1L << 22) &&
                    (size_t)M * ldx * 2 < (1ull << 32) && (size_t)N * ldw * 2 < (1ull << 32);
-  if (use_w4 && !no_pp && big && !f16) {
-    switch (epilogue) {
-      case EPI_BF16: launch_w4<EPI_BF16>(a, s); break;
-      case EPI_BF16_GELU: launch_w4<EPI_BF16_GELU>(a, s); break;
-      case EPI_F32: launch_w4<EPI_F32>(a, s); break;
-      case EPI_RESID: launch_w4<EPI_RESID>(a, s); break;
-      case EPI_F32_ACC: launch_w4<EPI_F32_ACC>(a, s); break;
-      default: WF_CHECK_ARG(false, "wf_gemm_bf16: unknown epilogue %d", epilogue);
-    }
-    WF_LAUNCH_CHECK("wf_gemm_bf16");
-    return WF_OK;
-  }
-  if (!no_pp && big) {
+  if (big) {
     switch (epilogue) {
       case EPI_BF16: launch_pp_any<EPI_BF16>(a, s); break;
       case EPI_BF16_GELU: launch_pp_any<EPI_BF16_GELU>(a, s); break;
@@ -1344,8 +852,8 @@ extern "C" int wf_gemm_bf16(const void* X, const void* W, const float* bias, voi
 
 // The same GEMM on fp16 operands (X, W fp16; epilogue 0 writes fp16): v_mfma_f32_32x32x16_f16, fp32 accumulation.  Epilogues 0 / 2 / 4.
 extern "C" int wf_gemm_f16(const void* X, const void* W, const float* bias, void* out, int M, int N, int K, int ldx, int ldw, int ldo,
-                           int epilogue, void* stream) {
-  return gemm_impl(X, W, bias, out, nullptr, M, N, K, ldx, ldw, ldo, epilogue, stream, 1);
+                           int epilogue, float acc_scale, void* stream) {
+  return gemm_impl(X, W, bias, out, nullptr, M, N, K, ldx, ldw, ldo, epilogue, stream, 1, acc_scale);
 }
 
 #ifdef WF_GEMM_TIMING
@@ -1382,13 +890,13 @@ static int gemm_batched_impl(const void* X, const void* W, void* out, int batch,
   a.bsx = bsx; a.bsw = bsw; a.bso = bso;
   a.f16 = f16;
   a.batch = batch;
+  a.acc_scale = 1.0f;
   hipStream_t s = (hipStream_t)stream;
   // problems that are large TOGETHER (the VAE mid-block's P . V products: 6240 x 384 x 18 720 per frame, 21 frames) take the ping-pong kernel
   // with the batch index on gridDim.y; the gate is gemm_impl's with the batch counted in
-  static const bool no_pp = getenv("WF_GEMM_NO_PP") != nullptr;
   const bool big = K % PK == 0 && M >= 1024 && N >= 256 && N % 4 == 0 && (long)M * N * batch >= (1L << 22) &&
                    (size_t)M * ldx * 2 < (1ull << 32) && (size_t)N * ldw * 2 < (1ull << 32);
-  if (big && !no_pp) {
+  if (big) {
     if (epilogue == EPI_BF16)
       launch_pp_any<EPI_BF16>(a, s);
     else

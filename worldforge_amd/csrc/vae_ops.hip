@@ -315,6 +315,16 @@ extern "C" int wf_f16_overflow_flag(int* out, int reset, void* stream) {
   return WF_OK;
 }
 
+// The same flag, asynchronously: a 4-byte copy into `pinned_host_out` (page-locked host memory owned by the caller) queued on `stream`
+// behind the producers launched so far.  No synchronisation: the caller reads the word after an event it records behind this call.
+extern "C" int wf_f16_overflow_flag_async(int* pinned_host_out, void* stream) {
+  WF_CHECK_ARG(pinned_host_out, "wf_f16_overflow_flag_async: null pointer");
+  if (hipMemcpyFromSymbolAsync(pinned_host_out, HIP_SYMBOL(g_f16_overflow), sizeof(unsigned int), 0, hipMemcpyDeviceToHost,
+                               (hipStream_t)stream) != hipSuccess)
+    return WF_EHIP;
+  return WF_OK;
+}
+
 static int rms_silu_x3_impl(const float* x, const float* gamma, void* out_x3, size_t npix, int C, int silu, void* stream, int f16) {
   WF_CHECK_ARG(x && gamma && out_x3, "wf_rms_silu_cl_x3: null pointer");
   WF_CHECK_ARG(C % 4 == 0 && C > 0 && C <= 1024, "wf_rms_silu_cl_x3: C=%d must be a multiple of 4 and <= 1024", C);

@@ -74,7 +74,7 @@ def ffn_padded_features(f: int) -> int:
     FFN-down reads the first `f` columns through the row stride, and every real element is the same K-ordered accumulation as before
     (the result does not depend on the tile width: tests/test_gpu_dit.py)."""
     fp = -(-f // 320) * 320
-    return fp if (fp - f) * 100 <= 3 * f and os.environ.get("WF_FFN_PAD", "1") != "0" else f
+    return fp if (fp - f) * 100 <= 3 * f else f
 
 
 def _pad_rows(t: torch.Tensor, rows: int) -> torch.Tensor:
@@ -86,7 +86,7 @@ def _pad_rows(t: torch.Tensor, rows: int) -> torch.Tensor:
 
 PROFILE_ATTN = None  # bench.py sets this to a list: (start, end) HIP events around every self-attention launch
 PROFILE_COMM = None  # bench.py (N > 1) sets this to a list; per layer one (start, end) HIP event pair around the compute stream's wait for the
-                     # K / V^T exchange -- or, for a segmented exchange (attention_segmented), the LIST of such pairs of the layer
+                     # K / V^T exchange -- or, for an own-first sweep (attention_exchange, modes chunked / bcast), the LIST of such pairs of the layer
 
 
 def comm_wait_ms(entry) -> float:
@@ -119,12 +119,16 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
               accumulate: bool = False, profile: bool = False, nsplit: Optional[int] = None, kmax2: Optional[torch.Tensor] = None,
               qmax2: Optional[torch.Tensor] = None):
     """q [H,Lq,128]; k [H,Lkp,128] and vt [H,Lkp/64,128,64], or their all-gathered per-rank shards k [P,H,S,128],
-    vt [P,H,S/64,128,64] (S = shard length, keys in shard-major order) -> out [Lq, H*128] bf16."""
+    vt [P,H,S/64,128,64] (S = shard length, keys in shard-major order; dense, or the strided views of a packed exchange buffer:
+    parallel.KVExchange, same slot stride for both) -> out [Lq, H*128] bf16."""
     H, Lq, D = q.shape
+    seg_stride = 0
     if k.dim() == 4:
         P, _, seg, _ = k.shape
         assert vt.shape == (P, H, seg // 64, 128, 64)
+        assert k[0].is_contiguous() and vt[0].is_contiguous() and k.stride(0) == vt.stride(0)
         Lkp = P * seg
+        seg_stride = 2 * k.stride(0)
     else:
         Lkp = seg = k.shape[1]
         assert vt.shape == (H, Lkp // 64, 128, 64)
@@ -132,104 +136,103 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
     prof = PROFILE_ATTN if profile else None
     if nsplit is None:
         nsplit = kv_splits(H, Lq, kv_len)
-    kmp, kmn, qmp, qmn = None, 0, None, 0
+    kmp, kmn, kms, qmp, qmn = None, 0, 0, None, 0
     if kmax2 is not None and qmax2 is not None:  # [H] or [P, H] f32 each (one vector per gathered shard); only with scale == 0 (pre-scaled Q)
         for t in (kmax2, qmax2):
-            assert t.dtype == torch.float32 and t.is_contiguous() and t.shape[-1] == H
+            assert t.dtype == torch.float32 and t.stride(-1) == 1 and t.shape[-1] == H
+        assert qmax2.is_contiguous()
         kmp, kmn, qmp, qmn = kmax2.data_ptr(), kmax2.numel() // H, qmax2.data_ptr(), qmax2.numel() // H
+        kms = kmax2.stride(0) if kmax2.dim() == 2 else 0
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     if nsplit > 1:
         ws = ops._workspace("attn_split", (_ffi.lib().wf_attn_split_workspace_bytes(H, Lq, nsplit) + 3) // 4, q.device)
-        call("wf_attn_fwd_split", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Lq, Lkp, kv_len, seg, out.stride(0),
-             float(scale), 1 if accumulate else 0, nsplit, ws.data_ptr(), kmp, kmn, qmp, qmn, ops.stream())
+        call("wf_attn_fwd_split", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Lq, Lkp, kv_len, seg, seg_stride, out.stride(0),
+             float(scale), 1 if accumulate else 0, nsplit, ws.data_ptr(), kmp, kmn, kms, qmp, qmn, ops.stream())
     else:
-        call("wf_attn_fwd", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Lq, Lkp, kv_len, seg, out.stride(0),
-             float(scale), 1 if accumulate else 0, kmp, kmn, qmp, qmn, ops.stream())
+        call("wf_attn_fwd", q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), H, Lq, Lkp, kv_len, seg, seg_stride, out.stride(0),
+             float(scale), 1 if accumulate else 0, kmp, kmn, kms, qmp, qmn, ops.stream())
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1))
     return out
 
 
-def segment_groups(P: int, rank: int, peer_groups: int = 2):
-    """The order in which rank `rank` of P walks the key segments of a sequence-parallel layer whose shards arrive by P broadcasts in
-    source order (parallel.Comm.exchange_segments_async): its OWN shard first (no wait), then the peers in arrival order, in at most
-    `peer_groups` + 1 runs of consecutive physical segments [a, b) that do not cross the own one.  -> [(a, b), ...]; a run is ready once
-    the event of source b - 1 has fired."""
-    per = max(1, -(-(P - 1) // max(1, peer_groups)))
-    runs = [(rank, rank + 1)]
-    for lo, hi in ((0, rank), (rank + 1, P)):
-        a = lo
-        while a < hi:
-            runs.append((a, min(a + per, hi)))
-            a = min(a + per, hi)
-    return runs
-
-
-def attention_segmented(q: torch.Tensor, k_all: torch.Tensor, vt_all: torch.Tensor, out: torch.Tensor, kv_len: int, rank: int,
-                        events, kmax_own: Optional[torch.Tensor], kmax_all: Optional[torch.Tensor], ev_kmax, qmax2: Optional[torch.Tensor],
-                        peer_groups: int = 2, profile: bool = False):
-    """Self-attention of one sequence-parallel layer in PARTS (wf_attn_fwd_part / wf_attn_merge; pre-scaled Q): k_all [P,H,S,128], vt_all
-    [P,H,S/64,128,64] whose slot `rank` is this rank's own shard and whose other slots are being filled by
-    exchange_segments_async -- `events` = (k events, v events), lists of P.  The own shard is walked at once, each later run of segments
-    (segment_groups) after the event of its last source; the exposed part of the exchange is what the compute stream still has to wait for
-    THEN (PROFILE_COMM records every wait).  Result = the one-launch sweep up to the re-association of the fp32 partial sums (the class of
-    the split KV sweep the 8-rank shards already use)."""
-    P, H, seg, _ = k_all.shape
-    Lq = q.shape[1]
-    assert vt_all.shape == (P, H, seg // 64, 128, 64) and q.shape[0] == H and seg % 64 == 0
-    runs = segment_groups(P, rank, peer_groups)
-    tps, ntiles = seg // 64, -(-kv_len // 64)
-    # inner splits per run: a part launch of W = ceil(Lq / 256) * H workgroups takes ceil(W / 256) rounds -- 640 workgroups (one rank of 8)
-    # would idle a sixth of the chip in EVERY part; two inner splits make it five full rounds (the decision kv_splits takes for the whole sweep)
-    w = -(-Lq // 256) * H
-    inner = 2 if (w / 256.0) / -(-w // 256) < 0.92 and len(runs) * 2 <= 8 else 1
-    slots, nparts = [], 0
-    for (a, b) in runs:
-        n_t = min(b * tps, ntiles) - a * tps
-        k = max(1, min(inner, n_t // 8))
-        slots.append((nparts, k))
-        nparts += k
-    nparts = max(nparts, 2)
-    assert 2 <= nparts <= 8, nparts
-    ws = ops._workspace("attn_split", (_ffi.lib().wf_attn_split_workspace_bytes(H, Lq, nparts) + 3) // 4, q.device)
-    prof = PROFILE_ATTN if profile else None
-    cprof = PROFILE_COMM
+def attention_exchange(q: torch.Tensor, ex, out: torch.Tensor, kv_len: int, scale: float, qmax2: Optional[torch.Tensor],
+                       use_bounds: bool = True, profile: bool = False, peer_groups: int = 2, release: bool = True,
+                       comm_profile: bool = True):
+    """Self-attention of one sequence-parallel layer over the exchange buffers `ex` (parallel.KVExchange, `launch`ed earlier): q [H,Lq,128]
+    attends to the first kv_len keys of the sequence -> out [Lq, H*128] bf16.
+      gather            wait for the one event, ONE launch over the P segments (split-KV when the query shard is short): the tiles of
+                        the single-GPU sweep in the same order.
+      chunked / bcast   own-first part launches (parallel.sweep_plan; wf_attn_fwd_part needs the pre-scaled Q form, scale == 0): the
+                        rank's own keys without any wait, then each window after the event of its chunk / last source -- the exposed
+                        part of the exchange is what the compute stream still has to wait for THEN (PROFILE_COMM records every wait)
+                        -- and one exact merge (wf_attn_merge).  Result = the one-launch sweep up to the re-association of the fp32
+                        partial sums (the class the 8-rank split sweep already has).
+    release: the compute stream ends up behind the LAST collective (KVExchange.wait_all) before the caller goes on to write the
+    exchange buffers again."""
+    from .parallel import sweep_plan
+    H, Lq, _ = q.shape
+    cprof = PROFILE_COMM if comm_profile else None
     waits = []
+
+    def timed_wait(i):
+        if cprof is not None:
+            cw0, cw1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            cw0.record()
+        ex.wait(i)
+        if cprof is not None:
+            cw1.record()
+            waits.append((cw0, cw1))
+
+    bounds = use_bounds and qmax2 is not None
+    if ex.mode == "gather":
+        timed_wait(0)
+        attention(q, ex.k[0], ex.vt[0], out, kv_len, scale, profile=profile, kmax2=ex.km[0] if bounds else None, qmax2=qmax2 if bounds else None)
+        if cprof is not None:
+            cprof.append(waits[0])
+        return out
+    assert scale == 0.0, "own-first sweeps are part launches: pre-scaled Q only"
+    steps, nparts = sweep_plan(ex, kv_len, -(-Lq // 256) * H, peer_groups)
+    prof = PROFILE_ATTN if profile else None
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    cur = torch.cuda.current_stream()
-    for i, (a, b) in enumerate(runs):
-        kmx = kmax_own
-        if i > 0:
-            if cprof is not None:
-                cw0, cw1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                cw0.record()
-            for evs in events:
-                if evs[b - 1] is not None:
-                    cur.wait_event(evs[b - 1])
-            if ev_kmax is not None:
-                cur.wait_event(ev_kmax)
-                ev_kmax = None
-            if cprof is not None:
-                cw1.record()
-                waits.append((cw0, cw1))
-            kmx = kmax_all
-        t0, t1 = a * tps, min(b * tps, ntiles)
-        if t0 >= t1:  # a trailing shard that holds padding only
-            t1 = t0 + 1
-        kmp, kmn, qmp, qmn = None, 0, None, 0
-        if kmx is not None and qmax2 is not None:
-            kmp, kmn, qmp, qmn = kmx.data_ptr(), kmx.numel() // H, qmax2.data_ptr(), qmax2.numel() // H
-        call("wf_attn_fwd_part", q.data_ptr(), k_all.data_ptr(), vt_all.data_ptr(), H, Lq, P * seg, kv_len, seg, t0, t1, slots[i][0],
-             slots[i][1], nparts, ws.data_ptr(), kmp, kmn, qmp, qmn, ops.stream())
-    call("wf_attn_merge", out.data_ptr(), H, Lq, out.stride(0), 0, nparts, ws.data_ptr(), ops.stream())
+    if nparts == 1:  # one window holds every key these queries see (LongCat's condition rows): a plain launch on that chunk's buffer
+        st = steps[0]
+        if st["wait"] is not None:
+            timed_wait(st["wait"])
+        g = st["chunk"]
+        a, n = st["km"]
+        attention(q, ex.k[g], ex.vt[g], out, ex.chunk_kv_len(kv_len, g), scale, nsplit=1, kmax2=ex.km[g][a:a + n] if bounds else None,
+                  qmax2=qmax2 if bounds else None)
+    else:
+        from .parallel import MAX_ATTN_PARTS
+        assert 2 <= nparts <= MAX_ATTN_PARTS, nparts
+        ws = ops._workspace("attn_split", (_ffi.lib().wf_attn_split_workspace_bytes(H, Lq, nparts) + 3) // 4, q.device)
+        waited = set()
+        for st in steps:
+            g = st["chunk"]
+            if st["wait"] is not None and st["wait"] not in waited:
+                timed_wait(st["wait"])
+                waited.update(range(st["wait"] + 1))  # stream order: the earlier collectives have finished too
+            sc = ex.chunk_len(g)
+            kmp, kmn, kms, qmp, qmn = None, 0, 0, None, 0
+            if bounds:
+                a, n = st["km"]
+                kmp, kmn, kms, qmp, qmn = ex.km[g][a].data_ptr(), n, ex.km_stride(g), qmax2.data_ptr(), qmax2.numel() // H
+            (t0, t1, inner), w2 = st["win"], st["win2"] or (0, 0, 0)
+            call("wf_attn_fwd_part", q.data_ptr(), ex.k[g].data_ptr(), ex.vt[g].data_ptr(), H, Lq, ex.P * sc, ex.chunk_kv_len(kv_len, g), sc,
+                 ex.seg_stride_bytes(g), t0, t1, inner, w2[0], w2[1], w2[2], st["slot"], nparts, ws.data_ptr(), kmp, kmn, kms, qmp, qmn,
+                 ops.stream())
+        call("wf_attn_merge", out.data_ptr(), H, Lq, out.stride(0), 0, nparts, ws.data_ptr(), ops.stream())
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1))
+    if release:
+        ex.wait_all()
     if cprof is not None:
         cprof.append(waits)   # one entry per layer: the list of (start, end) event pairs of its waits
     return out
@@ -474,14 +477,17 @@ class WanTransformer3DModel:
         return t
 
     def _context_kv(self, text: torch.Tensor, img: torch.Tensor):
-        """Per-layer cross-attention K / V cache for one (text, image) context: {layer: (k_text, vT_text, k_img, vT_img)}.  Keyed by
-        the identity AND version of the embedding storages and of the weight dict, so an in-place edit of the embeddings or a
-        weight reload starts a fresh entry; at most 4 contexts are kept (positive / negative prompt of the last two videos).
-        Enabled by WF_CTX_CACHE=1 (results are bit-identical either way; +0.7 % steps/s at the 81-frame 480p configuration)."""
-        if not os.environ.get("WF_CTX_CACHE"):
-            # opt-in: the reference recomputes these projections in every forward, and bench.py times the path as the reference runs it
+        """Per-layer cross-attention K / V cache for one (text, image) context: {layer: (k, vT)} in the fused [image | text] layout.  The
+        K / V of the prompt context depend on the prompt only -- not on the latents, the timestep or the step -- so the 130 forwards of a
+        video compute them once per prompt (the reference recomputes them in every forward, model.py:215-218; the values are the same
+        kernels on the same inputs: bit-identical, tests/test_gpu_dit.py).  Keyed by the identity AND version of the embedding storages
+        and of the weight dict, so an in-place edit of the embeddings or a weight reload starts a fresh entry; at most 4 contexts are kept
+        (positive / negative prompt of the last two videos; 17 MB per layer each).  On by default since round 5 (+0.8 % steps/s at the
+        81-frame 480p configuration; bench.py states it in `config.ctx_cache`); WF_CTX_CACHE=0 recomputes per forward -- the reference
+        arm of the bit-equality test."""
+        if os.environ.get("WF_CTX_CACHE", "1") == "0":
             return None
-        key = (text.data_ptr(), text._version, tuple(text.shape), img.data_ptr(), img._version, tuple(img.shape), id(self.w))
+        key = (text.data_ptr(), text._version, tuple(text.shape), img.data_ptr(), img._version, tuple(img.shape), id(self.w), self.cfg.num_layers, id(self.comm))
         cache = self.__dict__.setdefault("_ctx_cache", {})
         hit = cache.get(key)
         if hit is None:
@@ -490,6 +496,15 @@ class WanTransformer3DModel:
             # the tensors are held so that their storage (and hence data_ptr) cannot be recycled while the entry lives
             hit = cache[key] = {"_keep": (text, img)}
         return hit
+
+    def _exchange(self, tag: str, H: int, shard_len: int, mode: str, chunks: int):
+        """The K / V^T exchange buffers of the forward `tag` (parallel.KVExchange), allocated once per shape and mode."""
+        from .parallel import KVExchange
+        key = ("kvx" + tag, H, shard_len, mode, chunks, id(self.comm))
+        ex = self._ws.get(key)
+        if ex is None:
+            ex = self._ws[key] = KVExchange(self.comm, H, shard_len, mode, chunks, self.device)
+        return ex
 
     def _rope_tables(self, f, h, w):
         key = (f, h, w)
@@ -579,17 +594,20 @@ class WanTransformer3DModel:
             call("wf_v_transpose_seg", view.data_ptr(), src.stride(0), out.data_ptr(), L, out.shape[1] * 64, self.cfg.num_heads, hstride,
                  ops.stream())
 
+    # How a forward WITHOUT a second CFG branch exchanges K / V^T (parallel.KVExchange): "chunked" (default, `exchange_chunks` all-gathers,
+    # own shard first), "bcast" (per-source broadcasts, own shard first) or "gather" (one all-gather, one launch: bit-identical to one GPU
+    # up to 4 ranks).  The lock-step CFG pair always uses "gather": the other branch's layer hides the exchange.  bench.py --gpus N times
+    # the modes on the node at start-up and sets these (bench.calibrate_exchange).
+    exchange_mode = "chunked"
+    exchange_chunks = 2
+    pair_lockstep = True      # forward_tokens_pair under sequence parallelism: two forwards one layer apart (False: one after the other)
+    attn_prescale = True      # softmax_scale * log2(e) folded into Q by its producer (k_attn_w4<4>); False: in-kernel scale (k_attn_w4<0>)
+    attn_track_max = False    # True: withhold the norm bounds -> the kernel's max-tracking body (A/B and the tracked-body parity tests)
+
     def forward_tokens(self, x_in: torch.Tensor, t_value: float, text: torch.Tensor, img: torch.Tensor) -> torch.Tensor:
         """x_in [in_dim, T, h, w] bf16; text [<=512, text_dim]; img [n_img, img_dim] -> velocity [out_dim, T, h, w] f32."""
         out = [None]
-        # one forward on its own has no second CFG branch to hide the K / V^T exchange under: the exchange runs as per-source broadcasts and
-        # the attention walks the segments as they arrive, its own shard first (attention_segmented; `segmented_exchange = False` or
-        # WF_ATTN_SEGMENTED=0: the one-event all-gather of the lock-step pair, bit-identical to one GPU up to 4 ranks)
-        seg = getattr(self, "segmented_exchange", None)
-        if seg is None:
-            seg = os.environ.get("WF_ATTN_SEGMENTED", "1") != "0"
-        seg = bool(seg) and self.comm is not None and self.comm.world > 1 and hasattr(self.comm, "exchange_segments_async")
-        for _ in self._forward_steps(x_in, t_value, text, img, "", out, segmented=seg):
+        for _ in self._forward_steps(x_in, t_value, text, img, "", out, self.exchange_mode):
             pass
         return out[0]
 
@@ -599,15 +617,15 @@ class WanTransformer3DModel:
         negative prompt).  Under sequence parallelism the two are advanced in lock-step, one layer apart: while branch A's K / V^T
         all-gather of layer i is in flight on the communication stream, branch B computes its layer i-1 attention / FFN, and vice
         versa, so every exchange has a whole layer of the other branch to hide under.  Each branch issues exactly the kernels of
-        forward_tokens in the same order on its own buffers: results are bit-identical to two sequential calls."""
+        forward_tokens (exchange mode "gather") in the same order on its own buffers: results are bit-identical to two sequential calls."""
         if interleave is None:
-            interleave = self.comm is not None
+            interleave = self.comm is not None and self.pair_lockstep
         if not interleave:
             va = self.forward_tokens(x_in, t_value, text_a, img)
             return va, self.forward_tokens(x_in, t_value, text_b, img)
         oa, ob = [None], [None]
-        ga = self._forward_steps(x_in, t_value, text_a, img, "", oa)
-        gb = self._forward_steps(x_in, t_value, text_b, img, "#b", ob)
+        ga = self._forward_steps(x_in, t_value, text_a, img, "", oa, "gather")
+        gb = self._forward_steps(x_in, t_value, text_b, img, "#b", ob, "gather")
         live = [ga, gb]
         while live:
             for gen in list(live):
@@ -617,7 +635,7 @@ class WanTransformer3DModel:
                     live.remove(gen)
         return oa[0], ob[0]
 
-    def _forward_steps(self, x_in, t_value, text, img, tag, result, segmented=False):
+    def _forward_steps(self, x_in, t_value, text, img, tag, result, mode="gather"):
         """Generator over one forward: yields once per layer, right after that layer's K / V^T exchange has been launched (the
         point where another forward can usefully take over the compute stream).  `tag` separates the workspaces of concurrent
         forwards; the velocity lands in result[0]."""
@@ -631,9 +649,8 @@ class WanTransformer3DModel:
         d, H = cfg.dim, cfg.num_heads
         scale = 1.0 / math.sqrt(128.0)
         # self-attention: softmax_scale * log2(e) is folded into Q by its producer (in front of the one bf16 rounding) and the attention
-        # kernel is told so with softmax_scale = 0 (k_attn_w4<4>: score accumulators start from -m); WF_ATTN_PRESCALE=0 keeps the scale
-        # inside the kernel (A/B)
-        prescale = os.environ.get("WF_ATTN_PRESCALE", "1") != "0"
+        # kernel is told so with softmax_scale = 0 (k_attn_w4<4>: score accumulators start from -m)
+        prescale = bool(self.attn_prescale)
         q_scale, sa_scale = (scale * 1.4426950408889634, 0.0) if prescale else (1.0, scale)
         cos, sin = self._rope_tables(f, h2, w2)
         e, e0, ctx_t, ctx_i = self._embed_condition(t_value, text, img, tag)
@@ -662,36 +679,30 @@ class WanTransformer3DModel:
         hbuf = _buf("h", (L, d), bf)
         qkv = _buf("qkv", (L, 3 * d), bf)
         qh = _buf("qh", (H, L, 128), bf)
-        kh = _buf("kh", (H, Lp, 128), bf, zero=True)
-        vt = _buf("vt", (H, Lp // 64, 128, 64), bf)
-        # per-head max |k|^2 lets the kernel drop its running-max tracking when no score can overflow (wf_head_max_norm2); WF_ATTN_TRACK_MAX=1
-        # keeps the tracking (A/B)
-        km = _buf("kmax2", (H,), f32) if prescale and os.environ.get("WF_ATTN_TRACK_MAX", "0") != "1" else None
-        qm = _buf("qmax2", (H,), f32) if km is not None else None
-        fused_bound = km is not None and os.environ.get("WF_NORM_BOUND_PASS", "0") != "1"
+        # per-head max |k|^2 / |q|^2 (out of the producers' own pass: wf_rmsnorm_heads_bound) let the kernel drop its running-max tracking
+        # when no score can overflow; attn_track_max withholds them (A/B)
+        use_bounds = prescale and not self.attn_track_max
+        qm = _buf("qmax2", (H,), f32) if use_bounds else None
+        ex = None
         if comm is not None:
-            kh_all = _buf("kh_all", (comm.world, H, Lp, 128), bf, zero=True)
-            vt_all = _buf("vt_all", (comm.world, H, Lp // 64, 128, 64), bf)
-            km_all = _buf("kmax2_all", (comm.world, H), f32) if prescale else None
-            segmented = segmented and prescale and km is not None
-            if segmented:  # the producers write this rank's shard straight into its slot of the exchange buffers
-                kh, vt = kh_all[comm.rank], vt_all[comm.rank]
+            if not prescale or comm.world == 1:
+                mode = "gather"   # part launches are built for the pre-scaled-Q form
+            ex = self._exchange(tag, H, Lp, mode, int(self.exchange_chunks))
+        else:
+            kh = _buf("kh", (H, Lp, 128), bf, zero=True)
+            vt = _buf("vt", (H, Lp // 64, 128, 64), bf)
+            km = _buf("kmax2", (H,), f32) if use_bounds else None
         ao = _buf("ao", (L, d), bf)
         qc = _buf("qc", (L, d), bf)
         ffh = _buf("ffh", (L, ffn_padded_features(cfg.ffn_dim)), bf)
         Lt, Li = cfg.text_len, _pad64(n_img)
-        # the two cross-attentions of a layer (image context, then text context, summed: model.py:220-227) as ONE launch over a concatenated
-        # key / value buffer [image tiles | text tiles] (wf_attn_cross2_fwd; bit-identical to the two launches, WF_CROSS_FUSED=0 keeps those)
-        fused = os.environ.get("WF_CROSS_FUSED", "1") != "0"
+        # the two cross-attentions of a layer (image context, then text context, summed: model.py:220-227) are ONE launch over a concatenated
+        # key / value buffer [image tiles | text tiles] (wf_attn_cross2_fwd; bit-identical to two wf_attn_fwd launches: tests/test_gpu_dit.py)
         Lc = Li + Lt
         kvt = _buf("kvt", (cfg.text_len, 2 * d), bf)
         kvi = _buf("kvi", (n_img, 2 * d), bf)
-        kth = _buf("kth", (H, Lt, 128), bf, zero=True)
-        vtt = _buf("vtt", (H, Lt // 64, 128, 64), bf)
-        kih = _buf("kih", (H, Li, 128), bf, zero=True)
-        vti = _buf("vti", (H, Li // 64, 128, 64), bf)
-        kc = _buf("kc", (H, Lc, 128), bf, zero=True) if fused else None
-        vtc = _buf("vtc", (H, Lc // 64, 128, 64), bf) if fused else None
+        kc = _buf("kc", (H, Lc, 128), bf, zero=True)
+        vtc = _buf("vtc", (H, Lc // 64, 128, 64), bf)
         emod = _buf("emod", (6, d), f32)
 
         def context_operands(pl, kc_, vtc_):
@@ -708,37 +719,29 @@ class WanTransformer3DModel:
         # the token shard -- 3 % of a rank's GPU time at 8 ranks when every rank computes all 40 layers' (measured).  Each
         # rank computes the layers i = rank (mod P) only, the finished kernel operands ([H, rows, 128] keys, blocked V^T) are all-gathered
         # once per forward on the communication stream; layer i then reads slot [i % P][i // P].  Same kernels per layer: bit-identical.
+        # With the context cache (default) this happens on the first forward of a prompt only: the gathered buffers ARE the cache entry.
         ctx_shared = ctx_events = None
-        share_ctx = comm is not None and comm.world > 1 and ctx_kv is None and os.environ.get("WF_CTX_REPLICATED", "0") != "1"
+        share_ctx = comm is not None and comm.world > 1
+        if share_ctx and ctx_kv is not None and "shared" in ctx_kv:
+            (ctx_shared, ctx_events), share_ctx = ctx_kv["shared"], False   # (the events have long fired; waiting again costs nothing)
 
         def launch_context():
             """Called once, right after layer 0's K / V^T exchange has been launched: the context gathers queue BEHIND it on the communication
             stream (layer 0's self-attention needs its keys first, the context is not read before layer 0's cross-attention)."""
             P_, nl = comm.world, (cfg.num_layers + comm.world - 1) // comm.world
-            if fused:
-                loc = [_buf("ckvf_loc0", (nl, H, Lc, 128), bf, zero=True), _buf("ckvf_loc1", (nl, H, Lc // 64, 128, 64), bf)]
-                allb = [_buf(f"ckvf_all{j}", (P_,) + tuple(t.shape), bf) for j, t in enumerate(loc)]
-                for j in range(nl):
-                    li = comm.rank + P_ * j
-                    if li >= cfg.num_layers:
-                        break
-                    context_operands(f"blocks.{li}.", loc[0][j], loc[1][j])
-                return (allb, P_), [comm.all_gather_async(a_, l_) for a_, l_ in zip(allb, loc)]
-            loc = [_buf("ckv_loc0", (nl, H, Lt, 128), bf, zero=True), _buf("ckv_loc1", (nl, H, Lt // 64, 128, 64), bf),
-                   _buf("ckv_loc2", (nl, H, Li, 128), bf, zero=True), _buf("ckv_loc3", (nl, H, Li // 64, 128, 64), bf)]
-            allb = [_buf(f"ckv_all{j}", (P_,) + tuple(t.shape), bf) for j, t in enumerate(loc)]
+            mk = (lambda name, shape, zero=False: (torch.zeros if zero else torch.empty)(shape, dtype=bf, device=dev)) if ctx_kv is not None \
+                else (lambda name, shape, zero=False: _buf(name, shape, bf, zero))   # cached entries own their buffers
+            loc = [_buf("ckvf_loc0", (nl, H, Lc, 128), bf, zero=True), _buf("ckvf_loc1", (nl, H, Lc // 64, 128, 64), bf)]
+            allb = [mk(f"ckvf_all{j}", (P_,) + tuple(t.shape)) for j, t in enumerate(loc)]
             for j in range(nl):
                 li = comm.rank + P_ * j
                 if li >= cfg.num_layers:
                     break
-                pl = f"blocks.{li}."
-                gemm(ctx_t, W[pl + "cross_attn.kv.w"], W[pl + "cross_attn.kv.b"], kvt, EPI_BF16)
-                self._heads(kvt, 0, W[pl + "cross_attn.norm_k"], None, None, loc[0][j], Lt)
-                self._vt(kvt, d, loc[1][j], Lt)
-                gemm(ctx_i, W[pl + "cross_attn.kv_img.w"], W[pl + "cross_attn.kv_img.b"], kvi, EPI_BF16)
-                self._heads(kvi, 0, W[pl + "cross_attn.norm_k_img"], None, None, loc[2][j], n_img)
-                self._vt(kvi, d, loc[3][j], n_img)
-            return (allb, P_), [comm.all_gather_async(a_, l_) for a_, l_ in zip(allb, loc)]
+                context_operands(f"blocks.{li}.", loc[0][j], loc[1][j])
+            shared = ((allb, P_), [comm.all_gather_async(a_, l_) for a_, l_ in zip(allb, loc)])
+            if ctx_kv is not None:
+                ctx_kv["shared"] = shared
+            return shared
 
         for i in range(cfg.num_layers):
             p = f"blocks.{i}."
@@ -749,52 +752,27 @@ class WanTransformer3DModel:
             self._ln(x, emod[1], emod[0], hbuf, cfg.eps, plus_one=True)
             if comm is None:
                 gemm(hbuf, W[p + "qkv.w"], W[p + "qkv.b"], qkv, EPI_BF16)
-                # the per-head norm bounds come out of the producers' own pass (WF_NORM_BOUND_PASS=1: the separate wf_head_max_norm2 passes)
-                self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L, out_scale=q_scale, bound=qm if fused_bound else None)
-                self._heads(qkv, d, W[p + "self_attn.norm_k"], cos, sin, kh, L, bound=km if fused_bound else None)
+                self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L, out_scale=q_scale, bound=qm)
+                self._heads(qkv, d, W[p + "self_attn.norm_k"], cos, sin, kh, L, bound=km)
                 self._vt(qkv, 2 * d, vt, L)
-                if km is not None and not fused_bound:
-                    head_max_norm2(kh, L, km)
-                    head_max_norm2(qh, L, qm)
                 attention(qh, kh, vt, ao, L, sa_scale, profile=True, kmax2=km, qmax2=qm)
             else:
-                # K and V first, their all-gather runs on the communication stream under the Q projection
+                # K and V first: the producers write this rank's shard (and its norm bounds) straight into its slot of the exchange
+                # buffers, chunk by chunk; the exchange runs on the communication stream under the Q projection
                 gemm(hbuf, W[p + "qkv.w"][d:], W[p + "qkv.b"][d:], qkv[:, d:], EPI_BF16)
-                self._heads(qkv, d, W[p + "self_attn.norm_k"], cos, sin, kh, L, bound=km if fused_bound else None)
-                self._vt(qkv, 2 * d, vt, L)
-                if segmented:
-                    evs_kv = (comm.exchange_segments_async(kh_all), comm.exchange_segments_async(vt_all))
-                else:
-                    ev_k = comm.all_gather_async(kh_all, kh)
-                    ev_v = comm.all_gather_async(vt_all, vt)
-                if km is not None:  # every shard's per-head max |k|^2 travels with it (40 floats per rank)
-                    if not fused_bound:
-                        head_max_norm2(kh, L, km)
-                    ev_m = comm.all_gather_async(km_all, km)
+                for g in range(ex.G):
+                    r0, r1 = ex.chunk_rows(g, L)
+                    if r1 > r0:
+                        self._heads(qkv[r0:r1], d, W[p + "self_attn.norm_k"], cos[r0:r1], sin[r0:r1], ex.own_k(g), r1 - r0,
+                                    bound=ex.own_km(g) if use_bounds else None)
+                        self._vt(qkv[r0:r1], 2 * d, ex.own_vt(g), r1 - r0)
+                ex.launch()
                 if i == 0 and share_ctx:
                     ctx_shared, ctx_events = launch_context()
                 yield i
                 gemm(hbuf, W[p + "qkv.w"][:d], W[p + "qkv.b"][:d], qkv[:, :d], EPI_BF16)
-                self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L, out_scale=q_scale, bound=qm if fused_bound else None)
-                if segmented:
-                    if not fused_bound:
-                        head_max_norm2(qh, L, qm)
-                    attention_segmented(qh, kh_all, vt_all, ao, Lfull, comm.rank, evs_kv, km, km_all, ev_m, qm, profile=True,
-                                        peer_groups=int(os.environ.get("WF_ATTN_SEG_GROUPS", "2")))
-                cprof = PROFILE_COMM if not segmented else None
-                if cprof is not None:  # exposed communication = how long the compute stream stalls here
-                    cw0, cw1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    cw0.record()
-                for ev in () if segmented else (ev_k, ev_v) + ((ev_m,) if km is not None else ()):
-                    if ev is not None:
-                        torch.cuda.current_stream().wait_event(ev)
-                if cprof is not None:
-                    cw1.record()
-                    cprof.append((cw0, cw1))
-                if km is not None and not fused_bound and not segmented:  # this rank's own queries only
-                    head_max_norm2(qh, L, qm)
-                if not segmented:
-                    attention(qh, kh_all, vt_all, ao, Lfull, sa_scale, profile=True, kmax2=km_all if km is not None else None, qmax2=qm)
+                self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L, out_scale=q_scale, bound=qm)
+                attention_exchange(qh, ex, ao, Lfull, sa_scale, qm, use_bounds=use_bounds, profile=True)
             gemm(ao, W[p + "self_attn.o.w"], W[p + "self_attn.o.b"], x, EPI_RESID, gate=emod[2])
             # ---- cross-attention (model.py:310, 202-229) ----
             self._ln(x, W[p + "norm3.w"], W[p + "norm3.b"], hbuf, cfg.eps, plus_one=False)
@@ -810,37 +788,16 @@ class WanTransformer3DModel:
                             torch.cuda.current_stream().wait_event(ev)
                     ctx_events = None
                 allb, P_ = ctx_shared
-                if fused:
-                    kc, vtc = (a_[i % P_, i // P_] for a_ in allb)
-                else:
-                    kth, vtt, kih, vti = (a_[i % P_, i // P_] for a_ in allb)
-            elif kv is None and fused:
+                kc, vtc = (a_[i % P_, i // P_] for a_ in allb)
+            elif kv is None:
                 if ctx_kv is not None:  # own buffers per layer
                     kc, vtc = torch.zeros((H, Lc, 128), dtype=bf, device=dev), torch.empty((H, Lc // 64, 128, 64), dtype=bf, device=dev)
                 context_operands(p, kc, vtc)
                 if ctx_kv is not None:
                     ctx_kv[i] = (kc, vtc)
-            elif kv is None:
-                if ctx_kv is not None:  # own buffers per layer
-                    kth, vtt = torch.zeros((H, Lt, 128), dtype=bf, device=dev), torch.empty((H, Lt // 64, 128, 64), dtype=bf, device=dev)
-                    kih, vti = torch.zeros((H, Li, 128), dtype=bf, device=dev), torch.empty((H, Li // 64, 128, 64), dtype=bf, device=dev)
-                gemm(ctx_t, W[p + "cross_attn.kv.w"], W[p + "cross_attn.kv.b"], kvt, EPI_BF16)
-                self._heads(kvt, 0, W[p + "cross_attn.norm_k"], None, None, kth, Lt)
-                self._vt(kvt, d, vtt, Lt)
-                gemm(ctx_i, W[p + "cross_attn.kv_img.w"], W[p + "cross_attn.kv_img.b"], kvi, EPI_BF16)
-                self._heads(kvi, 0, W[p + "cross_attn.norm_k_img"], None, None, kih, n_img)
-                self._vt(kvi, d, vti, n_img)
-                if ctx_kv is not None:
-                    ctx_kv[i] = (kth, vtt, kih, vti)
-            elif fused:
+            else:
                 kc, vtc = kv
-            else:
-                kth, vtt, kih, vti = kv
-            if fused:
-                cross_attention2(qh, kc, vtc, ao, Li, n_img, Lt, scale)
-            else:
-                attention(qh, kih, vti, ao, n_img, scale)
-                attention(qh, kth, vtt, ao, Lt, scale, accumulate=True)
+            cross_attention2(qh, kc, vtc, ao, Li, n_img, Lt, scale)
             gemm(ao, W[p + "cross_attn.o.w"], W[p + "cross_attn.o.b"], x, EPI_RESID, gate=None)
             # ---- FFN (model.py:311-313) ----
             self._ln(x, emod[4], emod[3], hbuf, cfg.eps, plus_one=True)

@@ -28,7 +28,7 @@ import torch
 
 from . import ops
 from ._ffi import WF_BF16, WF_F32, call
-from .dit import EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_F32_ACC, _pad64, attention, gemm, head_max_norm2
+from .dit import EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_F32_ACC, _pad64, attention, attention_exchange, gemm, head_max_norm2
 
 
 @dataclass
@@ -267,15 +267,60 @@ class LongCatVideoTransformer3DModel:
         call("wf_v_transpose", view.data_ptr(), src.stride(0), out.data_ptr(), L, out.shape[1] * 64, self.cfg.num_heads, ops.stream())
 
     # ------------------------------------------------------------------------------------------------------------
+    # Exchange of a forward WITHOUT a lock-step partner (the distilled schedule has no CFG; see dit.WanTransformer3DModel for the modes);
+    # the two samples of a CFG batch are advanced in lock-step with the one-event all-gather (forward_tokens_pair)
+    exchange_mode = "chunked"
+    exchange_chunks = 2
+    pair_lockstep = True
+    attn_prescale = True
+    attn_track_max = False
+
+    def _exchange(self, tag: str, H: int, shard_len: int, mode: str, chunks: int):
+        from .parallel import KVExchange
+        key = ("kvx" + tag, H, shard_len, mode, chunks, id(self.comm))
+        ex = self._ws.get(key)
+        if ex is None:
+            ex = self._ws[key] = KVExchange(self.comm, H, shard_len, mode, chunks, self.device)
+        return ex
+
     def forward_tokens(self, x_in: torch.Tensor, timesteps, caption: torch.Tensor, caption_mask: Optional[torch.Tensor] = None,
                        num_cond_latents: int = 0) -> torch.Tensor:
         """One sample.  x_in [16, T, Hh, Ww] bf16; timesteps: T host floats; caption [N, caption_channels] bf16; caption_mask [N]
-        host / device ints (0 = padding) or None -> velocity [16, T, Hh, Ww] fp32  (LCD:279-366).
+        host / device ints (0 = padding) or None -> velocity [16, T, Hh, Ww] fp32  (LCD:279-366)."""
+        out = [None]
+        for _ in self._forward_steps(x_in, timesteps, caption, caption_mask, num_cond_latents, "", out, self.exchange_mode):
+            pass
+        return out[0]
+
+    def forward_tokens_pair(self, sample_a, sample_b, num_cond_latents: int = 0):
+        """The two samples of a CFG batch (pipeline_longcat_video.py:857-866: [negative, positive] concatenated on the batch axis; each
+        sample = (x_in, timesteps, caption, caption_mask) as for forward_tokens).  The reference's batch is one tensor through one network
+        call; here the two samples are two forwards advanced in LOCK-STEP, one layer apart, under sequence parallelism: while sample A's
+        K / V^T all-gather of block i is in flight on the communication stream, sample B computes its block i-1 attention / FFN, and vice
+        versa (the scheme of dit.WanTransformer3DModel.forward_tokens_pair).  Each sample issues exactly the kernels of forward_tokens in
+        exchange mode "gather" on its own buffers: bit-identical to two sequential calls."""
+        oa, ob = [None], [None]
+        ga = self._forward_steps(*sample_a, num_cond_latents, "", oa, "gather")
+        gb = self._forward_steps(*sample_b, num_cond_latents, "#b", ob, "gather")
+        live = [ga, gb]
+        while live:
+            for gen in list(live):
+                try:
+                    next(gen)
+                except StopIteration:
+                    live.remove(gen)
+        return oa[0], ob[0]
+
+    def _forward_steps(self, x_in, timesteps, caption, caption_mask, num_cond_latents, tag, result, mode="gather"):
+        """Generator over one forward: yields once per dense block, right after that block's K / V^T exchange has been launched (where
+        another forward can usefully take over the compute stream); `tag` separates the workspaces of concurrent forwards; the velocity
+        lands in result[0].
 
         With `comm` (one process per GPU) the tokens are split into contiguous shards, weights replicated: every rank runs the row-wise
-        work on its shard, K and blocked V^T shards are all-gathered once per block and consumed in place by the attention kernel
-        (segment addressing), the 64-column output rows are gathered at the end.  The condition / noise split of LCA:123-138 is by GLOBAL
-        token index: a rank's rows below the first frame boundary are condition queries (keys < nc), the rest noise queries."""
+        work on its shard, K and blocked V^T shards are exchanged once per block (parallel.KVExchange) and consumed in place by the
+        attention kernel (segment addressing), the 64-column output rows are gathered at the end.  The condition / noise split of
+        LCA:123-138 is by GLOBAL token index: a rank's rows below the first frame boundary are condition queries (keys < nc), the rest
+        noise queries."""
         cfg, W, dev = self.cfg, self.w, self.device
         bf, f32 = torch.bfloat16, torch.float32
         Cin, T, Hh, Ww = x_in.shape
@@ -288,7 +333,7 @@ class LongCatVideoTransformer3DModel:
         assert 0 <= nc < L
         scale = 1.0 / math.sqrt(128.0)
         cos, sin = self._rope_tables(T, h2, w2)
-        _buf = self._buf
+        _buf = lambda name, shape, dtype, zero=False: self._buf(name + tag, shape, dtype, zero)  # noqa: E731
         comm = self.comm
         use_bsa = self._bsa and T > 1  # LCA:57: "bsa will not be used in image training / sampling"
         gidx = perm = pos = None
@@ -369,32 +414,27 @@ class LongCatVideoTransformer3DModel:
         qkv = _buf("qkv", (L, 3 * C), bf)
         qh_c = _buf("qh_c", (H, max(nc, 1), 128), bf)
         qh_n = _buf("qh_n", (H, max(L - nc, 1), 128), bf)  # (a rank of a sequence-parallel job may hold condition rows only)
-        kh = _buf("kh", (H, Sp, 128), bf, zero=True)
-        vt = _buf("vt", (H, Sp // 64, 128, 64), bf)
         # dense self-attention (no block gating on Q): as in the Wan DiT (dit.py), softmax_scale * log2(e) is folded into Q by its producer and
         # the kernel runs its exp2-domain form (softmax_scale = 0), without max tracking where the per-head norm bound allows it.  The
-        # block-sparse pass keeps the in-kernel scale: its Q also feeds the gating.  WF_ATTN_PRESCALE=0 / WF_ATTN_TRACK_MAX=1 as in dit.py.
-        prescale = (not use_bsa) and os.environ.get("WF_ATTN_PRESCALE", "1") != "0"
+        # block-sparse pass keeps the in-kernel scale: its Q also feeds the gating.
+        prescale = (not use_bsa) and bool(self.attn_prescale)
         q_scale, sa_scale = (scale * 1.4426950408889634, 0.0) if prescale else (1.0, scale)
-        km = _buf("kmax2", (H,), f32) if prescale and os.environ.get("WF_ATTN_TRACK_MAX", "0") != "1" else None
-        qm_c = _buf("qmax2_c", (H,), f32) if km is not None else None
-        qm_n = _buf("qmax2_n", (H,), f32) if km is not None else None
-        segmented = False
-        if comm is not None:
-            kh_all = _buf("kh_all", (comm.world, H, Sp, 128), bf, zero=True)
-            vt_all = _buf("vt_all", (comm.world, H, Sp // 64, 128, 64), bf)
-            km_all = _buf("kmax2_all", (comm.world, H), f32) if km is not None else None
-            # The samples of a LongCat batch run one after the other (and the distilled schedule has no CFG at all, pipeline_longcat_video.py:
-            # 857-866): there is no second branch to hide the K / V^T exchange under.  Dense layers therefore exchange by per-source
-            # broadcasts and the noise-token attention walks the segments as they arrive, this rank's own shard first
-            # (dit.attention_segmented; `segmented_exchange = False` / WF_ATTN_SEGMENTED=0: the one-event all-gather, bit-identical to
-            # one GPU up to 4 ranks).  The producers then write straight into this rank's slot of the exchange buffers.
-            seg_opt = getattr(self, "segmented_exchange", None)
-            if seg_opt is None:
-                seg_opt = os.environ.get("WF_ATTN_SEGMENTED", "1") != "0"
-            segmented = bool(seg_opt) and comm.world > 1 and not use_bsa and km is not None and hasattr(comm, "exchange_segments_async")
-            if segmented:
-                kh, vt = kh_all[comm.rank], vt_all[comm.rank]
+        use_bounds = prescale and not self.attn_track_max
+        qm_c = _buf("qmax2_c", (H,), f32) if use_bounds else None
+        qm_n = _buf("qmax2_n", (H,), f32) if use_bounds else None
+        ex = kh = vt = km = None
+        if comm is not None and not use_bsa:
+            # dense blocks: K, V^T and the norm bounds of this rank's shard go straight into its slot of the exchange buffers
+            if not prescale or comm.world == 1:
+                mode = "gather"   # part launches are built for the pre-scaled-Q form
+            ex = self._exchange(tag, H, Sp, mode, int(self.exchange_chunks))
+        else:
+            kh = _buf("kh", (H, Sp, 128), bf, zero=True)
+            vt = _buf("vt", (H, Sp // 64, 128, 64), bf)
+            km = _buf("kmax2", (H,), f32) if use_bounds else None
+            if comm is not None:  # block-sparse blocks gather K / V^T densely (the sparse kernel addresses [P][H][S][128])
+                kh_all = _buf("kh_all", (comm.world, H, Sp, 128), bf, zero=True)
+                vt_all = _buf("vt_all", (comm.world, H, Sp // 64, 128, 64), bf)
         ao = _buf("ao", (L, C), bf)
         ys = _buf("ys", (L, C), bf)
         qc = _buf("qc", (L, C), bf)
@@ -419,9 +459,9 @@ class LongCatVideoTransformer3DModel:
             self.last_bsa_indices = []
 
         # sequence-parallel jobs: the caption K / V^T of layer i are computed by rank i (mod P) only and all-gathered once per forward (see
-        # dit.py: work that does not shrink with the token shard); WF_CTX_REPLICATED=1 keeps every rank computing all layers
+        # dit.py: work that does not shrink with the token shard)
         ctx_shared = ctx_events = None
-        if comm is not None and comm.world > 1 and os.environ.get("WF_CTX_REPLICATED", "0") != "1":
+        if comm is not None and comm.world > 1:
             P_, nl = comm.world, (cfg.depth + comm.world - 1) // comm.world
             loc = [_buf("ckv_loc0", (nl, H, Ltp, 128), bf, zero=True), _buf("ckv_loc1", (nl, H, Ltp // 64, 128, 64), bf)]
             allb = [_buf(f"ckv_all{j}", (P_,) + tuple(t.shape), bf) for j, t in enumerate(loc)]
@@ -480,43 +520,39 @@ class LongCatVideoTransformer3DModel:
             else:
                 self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_c, 0, nc, out_scale=q_scale)
                 self._heads(qkv, 0, W[p + "attn.q_norm"], cos, sin, qh_n, nc, L, out_scale=q_scale)
-                self._heads(qkv, C, W[p + "attn.k_norm"], cos, sin, kh, 0, L)
-                self._vt(qkv, 2 * C, vt, L)
-                kk, vv, kmx = kh, vt, km
-                if km is not None:  # zero rows past L do not raise a maximum: the whole (padded) shard is scanned
-                    head_max_norm2(kh, Sp, km)
-                seg_evs = ev_km = None
-                if segmented:
-                    seg_evs = (comm.exchange_segments_async(kh_all), comm.exchange_segments_async(vt_all))
-                    ev_km = comm.all_gather_async(km_all, km)
-                    kk, vv, kmx = kh_all, vt_all, km_all
-                elif comm is not None:
-                    evs = (comm.all_gather_async(kh_all, kh), comm.all_gather_async(vt_all, vt))
-                    if km is not None:
-                        evs = evs + (comm.all_gather_async(km_all, km),)
-                    for ev in evs:
-                        if ev is not None:
-                            torch.cuda.current_stream().wait_event(ev)
-                    kk, vv, kmx = kh_all, vt_all, (km_all if km is not None else None)
-                if segmented and L - nc > 0:
-                    # the noise queries first: their sweep is what the exchange hides under (the condition queries below need every event)
-                    from .dit import attention_segmented
+                if ex is None:
+                    self._heads(qkv, C, W[p + "attn.k_norm"], cos, sin, kh, 0, L)
+                    self._vt(qkv, 2 * C, vt, L)
+                    if use_bounds:  # zero rows past L do not raise a maximum: the whole (padded) shard is scanned
+                        head_max_norm2(kh, Sp, km)
+                else:
+                    for g in range(ex.G):
+                        r0, r1 = ex.chunk_rows(g, L)
+                        if r1 > r0:
+                            self._heads(qkv, C, W[p + "attn.k_norm"], cos, sin, ex.own_k(g), r0, r1)
+                            self._vt(qkv[r0:r1], 2 * C, ex.own_vt(g), r1 - r0)
+                            if use_bounds:
+                                head_max_norm2(ex.own_k(g), ex.chunk_len(g), ex.own_km(g))
+                    ex.launch()
+                    yield i
+                if use_bounds and nc > 0:
+                    head_max_norm2(qh_c, nc, qm_c)
+                if use_bounds and L - nc > 0:
                     head_max_norm2(qh_n, L - nc, qm_n)
-                    attention_segmented(qh_n, kh_all, vt_all, ao[nc:], L_all, comm.rank, seg_evs, km, km_all, ev_km, qm_n, profile=True,
-                                        peer_groups=int(os.environ.get("WF_ATTN_SEG_GROUPS", "2")))
-                    ev_km = None
-                if segmented:
-                    for ev in (seg_evs[0][-1], seg_evs[1][-1], ev_km):
-                        if ev is not None:
-                            torch.cuda.current_stream().wait_event(ev)
-                if nc > 0:
-                    if km is not None:
-                        head_max_norm2(qh_c, nc, qm_c)
-                    attention(qh_c, kk, vv, ao[:nc], nc_all, sa_scale, kmax2=kmx, qmax2=qm_c)  # condition tokens see condition tokens only (LCA:127-131)
-                if L - nc > 0 and not segmented:
-                    if km is not None:
-                        head_max_norm2(qh_n, L - nc, qm_n)
-                    attention(qh_n, kk, vv, ao[nc:], L_all, sa_scale, profile=True, kmax2=kmx, qmax2=qm_n)  # noise tokens see everything (LCA:133-134)
+                if ex is None:
+                    if nc > 0:  # condition tokens see condition tokens only (LCA:127-131)
+                        attention(qh_c, kh, vt, ao[:nc], nc_all, sa_scale, kmax2=km, qmax2=qm_c)
+                    if L - nc > 0:  # noise tokens see everything (LCA:133-134)
+                        attention(qh_n, kh, vt, ao[nc:], L_all, sa_scale, profile=True, kmax2=km, qmax2=qm_n)
+                else:
+                    # the noise queries first: their sweep is what the exchange hides under; the condition queries see the first nc_all
+                    # keys only (rank 0's first rows), their windows are ready by then
+                    if L - nc > 0:
+                        attention_exchange(qh_n, ex, ao[nc:], L_all, sa_scale, qm_n, use_bounds=use_bounds, profile=True, release=False)
+                    if nc > 0:
+                        attention_exchange(qh_c, ex, ao[:nc], nc_all, sa_scale, qm_c, use_bounds=use_bounds, release=False,
+                                           comm_profile=L - nc <= 0)
+                    ex.wait_all()
             gemm(ao, W[p + "attn.proj.w"], W[p + "attn.proj.b"], ys, EPI_BF16)
             self._resid(x, ys, gate_msa, ald, tpf, row0=lo, gidx=gidx)
             # ---- cross-attention on the noise tokens (LCD:108-111, LCA:218-276) ----
@@ -559,7 +595,7 @@ class LongCatVideoTransformer3DModel:
             yo = yt
         out = torch.empty((cfg.out_channels, T, Hh, Ww), dtype=f32, device=dev)
         call("wf_unpatchify", yo.data_ptr(), out.data_ptr(), cfg.out_channels, T, Hh, Ww, ops.stream())
-        return out
+        result[0] = out
 
     def __call__(self, hidden_states: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
                  encoder_attention_mask: Optional[torch.Tensor] = None, num_cond_latents: int = 0, return_kv: bool = False,
@@ -575,11 +611,14 @@ class LongCatVideoTransformer3DModel:
         cap = encoder_hidden_states
         if cap.dim() == 4:
             cap = cap[:, 0]
-        outs = []
+        samples = []
         for b in range(B):
             x = hidden_states[b]
             if x.dtype != torch.bfloat16:
                 x = ops.cast(x.contiguous(), torch.bfloat16)
             mask = encoder_attention_mask[b] if encoder_attention_mask is not None else None
-            outs.append(self.forward_tokens(x.contiguous(), ts[b].tolist(), cap[b].to(torch.bfloat16).contiguous(), mask, num_cond_latents))
-        return torch.stack(outs)
+            samples.append((x.contiguous(), ts[b].tolist(), cap[b].to(torch.bfloat16).contiguous(), mask))
+        if B == 2 and self.comm is not None and self.comm.world > 1 and self.pair_lockstep:
+            # the CFG batch (pipeline_longcat_video.py:857-866): two forwards in lock-step, each exchange hidden under the other's block
+            return torch.stack(self.forward_tokens_pair(samples[0], samples[1], num_cond_latents))
+        return torch.stack([self.forward_tokens(*smp, num_cond_latents) for smp in samples])

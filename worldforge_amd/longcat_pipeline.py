@@ -158,11 +158,18 @@ class LongCatVideoPipeline:
             if step_hook is not None:
                 step_hook(i, "end")
         if output_type == "latent":
+            self._check_vae_range()
             return latents
         z = ops.latent_denorm(ops.cast(latents, torch.float32), mean, std)
         video = self.vae.decode(z, return_dict=False)[0]
         video = torch.stack([ops.postprocess_video(v) for v in video])[:, added_c: new_frame_size + added_c]  # PIPE:1505
+        self._check_vae_range()
         return video.cpu().numpy() if output_type == "np" else video
+
+    def _check_vae_range(self):
+        """A VAE call of this job left the fp16 operand range (vae.AutoencoderKLWan.check_range): fail before handing anything back."""
+        if hasattr(self.vae, "check_range"):
+            self.vae.check_range()
 
     # ---- PIPE:619-1006 ----------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -267,8 +274,10 @@ class LongCatVideoPipeline:
                 step_hook(i, "end")
 
         if output_type == "latent":
+            self._check_vae_range()
             return latents
         z = ops.latent_denorm(ops.cast(latents, torch.float32), self.vae.config.latents_mean, self.vae.config.latents_std)
         video = self.vae.decode(z, return_dict=False)[0]
         video = torch.stack([ops.postprocess_video(v) for v in video])  # [B,F,H,W,C] in [0,1]
+        self._check_vae_range()
         return video.cpu().numpy() if output_type == "np" else video

@@ -265,6 +265,8 @@ class FlowMatchEulerDiscreteScheduler:
                 pred_original_sample=x0, encoded_video=enc, current_step=current_step, total_steps=total_steps, static=static,
                 use_distill=use_distill, max_replace_threshold=max_replace_threshold)
             ops.channel_swap_(enc, x0, channels)
+        if hasattr(vae, "check_range"):   # fp16 range flag of this round trip (see scheduler.UniPCMultistepScheduler.fuse_latents)
+            vae.check_range(wait=bool(use_pca_channel_selection))
         return ops.cast(enc, x0.dtype)
 
     def __len__(self):

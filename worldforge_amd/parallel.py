@@ -6,9 +6,11 @@ after patch-embed, per-rank RoPE slice, gather at the exit).  The native design 
 
   * tokens are split into P contiguous shards of `shard_len` = ceil(L / P) rounded up to 64 (the attention KV tile), the last
     shard is short; everything in the DiT except self-attention is token-local (weights replicated: 28 GB of 288 GB);
-  * per layer ONE all-gather of the K shard and ONE of the blocked V^T shard (each [H, shard_len, 128] bf16); the gathered
-    tensor [P, H, shard_len, 128] is consumed in place by the attention kernel (segment addressing, no re-layout);
-    xGMI is point-to-point, so the all-gather's P-1 peer transfers run on distinct links;
+  * per layer the K shard, the blocked V^T shard (each [H, shard_len, 128] bf16) and the shard's per-head norm bounds travel as ONE
+    packed slot [K | V^T | bounds] of an exchange buffer [P, slot] (KVExchange below): one in-place all-gather and one event per layer
+    ("gather"), G all-gathers of the g-th 1/G of every rank's keys ("chunked"), or P per-source broadcasts ("bcast").  The slots are
+    consumed in place by the attention kernel (segment addressing with a slot stride, no re-layout); xGMI is point-to-point, so an
+    all-gather's P-1 peer transfers run on distinct links at once, while per-source broadcasts keep one source's egress busy at a time;
   * the velocity shards are all-gathered once per forward; scheduler / injection math is replicated (it is tiny) and the
     CPU-generator noise is drawn identically on every rank (same seed), so no broadcast is needed inside the loop.
 Only all-gather / broadcast / barrier are used (BASELINE.json north_star); the single max-reduce is bench.py's timing.
@@ -51,14 +53,29 @@ def shard_plan(L: int, P: int) -> ShardPlan:
 class Comm:
     """Thin wrapper over a torch.distributed process group (RCCL on GPUs, gloo in the CPU tests)."""
 
-    def __init__(self, world: int, rank: int, group=None):
+    def __init__(self, world: int, rank: int, group=None, ranks=None):
         self.world, self.rank, self.group = world, rank, group
+        self.ranks = list(ranks) if ranks is not None else list(range(world))  # global ranks of the group's members (dist.broadcast takes a GLOBAL src)
         self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+
+    def split(self, n_groups: int) -> "Comm":
+        """n_groups contiguous sub-groups of world / n_groups ranks each -> the Comm of THIS rank's sub-group (`group_index` = which one).
+        Every rank creates every group (torch.distributed.new_group is collective over the whole job).  The 2 x 4 job of SURVEY 8e:
+        `world.split(2)` is the sequence-parallel group of one CFG branch, the VAE row slabs stay on `world`."""
+        assert self.world % n_groups == 0 and self.group is None, "split the job's own communicator into equal contiguous groups"
+        per = self.world // n_groups
+        groups = [dist.new_group(list(range(g * per, (g + 1) * per))) for g in range(n_groups)]
+        mine = self.rank // per
+        sub = Comm(per, self.rank % per, groups[mine], ranks=range(mine * per, (mine + 1) * per))
+        sub.group_index = mine
+        return sub
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         """out [P, *inp.shape] <- inp from every rank."""
         assert out.shape[0] == self.world and tuple(out.shape[1:]) == tuple(inp.shape) and out.is_contiguous() and inp.is_contiguous()
         if dist.get_backend(self.group) == "gloo":
+            if inp.data_ptr() == out[self.rank].data_ptr():  # in-place form (KVExchange): gloo copies input -> output[rank], keep them apart
+                inp = inp.clone()
             if inp.is_cuda:
                 # debug configuration only (several ranks sharing one GPU, WF_COMM_BACKEND=gloo): gloo's all_gather takes host
                 # tensors, so stage through the host
@@ -88,27 +105,28 @@ class Comm:
         return ev
 
     def broadcast(self, t: torch.Tensor, src: int = 0):
-        dist.broadcast(t, src=src, group=self.group)
+        dist.broadcast(t, src=self.ranks[src], group=self.group)
         return t
 
-    def exchange_segments_async(self, out: torch.Tensor):
-        """out [P, ...]: slot `rank` already holds this rank's shard (its producer wrote it on the current stream); every other slot is
+    def broadcast_slots_async(self, out: torch.Tensor):
+        """out [P, ...]: slot `rank` already holds this rank's data (its producers wrote it on the current stream); every other slot is
         filled by a broadcast from its owner -- P broadcasts in SOURCE order (every rank must issue the same collective sequence) on the
-        communication stream, one event per source.  Where all_gather_async hands back ONE event for the whole exchange, the consumer can
-        here start on slot s as soon as event s has fired (stream order: events 0 .. s-1 have fired by then): the attention kernel walks
-        its own shard with no wait at all and the segments that have arrived while the rest is still in flight (dit.attention_segmented)
-        -- the overlap a forward without a second CFG branch has no other way to get.  Returns the list of P events (None on CPU)."""
+        communication stream, ONE event per source.  Where all_gather_async hands back one event for the whole exchange, the consumer can
+        here start on slot s as soon as event s has fired (stream order: events 0 .. s-1 have fired by then).  A slot of KVExchange
+        carries a source's K shard, V^T shard and norm bounds together, so event s means "segment s is usable" (round 4 issued the K
+        broadcasts of all sources before the first V^T one: the first peer run waited for 13 of 16 broadcasts at 8 ranks).
+        Returns the list of P events (None on CPU)."""
         assert out.shape[0] == self.world and out.is_contiguous()
         gloo = dist.get_backend(self.group) == "gloo"
 
         def bcast(src):
             if gloo and out.is_cuda:  # debug configuration (ranks sharing one GPU over gloo): stage through the host
                 host = out[src].cpu()
-                dist.broadcast(host, src=src, group=self.group)
+                dist.broadcast(host, src=self.ranks[src], group=self.group)
                 if src != self.rank:
                     out[src].copy_(host)
             else:
-                dist.broadcast(out[src], src=src, group=self.group)
+                dist.broadcast(out[src], src=self.ranks[src], group=self.group)
 
         if self.stream is None:
             for src in range(self.world):
@@ -145,14 +163,25 @@ class LoopbackComm:
         self.world, self.rank, self.group = world, rank, None
         self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
 
+    def split(self, n_groups: int) -> "LoopbackComm":
+        per = self.world // n_groups
+        sub = LoopbackComm(per, self.rank % per)
+        sub.group_index = self.rank // per
+        return sub
+
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         assert out.shape[0] == self.world and tuple(out.shape[1:]) == tuple(inp.shape)
-        out.copy_(inp.unsqueeze(0).expand_as(out))
+        if inp.data_ptr() == out[self.rank].data_ptr():  # in-place form (KVExchange): the own slot stays, every peer slot is a copy of it
+            for src in range(self.world):
+                if src != self.rank:
+                    out[src].copy_(inp)
+        else:
+            out.copy_(inp.unsqueeze(0).expand_as(out))
         return out
 
     all_gather_async = Comm.all_gather_async
 
-    def exchange_segments_async(self, out: torch.Tensor):
+    def broadcast_slots_async(self, out: torch.Tensor):
         """Every peer slot is a copy of this rank's own (one copy + one event per source on the communication stream, like the real one)."""
         assert out.shape[0] == self.world and out.is_contiguous()
         if self.stream is None:
@@ -203,3 +232,185 @@ def gather_rows(comm: Comm, local: torch.Tensor, plan: ShardPlan) -> torch.Tenso
     out = torch.empty((plan.P, plan.shard_len, C), dtype=local.dtype, device=local.device)
     comm.all_gather(out, pad)
     return out.view(plan.padded_total, C)[:plan.L]
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The per-layer K / V^T exchange of the sequence-parallel self-attention
+# ------------------------------------------------------------------------------------------------------------------------------------
+EXCHANGE_MODES = ("gather", "chunked", "bcast")
+MAX_ATTN_PARTS = 12  # wf_attn_fwd_part / wf_attn_merge: partial slots per sweep
+
+
+def _slots(n_tiles: int, k: int) -> int:
+    """Partial slots a window of n_tiles in k splits fills (attn_launch: tiles per split = ceil(n / k), splits that get tiles)."""
+    if n_tiles <= 0:
+        return 0
+    k = max(1, k)
+    tps = -(-n_tiles // k)
+    return -(-n_tiles // tps)
+
+
+class KVExchange:
+    """Exchange buffers + collective protocol of ONE forward's self-attention layers on one rank (a second, concurrent forward -- the
+    other branch of a lock-step CFG pair -- owns its own object).
+
+    Layout.  The rank's keys (rows of its token shard, S = shard_len, a multiple of 64) are cut into G chunks of whole 64-key tiles
+    (G = 1 unless mode == "chunked").  Per chunk g one buffer [P, slot_g] bf16, slot = [ K [H, Sc, 128] | V^T [H, Sc/64, 128, 64] |
+    bounds: H f32 (+ pad to 256 bytes) ]: a source's K, V^T and per-head max |k|^2 of those keys travel in ONE collective, so one
+    event means "usable".  The producers write this rank's shard straight into slot `rank` (own_k / own_vt / own_km); the collectives
+    are in place.  The attention kernel reads the slots where they land: segment p of chunk g = slot p, addressed with
+    seg_stride_bytes = 2 * slot (wf_attn_fwd*).
+
+    Modes (`launch` issues the collectives on the communication stream, `dit.attention_exchange` consumes them):
+      gather   one all-gather, one event; the sweep is ONE launch over the P segments in rank order -- the key tiles are the
+               single-GPU tiles, so the result is bit-identical to one GPU (up to the split-KV merge at 8 ranks).  What the lock-step
+               CFG pair uses: the other branch's layer hides the exchange.
+      chunked  G all-gathers (chunk g = the g-th 1/G of EVERY rank's keys), one event each: all xGMI links busy all the time, and the
+               sweep walks own shard (no wait) -> chunk 0 of every peer -> chunk 1 ...  (G = 1: one all-gather, own shard first).
+      bcast    P broadcasts in source order, one event per source; own shard first, then the peers in arrival order.
+    chunked / bcast leave partial results per window (wf_attn_fwd_part) merged exactly at the end (wf_attn_merge): the one-launch
+    result up to the re-association of the fp32 partial sums."""
+
+    TAIL = 128  # bf16 elements = 256 bytes = 64 floats per slot for the norm bounds
+
+    def __init__(self, comm, H: int, shard_len: int, mode: str = "gather", chunks: int = 1, device=None):
+        assert mode in EXCHANGE_MODES, mode
+        assert shard_len % 64 == 0 and 0 < H <= 64
+        self.comm, self.P, self.rank, self.H, self.S, self.mode = comm, comm.world, comm.rank, H, shard_len, mode
+        tiles = shard_len // 64
+        G = max(1, min(int(chunks), tiles)) if mode == "chunked" else 1
+        self.G = G
+        self.tile_bounds = [tiles * g // G for g in range(G + 1)]
+        self.bufs, self.k, self.vt, self.km = [], [], [], []
+        for g in range(G):
+            sc = self.chunk_len(g)
+            n = H * sc * 128
+            buf = torch.zeros((self.P, 2 * n + self.TAIL), dtype=torch.bfloat16, device=device)
+            self.bufs.append(buf)
+            self.k.append(buf[:, :n].view(self.P, H, sc, 128))
+            self.vt.append(buf[:, n:2 * n].view(self.P, H, sc // 64, 128, 64))
+            self.km.append(buf[:, 2 * n:].view(torch.float32)[:, :H])
+        self.events = None
+
+    # ---- layout ----
+    def chunk_len(self, g: int) -> int:
+        return 64 * (self.tile_bounds[g + 1] - self.tile_bounds[g])
+
+    def chunk_rows(self, g: int, n_valid: int) -> Tuple[int, int]:
+        """Rows [r0, r1) of this rank's shard that chunk g holds, clipped to the shard's n_valid token rows (r1 == r0: padding only)."""
+        r0 = 64 * self.tile_bounds[g]
+        return r0, max(r0, min(64 * self.tile_bounds[g + 1], n_valid))
+
+    def chunk_kv_len(self, kv_len: int, g: int) -> int:
+        """Valid keys of chunk buffer g in ITS segment order when the first kv_len keys of the sequence (shard-major order) are valid:
+        the full shards' chunks, then the clipped chunk of the one partial shard -- still a prefix of the buffer's key order."""
+        full, rem = divmod(min(kv_len, self.P * self.S), self.S)
+        sc = self.chunk_len(g)
+        return full * sc + min(max(rem - 64 * self.tile_bounds[g], 0), sc)
+
+    def own_k(self, g: int = 0) -> torch.Tensor:
+        return self.k[g][self.rank]
+
+    def own_vt(self, g: int = 0) -> torch.Tensor:
+        return self.vt[g][self.rank]
+
+    def own_km(self, g: int = 0) -> torch.Tensor:
+        return self.km[g][self.rank]
+
+    def seg_stride_bytes(self, g: int = 0) -> int:
+        return 2 * self.bufs[g].shape[1]
+
+    def km_stride(self, g: int = 0) -> int:
+        return self.bufs[g].shape[1] // 2
+
+    # ---- protocol ----
+    def collectives(self):
+        """The collective sequence `launch` issues, as (kind, chunk | source) -- what every rank must issue identically, in this order."""
+        if self.mode == "bcast":
+            return [("broadcast", src) for src in range(self.P)]
+        return [("all_gather", g) for g in range(self.G)]
+
+    def launch(self):
+        """Issue this layer's exchange on the communication stream, behind the producers queued so far on the current stream."""
+        if self.mode == "bcast":
+            self.events = self.comm.broadcast_slots_async(self.bufs[0])
+        else:
+            self.events = [self.comm.all_gather_async(b, b[self.rank]) for b in self.bufs]
+        return self.events
+
+    def wait(self, i: int):
+        ev = self.events[i] if self.events is not None else None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def wait_all(self):
+        """The current stream waits for the LAST collective (stream order: hence for all of them).  Called at the end of every sweep: the
+        next layer's producers write this rank's slot on the compute stream, which the communication stream may still be sending from
+        (the all-gather's send side; this rank's own broadcast when it is the last source) -- a write-after-read across streams that no
+        data dependency of the sweep itself covers on every rank."""
+        if self.events:
+            self.wait(len(self.events) - 1)
+
+
+def segment_groups(P: int, rank: int, peer_groups: int = 2):
+    """The order in which rank `rank` of P walks the key segments whose slots arrive by P broadcasts in source order: its OWN shard first
+    (no wait), then the peers in arrival order, in at most `peer_groups` + 1 runs of consecutive physical segments [a, b) that do not
+    cross the own one.  -> [(a, b), ...]; a run is ready once the event of source b - 1 has fired."""
+    per = max(1, -(-(P - 1) // max(1, peer_groups)))
+    runs = [(rank, rank + 1)]
+    for lo, hi in ((0, rank), (rank + 1, P)):
+        a = lo
+        while a < hi:
+            runs.append((a, min(a + per, hi)))
+            a = min(a + per, hi)
+    return runs
+
+
+def sweep_plan(ex: KVExchange, kv_len: int, workgroups: int, peer_groups: int = 2, n_cu: int = 256):
+    """The part launches of one own-first sweep over `ex` (modes chunked / bcast) for queries that attend to the first kv_len keys.
+    -> (steps, nparts); a step = dict(chunk, wait: index into ex.events or None, win: (t0, t1, inner), win2: (t0, t1, inner) or None,
+    slot, km: (first segment, count)).  Tile indices are in the chunk buffer's own segment order.  `workgroups` = ceil(Lq / 256) * H of
+    one split: a launch that would leave much of its last round of `n_cu` workgroups idle gets two splits where it has one window.
+    A pure function of shapes and rank (never of timing): every rank of a job derives its own plan, the collectives are the same."""
+    P, r = ex.P, ex.rank
+    fill = (workgroups / n_cu) / -(-workgroups // n_cu)
+    n_tot = 2 if fill < 0.92 else 1
+    steps, slot = [], 0
+
+    def add(chunk, wait, win, win2, km):
+        nonlocal slot
+        n = _slots(win[1] - win[0], win[2]) + (_slots(win2[1] - win2[0], win2[2]) if win2 else 0)
+        steps.append(dict(chunk=chunk, wait=wait, win=win, win2=win2, slot=slot, km=km))
+        slot += n
+
+    if ex.mode == "bcast":
+        tps = ex.chunk_len(0) // 64
+        nt = -(-ex.chunk_kv_len(kv_len, 0) // 64)
+        runs = segment_groups(P, r, peer_groups)
+        inner = n_tot if len(runs) * n_tot <= 8 else 1
+        for i, (a, b) in enumerate(runs):
+            t0, t1 = a * tps, min(b * tps, nt)
+            if t0 >= t1:
+                continue
+            b = -(-t1 // tps)  # the last source this (possibly clipped) run really reads
+            add(0, None if i == 0 else b - 1, (t0, t1, max(1, min(inner, (t1 - t0) // 8))), None, (a, b - a))
+    else:
+        vt = [-(-ex.chunk_kv_len(kv_len, g) // 64) for g in range(ex.G)]
+        for g in range(ex.G):  # own shard: no wait
+            tps = ex.chunk_len(g) // 64
+            t0, t1 = r * tps, min((r + 1) * tps, vt[g])
+            if t0 < t1:
+                add(g, None, (t0, t1, 1), None, (r, 1))
+        for g in range(ex.G):  # every peer's chunk g, after all-gather g
+            tps = ex.chunk_len(g) // 64
+            before = (0, min(r * tps, vt[g]))
+            after = ((r + 1) * tps, vt[g])
+            wins = [w for w in (before, after) if w[0] < w[1]]
+            if not wins:
+                continue
+            if len(wins) == 2:
+                add(g, g, wins[0] + (1,), wins[1] + (1,), (0, P))
+            else:
+                n = wins[0][1] - wins[0][0]
+                add(g, g, wins[0] + (max(1, min(n_tot, n // 8)),), None, (0, P))
+    return steps, slot

@@ -190,7 +190,21 @@ class WanImageToVideoPipeline:
                 latent_model_input = self._model_input(latents, condition, transformer_dtype)
                 with tr.range("dit_cfg", step=i, round=r):
                     pair = getattr(self.transformer, "forward_cfg_pair", None) if self.do_classifier_free_guidance else None
-                    if pair is not None:
+                    split = getattr(self, "cfg_split", None) if self.do_classifier_free_guidance else None
+                    if split is not None:
+                        # CFG groups x sequence shards (SURVEY 8e "P = 8 = 2 x 4"; parallel.Comm.split): the ranks of group 0 run the
+                        # positive-prompt forward, those of group 1 the negative one -- ONE forward per rank and evaluation on a token
+                        # shard twice as long, half the K / V^T exchange -- and every rank then takes both velocities from one small
+                        # all-gather over the whole job (a rank's slot holds its group's full tensor: [P, ...] -> slots 0 and P / 2)
+                        world_comm, branch = split
+                        own = self.transformer(hidden_states=latent_model_input, timestep=timestep_for_transformer,
+                                               encoder_hidden_states=prompt_embeds if branch == 0 else negative_prompt_embeds,
+                                               encoder_hidden_states_image=image_embeds, attention_kwargs=attention_kwargs,
+                                               return_dict=False)[0].contiguous()
+                        both = torch.empty((world_comm.world,) + tuple(own.shape), dtype=own.dtype, device=own.device)
+                        world_comm.all_gather(both, own)
+                        noise_pred, noise_uncond = both[0], both[world_comm.world // 2]
+                    elif pair is not None:
                         # same two calls as below, advanced in lock-step so that under sequence parallelism each branch's K / V
                         # exchange overlaps the other branch's compute (dit.forward_tokens_pair); identical results
                         noise_pred, noise_uncond = pair(hidden_states=latent_model_input, timestep=timestep_for_transformer,
@@ -267,6 +281,8 @@ class WanImageToVideoPipeline:
                 video = torch.stack([ops.postprocess_video(v) for v in video])  # [B,F,H,W,C]
             if output_type == "np":
                 video = video.cpu().numpy()
+        if hasattr(self.vae, "check_range"):
+            self.vae.check_range()   # a VAE call of this job left the fp16 range: fail before handing anything back
         if tr.enabled:
             self.timing = tr.summary()
             if getattr(tr, "path", None):

@@ -282,6 +282,10 @@ class UniPCMultistepScheduler:
                 self.flf_log.append((int(kwargs.get("current_step", 0)), free,
                                      None if self._pca_selector.last_similarities is None else self._pca_selector.last_similarities.copy(),
                                      list(channels)))
+        if hasattr(vae, "check_range"):
+            # fp16 operand formats: a range flag raised by this round trip surfaces here -- after the gate's read-back the copy has landed
+            # (no extra wait); without a gate only if it already has (otherwise at the next VAE call / the pipeline's end)
+            vae.check_range(wait=bool(kwargs.get("use_pca_channel_selection") and not kwargs.get("resampling", False)))
         return ops.cast(enc, x0.dtype)
 
     # ---- SCHED:1423-1536 ---------------------------------------------------------------------------------

@@ -18,9 +18,14 @@ precision (the reference loads the VAE with torch_dtype=torch.float32, INFER:185
              guided job's 31 decode -> encode round trips this noise is enough to flip near-tied FLF gate decisions
              (tools/vae_precision_study.py).
   "fp16x3" -- DEFAULT since round 4 (alias "fp32").  The three-term split below on FP16 parts (hi = fp16(x), lo = fp16(x - hi): 22
-             significand bits, ~2^-22 per product -- 64x closer to IEEE fp32 than the bf16 split) on v_mfma_f32_32x32x16_f16: same
-             kernels, same cost.  fp16 cannot hold |x| > 65504: the producers raise a device flag and every encode / decode ends
-             with a check that turns it into a RuntimeError (never a silent inf) -- such weights need "bf16x3".
+             significand bits) on v_mfma_f32_32x32x16_f16: same kernels, same cost as the bf16 split.  Per product ~2^-22 WHERE lo IS A
+             NORMAL fp16, i.e. |x| >= 2^-3; below that lo is a subnormal with an absolute floor of 2^-25.  Round 5: every weight matrix is
+             stored times an exact power of two that lifts it into the normal range (undone in the kernels' epilogues, `acc_scale`), so
+             the floor only remains for small ACTIVATIONS, whose absolute error 2^-25 |w| is negligible against the products of the O(1)
+             ones.  Measured end to end against the fp32 goldens: see tests/test_gpu_vae.py (rel. L2) -- that, not the per-product
+             figure, is the claim.  fp16 cannot hold |x| > 65504: the producers raise a device flag; it is copied to the host
+             asynchronously and turned into a RuntimeError at the next check point (check_range; never a silent inf) -- such weights
+             need "bf16x3".
   "bf16x3" -- the default of rounds 2-3.  fp32-CLASS contractions on the bf16 matrix cores, NOT IEEE fp32: every operand x is carried as hi = bf16(x),
              lo = bf16(x - hi) and every contraction as hi.hi + lo.hi + hi.lo in fp32 accumulators (wf_split_bf16x3: activations
              [hi | lo | hi], weights [hi | hi | lo] on 3x the channels, the SAME conv / GEMM kernels; the dropped lo.lo term and the
@@ -52,7 +57,6 @@ LATENTS_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743, 3
                1.1253, 2.8251, 1.9160]  # vae.py:633-636
 
 BF, F32 = torch.bfloat16, torch.float32
-_LOG_CONV = bool(os.environ.get("WF_VAE_LOG_CONV"))  # debug: one line per convolution (layer, shape, operand layout)
 
 
 def encoder_plan() -> List[Tuple]:
@@ -184,6 +188,8 @@ class _LatentDist:
 class AutoencoderKLWan:
     dtype = torch.float32
 
+    ATTN_BATCH_BYTES = 6 << 30   # split operands of the mid-block attention's batched P . V launch kept at a time (_attn_x3)
+
     def __init__(self, device="cuda:0", comm=None, precision: str = "fp16x3"):
         if precision == "fp32":  # the fp32-CLASS mode of the round: three-term split operands, fp16 parts since round 4
             precision = "fp16x3"
@@ -210,12 +216,26 @@ class AutoencoderKLWan:
         W: Dict[str, torch.Tensor] = {}
         x3 = self.x3
 
-        def operand(w):  # f32 [..., Cin] (host) -> the matrix-core weight operand on the device
+        # W[key + ".scale"] (a Python float, fp16x3 only; absent = 1): acc_scale = 2^-k of a weight operand stored scaled by 2^k -- kept
+        # in the weight dict so that instances sharing `w` share it
+
+        def operand(w, key):  # f32 [..., Cin] (host) -> the matrix-core weight operand on the device
             w = w.to(F32)
             if not x3:
                 return w.to(device=dev, dtype=BF).contiguous()
-            if self.f16 and float(w.abs().max()) > 65504.0:
-                raise ValueError("a VAE weight exceeds the fp16 range: load with precision='bf16x3'")
+            if self.f16:
+                # hi = fp16(w), lo = fp16(w - hi): lo is an fp16 SUBNORMAL (absolute floor 2^-25) for |w| < 2^-3 -- VAE weights are ~0.02, so the
+                # split carried them to ~2^-18 relative, not the 2^-22 of its normal range.  Store the matrix times an exact
+                # power of two that puts its largest magnitude into [2^13, 2^14) (every weight above 2^-17 of it then has a normal lo; fp16 tops
+                # out at 2^16) and hand the kernels acc_scale = 2^-k: out = acc * 2^-k + bias, exact.
+                mx = float(w.abs().max())
+                if not math.isfinite(mx):
+                    raise ValueError("a VAE weight is not finite")
+                if mx > 0.0:
+                    k = 13 - math.floor(math.log2(mx))
+                    k = max(-126, min(126, k))
+                    w = w * (2.0 ** k)
+                    W[key + ".scale"] = 2.0 ** -k
             hi = w.to(self.OP)
             lo = (w - hi.to(F32)).to(self.OP)
             return torch.cat([hi, hi, lo], dim=-1).to(dev).contiguous()  # weight side of wf_split_bf16x3 / wf_split_f16x3
@@ -225,7 +245,7 @@ class AutoencoderKLWan:
             if w.dim() == 4:
                 w = w.unsqueeze(2)
             co, ci = w.shape[:2]
-            W[p + ".w"] = operand(w.permute(0, 2, 3, 4, 1).reshape(co, -1, ci))
+            W[p + ".w"] = operand(w.permute(0, 2, 3, 4, 1).reshape(co, -1, ci), p + ".w")
             W[p + ".b"] = sd[p + ".bias"].to(device=dev, dtype=F32).contiguous()
 
         def mfma_conv_padded(p, cin_pad=None, cout_pad=None):
@@ -239,7 +259,7 @@ class AutoencoderKLWan:
             wp[:co, :ci] = w
             bp = torch.zeros(cop, dtype=F32)
             bp[:co] = b
-            W[p + ".w"] = operand(wp.permute(0, 2, 3, 4, 1).reshape(cop, -1, cip))
+            W[p + ".w"] = operand(wp.permute(0, 2, 3, 4, 1).reshape(cop, -1, cip), p + ".w")
             W[p + ".b"] = bp.to(dev)
 
         def small_conv(p, cout_pad=None):  # -> f32 [taps, Cin, Cout]
@@ -256,7 +276,7 @@ class AutoencoderKLWan:
 
         def lin(p):  # 1x1(x1) conv as GEMM weight bf16 [Cout, Cin]
             w = sd[p + ".weight"]
-            W[p + ".w"] = operand(w.reshape(w.shape[0], w.shape[1]))
+            W[p + ".w"] = operand(w.reshape(w.shape[0], w.shape[1]), p + ".w")
             W[p + ".b"] = sd[p + ".bias"].to(device=dev, dtype=F32).contiguous()
 
         def gamma(p):
@@ -274,7 +294,7 @@ class AutoencoderKLWan:
                 for px in range(2):
                     wp = torch.stack([torch.stack([sum(w[:, :, dy, dx] for dy in groups[py][a] for dx in groups[px][b]) for b in range(2)], dim=-1)
                                       for a in range(2)], dim=-2)  # [Cout, Cin, 2, 2]
-                    W[f"{p}.ph{py}{px}.w"] = operand(wp.permute(0, 2, 3, 1).reshape(wp.shape[0], 4, wp.shape[1]))
+                    W[f"{p}.ph{py}{px}.w"] = operand(wp.permute(0, 2, 3, 1).reshape(wp.shape[0], 4, wp.shape[1]), f"{p}.ph{py}{px}.w")
 
         first_up = True
         for plan in (encoder_plan(), decoder_plan()):
@@ -296,8 +316,8 @@ class AutoencoderKLWan:
                     mfma_conv(p + ".resample.1")
                     if kind.startswith("up"):
                         # every upsampling conv but the first (small, and its row slabs of the sharded decoder may start on an odd row) runs
-                        # as four phase convolutions; WF_VAE_UP2_PHASES=0 keeps the gathered 3 x 3 form everywhere
-                        if not first_up and os.environ.get("WF_VAE_UP2_PHASES", "1") != "0":
+                        # as four phase convolutions
+                        if not first_up:
                             up_phases(p + ".resample.1")
                         first_up = False
                     if kind.endswith("3d"):
@@ -381,25 +401,27 @@ class AutoencoderKLWan:
         ob = out_bf_tensor if out_bf_tensor is not None else (torch.empty(shape, dtype=self.OP, device=x.device) if out_bf16 else None)
         W = self.w
         if (tuple(k) == (3, 3, 3) and st == 1 and ss == 1 and pt == 2 and ps == 1 and not up2 and not tsplit and To == Ti and Wo == Wi
-                and Cin % 32 == 0 and Cout % 32 == 0 and not os.environ.get("WF_CONV_NO_W4")):
+                and Cin % 32 == 0 and Cout % 32 == 0):
             # the FLOP-heavy layers: LDS-resident input patch kernel on re-packed weights (packed once per layer, cached).  Chosen by
             # layer type only, never by size: a row slab of the sharded VAE must run the same arithmetic as the whole image
             zp = self._zero_page(int(_ffi.lib().wf_conv3d_333_zero_page_bytes(Wi, Cst, layout)))
             call("wf_conv3d_333" + self._sfx, x.data_ptr(), self._packed333(p, Cout, Cin).data_ptr(), W[p + ".b"].data_ptr(),
                  resid.data_ptr() if resid is not None else None, of.data_ptr() if of is not None else None,
                  ob.data_ptr() if ob is not None else None, Ti, Hi, Wi, Cin, Ho, Cout, ps if ph is None else ph,
-                 zp.data_ptr(), zp.numel() * 2, layout, Cst, ops.stream())
+                 zp.data_ptr(), zp.numel() * 2, layout, Cst, *self._acc_scale(p + ".w"), ops.stream())
         else:
             assert layout == 0, "slice-major operands are for the 3x3x3 stride-1 kernel only"
             call("wf_conv3d_cl" + self._sfx, x.data_ptr(), W[p + ".w"].data_ptr(), W[p + ".b"].data_ptr(),
                  resid.data_ptr() if resid is not None else None, of.data_ptr() if of is not None else None,
                  ob.data_ptr() if ob is not None else None, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout, k[0], k[1], k[2], st, ss, pt,
-                 ps if ph is None else ph, ps, 1 if up2 else 0, 1 if tsplit else 0, self._zero_page().data_ptr(), ops.stream())
+                 ps if ph is None else ph, ps, 1 if up2 else 0, 1 if tsplit else 0, self._zero_page().data_ptr(), *self._acc_scale(p + ".w"),
+                 ops.stream())
         self.flops_last += 2 * To * Ho * Wo * Cout * k[0] * k[1] * k[2] * Cin
-        if _LOG_CONV:
-            print(f"[vae conv] {p}: k={tuple(k)} st={st} ss={ss} up2={up2} tsplit={tsplit} in={(Ti, Hi, Wi, Cin)} out={(To, Ho, Wo, Cout)} "
-                  f"layout={layout}", flush=True)
         return of, ob
+
+    def _acc_scale(self, wkey: str):
+        """The extra trailing argument of the *_f16 entry points that take a weight operand: () for the bf16 ones."""
+        return (float(self.w.get(wkey + ".scale", 1.0)),) if self.f16 else ()
 
     def _packed333(self, p, Cout, Cin):
         """[Cout][27][Cin] -> [27][Cin/16][Cout][16] copy of a 3x3x3 weight for wf_conv3d_333 (keyed by the weight tensor's identity so
@@ -435,7 +457,7 @@ class AutoencoderKLWan:
         """RMS_norm (+ SiLU) of the f32 stream -> the next layer's matrix-core operand.  blocked: the slice-major operand of the 3x3x3
         kernel, [T,H,C/16,W,16] (fp32-class mode: [hi | lo] slices, [T,H,2C/16,W,16])."""
         C = x.shape[-1]
-        if blocked and C % 32 == 0 and not os.environ.get("WF_CONV_NO_W4"):
+        if blocked and C % 32 == 0:
             T, H, Wd, _ = x.shape
             # halo: the kernel writes rows 1 .. H of a [T, H + 2, ...] slab operand directly (row slabs: _halo_fill adds the neighbours' rows)
             out = torch.empty((T, H + (2 if halo else 0), (2 if self.x3 else 1) * C // 16, Wd, 16), dtype=self.OP, device=x.device)
@@ -473,26 +495,58 @@ class AutoencoderKLWan:
         call("wf_split_f16x3" if self.f16 else "wf_split_bf16x3", x2.data_ptr(), x2.stride(0), out.data_ptr(), 3 * C, x2.shape[0], C, side, ops.stream())
         return out
 
-    def _gemm(self, x, w, bias, out, epi):
-        """out[M,N] = epi(x[M,K] @ w[N,K]^T + bias) on the operand type of this precision mode (wf_gemm_bf16 / wf_gemm_f16)."""
+    def _gemm(self, x, w, bias, out, epi, wkey=None):
+        """out[M,N] = epi(x[M,K] @ w[N,K]^T + bias) on the operand type of this precision mode (wf_gemm_bf16 / wf_gemm_f16).  wkey: the weight
+        dict key of `w` when it is a stored weight operand (its power-of-two scale is undone in the epilogue), None for activations."""
         if not self.f16:
             return gemm(x, w, bias, out, epi)
         M, K = x.shape
         N = w.shape[0]
         assert w.shape[1] == K and x.dtype == self.OP and w.dtype == self.OP and out.shape[0] == M and out.shape[1] == N
         call("wf_gemm_f16", x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), M, N, K,
-             x.stride(0), w.stride(0), out.stride(0), epi, ops.stream())
+             x.stride(0), w.stride(0), out.stride(0), epi, float(self.w.get(wkey + ".scale", 1.0)) if wkey else 1.0, ops.stream())
         return out
 
-    def _check_range(self, what: str):
-        """fp16 operand formats: a producer that met a value beyond +-65504 (or a NaN) raised the device flag -- fail loudly, never a
-        silent inf.  One 4-byte read per VAE call."""
+    def _note_range(self, what: str):
+        """fp16 operand formats: a producer that met a value beyond +-65504 (or a NaN) raised the sticky device flag.  Queue a 4-byte
+        copy of it into pinned host memory behind this call's kernels (wf_f16_overflow_flag_async) and an event -- NO host
+        synchronisation inside encode / decode (no hidden device syncs; round 4 synchronised the stream once per VAE call).
+        `check_range` reads it: the next VAE call does so when the event has already fired, the schedulers' `fuse_latents` and the
+        pipelines do at the points where they synchronise anyway (FLF gate read-back, final frames)."""
         if not self.f16:
             return
-        import ctypes
-        flag = ctypes.c_int(0)
-        call("wf_f16_overflow_flag", ctypes.byref(flag), 1, ops.stream())
-        if flag.value:
+        self.check_range(wait=False)   # an earlier call's flag, if it has landed meanwhile
+        if getattr(self, "_flag_host", None) is None:
+            self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        call("wf_f16_overflow_flag_async", self._flag_host.data_ptr(), ops.stream())
+        ev = torch.cuda.Event()
+        ev.record()
+        self._flag_pending = (ev, what)
+
+    def check_range(self, wait: bool = True):
+        """Turn a raised fp16 range flag of an earlier encode / decode into a RuntimeError -- never a silent inf.  wait=False: only if its
+        copy has already landed.  With `comm` every rank takes part in one tiny all-gather of the flag first, so that all ranks fail
+        together instead of one raising while its peers wait in the next collective; call it at the same program points on
+        every rank (the pipelines do)."""
+        pend = getattr(self, "_flag_pending", None)
+        if pend is None:
+            return
+        ev, what = pend
+        shared = self.comm is not None and getattr(self.comm, "world", 1) > 1
+        if not wait and (shared or not ev.query()):
+            return   # (a sharded VAE decides at explicit check points only: every rank must take the same branch)
+        ev.synchronize()
+        self._flag_pending = None
+        bad = int(self._flag_host[0])
+        if shared:
+            mine = torch.tensor([bad], dtype=torch.int32, device=self.device)
+            allr = torch.empty((self.comm.world, 1), dtype=torch.int32, device=self.device)
+            self.comm.all_gather(allr, mine)
+            bad = int(allr.max())
+        if bad:
+            import ctypes
+            flag = ctypes.c_int(0)
+            call("wf_f16_overflow_flag", ctypes.byref(flag), 1, ops.stream())   # reset (synchronous: we are about to raise)
             raise RuntimeError(f"AutoencoderKLWan.{what}: an activation left the fp16 range (|x| > 65504) or was NaN under precision="
                                f"{self.precision!r}; use precision='bf16x3' (8-bit exponent) for these weights / inputs")
 
@@ -508,7 +562,7 @@ class AutoencoderKLWan:
         if cin != cout:
             xb = self._operand(x)
             h = torch.empty((T, H, Wd, cout), dtype=F32, device=x.device)
-            self._gemm(xb.view(-1, xb.shape[-1]), W[p + ".shortcut.w"], W[p + ".shortcut.b"], h.view(-1, cout), EPI_F32)
+            self._gemm(xb.view(-1, xb.shape[-1]), W[p + ".shortcut.w"], W[p + ".shortcut.b"], h.view(-1, cout), EPI_F32, wkey=p + ".shortcut.w")
             self.flops_last += 2 * T * H * Wd * xb.shape[-1] * cout
             del xb
         else:
@@ -558,7 +612,7 @@ class AutoencoderKLWan:
         T, C = x.shape[0], x.shape[-1]
         W = self.w
         qkv = torch.zeros((T * hw + 64, 3 * C), dtype=F32, device=x.device)  # + 64 rows: the last frame's padded K rows stay in-bounds
-        self._gemm(a.view(-1, 3 * C), W[p + ".to_qkv.w"], W[p + ".to_qkv.b"], qkv[:T * hw], EPI_F32)
+        self._gemm(a.view(-1, 3 * C), W[p + ".to_qkv.w"], W[p + ".to_qkv.b"], qkv[:T * hw], EPI_F32, wkey=p + ".to_qkv.w")
         del a
         S = torch.empty((nq, hwp), dtype=F32, device=x.device)
         P = torch.empty((nq, hwp), dtype=F32, device=x.device)
@@ -566,27 +620,27 @@ class AutoencoderKLWan:
         Of = torch.empty((T * nq, C), dtype=F32, device=x.device)
         scale = 1.0 / math.sqrt(C)
         # The P . V product of a frame is nq x C x 3 hwp: ceil(nq / 128) x 3 workgroups of the 128 x 128 kernel -- 147 at 480p, 37 on a row group's
-        # query slab -- i.e. a fraction of the chip, 21 times in a row.  The three-term operands of ALL frames are therefore kept (4.9 GB at 480p)
-        # and the T products run as ONE batched launch; per frame the arithmetic is that of the single call (same kernel, same tiles).
-        batched = not os.environ.get("WF_VAE_ATTN_UNBATCHED")  # (debug switch: the per-frame launches of rounds 2-3)
-        if batched:
-            P3 = torch.empty((T, nq, 3 * hwp), dtype=self.OP, device=x.device)
-            V3 = torch.empty((T, C, 3 * hwp), dtype=self.OP, device=x.device)
-        for t in range(T):
-            blk = qkv[t * hw:t * hw + hwp]
-            self._gemm(self._operand(blk[q0:q0 + nq, 0:C], 0), self._operand(blk[:, C:2 * C], 1), None, S, EPI_F32)
-            call("wf_softmax_rows_f32", S.data_ptr(), hwp, P.data_ptr(), hwp, nq, hw, float(scale), ops.stream())
-            call("wf_transpose_f32", blk[:, 2 * C:].data_ptr(), 3 * C, Vt.data_ptr(), hwp, hw, C, ops.stream())
-            if batched:
-                self._operand(P, 0, out=P3[t])
-                self._operand(Vt, 1, out=V3[t])
-            else:
-                self._gemm(self._operand(P, 0), self._operand(Vt, 1), None, Of[t * nq:(t + 1) * nq], EPI_F32)
-        if batched:
-            call("wf_gemm_f16_batched" if self.f16 else "wf_gemm_bf16_batched", P3.data_ptr(), V3.data_ptr(), Of.data_ptr(), T, nq, C, 3 * hwp, 3 * hwp, 3 * hwp, C, nq * 3 * hwp,
-                 C * 3 * hwp, nq * C, EPI_F32, ops.stream())
-            del P3, V3
-        self._gemm(self._operand(Of), W[p + ".proj.w"], W[p + ".proj.b"], x.view(-1, C), EPI_F32_ACC)
+        # query slab -- i.e. a fraction of the chip, 21 times in a row.  The three-term operands of a CHUNK of frames are therefore kept and
+        # their products run as ONE batched launch; per frame the arithmetic is that of the single call (same kernel, same tiles).  The chunk
+        # is bounded by a byte budget (ATTN_BATCH_BYTES: 4.9 GB at 480p = all 21 frames in one launch; 720p on one GPU = 26 GB unchunked,
+        # ADVICE r4): whole frames while they fit, never fewer than one.
+        per_frame = (nq + C) * 3 * hwp * 2
+        tb = max(1, min(T, self.ATTN_BATCH_BYTES // per_frame))
+        P3 = torch.empty((tb, nq, 3 * hwp), dtype=self.OP, device=x.device)
+        V3 = torch.empty((tb, C, 3 * hwp), dtype=self.OP, device=x.device)
+        for t0 in range(0, T, tb):
+            n = min(tb, T - t0)
+            for t in range(t0, t0 + n):
+                blk = qkv[t * hw:t * hw + hwp]
+                self._gemm(self._operand(blk[q0:q0 + nq, 0:C], 0), self._operand(blk[:, C:2 * C], 1), None, S, EPI_F32)
+                call("wf_softmax_rows_f32", S.data_ptr(), hwp, P.data_ptr(), hwp, nq, hw, float(scale), ops.stream())
+                call("wf_transpose_f32", blk[:, 2 * C:].data_ptr(), 3 * C, Vt.data_ptr(), hwp, hw, C, ops.stream())
+                self._operand(P, 0, out=P3[t - t0])
+                self._operand(Vt, 1, out=V3[t - t0])
+            call("wf_gemm_f16_batched" if self.f16 else "wf_gemm_bf16_batched", P3.data_ptr(), V3.data_ptr(), Of[t0 * nq:].data_ptr(), n, nq, C,
+                 3 * hwp, 3 * hwp, 3 * hwp, C, nq * 3 * hwp, C * 3 * hwp, nq * C, EPI_F32, ops.stream())
+        del P3, V3
+        self._gemm(self._operand(Of), W[p + ".proj.w"], W[p + ".proj.b"], x.view(-1, C), EPI_F32_ACC, wkey=p + ".proj.w")
         self.flops_last += 3 * (T * (4 * nq * hw * C) + 2 * T * hw * C * 3 * C + 2 * T * nq * C * C)
         return x
 
@@ -607,7 +661,7 @@ class AutoencoderKLWan:
         out[0].copy_(y[0])  # frame 0 by-passes time_conv (vae.py:146-148)
         W = self.w
         call("wf_conv3d_cl" + self._sfx, yb.data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
-             out[1:].data_ptr(), None, T, Ho, Wo, yb.shape[-1], To, Ho, Wo, C, 3, 1, 1, 2, 1, 0, 0, 0, 0, 0, None, ops.stream())
+             out[1:].data_ptr(), None, T, Ho, Wo, yb.shape[-1], To, Ho, Wo, C, 3, 1, 1, 2, 1, 0, 0, 0, 0, 0, None, *self._acc_scale(p + ".time_conv.w"), ops.stream())
         self.flops_last += 2 * To * Ho * Wo * C * 3 * yb.shape[-1]
         return out
 
@@ -633,7 +687,7 @@ class AutoencoderKLWan:
             for px in range(2):
                 call("wf_conv3d_cl_scatter" + self._sfx, xb.data_ptr(), W[f"{p}.ph{py}{px}.w"].data_ptr(), W[p + ".b"].data_ptr(), None, out.data_ptr(), None,
                      T, Hs, Wd, Cin, T, n_rows, Wd, Cout, 1, 2, 2, 1, 1, 0, 1 - py + row_off, 1 - px, self._zero_page().data_ptr(),
-                     out_rows, 2 * Wd, 2, py, 2, px, ops.stream())
+                     out_rows, 2 * Wd, 2, py, 2, px, *self._acc_scale(f"{p}.ph{py}{px}.w"), ops.stream())
         self.flops_last += 4 * 2 * T * n_rows * Wd * Cout * 4 * Cin
         return out
 
@@ -694,7 +748,7 @@ class AutoencoderKLWan:
     def _halo_operand(self, x, gamma):
         """RMS_norm + SiLU of a row slab as the halo-padded conv operand: the norm kernel writes the slab's own rows in place (no copy)."""
         C = x.shape[-1]
-        if C % 32 == 0 and not os.environ.get("WF_CONV_NO_W4"):
+        if C % 32 == 0:
             return self._halo_fill(self._rms(x, gamma, blocked=True, halo=True))
         return self._halo_pad(self._rms(x, gamma, blocked=True))
 
@@ -718,9 +772,7 @@ class AutoencoderKLWan:
     def _row_groups(self, h: int, even: bool = False) -> int:
         """Row groups for a stage of h rows: the largest divisor G of the world size with h % G == 0 (and an even number of rows per group
         if a stride-2 conv follows); world / G consecutive ranks then compute the same slab (the low-resolution stage: 60 rows on 8 ranks =
-        4 groups of 15, computed twice each, instead of the whole stage on every rank).  WF_VAE_LOWRES_REPLICATED=1: 1 (the old scheme)."""
-        if os.environ.get("WF_VAE_LOWRES_REPLICATED"):
-            return 1
+        4 groups of 15, computed twice each, instead of the whole stage on every rank)."""
         P = self.comm.world
         for G in range(P, 0, -1):
             if P % G == 0 and h % G == 0 and (not even or (h // G) % 2 == 0):
@@ -738,7 +790,7 @@ class AutoencoderKLWan:
         if cin != cout:
             xb = self._operand(x)
             h = torch.empty((T, Hs, Wd, cout), dtype=F32, device=x.device)
-            self._gemm(xb.view(-1, xb.shape[-1]), W[p + ".shortcut.w"], W[p + ".shortcut.b"], h.view(-1, cout), EPI_F32)
+            self._gemm(xb.view(-1, xb.shape[-1]), W[p + ".shortcut.w"], W[p + ".shortcut.b"], h.view(-1, cout), EPI_F32, wkey=p + ".shortcut.w")
             del xb
         else:
             h = x
@@ -757,7 +809,7 @@ class AutoencoderKLWan:
         if self.x3:
             yf = torch.empty((1 + 2 * (T - 1), H, Wd, C), dtype=F32, device=xb.device)  # frame 0 is not written (tsplit: 1 + 2t + h)
             call("wf_conv3d_cl" + self._sfx, xb[1:].data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
-                 yf.data_ptr(), None, T - 1, H, Wd, Cop, T - 1, H, Wd, 2 * C, 3, 1, 1, 1, 1, 2, 0, 0, 0, 1, None, ops.stream())
+                 yf.data_ptr(), None, T - 1, H, Wd, Cop, T - 1, H, Wd, 2 * C, 3, 1, 1, 1, 1, 2, 0, 0, 0, 1, None, *self._acc_scale(p + ".time_conv.w"), ops.stream())
             yb = torch.empty((1 + 2 * (T - 1), H, Wd, Cop), dtype=self.OP, device=xb.device)
             yb[0].copy_(xb[0])
             self._operand(yf[1:], out=yb[1:])
@@ -765,7 +817,7 @@ class AutoencoderKLWan:
         yb = torch.empty((1 + 2 * (T - 1), H, Wd, C), dtype=BF, device=xb.device)
         yb[0].copy_(xb[0])
         call("wf_conv3d_cl" + self._sfx, xb[1:].data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
-             None, yb.data_ptr(), T - 1, H, Wd, C, T - 1, H, Wd, 2 * C, 3, 1, 1, 1, 1, 2, 0, 0, 0, 1, None, ops.stream())
+             None, yb.data_ptr(), T - 1, H, Wd, C, T - 1, H, Wd, 2 * C, 3, 1, 1, 1, 1, 2, 0, 0, 0, 1, None, *self._acc_scale(p + ".time_conv.w"), ops.stream())
         return yb
 
     def _up_slab(self, xsrc_b, p, C, temporal, s0, y0, Ho, h_src):
@@ -804,7 +856,7 @@ class AutoencoderKLWan:
         out[0].copy_(y[0])
         W = self.w
         call("wf_conv3d_cl" + self._sfx, yb.data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
-             out[1:].data_ptr(), None, T, Ho, Wo, yb.shape[-1], To, Ho, Wo, C, 3, 1, 1, 2, 1, 0, 0, 0, 0, 0, None, ops.stream())
+             out[1:].data_ptr(), None, T, Ho, Wo, yb.shape[-1], To, Ho, Wo, C, 3, 1, 1, 2, 1, 0, 0, 0, 0, 0, None, *self._acc_scale(p + ".time_conv.w"), ops.stream())
         return out
 
     def can_shard(self, H_lat: int) -> bool:
@@ -1009,14 +1061,14 @@ class AutoencoderKLWan:
         y0 = self.comm.rank * Hs
         fused = ops.blend_pixels(self._row_slab_of(ref, y0, Hs), self._row_slab_of(mask, y0, Hs), slab.unsqueeze(0))
         mom = self._encode_one_sharded(None, slab=fused[0]).unsqueeze(0)
-        self._check_range("decode_blend_encode")
+        self._note_range("decode_blend_encode")
         return _LatentDist(mom[:, :Z_DIM].contiguous(), mom[:, Z_DIM:])
 
     @torch.no_grad()
     def encode(self, x: torch.Tensor, return_dict: bool = True):
         x = x.to(device=self.device, dtype=F32).contiguous()
         moments = torch.stack([self._encode_one(v) for v in x])
-        self._check_range("encode")
+        self._note_range("encode")
         post = _LatentDist(moments[:, :Z_DIM].contiguous(), moments[:, Z_DIM:])
         if not return_dict:
             return (post,)
@@ -1026,7 +1078,7 @@ class AutoencoderKLWan:
     def decode(self, z: torch.Tensor, return_dict: bool = True):
         z = z.to(device=self.device, dtype=F32).contiguous()
         out = torch.stack([self._decode_one(v) for v in z])
-        self._check_range("decode")
+        self._note_range("decode")
         if not return_dict:
             return (out,)
         return SimpleNamespace(sample=out)
