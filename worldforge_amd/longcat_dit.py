@@ -392,7 +392,7 @@ class LongCatVideoTransformer3DModel:
         t0 = self._gemm_f32(tf, W["t_embedder.mlp.0.w"], W["t_embedder.mlp.0.b"], _buf("t0", (T, Ct), f32))
         t = self._gemm_f32(self._act(t0, f32, 0), W["t_embedder.mlp.2.w"], W["t_embedder.mlp.2.b"], _buf("t", (T, Ct), f32))
         st = self._act(t, f32, 0)  # SiLU(t), shared by every adaLN_modulation (LCD:40-43, LCB:156)
-        ada = self._gemm_f32(st, W["ada.w"], W["ada.b"], _buf("ada", (T, cfg.depth * 6 * C), f32))
+        ada = self._gemm_f32(st, W["ada.w"], W["ada.b"], _buf("ada", (T, W["ada.w"].shape[0]), f32))   # (all stored blocks: a run on the first cfg.depth blocks only reads its own columns)
         fmod = self._gemm_f32(st, W["final_layer.adaLN_modulation.1.w"], W["final_layer.adaLN_modulation.1.b"], _buf("fmod", (T, 2 * C), f32))
         # caption: Linear -> GELU(tanh) -> Linear (LCB:225-228), valid tokens only (LCD:319-325)
         cap = caption
