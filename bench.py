@@ -955,6 +955,9 @@ def main(argv=None):
             out["per_rank"] = per_rank
         if exchange is not None:
             out["exchange"] = exchange
+            if exchange.get("selected", "").startswith("cfg2+") and a.as_rank_of <= 1:
+                out["config"]["parallelism"] = (f"cfg2 x sp{world // 2} (two CFG groups of {world // 2} rank(s): token-sharded DiT inside a group, one velocity all-gather "
+                                                f"per evaluation between them; VAE row-sharded over all {world} ranks, {_transport()})")
         if attn_ms:
             avg = sum(attn_ms) / len(attn_ms)
             ach = attn_flop / (avg * 1e-3) / 1e12
