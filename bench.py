@@ -281,11 +281,29 @@ def main_longcat(a):
         ccal = torch.cat([pe, ne])[:nb].to(device)
         mcal = torch.cat([pm, nm])[:nb]
         names = ["chunked2", "chunked4", "chunked1", "bcast", "gather"] if a.distill else ["lockstep", "chunked2", "chunked4", "chunked1", "bcast", "gather"]
-        if a.exchange.startswith("cfg2+"):
-            raise SystemExit("bench.py: the CFG-group split is built for the Wan pipeline")
-        exchange = calibrate_exchange(model, comm, lambda name: model(xcal, tcal, ccal, mcal, num_cond_latents=1), names, "depth", device, a.exchange)
+        ctx = None
+        if not a.distill and comm.world % 2 == 0:   # the CFG batch as two CFG groups x sequence shards (longcat_pipeline.cfg_split)
+            sub = comm.split(2)
+            ctx = {"world": comm, "sub": sub, "pipe": pipe}
+            # the CFG groups come FIRST for LongCat (the default unless another candidate is >= 3 % faster on the node): as one rank of 8 they
+            # are 16-18 % ahead of the lock-step pair in compute (profiles/r5_e_longcat_cfg_asrank8_*: 1.39-1.42 vs 1.20 steps/s), more
+            # than any exposed exchange of a 4-rank group could cost
+            names = (["cfg2+chunked2", "cfg2+chunked1", "cfg2+gather"] if sub.world > 1 else ["cfg2+gather"]) + names
+        if a.exchange.startswith("cfg2+") and ctx is None:
+            raise SystemExit("bench.py: --exchange cfg2+... needs the CFG batch (not --distill) and an even number of ranks")
+
+        def run_cal(name):
+            if name.startswith("cfg2+"):
+                b = ctx["sub"].group_index
+                v = model(xcal[b:b + 1], tcal[b:b + 1], ccal[b:b + 1], mcal[b:b + 1], num_cond_latents=1).contiguous()
+                both = torch.empty((comm.world,) + tuple(v.shape), dtype=v.dtype, device=device)
+                comm.all_gather(both, v)
+            else:
+                model(xcal, tcal, ccal, mcal, num_cond_latents=1)
+
+        exchange = calibrate_exchange(model, comm, run_cal, names, "depth", device, a.exchange, ctx=ctx)
         if a.as_rank_of > 1 and a.exchange == "auto":
-            apply_exchange(model, names[0])
+            apply_exchange(model, names[0], ctx)
             exchange.update(selected=names[0], selection="default (simulated rank: the calibration shows each mode's compute cost only)")
         del xcal
     K, Wm = a.steps, a.warmup

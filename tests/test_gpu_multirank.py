@@ -338,6 +338,50 @@ def test_longcat_guided_sampler_on_sharded_dit_and_vae_equals_single(P):
         assert torch.equal(got, want), (r, (got - want).abs().max())
 
 
+@pytest.mark.parametrize("P", [2, 4])
+def test_longcat_cfg_groups_by_sequence_shards_equals_single(P):
+    """The LongCat guided i2v job with CFG (batch [negative, positive]) as two CFG groups x P / 2 sequence shards (longcat_pipeline.cfg_split;
+    P = 2: one sample per GPU, no K / V^T exchange at all): every rank must produce the single-GPU frames bit for bit."""
+    from oracle import longcat_dit as olc
+    from worldforge_amd.longcat_dit import LongCatConfig, LongCatVideoTransformer3DModel
+    from worldforge_amd.longcat_pipeline import LongCatVideoPipeline
+    from worldforge_amd.longcat_scheduler import FlowMatchEulerDiscreteScheduler
+    from worldforge_amd.vae import AutoencoderKLWan
+    kw = dict(hidden_size=256, depth=2, num_heads=2, caption_channels=64, adaln_tembed_dim=64)
+    W = olc.random_weights(olc.LongCatConfig(**kw), seed=5)
+    Fr, H, Wd = 9, 128, 160
+    g = torch.Generator().manual_seed(3)
+    image = torch.rand(3, H, Wd, generator=g)
+    ref = torch.rand(1, 3, Fr, H, Wd, generator=g)
+    mask = (torch.rand(1, 1, Fr, H, Wd, generator=g) > 0.3).float()
+    pe, ne = _rand((1, 1, 20, 64), 7).to(BF), _rand((1, 1, 20, 64), 8).to(BF)
+    pm, nm = torch.ones(1, 20, dtype=torch.int64), torch.ones(1, 20, dtype=torch.int64)
+    nm[:, 9:] = 0
+    m0 = LongCatVideoTransformer3DModel(LongCatConfig(**kw), DEV).load_state_dict(W)
+    v0 = AutoencoderKLWan(DEV).init_random(seed=1)
+
+    def run(world):
+        sub = world.split(2) if world is not None else None
+        m = LongCatVideoTransformer3DModel(LongCatConfig(**kw), DEV, comm=sub if (sub is not None and sub.world > 1) else None)
+        m.w = m0.w
+        m.exchange_mode = "gather"
+        v = AutoencoderKLWan(DEV, comm=world)
+        v.w = v0.w
+        pipe = LongCatVideoPipeline(v, FlowMatchEulerDiscreteScheduler(shift=3.0), m, device=DEV)
+        if world is not None:
+            pipe.cfg_split = (world, sub.group_index)
+        out = pipe.generate_i2v(image=image, height=H, width=Wd, prompt_embeds=pe, prompt_attention_mask=pm, negative_prompt_embeds=ne,
+                                negative_prompt_attention_mask=nm, num_frames=Fr, num_inference_steps=4, guidance_scale=4.0,
+                                generator=torch.Generator().manual_seed(42), video_ref=ref, mask=mask, guided=True, resample_steps=2,
+                                guide_steps=3, resample_round=3, use_pca_channel_selection=True, static=True)
+        return torch.from_numpy(out).clone()
+
+    want = run(None)
+    assert torch.isfinite(want).all()
+    for r, got in enumerate(_run_ranks(P, run)):
+        assert torch.equal(got, want), (r, (got - want).abs().max())
+
+
 @pytest.mark.parametrize("P,ncl,T", [(2, 4, 8), (4, 4, 8), (3, 0, 12)])
 def test_token_sharded_longcat_dit_with_block_sparse_attention_equals_single(P, ncl, T):
     """The refine-pass DiT (block-sparse self-attention, network resident in 3D-block token order), sequence parallel over whole

@@ -239,8 +239,20 @@ class LongCatVideoPipeline:
                     ts = torch.cat([ts] * 2)
                 ts = ts.unsqueeze(-1).repeat(1, x_in.shape[2])
                 ts[:, :1] = 0
-                noise_pred = self.dit(hidden_states=x_in, timestep=ts, encoder_hidden_states=pe, encoder_attention_mask=pm,
-                                      num_cond_latents=1)
+                split = getattr(self, "cfg_split", None) if do_cfg and x_in.shape[0] == 2 else None
+                if split is not None:
+                    # CFG groups x sequence shards (parallel.Comm.split, as pipeline.WanImageToVideoPipeline.cfg_split): the CFG
+                    # batch [negative, positive] of pipeline_longcat_video.py:857-866 is two samples -- group b of the job's ranks runs sample
+                    # b as ONE forward, one all-gather over the whole job hands every rank both velocities (slots 0 and P / 2)
+                    world_comm, b = split
+                    own = self.dit(hidden_states=x_in[b:b + 1], timestep=ts[b:b + 1], encoder_hidden_states=pe[b:b + 1],
+                                   encoder_attention_mask=pm[b:b + 1], num_cond_latents=1).contiguous()
+                    both = torch.empty((world_comm.world,) + tuple(own.shape), dtype=own.dtype, device=own.device)
+                    world_comm.all_gather(both, own)
+                    noise_pred = torch.cat([both[0], both[world_comm.world // 2]])
+                else:
+                    noise_pred = self.dit(hidden_states=x_in, timestep=ts, encoder_hidden_states=pe, encoder_attention_mask=pm,
+                                          num_cond_latents=1)
                 if do_cfg:
                     # CFG-zero (PIPE:875-885) and the sign flip of PIPE:888 in one launch per sample
                     u, c = noise_pred.chunk(2)
