@@ -35,6 +35,11 @@ ATTN_PMC_FILE = os.path.join(ROOT, "profiles", "attn_pmc_latest.json")
 
 
 BOX_CALIB_REFERENCE_TFLOPS = 1800.0  # the bare-MFMA rate `value_normalised` is quoted at (round 3's lab box: 1818 on N(0,1) operands)
+# How strongly the bench follows that rate, FITTED on round 5's nine 1-GPU lines from seven boxes (calibration 1781 ... 1844 TFLOP/s, value
+# 0.2510 ... 0.2549): log-log slope 0.40 -- the window is part matrix pipe at the power cap, part HBM-bound helpers and
+# epilogues, and the attention kernel's own time follows the bare stream with a slope of only 0.12.  A proportional correction (exponent 1)
+# over-corrects: it WIDENS the spread of those lines from 1.5 % to 2.2 %; exponent 0.4 narrows it to 1.05 %.
+BOX_CALIB_EXPONENT = 0.4
 _CALIB = {}
 
 
@@ -552,9 +557,9 @@ def also_wan_720p(pipe, model, cfg, device, frames=81):
 
 
 def also_longcat(device, height=480, width=832, frames=93):
-    """BASELINE config 4 (LongCat-Video distilled 480p, 16 steps + the 720p refine pass) on a random-init 13.6 B model: steps 0..2 of the
-    distilled 16-step schedule (1 guided step = 3 IRR rounds + FLF + DSG, 2 plain; no CFG, no warm-up step), then steps 0 and 1 of the 704 x
-    1280 refine pass (block-sparse self-attention at 98 560 tokens; step 1 reported)."""
+    """BASELINE config 4 (LongCat-Video distilled 480p, 16 steps + the 720p refine pass) on a random-init 13.6 B model: steps 1..3 of the
+    distilled 16-step schedule (1 guided step = 3 IRR rounds + FLF + DSG, 2 plain; no CFG) after one guided warm-up step, then steps 0 and 1
+    of the 704 x 1280 refine pass (block-sparse self-attention at 98 560 tokens; step 1 reported)."""
     from worldforge_amd import dit as wdit
     from worldforge_amd.longcat_dit import LongCatConfig, LongCatVideoTransformer3DModel
     from worldforge_amd.longcat_pipeline import LongCatVideoPipeline
@@ -581,16 +586,16 @@ def also_longcat(device, height=480, width=832, frames=93):
     def hook(i, phase):
         torch.cuda.synchronize()
         marks[(phase[0], i)] = time.perf_counter()
-        if phase == "start" and i == 0:
+        if phase == "start" and i == 1:
             wdit.PROFILE_ATTN = []
-        if phase == "end" and i == 2:
+        if phase == "end" and i == 3:
             raise _Stop
 
-    try:
+    try:   # steps 0 and 1 guided, 2 and 3 plain; step 0 is the warm-up (a cold pipeline's first guided step measured 1-1.5 s long)
         pipe.generate_i2v(image=image, height=height, width=width, prompt_embeds=pe, prompt_attention_mask=pm, negative_prompt_embeds=ne,
                           negative_prompt_attention_mask=nm, num_frames=frames, num_inference_steps=16, use_distill=True, guidance_scale=1.0,
                           generator=torch.manual_seed(42), output_type="latent", video_ref=ref, mask=mask, guided=True, resample_steps=3,
-                          guide_steps=1, resample_round=1, omega=1.8, omega_resample=1.0, use_pca_channel_selection=True, static=True,
+                          guide_steps=2, resample_round=2, omega=1.8, omega_resample=1.0, use_pca_channel_selection=True, static=True,
                           step_hook=hook)
     except _Stop:
         pass
@@ -598,10 +603,10 @@ def also_longcat(device, height=480, width=832, frames=93):
     tpf = (height // 16) * (width // 16)
     L = T * tpf
     frac, avg = _attn_frac(wdit, 4.0 * (L - tpf) * L * 128 * cfg.num_heads)
-    gms = 1e3 * (marks[("e", 0)] - marks[("s", 0)])
-    pms = sum(1e3 * (marks[("e", i)] - marks[("s", i)]) for i in (1, 2)) / 2
-    out = {"workload": f"LongCat-Video 13.6B distilled i2v, {frames}f {height}x{width}, 16-step schedule, IRR x3 + FLF + DSG, no CFG; timed steps 0..2 = "
-                       "1 guided + 2 plain, no warm-up step",
+    gms = 1e3 * (marks[("e", 1)] - marks[("s", 1)])
+    pms = sum(1e3 * (marks[("e", i)] - marks[("s", i)]) for i in (2, 3)) / 2
+    out = {"workload": f"LongCat-Video 13.6B distilled i2v, {frames}f {height}x{width}, 16-step schedule, IRR x3 + FLF + DSG, no CFG; timed steps 1..3 = "
+                       "1 guided + 2 plain after one guided warm-up step",
            "tokens": L, "steps_per_s": 16.0 / ((6 * gms + 10 * pms) / 1e3), "steps_per_s_basis": "the 16-step job's 6 guided : 10 plain mix of the timed step times",
            "guided_step_ms": gms, "plain_step_ms": pms, "attn_frac": frac, "attn_avg_launch_ms": avg}
     # ---- the 720p refine pass (pipeline_longcat_video.py:1271-1511) on the same weights with block-sparse self-attention
@@ -958,11 +963,12 @@ def main(argv=None):
             out["job50_steps_per_s"] = 50.0 / ((15 * g + 35 * p) / 1e3)
         if "calib0" in marks and "calib1" in marks:
             # DIAGNOSTIC, not the contract: `value` is what this box did; `value_normalised` is what a box sustaining the reference
-            # bare-MFMA rate would have done if throughput followed that rate (the timed kernels are ~90 % matrix-pipe bound at the power cap)
+            # bare-MFMA rate would have done, with the measured elasticity of the bench against that rate (BOX_CALIB_EXPONENT)
             cal = 0.5 * (marks["calib0"] + marks["calib1"])
             out["box_calib_tflops"] = {"before": marks["calib0"], "after": marks["calib1"], "mean": cal, "reference": BOX_CALIB_REFERENCE_TFLOPS,
                                        "kernel": "wf_calib_mfma: register-only v_mfma_f32_32x32x16_bf16 stream, N(0,1) operands, 256 x 4 waves"}
-            out["value_normalised"] = out["value"] * BOX_CALIB_REFERENCE_TFLOPS / cal
+            out["value_normalised"] = out["value"] * (BOX_CALIB_REFERENCE_TFLOPS / cal) ** BOX_CALIB_EXPONENT
+            out["box_calib_tflops"]["exponent"] = BOX_CALIB_EXPONENT
         if a.as_rank_of > 1:  # one simulated rank: label it so that it cannot be mistaken for a measurement of N GPUs
             out["metric"] += f" -- ONE simulated rank of {a.as_rank_of}: compute and local copies only, NOT a contract line"
             out["simulated_rank_of"], out["simulated_rank"] = a.as_rank_of, comm.rank
