@@ -119,3 +119,62 @@ def test_comm_probe_parses_rccl_logs_and_gpu_count_needs_no_hip(tmp_path, monkey
         monkeypatch.delenv(v, raising=False)
     n = bench.visible_gpu_count()          # from /sys/class/kfd (None where that is unreadable, 0 in a GPU-less container)
     assert n is None or n >= 0
+
+
+def test_exchange_calibration_picks_by_extrapolated_time_and_keeps_the_default_on_ties(monkeypatch):
+    """bench.calibrate_exchange (N > 1 runs, before the timed window): times every candidate on a model cut to 4 and to 12 layers, extrapolates
+    linearly to the full depth (a candidate with a large per-forward fixed cost but a cheap layer must win against one that looks better at 4
+    layers), keeps the FIRST candidate unless another is >= 3 % faster, drops a candidate whose host side refuses the shape (never the
+    default), switches the model's communicator / the pipeline's CFG branch for the `cfg2+` candidates, and reports every estimate."""
+    import time
+    import types
+
+    import torch
+
+    import bench
+
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+
+    class FakeComm:
+        def __init__(self, world, group_index=0):
+            self.world, self.group_index = world, group_index
+
+        def barrier(self):
+            pass
+
+        def all_reduce_max(self, t):
+            return t
+
+    world, sub = FakeComm(8), FakeComm(4, group_index=1)
+    model = types.SimpleNamespace(cfg=types.SimpleNamespace(num_layers=40), comm=world, _ws={("kvx", 1): object(), ("x", 2): object()},
+                                  pair_lockstep=None, exchange_mode=None, exchange_chunks=None)
+    pipe = types.SimpleNamespace(cfg_split=None)
+    ctx = {"world": world, "sub": sub, "pipe": pipe}
+    # per-candidate cost model in ms: fixed + per-layer * depth
+    cost = {"lockstep": (2.0, 1.00), "chunked2": (2.0, 1.02), "cfg2+chunked2": (6.0, 0.80), "bcast": (0.5, 1.10), "gather": (2.0, 0.99)}
+    seen = []
+
+    def run(name):
+        if name == "bcast":
+            raise ValueError("this shape is not served")
+        seen.append((name, model.cfg.num_layers, model.comm is sub, pipe.cfg_split))
+        fixed, per = cost[name]
+        time.sleep((fixed + per * model.cfg.num_layers) * 1e-3)
+
+    out = bench.calibrate_exchange(model, world, run, list(cost), "num_layers", torch.device("cpu"), "auto", reps=2, ctx=ctx)
+    assert model.cfg.num_layers == 40 and ("kvx", 1) not in model._ws and ("x", 2) in model._ws
+    assert set(out["dropped"]) == {"bcast"} and "bcast" not in out["estimated_ms_per_evaluation"]
+    est = out["estimated_ms_per_evaluation"]
+    # at 4 layers cfg2+chunked2 (6 + 3.2 = 9.2 ms) looks WORSE than lockstep (6.0 ms); extrapolated to 40 layers it wins (38 vs 42 ms)
+    assert out["timed_ms"]["cfg2+chunked2"]["4"] > out["timed_ms"]["lockstep"]["4"]
+    assert est["cfg2+chunked2"] < 0.97 * est["lockstep"] and out["selected"] == "cfg2+chunked2"
+    assert model.comm is sub and pipe.cfg_split == (world, 1) and (model.pair_lockstep, model.exchange_mode, model.exchange_chunks) == (False, "chunked", 2)
+    assert any(s[0] == "cfg2+chunked2" and s[2] and s[3] == (world, 1) for s in seen) and all(not s[2] and s[3] is None for s in seen if s[0] == "lockstep")
+    # `gather` is ~1 % faster than the default: inside the 3 % band -> the default stays
+    cost.pop("cfg2+chunked2")
+    model.comm, pipe.cfg_split = world, None
+    out2 = bench.calibrate_exchange(model, world, run, ["lockstep", "chunked2", "gather"], "num_layers", torch.device("cpu"), "auto", reps=2, ctx=ctx)
+    assert out2["selected"] == "lockstep" and model.comm is world and pipe.cfg_split is None and model.pair_lockstep is True
+    # forced
+    out3 = bench.calibrate_exchange(model, world, run, ["lockstep"], "num_layers", torch.device("cpu"), "cfg2+gather", ctx=ctx)
+    assert out3["selected"] == "cfg2+gather" and model.comm is sub and model.exchange_mode == "gather"
