@@ -2,7 +2,7 @@
 
 `within(name, measured, bound)` asserts `measured <= bound`; with `WF_TOL_LOG=<file>` it also appends `name measured bound` so that one
 run of the suite on the GPU shows every bar next to the error it actually sees.  Policy: a bar sits at <= 2x the error measured on an
-MI355X (the value is quoted in the comment at the call site); profiles/r4_tolerances.txt is the log the bars of this round were set from.
+MI355X (the value is quoted in the comment at the call site); profiles/r5_tolerances.txt is the log of the round-end run at HEAD (tools/gpurun_scripts/final.sh regenerates it).
 """
 import os
 
