@@ -116,7 +116,7 @@ def test_timed_self_attention_production_chain_vs_oracle(grid):
     eu = _compare(out_u, want, ROWS[grid], heads, tol_abs, 1e-2, f"timed_attn.untracked.L{L}")
     out_t = torch.empty_like(out_u)
     with _BodyCounter() as n:
-        dit.attention(c["qh"], c["kh"], c["vt"], out_t, L, 0.0, nsplit=1)           # no bounds -> running-max tracking (WF_ATTN_TRACK_MAX=1)
+        dit.attention(c["qh"], c["kh"], c["vt"], out_t, L, 0.0, nsplit=1)           # no bounds -> running-max tracking (`model.attn_track_max = True`)
     assert (n.tracked, n.untracked) == (_wgs(L), 0), (n.tracked, n.untracked)
     et = _compare(out_t, want, ROWS[grid], heads, tol_abs, 1e-2, f"timed_attn.tracked.L{L}")
     # the two bodies differ only in the reference max m of each row (exact for any m up to fp32 rounding of exp2 / the row sums)
