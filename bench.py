@@ -371,7 +371,7 @@ def main_longcat(a):
     per_rank = None
     if comm is not None:
         # every rank's own figures: its noise-token self-attention time and how long its compute stream stalled per layer waiting for
-        # segments of the K / V^T exchange (the segmented exchange: only what has not arrived when the attention gets to it)
+        # windows of the K / V^T exchange (own-first sweeps: only what has not arrived when the attention gets to it)
         mine = torch.tensor([sum(attn_ms) / max(len(attn_ms), 1), sum(comm_ms) / max(len(comm_ms), 1), float(len(comm_ms))],
                             dtype=torch.float64, device=device)
         allr = torch.empty((comm.world, 3), dtype=torch.float64, device=device)

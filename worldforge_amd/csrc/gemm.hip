@@ -249,7 +249,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_gemm(GemmArgs a) {
 #define WF_GEMM_DMA_RSPLIT 5  // (PHASE 2) how many of a wave's 9 (8) pieces go to the tail of its first READ phase instead of the MFMA gaps (lab: 0 -> 89.2 %, 3 -> 90.8, 5 -> 92-93.5, 6 / 7 -> 92.4, 9 -> 86.6 % of the pipe)
 #endif
 #ifdef WF_GEMM_TIMING
-// lab builds (WF_EXTRA_HIPCC_FLAGS=-DWF_GEMM_TIMING): k_gemm_w4 fills [0..7] (tools/gemm_timing.py); k_gemm_pp adds, per workgroup (its
+// lab builds (WF_EXTRA_HIPCC_FLAGS=-DWF_GEMM_TIMING): slots [0..7] belonged to k_gemm_w4 (removed in round 5); k_gemm_pp adds, per workgroup (its
 // wave 0): [8] prologue, [9] K loop, [10] epilogue shader cycles, [11] workgroups, [12] cycles of wave 4 (group B) K loop
 __device__ unsigned long long g_gemm_cycles[16];
 #endif
