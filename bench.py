@@ -262,7 +262,7 @@ def main_longcat(a):
     if a.as_rank_of > 1:   # one simulated rank of N on this GPU (parallel.LoopbackComm): the compute-bound ceiling of the N-GPU job
         if world != 1:
             raise SystemExit("bench.py: --as-rank-of is a one-process mode")
-        comm = parallel.LoopbackComm(a.as_rank_of, a.as_rank if a.as_rank >= 0 else a.as_rank_of // 2)
+        comm = simulated_comm(a)
     cfg = LongCatConfig(depth=a.layers if a.layers != 40 else 48)
     frames = a.frames if a.frames != 81 else 93
     t0 = time.time()
@@ -311,7 +311,7 @@ def main_longcat(a):
                 model(xcal, tcal, ccal, mcal, num_cond_latents=1)
 
         exchange = calibrate_exchange(model, comm, run_cal, names, "depth", device, a.exchange, ctx=ctx)
-        if a.as_rank_of > 1 and a.exchange == "auto":
+        if a.as_rank_of > 1 and a.exchange == "auto" and not a.emulate_comm:
             apply_exchange(model, names[0], ctx)
             exchange.update(selected=names[0], selection="default (simulated rank: the calibration shows each mode's compute cost only)")
         del xcal
@@ -398,6 +398,10 @@ def main_longcat(a):
             out["simulated_rank_of"], out["simulated_rank"] = a.as_rank_of, comm.rank
             out["config"]["parallelism"] = (f"rank {comm.rank} of sp{a.as_rank_of} on one GPU (parallel.LoopbackComm: collectives served from local "
                                             "data); value = what the N-GPU job would reach if communication were free")
+            if a.emulate_comm:
+                out["metric"] += "; communication EMULATED by a bandwidth model (stream-ordered delays), not measured"
+                out["comm_model"] = dict(comm.model)
+                out["config"]["parallelism"] += " -- under the bandwidth model of `comm_model`"
             per_rank = per_rank[comm.rank:comm.rank + 1] if per_rank else per_rank
         if per_rank is not None:
             out["per_rank"] = per_rank
@@ -640,6 +644,16 @@ def also_longcat(device, height=480, width=832, frames=93):
     return out
 
 
+def simulated_comm(a):
+    """parallel.LoopbackComm for --as-rank-of N (+ the bandwidth model of --emulate-comm)."""
+    from worldforge_amd import parallel
+    model = None
+    if a.emulate_comm:
+        ag, link, lat = (float(x) for x in a.emulate_comm.split(","))
+        model = {"allgather_gbps": ag, "link_gbps": link, "latency_us": lat}
+    return parallel.LoopbackComm(a.as_rank_of, a.as_rank if a.as_rank >= 0 else a.as_rank_of // 2, model)
+
+
 def launch_ranks(n: int, argv, script: str = None) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, RCCL rendezvous on 127.0.0.1) and
     wait for them.  This parent never touches the GPU (no torch.cuda call that initialises HIP, no libwf_hip.so) and never
@@ -777,6 +791,11 @@ def main(argv=None):
                          "served from local data, values meaningless) and report that rank's step time -- the compute-bound ceiling of the "
                          "N-GPU throughput.  --as-rank picks the rank (default N // 2: halo rows on both sides)")
     ap.add_argument("--as-rank", type=int, default=-1)
+    ap.add_argument("--emulate-comm", default=None, metavar="AG_GBPS,LINK_GBPS,LATENCY_US",
+                    help="with --as-rank-of: a BANDWIDTH MODEL of the interconnect (NOT a measurement): every collective of the simulated rank "
+                         "also queues a stream-ordered delay of latency + bytes / rate -- all-gathers at AG_GBPS per rank (received bytes), "
+                         "per-source broadcasts at LINK_GBPS (one xGMI link: 153), e.g. 330,153,20.  The exchange calibration then SELECTS "
+                         "under that model and the line reports what each mode would expose")
     ap.add_argument("--exchange", default="auto", choices=["auto"] + list(EXCHANGES) + ["cfg2+" + k for k in EXCHANGES if k != "lockstep"],
                     help="N > 1: how the sequence-parallel self-attention exchanges K / V^T (worldforge_amd/parallel.py KVExchange).  auto "
                          "(default): time a few real-width layers with every candidate on THIS node before the timed window and keep the "
@@ -811,7 +830,7 @@ def main(argv=None):
     if a.as_rank_of > 1:
         if world != 1:
             raise SystemExit("bench.py: --as-rank-of is a one-process mode")
-        comm = parallel.LoopbackComm(a.as_rank_of, a.as_rank if a.as_rank >= 0 else a.as_rank_of // 2)
+        comm = simulated_comm(a)
 
     cfg = wdit.DiTConfig.wan_i2v_14b()
     cfg.num_layers = a.layers
@@ -850,7 +869,7 @@ def main(argv=None):
         if forced.startswith("cfg2+") and ctx is None:
             raise SystemExit("bench.py: --exchange cfg2+... needs an even number of ranks")
         exchange = calibrate_exchange(model, comm, run_cal, names, "num_layers", device, forced, ctx=ctx)
-        if a.as_rank_of > 1 and a.exchange == "auto":   # communication is free on a simulated rank: the timings are the modes' COMPUTE cost
+        if a.as_rank_of > 1 and a.exchange == "auto" and not a.emulate_comm:   # communication is free on a simulated rank: the timings are the modes' COMPUTE cost
             apply_exchange(model, names[0], ctx)
             exchange.update(selected=names[0], selection="default (simulated rank: the calibration shows each mode's compute cost only)")
         del xcal
@@ -982,6 +1001,11 @@ def main(argv=None):
             out["simulated_rank_of"], out["simulated_rank"] = a.as_rank_of, comm.rank
             out["config"]["parallelism"] = (f"rank {comm.rank} of sp{a.as_rank_of} on one GPU (parallel.LoopbackComm: collectives served from local "
                                             "data); value = what the N-GPU job would reach if communication were free")
+            if a.emulate_comm:
+                out["metric"] += "; communication EMULATED by a bandwidth model (stream-ordered delays), not measured"
+                out["comm_model"] = dict(comm.model, note="every collective = local copies + a delay of latency_us + bytes / rate on its stream: all-gathers at "
+                                                          "allgather_gbps per rank (received bytes), per-source broadcasts at link_gbps")
+                out["config"]["parallelism"] += " -- under the bandwidth model of `comm_model`"
             per_rank = per_rank[comm.rank:comm.rank + 1] if per_rank else per_rank
         if per_rank is not None:
             out["per_rank"] = per_rank

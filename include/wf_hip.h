@@ -468,6 +468,9 @@ int wf_depth_edge_mask(const float* depth, int H, int W, double edge_threshold, 
  * wave, iters x 16 MFMAs each): what THIS box sustains on the matrix pipe alone under its power limit.  src: 1 MiB of bf16 operand values
  * (N(0,1): the rate depends on the data), sink: >= 4 bytes; *flop (host, may be NULL) receives the launch's flop count.  Asynchronous. */
 int wf_calib_mfma(const void* src, float* sink, int iters, double* flop, void* stream);
+/* A stream-ordered delay of `us` microseconds (one wave polling the 100 MHz wall clock): the stand-in for a collective's transfer time when
+ * one GPU plays one rank of N under a bandwidth model (parallel.LoopbackComm(link model), bench.py --as-rank-of N --emulate-comm). */
+int wf_delay_us(double us, void* stream);
 
 #ifdef __cplusplus
 }

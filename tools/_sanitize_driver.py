@@ -229,6 +229,22 @@ ok("wf_conv3d_333_f16", buf(2 * T_ * H_ * W_ * Ci), buf(2 * 27 * (Ci // 16) * Co
 ok("wf_rms_silu_cl_x3_f16", f32(npix * Ci), f32(Ci), buf(2 * npix * 3 * Ci), npix, Ci, 1, None)
 ok("wf_rms_silu_cl_blocked_f16", f32(npix * Ci), f32(Ci), buf(2 * npix * 2 * Ci), npix, Ci, 1, W_, 1, 0, None)
 ok("wf_split_f16x3", f32(npix * Ci), Ci, buf(2 * npix * 3 * Ci), 3 * Ci, npix, Ci, 0, None)
+# round 5: the asynchronous range flag (a 4-byte copy into caller memory, no launch), the calibration stream, the stream-ordered delay
+flag = np.full(1, 7, dtype=np.int32)
+KEEP.append(flag)
+assert dll.wf_f16_overflow_flag_async(flag.ctypes.data, None) == 0 and int(flag[0]) == 0, "wf_f16_overflow_flag_async"
+bad("wf_f16_overflow_flag_async", None, None)
+flop = ctypes.c_double(0.0)
+ok("wf_calib_mfma", buf(1 << 20), f32(4), 10, ctypes.addressof(flop), None)
+assert flop.value == 256.0 * 4 * 10 * 16 * 2 * 32 * 32 * 16, flop.value
+ok("wf_calib_mfma", buf(1 << 20), f32(4), 1, None, None)
+bad("wf_calib_mfma", None, f32(4), 10, None, None)
+bad("wf_calib_mfma", buf(1 << 20), f32(4), 0, None, None)
+ok("wf_delay_us", 5.0, None)
+before_ = launches.value
+assert dll.wf_delay_us(0.0, None) == 0 and launches.value == before_, "a zero delay launches nothing"
+bad("wf_delay_us", -1.0, None)
+bad("wf_delay_us", 1.0e7, None)
 for (M, N, K, epi) in ((4095, 1152, 1152, 2), (300, 384, 1152, 4), (2048, 2560, 384, 0)):
     ok("wf_gemm_f16", buf(2 * M * K), buf(2 * N * K), f32(N), buf((2 if epi == 0 else 4) * M * N), M, N, K, K, K, N, epi, 0.25, None)
 bad("wf_gemm_f16", buf(64), buf(64), None, buf(64), 4, 4, 8, 8, 8, 4, 3, 1.0, None)                           # the gated-residual epilogue is not built for fp16 operands

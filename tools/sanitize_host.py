@@ -57,6 +57,7 @@ int hipDeviceGetAttribute(int* v, int a, int d) { (void)a; (void)d; *v = 256; re
 int hipGetDevicePropertiesR0600(void* p, int d) { (void)p; (void)d; return 100; }   /* "no device": wf_device_info must report the error */
 int hipMemcpyToSymbol(const void* s, const void* src, size_t n, size_t o, int k) { (void)s; (void)src; (void)n; (void)o; (void)k; return 0; }
 int hipMemcpyFromSymbol(void* d, const void* s, size_t n, size_t o, int k) { (void)s; (void)o; (void)k; memset(d, 0, n); return 0; }
+int hipMemcpyFromSymbolAsync(void* d, const void* s, size_t n, size_t o, int k, void* st) { (void)s; (void)o; (void)k; (void)st; memset(d, 0, n); return 0; }
 """
 
 

@@ -43,7 +43,24 @@ __global__ __launch_bounds__(256, 1) void k_calib_mfma(const u32x4* __restrict__
   if (s == 12345.678f) sink[0] = s;  // never true for the data the host provides; keeps the loop alive
 }
 
+// A stream-ordered delay: one wave spinning on the constant-rate wall clock (100 MHz) with s_sleep between polls.  parallel.LoopbackComm
+// uses it to stand in for the TRANSFER TIME of a collective when one GPU plays one rank of N under a bandwidth model (bench.py
+// --as-rank-of N --emulate-comm ...): the local copies that serve the collective cost a few hundred microseconds, a real exchange over
+// xGMI takes bytes / rate.  Like an RCCL copy kernel it needs a CU slot to start and holds one while it runs.
+__global__ void k_delay(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 }  // namespace
+
+extern "C" int wf_delay_us(double us, void* stream) {
+  WF_CHECK_ARG(us >= 0.0 && us < 5.0e6, "wf_delay_us: %f microseconds out of range (0 .. 5 s)", us);
+  if (us <= 0.0) return WF_OK;
+  hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)(us * 100.0));
+  WF_LAUNCH_CHECK("wf_delay_us");
+  return WF_OK;
+}
 
 // One launch of the calibration stream: 256 workgroups x 4 waves x iters x 16 MFMAs of 2 * 32 * 32 * 16 flop.  src: 1 MiB of bf16 operand
 // data in device memory (the host fills it with N(0,1) values: the rate depends on the data -- zeros run 35 % faster), sink: >= 4 bytes.

@@ -159,13 +159,28 @@ class LoopbackComm:
     "peer" shard is a copy of this rank's).  `bench.py --as-rank-of N` times it: the per-rank step time is the compute-bound ceiling of the
     scaling curve, measured instead of guessed while no multi-GPU node is available."""
 
-    def __init__(self, world: int, rank: int = 0):
+    def __init__(self, world: int, rank: int = 0, model: Optional[dict] = None):
+        """model (optional): a BANDWIDTH MODEL of the interconnect -- dict(allgather_gbps, link_gbps, latency_us).  Every collective then also
+        queues a stream-ordered delay (wf_delay_us) of latency + bytes / rate behind its local copies: an all-gather of B bytes per rank takes
+        (world - 1) B / allgather_gbps (what a rank has to RECEIVE, at the aggregate rate RCCL's all-gather reaches per rank), a per-source
+        broadcast of B bytes B / link_gbps (one xGMI link out of the source to each peer).  A model, not a measurement: it puts realistic
+        transfer times on the communication stream so that the overlap machinery (events, own-first sweeps, the lock-step pair) shows on one
+        GPU what each exchange mode would EXPOSE under that model (bench.py --as-rank-of N --emulate-comm)."""
         self.world, self.rank, self.group = world, rank, None
+        self.model = dict(model) if model else None
         self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+
+    def _delay(self, nbytes: float, rate_key: str):
+        if self.model is None or not torch.cuda.is_available():
+            return
+        from . import ops
+        from ._ffi import call
+        us = float(self.model.get("latency_us", 0.0)) + nbytes / (float(self.model[rate_key]) * 1e9) * 1e6
+        call("wf_delay_us", us, ops.stream())
 
     def split(self, n_groups: int) -> "LoopbackComm":
         per = self.world // n_groups
-        sub = LoopbackComm(per, self.rank % per)
+        sub = LoopbackComm(per, self.rank % per, self.model)
         sub.group_index = self.rank // per
         return sub
 
@@ -177,6 +192,7 @@ class LoopbackComm:
                     out[src].copy_(inp)
         else:
             out.copy_(inp.unsqueeze(0).expand_as(out))
+        self._delay((self.world - 1) * inp.numel() * inp.element_size(), "allgather_gbps")
         return out
 
     all_gather_async = Comm.all_gather_async
@@ -196,6 +212,7 @@ class LoopbackComm:
             for src in range(self.world):
                 if src != self.rank:
                     out[src].copy_(out[self.rank])
+                self._delay(out[src].numel() * out.element_size(), "link_gbps")   # (the own broadcast occupies the stream as long as a peer's)
                 ev = torch.cuda.Event()
                 ev.record(self.stream)
                 evs.append(ev)
