@@ -182,6 +182,18 @@ class SimComm:
         self.all_gather(out, inp)
         return None
 
+    def neighbor_rows(self, top, bottom, d=1):
+        """parallel.Comm.neighbor_rows: (bottom row of rank - d, top row of rank + d), None at the ends."""
+        sh = self.sh
+        sh["slots"][self.rank] = (top.clone(), bottom.clone())
+        torch.cuda.current_stream().synchronize()
+        sh["bar"].wait()
+        up = sh["slots"][self.rank - d][1].clone() if self.rank - d >= 0 else None
+        down = sh["slots"][self.rank + d][0].clone() if self.rank + d < self.world else None
+        torch.cuda.current_stream().synchronize()
+        sh["bar"].wait()
+        return up, down
+
     def broadcast_slots_async(self, out):
         """parallel.Comm.broadcast_slots_async: slot `rank` of `out` is this rank's data; the other slots come from their owners."""
         sh = self.sh

@@ -131,6 +131,15 @@ def _split_worker(rank, world, port, ret):
     ex.own_k().fill_(float(rank))
     ex.launch()
     ok &= [float(ex.k[0][j].max()) for j in range(per)] == [float(r) for r in sub.ranks]
+    # the row-sharded VAE's halo exchange: two-rank groups with each neighbour at distance d (d = ranks per row group), two phases
+    for d in (1, 2):
+        top, bottom = torch.full((2, 3), 10.0 * rank + 1), torch.full((2, 3), 10.0 * rank + 2)
+        up, down = comm.neighbor_rows(top, bottom, d)
+        ok &= (up is None) == (rank - d < 0) and (down is None) == (rank + d >= world)
+        if up is not None:
+            ok &= float(up.min()) == float(up.max()) == 10.0 * (rank - d) + 2      # the upper neighbour's BOTTOM row
+        if down is not None:
+            ok &= float(down.min()) == float(down.max()) == 10.0 * (rank + d) + 1  # the lower neighbour's TOP row
     # ... while the whole job still gathers over everyone (the velocity exchange between the two CFG groups, pipeline.cfg_split)
     allv = torch.empty(world, 3)
     comm.all_gather(allv, mine)
@@ -257,6 +266,20 @@ def test_sweep_plan_covers_every_valid_key_once_own_shard_first(mode, chunks):
                         valid = -(-ex.chunk_kv_len(kv_len, g) // 64)
                         assert sorted(seen[g]) == list(range(valid)), (L, P, r, g, kv_len)
                     assert sum(ex.chunk_kv_len(kv_len, g) for g in range(ex.G)) == min(kv_len, P * plan.shard_len)
+
+
+def test_loopback_comm_serves_the_halo_exchange():
+    from worldforge_amd import parallel
+    top, bottom = torch.full((2, 3), 1.0), torch.full((2, 3), 2.0)
+    for rank, want in ((0, (False, True)), (2, (True, True)), (3, (True, False))):
+        up, down = parallel.LoopbackComm(4, rank).neighbor_rows(top, bottom, 1)
+        assert ((up is not None), (down is not None)) == want
+        assert up is None or torch.equal(up, bottom)
+        assert down is None or torch.equal(down, top)
+    up, down = parallel.LoopbackComm(8, 5).neighbor_rows(top, bottom, 2)
+    assert up is not None and down is not None
+    up, down = parallel.LoopbackComm(8, 6).neighbor_rows(top, bottom, 2)
+    assert up is not None and down is None
 
 
 def test_loopback_comm_serves_the_packed_exchange():

@@ -144,6 +144,48 @@ class Comm:
         out.record_stream(self.stream)
         return evs
 
+    def _pair_groups(self, d: int):
+        """The two-rank groups (lo, lo + d) of this communicator, created once per distance (torch.distributed.new_group is collective over
+        the WHOLE job: every rank of the job must reach this call, in the same order -- the row-sharded VAE does, at its first halo)."""
+        cache = self.__dict__.setdefault("_pairs", {})
+        if d not in cache:
+            cache[d] = [dist.new_group([self.ranks[lo], self.ranks[lo + d]]) for lo in range(self.world - d)]
+        return cache[d]
+
+    def neighbor_rows(self, top: torch.Tensor, bottom: torch.Tensor, d: int = 1):
+        """Halo exchange of the row-sharded VAE: this rank's first (`top`) and last (`bottom`) rows -> (the bottom row of rank - d, the top
+        row of rank + d), None at the ends of the chain.  Two all-gathers inside TWO-RANK groups (this rank with each neighbour) where rounds
+        1-4 all-gathered every rank's two rows over the whole job: a rank receives the 2 rows it needs instead of 2 (P - 1) -- 7x less
+        traffic at 8 ranks, 360 MB -> 52 MB per full-resolution 3 x 3 layer.  Deadlock-free by construction: pair (lo, lo + d) belongs to
+        phase (lo // d) % 2, a rank is in at most one pair per phase, and every rank runs phase 0 before phase 1."""
+        assert top.shape == bottom.shape and top.dtype == bottom.dtype
+        r, P = self.rank, self.world
+        up = down = None
+        if d >= P:
+            return up, down
+        groups = self._pair_groups(d)
+        gloo = dist.get_backend(self.group) == "gloo"
+        for phase in (0, 1):
+            for lo, role, mine in ((r, 0, bottom), (r - d, 1, top)):   # role 0: this rank is the UPPER member of the pair (sends its bottom row)
+                if lo < 0 or lo + d >= P or (lo // d) % 2 != phase:
+                    continue
+                mine = mine.contiguous()
+                both = torch.empty((2,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+                if gloo:
+                    if mine.is_cuda:   # debug transport: stage through the host
+                        host = torch.empty(both.shape, dtype=both.dtype)
+                        dist.all_gather([host[0], host[1]], mine.cpu(), group=groups[lo])
+                        both.copy_(host)
+                    else:
+                        dist.all_gather([both[0], both[1]], mine, group=groups[lo])
+                else:
+                    dist.all_gather_into_tensor(both.view(-1), mine.view(-1), group=groups[lo])
+                if role == 0:
+                    down = both[1]   # the lower neighbour's top row
+                else:
+                    up = both[0]     # the upper neighbour's bottom row
+        return up, down
+
     def barrier(self):
         dist.barrier(group=self.group)
 
@@ -196,6 +238,16 @@ class LoopbackComm:
         return out
 
     all_gather_async = Comm.all_gather_async
+
+    def neighbor_rows(self, top: torch.Tensor, bottom: torch.Tensor, d: int = 1):
+        """Comm.neighbor_rows served locally: the "neighbours'" rows are copies of this rank's own; under a bandwidth model each of the (up
+        to) two pair all-gathers costs latency + one row / link rate."""
+        up = bottom.clone() if self.rank - d >= 0 else None
+        down = top.clone() if self.rank + d < self.world else None
+        for t in (up, down):
+            if t is not None:
+                self._delay(t.numel() * t.element_size(), "link_gbps")
+        return up, down
 
     def broadcast_slots_async(self, out: torch.Tensor):
         """Every peer slot is a copy of this rank's own (one copy + one event per source on the communication stream, like the real one)."""

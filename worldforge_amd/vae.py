@@ -726,21 +726,20 @@ class AutoencoderKLWan:
         return self._halo_fill(out)
 
     def _halo_fill(self, out):
-        """out [T,Hs+2,...] whose rows 1 .. Hs are this rank's: rows 0 and Hs+1 <- the neighbours' boundary rows (zeros at the image edge)."""
+        """out [T,Hs+2,...] whose rows 1 .. Hs are this rank's: rows 0 and Hs+1 <- the neighbours' boundary rows (zeros at the image edge).
+        Round 5: exchanged with the two neighbours only (parallel.Comm.neighbor_rows: all-gathers inside two-rank groups), not all-gathered
+        over the whole job -- a rank receives the 2 rows it needs instead of 2 (P - 1)."""
         comm = self.comm
         T, Hs = out.shape[0], out.shape[1] - 2
         a = out[:, 1:Hs + 1]
-        mine = torch.stack([a[:, 0], a[:, Hs - 1]])  # [2,T,W,C]
-        allb = torch.empty((comm.world,) + tuple(mine.shape), dtype=a.dtype, device=a.device)
-        comm.all_gather(allb, mine.contiguous())
         reps = self._reps  # ranks per row group (1: every rank its own slab; > 1: `reps` consecutive ranks hold the same slab)
-        up, down = comm.rank - reps, comm.rank + reps
-        if up >= 0:
-            out[:, 0].copy_(allb[up, 1])
+        up, down = comm.neighbor_rows(a[:, 0], a[:, Hs - 1], reps)
+        if up is not None:
+            out[:, 0].copy_(up)
         else:
             out[:, 0].zero_()
-        if down < comm.world:
-            out[:, Hs + 1].copy_(allb[down, 0])
+        if down is not None:
+            out[:, Hs + 1].copy_(down)
         else:
             out[:, Hs + 1].zero_()
         return out
