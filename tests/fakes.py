@@ -194,6 +194,10 @@ class SimComm:
         sh["bar"].wait()
         return up, down
 
+    def neighbor_rows_async(self, top, bottom, d=1):
+        res = self.neighbor_rows(top, bottom, d)
+        return lambda: res
+
     def broadcast_slots_async(self, out):
         """parallel.Comm.broadcast_slots_async: slot `rank` of `out` is this rank's data; the other slots come from their owners."""
         sh = self.sh

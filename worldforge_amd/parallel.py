@@ -186,6 +186,32 @@ class Comm:
                     up = both[0]     # the upper neighbour's bottom row
         return up, down
 
+    def neighbor_rows_async(self, top: torch.Tensor, bottom: torch.Tensor, d: int = 1):
+        """neighbor_rows on the communication stream, behind the work queued so far on the current stream -> a callable that makes the
+        current stream wait for it and returns (up, down).  The row-sharded VAE sends its two border rows first and produces the rest of
+        the slab's operand while they travel (vae._halo_operand)."""
+        if self.stream is None:
+            res = self.neighbor_rows(top, bottom, d)
+            return lambda: res
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            up, down = self.neighbor_rows(top, bottom, d)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        for t in (top, bottom):
+            t.record_stream(self.stream)
+
+        def done():
+            c = torch.cuda.current_stream()
+            c.wait_event(ev)
+            for t in (up, down):
+                if t is not None:
+                    t.record_stream(c)   # allocated on the communication stream, consumed on this one
+            return up, down
+
+        return done
+
     def barrier(self):
         dist.barrier(group=self.group)
 
@@ -248,6 +274,8 @@ class LoopbackComm:
             if t is not None:
                 self._delay(t.numel() * t.element_size(), "link_gbps")
         return up, down
+
+    neighbor_rows_async = Comm.neighbor_rows_async
 
     def broadcast_slots_async(self, out: torch.Tensor):
         """Every peer slot is a copy of this rank's own (one copy + one event per source on the communication stream, like the real one)."""
