@@ -725,6 +725,27 @@ class AutoencoderKLWan:
         out[:, 1:Hs + 1].copy_(a)
         return self._halo_fill(out)
 
+    def _halo_pad_of(self, x, producer):
+        """_halo_pad(producer(x)) with the two border rows produced FIRST: their operand rows travel to the neighbours on the communication
+        stream (Comm.neighbor_rows_async) while `producer` runs on the whole slab.  x f32 [T,Hs,W,C]; producer: f32 rows [T,n,W,C] -> operand
+        rows [T,n,...] with per-pixel arithmetic (the split / norm kernels): bit-identical to exchanging rows of the produced slab."""
+        T, Hs = x.shape[:2]
+        e_op = producer(torch.stack([x[:, 0], x[:, Hs - 1]], dim=1))
+        pending = self.comm.neighbor_rows_async(e_op[:, 0], e_op[:, 1], self._reps)
+        a = producer(x)
+        out = torch.empty((T, Hs + 2) + tuple(a.shape[2:]), dtype=a.dtype, device=a.device)
+        out[:, 1:Hs + 1].copy_(a)
+        up, down = pending()
+        if up is not None:
+            out[:, 0].copy_(up)
+        else:
+            out[:, 0].zero_()
+        if down is not None:
+            out[:, Hs + 1].copy_(down)
+        else:
+            out[:, Hs + 1].zero_()
+        return out
+
     def _halo_fill(self, out):
         """out [T,Hs+2,...] whose rows 1 .. Hs are this rank's: rows 0 and Hs+1 <- the neighbours' boundary rows (zeros at the image edge).
         Round 5: exchanged with the two neighbours only (parallel.Comm.neighbor_rows: all-gathers inside two-rank groups), not all-gathered
@@ -858,7 +879,7 @@ class AutoencoderKLWan:
     def _down_slab(self, x, p, C, temporal):
         """fp32 slab [T,Hs,W,C] -> [T',Hs/2,W/2,C]  (ZeroPad2d((0,1,0,1)) + stride-2 conv: bottom halo row only)."""
         T, Hs, Wd, _ = x.shape
-        xpad = self._halo_pad(self._operand(x))
+        xpad = self._halo_pad_of(x, self._operand)
         Ho, Wo = Hs // 2, Wd // 2
         if not temporal or T == 1:
             y, _ = self._conv(xpad, p + ".resample.1", T, Ho, Wo, C, (1, 3, 3), ss=2, ps=0, ph=-1)
@@ -922,7 +943,7 @@ class AutoencoderKLWan:
                 x = self._res_slab(x, p, cin, cout)
             elif kind in ("up2d", "up3d"):
                 Hcur = x.shape[1]
-                x = self._up_slab(self._halo_pad(self._operand(x)), p, cin, kind == "up3d", row0 - 1, 2 * row0, 2 * Hcur, h_cur)
+                x = self._up_slab(self._halo_pad_of(x, self._operand), p, cin, kind == "up3d", row0 - 1, 2 * row0, 2 * Hcur, h_cur)
                 row0 *= 2
                 h_cur *= 2
             elif kind == "head":
