@@ -294,3 +294,26 @@ def test_loopback_comm_serves_the_packed_exchange():
         assert len(evs) == (4 if mode == "bcast" else ex.G)
         for g in range(ex.G):
             assert all(torch.equal(ex.bufs[g][r], ex.bufs[g][2]) for r in range(4)) and float(ex.km[g].min()) == 7.0
+
+
+def test_halo_pair_schedule_is_deadlock_free():
+    """Comm.neighbor_rows runs the two-rank all-gathers in two phases: pair (lo, lo + d) in phase (lo // d) % 2.  For every chain length and
+    neighbour distance: every adjacent pair (at distance d) is served exactly once, and within a phase no rank is in two pairs -- blocking
+    two-rank collectives issued phase by phase can then never wait on each other in a cycle."""
+    for P in range(1, 12):
+        for d in range(1, 6):
+            pairs = [(lo, lo + d) for lo in range(P - d)]
+            by_phase = {0: [], 1: []}
+            for lo, hi in pairs:
+                by_phase[(lo // d) % 2].append((lo, hi))
+            for ph, ps in by_phase.items():
+                members = [r for p in ps for r in p]
+                assert len(members) == len(set(members)), (P, d, ph, ps)
+            # what each rank executes (the loop of Comm.neighbor_rows): its own view must be the same set of pairs
+            mine = set()
+            for r in range(P):
+                for phase in (0, 1):
+                    for lo in (r, r - d):
+                        if lo >= 0 and lo + d < P and (lo // d) % 2 == phase:
+                            mine.add((lo, lo + d))
+            assert mine == set(pairs)
