@@ -78,6 +78,12 @@ int wf_blend_pixels(const float* ref, const float* mask, const float* dec, float
 
 /* PIPE:744 (diffusers VideoProcessor.postprocess_video)  out = clamp(x/2 + 0.5, 0, 1), [C,F,H,W] -> [F,H,W,C]. */
 int wf_postprocess_video(const float* x, float* out, int C, int F, int H, int W, void* stream);
+/* The two pixel-space statements above as eager PyTorch evaluates them behind a BF16 VAE module -- the dtype the LongCat entry loads its
+ * VAE in (longcat_for_worldforge/run_longcat_worldforge_single.py:205): dec / out bf16, the fp32 ref and mask rounded to bf16 first
+ * (longcat_video/modules/scheduling_flow_match_euler_discrete.py:1152-1153) and every statement of :1156-1164 rounded to bf16;
+ * the post-processing of a bf16 video (pipeline_longcat_video.py:1002) likewise, returned as f32. */
+int wf_blend_pixels_bf16(const float* ref, const float* mask, const void* dec, void* out, int B, int C, size_t inner, void* stream);
+int wf_postprocess_video_bf16(const void* x, float* out, int C, int F, int H, int W, void* stream);
 
 /* dtype conversion / bf16 rounding of latent-shaped tensors (PIPE:590 .to(bf16), PIPE:708). */
 int wf_cast(const void* in, int dt_in, void* out, int dt_out, size_t n, void* stream);
@@ -416,6 +422,18 @@ int wf_f16_overflow_flag_async(int* pinned_host_out, void* stream);
  * [N, ld] f32 (first C channels) -> [C, N] f32 with optional clamp (autoencoder_kl_wan.py:1222).  N = T*H*W. */
 int wf_ncthw_to_cl(const float* in, float* out_f32, void* out_bf16, int C, int Cpad, size_t N, void* stream);
 int wf_cl_to_ncthw(const float* in, float* out, int C, int ld, size_t N, float clamp, void* stream);
+/* ---- the one-term fp16 operand format of the VAE ("fp16", round 6) -------------------------------------------------------------------
+ * What an fp32 convolution keeps of its operands when TF32 is allowed: cuDNN fp32 convolutions are TF32-eligible under PyTorch's
+ * defaults (torch.backends.cudnn.allow_tf32 = True; the LongCat entry also sets it explicitly, run_longcat_worldforge_single.py:144-146),
+ * i.e. 10 explicit mantissa bits per multiplicand and fp32 accumulation.  fp16 has the same 10 explicit bits: the one-term mode feeds
+ * hi = fp16(x) alone to the *_f16 conv / GEMM kernels above (weights stored power-of-two scaled, acc_scale epilogue, range flag) at one
+ * third of the three-term mode's matrix work.  These are the producers of that operand; every one raises the range flag of
+ * wf_f16_overflow_flag.  wf_cast_f16: src f32 [rows, C] (row stride ld_src) -> dst fp16 [rows, C] (row stride ld_dst), C and the strides
+ * multiples of 4.  The others are their bf16 namesakes with an fp16 16-bit output. */
+int wf_cast_f16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, size_t rows, int C, void* stream);
+int wf_rms_silu_cl_f16(const float* x, const float* gamma, void* out_f16, float* out_f32, size_t npix, int C, int silu, void* stream);
+int wf_softmax_rows_f16(const float* S, int lds, void* P, int ldp, int M, int N, float scale, void* stream);
+int wf_ncthw_to_cl_f16(const float* in, float* out_f32, void* out_f16, int C, int Cpad, size_t N, void* stream);
 
 /* ---- stage-1 forward warping (vggt/modules/utils_warp.py:863-945, warp_single_img without crack filling) ------------------------- */
 /* Depth-guided forward splat of one image to n_cameras new views: un-project (fp64) -> world -> each camera -> project -> nearest pixel,

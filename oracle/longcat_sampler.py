@@ -37,6 +37,7 @@ class LongCatSamplerConfig:
     use_pca_channel_selection: bool = False
     max_replace_threshold: Optional[int] = None
     dit_dtype: torch.dtype = torch.bfloat16
+    vae_dtype: torch.dtype = torch.float32   # `vae.dtype`; the LongCat entry loads the VAE in bf16 (run_longcat_worldforge_single.py:205)
     flow_backend: str = "tdiff"      # "farneback" = the branch taken where cv2 imports (SCHED:45-51)
 
 
@@ -167,21 +168,25 @@ def select_from_similarities(sims: Sequence[float], current_step: int, use_disti
 
 def fuse_latents(x0_full: torch.Tensor, ref: torch.Tensor, mask: torch.Tensor, *, decode: Callable, encode_mode: Callable, mean, std,
                  use_flf: bool, current_step: int, use_distill: bool = False, max_replace_threshold: Optional[int] = None,
-                 flow_backend: str = "tdiff") -> torch.Tensor:
+                 flow_backend: str = "tdiff", vae_dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """SCHED:1072-1233: de-normalise -> decode -> ref*mask + dec*(1-mask) at the exact decoded size (no alignment: a shape mismatch
-    raises inside the reference's try block and returns the prediction unchanged) -> encode (mode) -> normalise -> FLF."""
-    dec = decode(denormalize(x0_full, mean, std))
+    raises inside the reference's try block and returns the prediction unchanged) -> encode (mode) -> normalise -> FLF.
+    vae_dtype: the two `.to(dtype=vae.dtype)` hand-offs (SCHED:1124, 1166); the blend runs in the decoded video's dtype (:1152-1164) and
+    the normalisation promotes the encoded latents back to the prediction's dtype (:1183, constants in that dtype :1113-1120)."""
+    dec = decode(denormalize(x0_full, mean, std).to(vae_dtype))
     if ref.shape != dec.shape or mask.shape[1] != 1 or tuple(mask.shape[2:]) != tuple(dec.shape[2:]):
         return x0_full
     r = 2.0 * ref.to(dec.dtype) - 1.0
     m = mask.to(dec.dtype)
     if m.shape[1] != dec.shape[1]:
         m = m.repeat(1, dec.shape[1], 1, 1, 1)
-    fused = r * m + dec * (1 - m)
+    fused = (r * m + dec * (1 - m)).to(vae_dtype)
     enc = encode_mode(fused)
     if enc.shape != x0_full.shape:
         return x0_full
-    enc = normalize(enc, mean, std)
+    m_ = torch.tensor(mean).view(1, -1, 1, 1, 1).to(x0_full.device, x0_full.dtype)
+    s_ = 1.0 / torch.tensor(std).view(1, -1, 1, 1, 1).to(x0_full.device, x0_full.dtype)
+    enc = (enc - m_) * s_   # = normalize(enc) for an fp32 VAE; a bf16 `enc` is promoted by the fp32 constants
     if use_flf:
         for c in select_from_similarities(channel_similarities(x0_full, enc, flow_backend), current_step, use_distill, max_replace_threshold):
             if 0 <= c < enc.shape[1]:
@@ -240,7 +245,8 @@ def run(cfg: LongCatSamplerConfig, *, latents: torch.Tensor, dit: Callable, prom
                 def fuse(x0_full):
                     return fuse_latents(x0_full, video_ref, mask, decode=decode, encode_mode=encode_mode, mean=mean, std=std,
                                         use_flf=cfg.use_pca_channel_selection, current_step=i, use_distill=cfg.use_distill,
-                                        max_replace_threshold=cfg.max_replace_threshold, flow_backend=cfg.flow_backend)
+                                        max_replace_threshold=cfg.max_replace_threshold, flow_backend=cfg.flow_backend,
+                                        vae_dtype=cfg.vae_dtype)
             prev, pred_x0 = euler(v[:, :, 1:], latents[:, :, 1:].to(torch.float32), fuse)
             if trace is not None:
                 trace.append(("step", i, r, prev.clone(), pred_x0.clone()))
@@ -260,10 +266,11 @@ def run(cfg: LongCatSamplerConfig, *, latents: torch.Tensor, dit: Callable, prom
     return latents
 
 
-def decode_final(latents: torch.Tensor, decode: Callable, mean, std):
-    """PIPE:998-1004: de-normalise, decode, (x/2+0.5).clamp(0,1) -> [B,F,H,W,C]."""
-    video = decode(denormalize(latents.to(torch.float32), mean, std))
-    return (video / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 4, 1)
+def decode_final(latents: torch.Tensor, decode: Callable, mean, std, vae_dtype: torch.dtype = torch.float32):
+    """PIPE:998-1004: latents.to(vae.dtype), de-normalise IN THAT DTYPE, decode, (x/2+0.5).clamp(0,1) in the video's dtype
+    (diffusers VideoProcessor.denormalize) -> float -> [B,F,H,W,C]."""
+    video = decode(denormalize(latents.to(vae_dtype), mean, std))
+    return (video / 2 + 0.5).clamp(0, 1).float().permute(0, 2, 3, 4, 1)
 
 
 # ---- 720p refine pass (PIPE:1271-1511) --------------------------------------------------------------------------------------
@@ -315,7 +322,7 @@ def refine_schedule(num_inference_steps: int, shift: float, t_thresh: float):
 def run_refine(*, stage1_frames: torch.Tensor, image: torch.Tensor, height: int, width: int, dit: Callable, prompt_embeds, prompt_mask,
                encode_sample: Callable, decode: Callable, mean, std, generator, num_inference_steps: int = 50, shift: float = 1.0,
                t_thresh: float = 0.5, spatial_refine_only: bool = False, num_cond_frames: int = 1, dit_dtype=torch.bfloat16,
-               trace: Optional[list] = None, gpu_upsample: bool = False):
+               trace: Optional[list] = None, gpu_upsample: bool = False, vae_dtype: torch.dtype = torch.float32):
     """PIPE:1394-1503 for one sample with an image condition.  image [1,3,H,W] in [-1,1] or None.  Returns frames [1,F,H,W,3]."""
     sigmas, timesteps = refine_schedule(num_inference_steps, shift, t_thresh)
     nf = stage1_frames.shape[0]
@@ -339,5 +346,5 @@ def run_refine(*, stage1_frames: torch.Tensor, image: torch.Tensor, height: int,
         latents[:, :, ncl:] = (latents[:, :, ncl:].to(torch.float32) + (sigmas[i + 1] - sigmas[i]) * v[:, :, ncl:]).to(v.dtype)
         if trace is not None:
             trace.append(latents.clone())
-    frames = decode_final(latents, decode, mean, std)
+    frames = decode_final(latents, decode, mean, std, vae_dtype)
     return frames[:, added_c: new_frame_size + added_c]

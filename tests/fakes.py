@@ -57,7 +57,8 @@ class _Dist:
 
     def sample(self, generator=None):
         """Posterior sample with a fixed small std (LongCat's prepare_latents draws it: pipeline_longcat_video.py:278)."""
-        noise = torch.randn(self._mu.shape, generator=generator, dtype=torch.float32)
+        # drawn in the distribution's dtype, as diffusers' DiagonalGaussianDistribution.sample does (randn_tensor(..., dtype=parameters.dtype))
+        noise = torch.randn(self._mu.shape, generator=generator, dtype=self._mu.dtype)
         return self._mu + noise.to(self._mu.device) * 0.05
 
 
@@ -97,8 +98,11 @@ class FakeVAE:
     """decode: channel mix 16->3, nearest x8 spatial, latent frame t -> output frames (1 + 4(T-1)), clamp(-1,1);
     encode: frames 0,4,8,.., pixels ::8, channel mix 3->16."""
 
-    def __init__(self):
-        self.dtype = torch.float32
+    def __init__(self, dtype=torch.float32):
+        # dtype = the module dtype (`vae.dtype`): torch.bfloat16 is how the LongCat entry loads its VAE
+        # (run_longcat_worldforge_single.py:205).  Like a module in that dtype, the stand-in then refuses inputs of another dtype, computes
+        # every element-wise step in it (one rounding per step) and returns it.
+        self.dtype = dtype
         self.config = SimpleNamespace(z_dim=16, latents_mean=VAE_MEAN, latents_std=VAE_STD, scale_factor_temporal=4, scale_factor_spatial=8)
         self.temperal_downsample = [False, True, True]
         self.wd = _coef(3, 16, 77, 0.3)
@@ -108,6 +112,8 @@ class FakeVAE:
 
     def decode(self, z, return_dict=False):
         self.n_dec += 1
+        if self.dtype != torch.float32 and z.dtype != self.dtype:
+            raise RuntimeError(f"FakeVAE({self.dtype}).decode: input is {z.dtype} (a module in {self.dtype} refuses it)")
         B, C, T, h, w = z.shape
         chans = []
         for o in range(3):
@@ -123,7 +129,9 @@ class FakeVAE:
 
     def encode(self, x):
         self.n_enc += 1
-        s = x.float()[:, :, ::4, ::8, ::8]
+        if self.dtype != torch.float32 and x.dtype != self.dtype:
+            raise RuntimeError(f"FakeVAE({self.dtype}).encode: input is {x.dtype} (a module in {self.dtype} refuses it)")
+        s = x.to(self.dtype)[:, :, ::4, ::8, ::8]
         chans = []
         for o in range(16):
             acc = s[:, 0] * float(self.we[o, 0])

@@ -14,7 +14,7 @@ import torch
 from oracle import inject as oinj
 from oracle import longcat_sampler as ols
 from tests.fakes import FakeLongCatDiT, FakeVAE
-from tests.test_oracle_longcat_sampler import CASES, GOLD, case_inputs
+from tests.test_oracle_longcat_sampler import CASES, GOLD, TRAJ, case_inputs, golden_pipe
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
@@ -63,14 +63,30 @@ def test_scheduler_schedule_equals_reference():
         sch.step(torch.zeros(1, device=DEV), 3, torch.zeros(1, device=DEV))
 
 
-@pytest.mark.parametrize("name", list(CASES))
-def test_pipeline_matches_reference_trajectory(name):
+def _close(got, want, atol, msg="", bf16_module=False):
+    """|got - want| <= atol.  Behind a bf16 VAE stand-in a 1e-7 difference of a global reduction (fixed tree on the GPU, torch's order on
+    the CPU) can flip ONE bf16 rounding of the pixel round trip: such elements may be off by a bf16 ulp of an O(1) value (2^-7) as long as
+    they are rare (< 0.1 %)."""
+    err = np.abs(np.asarray(got, dtype=np.float64) - np.asarray(want, dtype=np.float64))
+    if not bf16_module:
+        assert err.max() <= atol, f"{msg}: {err.max()}"
+        return
+    assert err.max() <= 2.0 ** -6, f"{msg}: {err.max()}"
+    assert (err > atol).mean() < 1e-3, f"{msg}: {(err > atol).mean()} of the elements off by more than {atol}"
+
+
+@pytest.mark.parametrize("name,vae_dtype", TRAJ)
+def test_pipeline_matches_reference_trajectory(name, vae_dtype):
+    """g12: fp32 VAE stand-in.  g12b: the stand-in as a BF16 module (the LongCat entry's VAE dtype, run_longcat_worldforge_single.py:205),
+    which refuses non-bf16 inputs: the `.to(vae.dtype)` hand-offs, the bf16 blend kernel and the bf16 final de-normalisation /
+    post-processing are all on this path."""
     from worldforge_amd.longcat_pipeline import LongCatVideoPipeline
     from worldforge_amd.longcat_scheduler import FlowMatchEulerDiscreteScheduler
     c = CASES[name]
-    G = np.load(os.path.join(GOLD, f"g12_longcat_pipe_{name}.npz"))
+    G = golden_pipe(name, vae_dtype)
+    bfm = vae_dtype == torch.bfloat16
     image, ref, mask, pe, pm, ne, nm = case_inputs(c)
-    dit, vae = FakeLongCatDiT(), FakeVAE()
+    dit, vae = FakeLongCatDiT(), FakeVAE(vae_dtype)
     sch = FlowMatchEulerDiscreteScheduler(shift=c["shift"], flow_backend="tdiff")  # the fixtures were recorded without cv2
     pipe = LongCatVideoPipeline(vae, sch, dit, device=DEV)
     calls = []
@@ -102,13 +118,13 @@ def test_pipeline_matches_reference_trajectory(name):
     assert len(calls) == int(G["n_step_calls"][0])
     assert [dit.calls, vae.n_enc, vae.n_dec] == G["n_calls"].tolist()
     for j, (prev, x0) in enumerate(calls):
-        np.testing.assert_allclose(prev, G[f"call{j}_prev"], rtol=0, atol=2e-4, err_msg=f"{name} call {j} prev")
-        np.testing.assert_allclose(x0, G[f"call{j}_x0"], rtol=0, atol=2e-4, err_msg=f"{name} call {j} x0")
-    np.testing.assert_allclose(frames, G["frames"], rtol=0, atol=1e-3)
+        _close(prev, G[f"call{j}_prev"], 2e-4, f"{name} call {j} prev", bfm)
+        _close(x0, G[f"call{j}_x0"], 2e-4, f"{name} call {j} x0", bfm)
+    _close(frames, G["frames"], 1e-3, f"{name} frames", bfm)
 
 
-@pytest.mark.parametrize("name", ["spatial", "spatiotemporal"])
-def test_refine_pass_matches_reference(name):
+@pytest.mark.parametrize("name,vae_dtype", [("spatial", torch.float32), ("spatiotemporal", torch.float32), ("spatial", torch.bfloat16)])
+def test_refine_pass_matches_reference(name, vae_dtype):
     """generate_refine (PIPE:1271-1511) on the HIP path.  The reference trajectory recorded here (golden g15) went through torch's CPU
     bf16 interpolation kernels, which round between passes (up to 1.5 grey levels off the fp32 interpolation); on a GPU the reference
     interpolates in fp32 and rounds once per op, which is what wf_refine_upsample_u8 implements.  So: (1) the up-sampled video must equal
@@ -118,9 +134,9 @@ def test_refine_pass_matches_reference(name):
     from worldforge_amd.longcat_pipeline import LongCatVideoPipeline
     from worldforge_amd.longcat_scheduler import FlowMatchEulerDiscreteScheduler
     c = REFINE_CASES[name]
-    G = np.load(os.path.join(GOLD, f"g15_longcat_refine_{name}.npz"))
+    G = np.load(os.path.join(GOLD, f"g15_longcat_refine_{name}.npz" if vae_dtype == torch.float32 else f"g15b_longcat_refine_{name}_vaebf16.npz"))
     frames, image, pe, pm = refine_inputs(c)
-    dit, vae = FakeLongCatDiT(), FakeVAE()
+    dit, vae = FakeLongCatDiT(), FakeVAE(vae_dtype)   # bf16: pins the bf16 sample / normalisation / noise draw / mix of PIPE:1430-1433
     sch = FlowMatchEulerDiscreteScheduler(shift=c["shift"])
     pipe = LongCatVideoPipeline(vae, sch, dit, device=DEV)
     ups, lats = [], []
@@ -140,13 +156,13 @@ def test_refine_pass_matches_reference(name):
     assert (up != want_up).float().mean().item() < 0.01
     assert torch.equal(ups[0][:, :, :12], ups[0][:, :, 12:13].expand(-1, -1, 12, -1, -1))  # front padding repeats the first frame
     # (2) the oracle on the GPU-semantics up-sampling
-    dit2, vae2 = FakeLongCatDiT(), FakeVAE()
+    dit2, vae2 = FakeLongCatDiT(), FakeVAE(vae_dtype)
     trace = []
     want = ols.run_refine(stage1_frames=frames, image=(2.0 * image - 1.0)[None], height=c["H"], width=c["W"], dit=dit2, prompt_embeds=pe,
                           prompt_mask=pm, encode_sample=lambda x, g: vae2.encode(x).latent_dist.sample(g),
                           decode=lambda z: vae2.decode(z)[0], mean=vae2.config.latents_mean, std=vae2.config.latents_std,
                           generator=torch.manual_seed(42), num_inference_steps=c["steps"], shift=c["shift"], t_thresh=c["t"],
-                          spatial_refine_only=c["sro"], trace=trace, gpu_upsample=True)
+                          spatial_refine_only=c["sro"], trace=trace, gpu_upsample=True, vae_dtype=vae_dtype)
     assert [len(lats), dit.calls, vae.n_enc, vae.n_dec] == G["n"].tolist()
     for j, l in enumerate(lats):
         np.testing.assert_allclose(l, trace[j][:, :, 4:].numpy(), rtol=0, atol=2e-3)

@@ -492,3 +492,117 @@ def test_upsample_conv_as_four_phase_convs(cfg):
     with pytest.raises(RuntimeError):   # a scattered grid that does not fit the output tensor is refused
         _ffi.call("wf_conv3d_cl_scatter", xd.data_ptr(), keep[0].data_ptr(), bd.data_ptr(), None, out.data_ptr(), None, T, H, W, cin, T, H, W, cout,
                   1, 2, 2, 1, 1, 0, 1, 1, zp.data_ptr(), 2 * H - 1, 2 * W, 2, 1, 2, 0, ops.stream())
+
+
+# ---- precision="fp16": one fp16 term per operand = the multiplicand width of a TF32 convolution (round 6) -------------------------------
+# The yardstick is the reference's own reduced-precision arithmetic: g8c = the executed class (autoencoder_kl_wan.py) run by eager
+# PyTorch in bf16 on CPU, the dtype the LongCat entry loads it in (run_longcat_worldforge_single.py:205), recorded together with its
+# distance from the class's fp32 run.
+@pytest.fixture(scope="module")
+def model_fp16():
+    from worldforge_amd.vae import AutoencoderKLWan
+    m = AutoencoderKLWan(DEV, precision="tf32").load_state_dict(ovae.random_weights(seed=5))
+    assert m.precision == "fp16" and m.f16 and not m.x3 and m.wide and m.OP == torch.float16
+    return m
+
+
+def test_cast_f16_and_producers_raise_the_range_flag():
+    import ctypes
+    from worldforge_amd import _ffi, ops
+    flag = ctypes.c_int(-1)
+    _ffi.call("wf_f16_overflow_flag", ctypes.byref(flag), 1, ops.stream())
+    g = torch.Generator().manual_seed(2)
+    src = torch.randn(7, 64, generator=g).to(DEV)
+    dst = torch.empty(7, 40, dtype=torch.float16, device=DEV)
+    _ffi.call("wf_cast_f16", src.data_ptr(), 64, dst.data_ptr(), 40, 7, 40, ops.stream())      # strided source and destination rows
+    assert torch.equal(dst, src[:, :40].to(torch.float16))
+    _ffi.call("wf_f16_overflow_flag", ctypes.byref(flag), 1, ops.stream())
+    assert flag.value == 0
+    src[3, 9] = -7.0e4
+    _ffi.call("wf_cast_f16", src.data_ptr(), 64, dst.data_ptr(), 40, 7, 40, ops.stream())
+    _ffi.call("wf_f16_overflow_flag", ctypes.byref(flag), 1, ops.stream())
+    assert flag.value == 1
+    # the layout kernel at the VAE's input
+    v = torch.randn(3, 50, generator=g).to(DEV)
+    out = torch.empty(50, 32, dtype=torch.float16, device=DEV)
+    _ffi.call("wf_ncthw_to_cl_f16", v.data_ptr(), None, out.data_ptr(), 3, 32, 50, ops.stream())
+    assert torch.equal(out[:, :3], v.t().to(torch.float16)) and not out[:, 3:].any()
+    v[1, 4] = float("nan")
+    _ffi.call("wf_ncthw_to_cl_f16", v.data_ptr(), None, out.data_ptr(), 3, 32, 50, ops.stream())
+    _ffi.call("wf_f16_overflow_flag", ctypes.byref(flag), 1, ops.stream())
+    assert flag.value == 1
+    # RMS-norm with the fp16 output, softmax with fp16 probabilities
+    x = torch.randn(11, 384, generator=g).to(DEV)
+    gam = (1 + 0.1 * torch.randn(384, generator=g)).to(DEV)
+    o16 = torch.empty(11, 384, dtype=torch.float16, device=DEV)
+    o32 = torch.empty(11, 384, device=DEV)
+    _ffi.call("wf_rms_silu_cl_f16", x.data_ptr(), gam.data_ptr(), o16.data_ptr(), o32.data_ptr(), 11, 384, 0, ops.stream())
+    assert torch.equal(o16, o32.to(torch.float16))
+    S = torch.randn(5, 72, generator=g).to(DEV)
+    P16 = torch.empty(5, 80, dtype=torch.float16, device=DEV)
+    Pb = torch.empty(5, 80, dtype=BF, device=DEV)
+    _ffi.call("wf_softmax_rows_f16", S.data_ptr(), 72, P16.data_ptr(), 80, 5, 70, 0.5, ops.stream())
+    _ffi.call("wf_softmax_rows", S.data_ptr(), 72, Pb.data_ptr(), 80, 5, 70, 0.5, ops.stream())
+    want = torch.softmax(S[:, :70] * 0.5, dim=-1)
+    assert (P16[:, :70].float() - want).abs().max().item() <= 2.0 ** -11 and not P16[:, 70:].any()
+    assert (P16[:, :70].float() - want).abs().max().item() < (Pb[:, :70].float() - want).abs().max().item()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fp16_mode_is_closer_to_fp32_than_the_references_bf16_run(name, model_fp16, model, golden_dir):
+    """One-term fp16 ("fp16" / "tf32") and one-term bf16 ("bf16") operands with fp32 accumulation and an f32 stream, against the fp32
+    goldens of the executed class (g8b) -- and against what the reference's OWN bf16 VAE (the LongCat entry's dtype) leaves, g8c."""
+    from tests._tol import within
+    g = np.load(os.path.join(golden_dir, "g8_vae.npz"))
+    g32 = np.load(os.path.join(golden_dir, "g8b_vae_akw.npz"))
+    gbf = np.load(os.path.join(golden_dir, "g8c_vae_akw_bf16.npz"))
+    x, z = torch.from_numpy(g[f"{name}_x"]).to(DEV), torch.from_numpy(g[f"{name}_z"]).to(DEV)
+    mu_ref, dec_ref = torch.from_numpy(g32[f"{name}_mu"]), torch.from_numpy(g32[f"{name}_dec"])
+    ref_mu_rel, ref_dec_rel = float(gbf[f"{name}_mu_rel"]), float(gbf[f"{name}_dec_rel"])
+    # the fixture's own figure is what its arrays say
+    assert abs(_rel(torch.from_numpy(gbf[f"{name}_mu"]), mu_ref) - ref_mu_rel) <= 1e-6 * ref_mu_rel + 1e-9
+    assert 1e-2 <= ref_mu_rel <= 2.5e-2 and 1e-2 <= ref_dec_rel <= 3e-2
+    out = {}
+    for mode, m in (("fp16", model_fp16), ("bf16", model)):
+        mu = m.encode(x).latent_dist.mode().cpu()
+        dec = m.decode(z, return_dict=False)[0].cpu()
+        m.check_range()
+        out[mode] = (_rel(mu, mu_ref), _rel(dec, dec_ref), (dec - dec_ref).abs().max().item())
+        print(f"[{mode} {name}] rel L2 from fp32: mu {out[mode][0]:.3e} dec {out[mode][1]:.3e} max abs dec {out[mode][2]:.3e}   "
+              f"(the reference's bf16 run: mu {ref_mu_rel:.3e} dec {ref_dec_rel:.3e})")
+        # no farther from fp32 than the reference's own bf16 arithmetic is
+        assert out[mode][0] <= ref_mu_rel and out[mode][1] <= ref_dec_rel, (mode, out[mode])
+    # measured on MI355X (profiles/r6_tolerances.txt); bars at <= 2x
+    within(f"vae.fp16.mu.rel_l2.{name}", out["fp16"][0], FP16_BARS[name][0])
+    within(f"vae.fp16.dec.rel_l2.{name}", out["fp16"][1], FP16_BARS[name][1])
+    within(f"vae.fp16.dec.max_abs.{name}", out["fp16"][2], FP16_BARS[name][2])
+    # 11 significand bits against 8: the one-term fp16 mode is several times closer to fp32 than the one-term bf16 mode
+    assert out["fp16"][0] < 0.25 * out["bf16"][0] and out["fp16"][1] < 0.25 * out["bf16"][1]
+
+
+# per-case bars of the one-term fp16 mode: (mu rel L2, dec rel L2, dec max abs) at 2x what an MI355X measures (profiles/r6_a_pytest.log:
+# 1.03e-3 / 1.39e-3 / 3.19e-3, 1.03e-3 / 1.33e-3 / 2.87e-3, 1.04e-3 / 1.18e-3 / 1.36e-3, 1.21e-3 / 1.43e-3 / 2.92e-3) -- 15x closer to the
+# fp32 network than the reference's own bf16 module (1.5e-2 / 2.1e-2, g8c) and 7.5x closer than one-term bf16 operands
+FP16_BARS = {"f9_32x32": (2.06e-3, 2.78e-3, 6.4e-3), "f5_48x40": (2.07e-3, 2.65e-3, 5.75e-3), "f1_32x32": (2.08e-3, 2.35e-3, 2.72e-3),
+             "f17_16x24": (2.41e-3, 2.86e-3, 5.84e-3)}
+
+
+@pytest.mark.parametrize("P,H", [(2, 64), (8, 96)])
+def test_fp16_mode_row_sharded_equals_unsharded(P, H, model_fp16):
+    from tests.test_gpu_multirank import _run_ranks
+    from worldforge_amd.vae import AutoencoderKLWan
+    g = torch.Generator().manual_seed(21)
+    x = (torch.rand(1, 3, 9, H, 96, generator=g) * 2 - 1).to(DEV)
+    z = torch.randn(1, 16, 3, H // 8, 12, generator=g).to(DEV)
+    mu0 = model_fp16.encode(x).latent_dist.mode().clone()
+    dec0 = model_fp16.decode(z, return_dict=False)[0].clone()
+
+    def run(comm):
+        v = AutoencoderKLWan(DEV, comm=comm, precision="fp16")
+        v.w = model_fp16.w
+        assert v.can_shard(H // 8)
+        return v.encode(x).latent_dist.mode().clone(), v.decode(z, return_dict=False)[0].clone()
+
+    for r, (mu, dec) in enumerate(_run_ranks(P, run)):
+        assert torch.equal(mu, mu0), (r, (mu - mu0).abs().max())
+        assert torch.equal(dec, dec0), (r, (dec - dec0).abs().max())

@@ -36,19 +36,29 @@ def case_inputs(c):
     return image, ref, mask, pe, pm, ne, nm
 
 
-def sampler_config(c):
-    return ols.LongCatSamplerConfig(num_inference_steps=c["steps"], guidance_scale=c["cfg"], shift=c["shift"], use_distill=c["distill"],
+def sampler_config(c, vae_dtype=torch.float32):
+    return ols.LongCatSamplerConfig(vae_dtype=vae_dtype, num_inference_steps=c["steps"], guidance_scale=c["cfg"], shift=c["shift"], use_distill=c["distill"],
                                     guided=c["guided"], resample_steps=c["R"], guide_steps=c["guide"], resample_round=c["rnd"],
                                     omega=c["omega"], omega_resample=c["omega_r"], use_pca_channel_selection=c["flf"],
                                     max_replace_threshold=c["maxrep"])
 
 
-@pytest.mark.parametrize("name", list(CASES))
-def test_sampler_matches_reference_trajectory(name):
+# (case, VAE dtype): g12 = fp32 VAE stand-in; g12b = the stand-in in bf16, the dtype the LongCat entry loads its VAE in
+# (run_longcat_worldforge_single.py:205) -- pins the `.to(vae.dtype)` hand-offs of fuse_latents and of the final decode
+TRAJ = [(n, torch.float32) for n in CASES] + [("irr_flf", torch.bfloat16), ("nocfg_distill", torch.bfloat16)]
+
+
+def golden_pipe(name, vae_dtype):
+    f = f"g12_longcat_pipe_{name}.npz" if vae_dtype == torch.float32 else f"g12b_longcat_pipe_{name}_vaebf16.npz"
+    return np.load(os.path.join(GOLD, f))
+
+
+@pytest.mark.parametrize("name,vae_dtype", TRAJ)
+def test_sampler_matches_reference_trajectory(name, vae_dtype):
     c = CASES[name]
-    G = np.load(os.path.join(GOLD, f"g12_longcat_pipe_{name}.npz"))
+    G = golden_pipe(name, vae_dtype)
     image, ref, mask, pe, pm, ne, nm = case_inputs(c)
-    dit, vae = FakeLongCatDiT(), FakeVAE()
+    dit, vae = FakeLongCatDiT(), FakeVAE(vae_dtype)
     mean, std = vae.config.latents_mean, vae.config.latents_std
     gen = torch.manual_seed(42)
     sig, ts = ols.make_schedule(ols.timesteps_sigmas(c["steps"], c["distill"]), c["shift"])
@@ -57,7 +67,7 @@ def test_sampler_matches_reference_trajectory(name):
     assert np.array_equal(lat.numpy(), G["latents0"])
     do_cfg = c["cfg"] > 1.0
     trace = []
-    out = ols.run(sampler_config(c), latents=lat, dit=dit, prompt_embeds=torch.cat([ne, pe]) if do_cfg else pe,
+    out = ols.run(sampler_config(c, vae_dtype), latents=lat, dit=dit, prompt_embeds=torch.cat([ne, pe]) if do_cfg else pe,
                   prompt_mask=torch.cat([nm, pm]) if do_cfg else pm, video_ref=ref, mask=mask,
                   decode=lambda z: vae.decode(z)[0], encode_mode=lambda v: vae.encode(v).latent_dist.mode(), mean=mean, std=std,
                   generator=gen, trace=trace)
@@ -76,7 +86,7 @@ def test_sampler_matches_reference_trajectory(name):
             j += 1
     assert j == int(G["n_step_calls"][0]) and k == len(steps)
     assert [dit.calls, vae.n_enc, vae.n_dec] == (G["n_calls"] - np.array([0, 0, 1])).tolist()  # the final decode comes next
-    frames = ols.decode_final(out, lambda z: vae.decode(z)[0], mean, std)
+    frames = ols.decode_final(out, lambda z: vae.decode(z)[0], mean, std, vae_dtype)
     np.testing.assert_allclose(frames.numpy(), G["frames"], rtol=0, atol=2e-5)
 
 
@@ -105,14 +115,14 @@ def refine_inputs(c):
     return frames, image, pe, pm
 
 
-@pytest.mark.parametrize("name", list(REFINE_CASES))
-def test_refine_pass_matches_reference(name):
+@pytest.mark.parametrize("name,vae_dtype", [(n, torch.float32) for n in REFINE_CASES] + [("spatial", torch.bfloat16)])
+def test_refine_pass_matches_reference(name, vae_dtype):
     """G15: the unmodified generate_refine (schedule truncation, bf16 upsampling chain, granularity padding, noise mixing, condition
     latents, Euler loop without CFG, frame slicing)."""
     c = REFINE_CASES[name]
-    G = np.load(os.path.join(GOLD, f"g15_longcat_refine_{name}.npz"))
+    G = np.load(os.path.join(GOLD, f"g15_longcat_refine_{name}.npz" if vae_dtype == torch.float32 else f"g15b_longcat_refine_{name}_vaebf16.npz"))
     frames, image, pe, pm = refine_inputs(c)
-    dit, vae = FakeLongCatDiT(), FakeVAE()
+    dit, vae = FakeLongCatDiT(), FakeVAE(vae_dtype)
     mean, std = vae.config.latents_mean, vae.config.latents_std
     sig, ts = ols.refine_schedule(c["steps"], c["shift"], c["t"])
     assert np.array_equal(sig.numpy(), G["sigmas"]) and np.array_equal(ts.numpy(), G["timesteps"])
@@ -125,7 +135,8 @@ def test_refine_pass_matches_reference(name):
     out = ols.run_refine(stage1_frames=frames, image=(2.0 * image - 1.0)[None], height=c["H"], width=c["W"], dit=dit, prompt_embeds=pe,
                          prompt_mask=pm, encode_sample=lambda x, g: vae.encode(x).latent_dist.sample(g),
                          decode=lambda z: vae.decode(z)[0], mean=mean, std=std, generator=torch.manual_seed(42),
-                         num_inference_steps=c["steps"], shift=c["shift"], t_thresh=c["t"], spatial_refine_only=c["sro"], trace=trace)
+                         num_inference_steps=c["steps"], shift=c["shift"], t_thresh=c["t"], spatial_refine_only=c["sro"], trace=trace,
+                         vae_dtype=vae_dtype)
     assert len(trace) == int(G["n"][0])
     for j, lat in enumerate(trace):
         np.testing.assert_allclose(lat[:, :, ncl:].numpy(), G[f"step{j}"], rtol=0, atol=2e-5)

@@ -400,6 +400,46 @@ if __name__ == "__main__" and "vae_akw" in sys.argv[1:]:
     g_vae_akw()
 
 
+def g_vae_akw_bf16(out_dir=OUT):
+    """G8c: the executed class IN THE DTYPE THE LONGCAT ENTRY LOADS IT (run_longcat_worldforge_single.py:205
+    `AutoencoderKLWan.from_pretrained(..., torch_dtype=torch.bfloat16)`): the g8b model `.to(torch.bfloat16)`, inputs cast with the
+    `.to(dtype=vae.dtype)` of the LongCat fuse_latents (scheduling_flow_match_euler_discrete.py:1124, 1166), run by eager PyTorch on
+    CPU.  Weights, activations, the residual stream and the accumulator hand-offs between layers are all bf16 there.  The fixture
+    holds the outputs (as f32) and their distance from the class's own fp32 run (g8b): the yardstick a reduced-precision VAE mode of
+    the build is held against (tests/test_gpu_vae.py: no farther from fp32 than the reference's own arithmetic is)."""
+    akw = _load_akw()
+    from oracle import vae as ovae
+    from worldforge_amd.vae import diffusers_key_map
+
+    m = akw.AutoencoderKLWan()
+    m.eval()
+    sd = m.state_dict()
+    W = ovae.random_weights(seed=5)
+    inv = {v: k for k, v in diffusers_key_map().items()}
+    m.load_state_dict({f"{inv[k.rpartition('.')[0]]}.{k.rpartition('.')[2]}": v.reshape(sd[f"{inv[k.rpartition('.')[0]]}.{k.rpartition('.')[2]}"].shape)
+                       for k, v in W.items()}, strict=True)
+    m = m.to(torch.bfloat16)
+    g8 = np.load(os.path.join(OUT, "g8_vae.npz"))
+    g8b = np.load(os.path.join(OUT, "g8b_vae_akw.npz"))
+    out = {}
+    with torch.no_grad():
+        for name in ("f9_32x32", "f5_48x40", "f1_32x32", "f17_16x24"):
+            x, z = torch.from_numpy(g8[f"{name}_x"]), torch.from_numpy(g8[f"{name}_z"])
+            mu = m.encode(x.to(dtype=m.dtype)).latent_dist.mode()
+            dec = m.decode(z.to(dtype=m.dtype), return_dict=False)[0]
+            assert mu.dtype == torch.bfloat16 and dec.dtype == torch.bfloat16
+            out[f"{name}_mu"], out[f"{name}_dec"] = t2n(mu), t2n(dec)
+            mu32, dec32 = torch.from_numpy(g8b[f"{name}_mu"]), torch.from_numpy(g8b[f"{name}_dec"])
+            out[f"{name}_mu_rel"] = np.float64(((mu.float() - mu32).norm() / mu32.norm()).item())
+            out[f"{name}_dec_rel"] = np.float64(((dec.float() - dec32).norm() / dec32.norm()).item())
+            print("g8c", name, "rel L2 of the bf16 run from the fp32 run: mu", out[f"{name}_mu_rel"], "dec", out[f"{name}_dec_rel"])
+    np.savez_compressed(os.path.join(out_dir, "g8c_vae_akw_bf16.npz"), **out)
+
+
+if __name__ == "__main__" and "vae_akw_bf16" in sys.argv[1:]:
+    g_vae_akw_bf16()
+
+
 # ------------------------------------------------------------------------------------------------------------
 def g_longcat_dit():
     """G11: the unmodified LongCatVideoTransformer3DModel (fp32, CPU; its flash-attn calls served by tools/refshim_flash/flash_attn) with
@@ -532,9 +572,13 @@ def lc_case_inputs(c):
     return image, ref, mask, pe, pm, ne, nm
 
 
-def g_longcat_pipe():
+def g_longcat_pipe(vae_dtype=torch.float32, cases=None, fmt="g12_longcat_pipe_{}.npz"):
     """G12: LongCatVideoPipeline.generate_i2v + FlowMatchEulerDiscreteScheduler, unmodified, with deterministic stand-ins for the DiT,
-    the VAE and the text encoder (encode_prompt) and a fixed target size instead of the resolution-bucket lookup."""
+    the VAE and the text encoder (encode_prompt) and a fixed target size instead of the resolution-bucket lookup.
+    G12b (`longcat_pipe_bf16vae`): the same with the VAE stand-in IN BF16, the dtype the LongCat entry loads its VAE in
+    (run_longcat_worldforge_single.py:205): pins the `.to(dtype=vae.dtype)` hand-offs of fuse_latents
+    (scheduling_flow_match_euler_discrete.py:1124, 1166), the bf16 pixel blend (:1152-1164), the bf16 posterior sample of
+    prepare_latents and the final `latents.to(self.vae.dtype)` + bf16 de-normalisation (pipeline_longcat_video.py:999-1001)."""
     from tests.fakes import FakeLongCatDiT
 
     _longcat_paths()
@@ -542,8 +586,10 @@ def g_longcat_pipe():
     from longcat_video.pipeline_longcat_video import LongCatVideoPipeline
 
     for name, c in LC_PIPE_CASES.items():
+        if cases is not None and name not in cases:
+            continue
         image, ref, mask, pe, pm, ne, nm = lc_case_inputs(c)
-        dit, vae = FakeLongCatDiT(), FakeVAE()
+        dit, vae = FakeLongCatDiT(), FakeVAE(vae_dtype)
         sch = FlowMatchEulerDiscreteScheduler(shift=c["shift"])
         pipe = LongCatVideoPipeline(tokenizer=None, text_encoder=None, vae=vae, scheduler=sch, dit=dit)
         pipe.device = "cpu"
@@ -579,12 +625,14 @@ def g_longcat_pipe():
         for j, (p, x0) in enumerate(calls):
             rec[f"call{j}_prev"], rec[f"call{j}_x0"] = p, x0
         rec["n_step_calls"] = np.array([len(calls)])
-        np.savez_compressed(os.path.join(OUT, f"g12_longcat_pipe_{name}.npz"), **rec)
-        print("g12", name, "dit/enc/dec calls", rec["n_calls"], "step calls", len(calls), "frames", rec["frames"].shape)
+        np.savez_compressed(os.path.join(OUT, fmt.format(name)), **rec)
+        print(fmt.format(name), name, "dit/enc/dec calls", rec["n_calls"], "step calls", len(calls), "frames", rec["frames"].shape)
 
 
 if __name__ == "__main__" and "longcat_pipe" in sys.argv[1:]:
     g_longcat_pipe()
+if __name__ == "__main__" and "longcat_pipe_bf16vae" in sys.argv[1:]:
+    g_longcat_pipe(torch.bfloat16, cases=("irr_flf", "nocfg_distill"), fmt="g12b_longcat_pipe_{}_vaebf16.npz")
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -677,8 +725,10 @@ def lc_refine_inputs(c):
     return frames, image, pe, pm
 
 
-def g_longcat_refine():
-    """G15: LongCatVideoPipeline.generate_refine, unmodified, with the deterministic DiT / VAE / text-encoder stand-ins."""
+def g_longcat_refine(vae_dtype=torch.float32, cases=None, fmt="g15_longcat_refine_{}.npz"):
+    """G15: LongCatVideoPipeline.generate_refine, unmodified, with the deterministic DiT / VAE / text-encoder stand-ins.
+    G15b (`longcat_refine_bf16vae`): with the VAE stand-in in bf16 (see G12b): the bf16 posterior sample, bf16 normalisation, bf16 noise
+    draw and bf16 noise mix of pipeline_longcat_video.py:1430-1433."""
     from tests.fakes import FakeLongCatDiT
 
     _longcat_paths()
@@ -689,8 +739,10 @@ def g_longcat_refine():
     lcp.torch_gc = lambda: None  # memory housekeeping that calls torch.cuda.ipc_collect() unconditionally (no GPU here); no arithmetic
 
     for name, c in LC_REFINE_CASES.items():
+        if cases is not None and name not in cases:
+            continue
         frames, image, pe, pm = lc_refine_inputs(c)
-        dit, vae = FakeLongCatDiT(), FakeVAE()
+        dit, vae = FakeLongCatDiT(), FakeVAE(vae_dtype)
         sch = FlowMatchEulerDiscreteScheduler(shift=c["shift"])
         pipe = LongCatVideoPipeline(tokenizer=None, text_encoder=None, vae=vae, scheduler=sch, dit=dit)
         pipe.device = "cpu"
@@ -721,12 +773,14 @@ def g_longcat_refine():
         for j, l in enumerate(lats):
             rec[f"step{j}"] = l
         rec["n"] = np.array([len(lats), dit.calls, vae.n_enc, vae.n_dec])
-        np.savez_compressed(os.path.join(OUT, f"g15_longcat_refine_{name}.npz"), **rec)
-        print("g15", name, rec["n"], rec["frames"].shape, rec["video_up"].shape)
+        np.savez_compressed(os.path.join(OUT, fmt.format(name)), **rec)
+        print(fmt.format(name), name, rec["n"], rec["frames"].shape, rec["video_up"].shape)
 
 
 if __name__ == "__main__" and "longcat_refine" in sys.argv[1:]:
     g_longcat_refine()
+if __name__ == "__main__" and "longcat_refine_bf16vae" in sys.argv[1:]:
+    g_longcat_refine(torch.bfloat16, cases=("spatial",), fmt="g15b_longcat_refine_{}_vaebf16.npz")
 
 
 def g_bsa_cdf():

@@ -1,11 +1,11 @@
-"""VAE decode + encode at the C2 size (81 x 480 x 832), default fp32-class operands and the bf16 mode: ms per call and MFMA TFLOP/s issued."""
+"""VAE decode + encode at the C2 size (81 x 480 x 832), default fp32-class operands (fp16x3), the one-term fp16 mode and the bf16 mode: ms per call and MFMA TFLOP/s issued."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from worldforge_amd.vae import AutoencoderKLWan
 
 dev = torch.device("cuda:0")
-for prec in ("fp32", "bf16"):
+for prec in (sys.argv[1:] or ["fp32", "fp16", "bf16"]):
     vae = AutoencoderKLWan(dev, precision=prec).init_random(seed=1)
     z = torch.randn(1, 16, 21, 60, 104, device=dev)
     video = torch.rand(1, 3, 81, 480, 832, device=dev) * 2 - 1

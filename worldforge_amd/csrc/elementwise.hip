@@ -268,6 +268,35 @@ extern "C" int wf_blend_pixels(const float* ref, const float* mask, const float*
   return WF_OK;
 }
 
+// The same blend as eager PyTorch evaluates it when the VAE is a bf16 module (LongCat: run_longcat_worldforge_single.py:205): the decoded
+// video is bf16, `video_latents.to(decoded_video.dtype)` / `mask.to(...)` round the fp32 reference and mask to bf16
+// (scheduling_flow_match_euler_discrete.py:1152-1153) and every statement of :1156-1164 rounds its result to bf16:
+//   v = bf16(2 * r) ; v = bf16(v - 1) ; a = bf16(v * m) ; om = bf16(1 - m) ; b = bf16(dec * om) ; fused = bf16(a + b)
+__global__ void k_blend_bf16(const float* __restrict__ ref, const float* __restrict__ mask, const uint16_t* __restrict__ dec,
+                             uint16_t* __restrict__ out, int C, size_t inner, size_t n) {
+  EW_LOOP(i, n) {
+    size_t b = i / ((size_t)C * inner);
+    size_t p = i % inner;
+    const float m = rbf(mask[b * inner + p]);
+    float v = rbf(2.0f * rbf(ref[i]));
+    v = rbf(v - 1.0f);
+    const float a = rbf(v * m);
+    const float om = rbf(1.0f - m);
+    const float bb = rbf(bf16_to_f32(dec[i]) * om);
+    out[i] = f32_to_bf16(a + bb);
+  }
+}
+extern "C" int wf_blend_pixels_bf16(const float* ref, const float* mask, const void* dec, void* out, int B, int C, size_t inner,
+                                    void* stream) {
+  WF_CHECK_ARG(ref && mask && dec && out, "wf_blend_pixels_bf16: null pointer");
+  size_t n = (size_t)B * C * inner;
+  if (n == 0) return WF_OK;
+  hipLaunchKernelGGL(k_blend_bf16, dim3(grid_for(n, EW_BLOCK, 8192)), dim3(EW_BLOCK), 0, (hipStream_t)stream, ref, mask,
+                     (const uint16_t*)dec, (uint16_t*)out, C, inner, n);
+  WF_LAUNCH_CHECK("wf_blend_pixels_bf16");
+  return WF_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // PIPE:744  (video / 2 + 0.5).clamp(0, 1), [C,F,H,W] -> [F,H,W,C]
 // ------------------------------------------------------------------------------------------------
@@ -278,6 +307,24 @@ __global__ void k_post(const float* __restrict__ x, float* __restrict__ out, int
     float v = x[(size_t)c * fhw + p] / 2.0f + 0.5f;
     out[i] = fminf(fmaxf(v, 0.0f), 1.0f);
   }
+}
+// a bf16 video (bf16 VAE module): diffusers' VideoProcessor.denormalize runs in the video's dtype -- bf16(x / 2), bf16(+ 0.5), clamp --
+// and pt_to_numpy converts to float afterwards
+__global__ void k_post_bf16(const uint16_t* __restrict__ x, float* __restrict__ out, int C, size_t fhw, size_t n) {
+  EW_LOOP(i, n) {
+    size_t p = i / C;
+    int c = (int)(i % C);
+    float v = rbf(rbf(bf16_to_f32(x[(size_t)c * fhw + p]) / 2.0f) + 0.5f);
+    out[i] = fminf(fmaxf(v, 0.0f), 1.0f);
+  }
+}
+extern "C" int wf_postprocess_video_bf16(const void* x, float* out, int C, int F, int H, int W, void* stream) {
+  size_t fhw = (size_t)F * H * W, n = fhw * C;
+  if (n == 0) return WF_OK;
+  WF_CHECK_ARG(x && out, "wf_postprocess_video_bf16: null pointer");
+  hipLaunchKernelGGL(k_post_bf16, dim3(grid_for(n, EW_BLOCK, 4096)), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const uint16_t*)x, out, C, fhw, n);
+  WF_LAUNCH_CHECK("wf_postprocess_video_bf16");
+  return WF_OK;
 }
 extern "C" int wf_postprocess_video(const float* x, float* out, int C, int F, int H, int W, void* stream) {
   size_t fhw = (size_t)F * H * W, n = fhw * C;

@@ -18,6 +18,14 @@ __device__ __forceinline__ float r16(int f16, float x) {  // x rounded through t
   if (f16) return (float)(_Float16)x;
   return rbf(x);
 }
+__device__ __forceinline__ uint16_t f32_to_f16(float x) {
+  union {
+    _Float16 h;
+    uint16_t u;
+  } c;
+  c.h = (_Float16)x;
+  return c.u;
+}
 __device__ __forceinline__ void note_range(int f16, const float (&y)[4]) {
   if (f16 && !(fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))) <= 65504.0f)) g_f16_overflow = 1u;  // NaN too
 }
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(256) void k_rms_silu(const float* __restrict__ x, c
 
 // softmax over each row of S [M, N] f32 (row stride lds) * scale -> P bf16 [M, ldp], columns N..ldp zero-filled
 __global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ S, int lds, uint16_t* __restrict__ P, int ldp,
-                                                      int N, float scale) {
+                                                      int N, float scale, int f16) {
   __shared__ float sm[8];
   const size_t row = blockIdx.x;
   const float* s = S + row * lds;
@@ -130,7 +138,10 @@ __global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ 
   sum = (sm[4] + sm[5]) + (sm[6] + sm[7]);
   const float inv = 1.0f / sum;
   uint16_t* p = P + row * ldp;
-  for (int i = threadIdx.x; i < ldp; i += 256) p[i] = i < N ? f32_to_bf16(__expf((s[i] - mx) * scale) * inv) : (uint16_t)0;
+  for (int i = threadIdx.x; i < ldp; i += 256) {
+    const float v = i < N ? __expf((s[i] - mx) * scale) * inv : 0.f;   // in [0, 1]: inside the fp16 range
+    p[i] = f16 ? f32_to_f16(v) : f32_to_bf16(v);
+  }
 }
 
 // fp32-class operands for the bf16 matrix cores: x = hi + lo, hi = bf16(x), lo = bf16(x - hi) (x - hi is exact in fp32; the
@@ -155,6 +166,23 @@ __global__ __launch_bounds__(256) void k_split3(const float* __restrict__ src, l
     reinterpret_cast<u32x2*>(o)[id] = hi;
     reinterpret_cast<u32x2*>(o + C)[id] = side ? hi : lo;
     reinterpret_cast<u32x2*>(o + 2 * C)[id] = side ? lo : hi;
+  }
+}
+
+// One-term fp16 operand (the VAE's "fp16" mode: 11 significand bits, what a TF32 convolution keeps of an fp32 operand): src f32
+// [rows, C] -> dst fp16 [rows, C], with the range flag of the three-term producers.
+__global__ __launch_bounds__(256) void k_cast_f16(const float* __restrict__ src, long ld_src, uint16_t* __restrict__ dst, long ld_dst,
+                                                  size_t rows, int C) {
+  const int nvec = C >> 2;
+  const size_t n = rows * (size_t)nvec;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / nvec;
+    const int id = (int)(i % nvec);
+    const float4 v = reinterpret_cast<const float4*>(src + r * ld_src)[id];
+    const float y[4] = {v.x, v.y, v.z, v.w};
+    note_range(1, y);
+    const u32x2 hi = {pack16x2(1, y[0], y[1]), pack16x2(1, y[2], y[3])};
+    reinterpret_cast<u32x2*>(dst + r * ld_dst)[id] = hi;
   }
 }
 
@@ -199,14 +227,17 @@ __global__ void k_transpose(const E* __restrict__ in, int ld_in, E* __restrict__
 }
 
 // [C, N] -> [N, Cpad] (N = T*H*W; channels C..Cpad zero), in f32 -> out f32 or bf16
-__global__ void k_to_cl(const float* __restrict__ in, float* __restrict__ of, uint16_t* __restrict__ ob, int C, int Cpad, size_t N) {
+__global__ void k_to_cl(const float* __restrict__ in, float* __restrict__ of, uint16_t* __restrict__ ob, int C, int Cpad, size_t N, int f16) {
   const size_t n = N * Cpad;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % Cpad);
     const size_t p = i / Cpad;
     const float v = c < C ? in[(size_t)c * N + p] : 0.f;
     if (of) of[i] = v;
-    if (ob) ob[i] = f32_to_bf16(v);
+    if (ob) {
+      if (f16 && !(fabsf(v) <= 65504.0f)) g_f16_overflow = 1u;
+      ob[i] = f16 ? f32_to_f16(v) : f32_to_bf16(v);
+    }
   }
 }
 // [N, ld] f32 (first C channels) -> [C, N] f32, optional clamp
@@ -223,8 +254,8 @@ __global__ void k_from_cl(const float* __restrict__ in, float* __restrict__ out,
 
 }  // namespace
 
-extern "C" int wf_rms_silu_cl(const float* x, const float* gamma, void* out_bf16, float* out_f32, size_t npix, int C, int silu,
-                              void* stream) {
+static int rms_silu_impl(const float* x, const float* gamma, void* out_bf16, float* out_f32, size_t npix, int C, int silu, void* stream,
+                         int f16) {
   WF_CHECK_ARG(x && gamma && (out_bf16 || out_f32), "wf_rms_silu_cl: null pointer");
   WF_CHECK_ARG(C % 4 == 0 && C > 0 && C <= 1024, "wf_rms_silu_cl: C=%d must be a multiple of 4 and <= 1024", C);
   if (npix == 0) return WF_OK;
@@ -234,23 +265,39 @@ extern "C" int wf_rms_silu_cl(const float* x, const float* gamma, void* out_bf16
   const float sc = sqrtf((float)C);
   hipStream_t st = (hipStream_t)stream;
   if (G == 8)
-    hipLaunchKernelGGL(k_rms_silu<8>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix, 0);
+    hipLaunchKernelGGL(k_rms_silu<8>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix, 0, 0, f16);
   else if (G == 16)
-    hipLaunchKernelGGL(k_rms_silu<16>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix, 0);
+    hipLaunchKernelGGL(k_rms_silu<16>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix, 0, 0, f16);
   else if (G == 32)
-    hipLaunchKernelGGL(k_rms_silu<32>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix, 0);
+    hipLaunchKernelGGL(k_rms_silu<32>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix, 0, 0, f16);
   else
-    hipLaunchKernelGGL(k_rms_silu<64>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix, 0);
+    hipLaunchKernelGGL(k_rms_silu<64>, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (uint16_t*)out_bf16, out_f32, C, sc, silu, npix, 0, 0, f16);
   WF_LAUNCH_CHECK("wf_rms_silu_cl");
   return WF_OK;
+}
+extern "C" int wf_rms_silu_cl(const float* x, const float* gamma, void* out_bf16, float* out_f32, size_t npix, int C, int silu,
+                              void* stream) {
+  return rms_silu_impl(x, gamma, out_bf16, out_f32, npix, C, silu, stream, 0);
+}
+extern "C" int wf_rms_silu_cl_f16(const float* x, const float* gamma, void* out_f16, float* out_f32, size_t npix, int C, int silu,
+                                  void* stream) {
+  return rms_silu_impl(x, gamma, out_f16, out_f32, npix, C, silu, stream, 1);
 }
 
 extern "C" int wf_softmax_rows(const float* S, int lds, void* P, int ldp, int M, int N, float scale, void* stream) {
   WF_CHECK_ARG(S && P, "wf_softmax_rows: null pointer");
   WF_CHECK_ARG(N > 0 && ldp >= N && lds >= N, "wf_softmax_rows: bad sizes");
   if (M == 0) return WF_OK;
-  hipLaunchKernelGGL(k_softmax_rows, dim3(M), dim3(256), 0, (hipStream_t)stream, S, lds, (uint16_t*)P, ldp, N, scale);
+  hipLaunchKernelGGL(k_softmax_rows, dim3(M), dim3(256), 0, (hipStream_t)stream, S, lds, (uint16_t*)P, ldp, N, scale, 0);
   WF_LAUNCH_CHECK("wf_softmax_rows");
+  return WF_OK;
+}
+extern "C" int wf_softmax_rows_f16(const float* S, int lds, void* P, int ldp, int M, int N, float scale, void* stream) {
+  WF_CHECK_ARG(S && P, "wf_softmax_rows_f16: null pointer");
+  WF_CHECK_ARG(N > 0 && ldp >= N && lds >= N, "wf_softmax_rows_f16: bad sizes");
+  if (M == 0) return WF_OK;
+  hipLaunchKernelGGL(k_softmax_rows, dim3(M), dim3(256), 0, (hipStream_t)stream, S, lds, (uint16_t*)P, ldp, N, scale, 1);
+  WF_LAUNCH_CHECK("wf_softmax_rows_f16");
   return WF_OK;
 }
 
@@ -299,6 +346,16 @@ extern "C" int wf_split_bf16x3(const float* src, int64_t ld_src, void* dst, int6
 }
 extern "C" int wf_split_f16x3(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, size_t rows, int C, int side, void* stream) {
   return split_x3_impl(src, ld_src, dst, ld_dst, rows, C, side, stream, 1);
+}
+extern "C" int wf_cast_f16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, size_t rows, int C, void* stream) {
+  WF_CHECK_ARG(src && dst, "wf_cast_f16: null pointer");
+  WF_CHECK_ARG(C > 0 && C % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && ld_src >= C && ld_dst >= C,
+               "wf_cast_f16: C=%d ld_src=%ld ld_dst=%ld (C, strides multiples of 4)", C, (long)ld_src, (long)ld_dst);
+  if (rows == 0) return WF_OK;
+  hipLaunchKernelGGL(k_cast_f16, dim3(grid_for(rows * (size_t)(C / 4), 256, 16384)), dim3(256), 0, (hipStream_t)stream, src, ld_src,
+                     (uint16_t*)dst, ld_dst, rows, C);
+  WF_LAUNCH_CHECK("wf_cast_f16");
+  return WF_OK;
 }
 // Sticky range flag of the fp16 producers: *out = 1 if any value beyond the fp16 range (or a NaN) was converted since the last reset.
 // Synchronous (a 4-byte device -> host copy on the NULL stream after `stream` has drained).
@@ -353,14 +410,20 @@ extern "C" int wf_rms_silu_cl_x3_f16(const float* x, const float* gamma, void* o
   return rms_silu_x3_impl(x, gamma, out_x3, npix, C, silu, stream, 1);
 }
 
-extern "C" int wf_ncthw_to_cl(const float* in, float* out_f32, void* out_bf16, int C, int Cpad, size_t N, void* stream) {
-  WF_CHECK_ARG(in && (out_f32 || out_bf16), "wf_ncthw_to_cl: null pointer");
+static int ncthw_to_cl_impl(const float* in, float* out_f32, void* out_16, int C, int Cpad, size_t N, void* stream, int f16) {
+  WF_CHECK_ARG(in && (out_f32 || out_16), "wf_ncthw_to_cl: null pointer");
   WF_CHECK_ARG(Cpad >= C && C > 0, "wf_ncthw_to_cl: Cpad (%d) must be >= C (%d)", Cpad, C);
   if (N == 0) return WF_OK;
   hipLaunchKernelGGL(k_to_cl, dim3(grid_for(N * Cpad, 256, 8192)), dim3(256), 0, (hipStream_t)stream, in, out_f32,
-                     (uint16_t*)out_bf16, C, Cpad, N);
+                     (uint16_t*)out_16, C, Cpad, N, f16);
   WF_LAUNCH_CHECK("wf_ncthw_to_cl");
   return WF_OK;
+}
+extern "C" int wf_ncthw_to_cl(const float* in, float* out_f32, void* out_bf16, int C, int Cpad, size_t N, void* stream) {
+  return ncthw_to_cl_impl(in, out_f32, out_bf16, C, Cpad, N, stream, 0);
+}
+extern "C" int wf_ncthw_to_cl_f16(const float* in, float* out_f32, void* out_f16, int C, int Cpad, size_t N, void* stream) {
+  return ncthw_to_cl_impl(in, out_f32, out_f16, C, Cpad, N, stream, 1);
 }
 
 extern "C" int wf_cl_to_ncthw(const float* in, float* out, int C, int ld, size_t N, float clamp, void* stream) {

@@ -133,10 +133,24 @@ class LongCatVideoPipeline:
         added_n = nnl * tsc - num_noise_frames
         up = torch.cat([up[:, :, 0:1].repeat(1, 1, added_c, 1, 1), up, up[:, :, -1:].repeat(1, 1, added_n, 1, 1)], dim=2)
         mean, std = self.vae.config.latents_mean, self.vae.config.latents_std
-        lat = ops.latent_norm(self.vae.encode(up).latent_dist.sample(generator).to(dev, torch.float32), mean, std)
-        noise = self._randn(tuple(lat.shape), generator).to(lat.dtype)
-        latents = ops.add_noise(lat, noise, 1 - t_thresh, t_thresh)  # (1 - t) * latent + t * noise
-        del up, lat, noise
+        samp = self.vae.encode(up if getattr(self.vae, "dtype", torch.float32) == torch.float32 else ops.cast(up, self.vae.dtype)) \
+            .latent_dist.sample(generator).to(dev)
+        if samp.dtype == torch.float32:
+            lat = ops.latent_norm(samp, mean, std)
+            noise = self._randn(tuple(lat.shape), generator).to(lat.dtype)
+            latents = ops.add_noise(lat, noise, 1 - t_thresh, t_thresh)  # (1 - t) * latent + t * noise
+        else:
+            # a bf16 VAE module hands back a bf16 sample: PIPE:1431-1433 then normalise in bf16 (constants in bf16), draw the noise IN BF16
+            # (a different stream of the generator than an fp32 draw) and mix in bf16; prepare_latents casts the result to fp32 (PIPE:234)
+            m = torch.tensor(mean).view(1, -1, 1, 1, 1).to(dev, samp.dtype)
+            istd = 1.0 / torch.tensor(std).view(1, -1, 1, 1, 1).to(dev, samp.dtype)
+            lat = (samp - m) * istd
+            if generator is not None and generator.device.type == "cpu":
+                noise = torch.randn(lat.shape, generator=generator, dtype=lat.dtype).to(dev)
+            else:
+                noise = torch.randn(lat.shape, generator=generator, dtype=lat.dtype, device=dev)
+            latents = ((1 - t_thresh) * lat + t_thresh * noise).to(torch.float32)
+        del up, noise
         if image is not None:  # PIPE:262-284: the condition frame, front-padded, encoded (posterior sample), normalised
             img = self._preprocess_image(image, height, width).to(dev, dit_dtype)
             enc_in = img[0].unsqueeze(0).unsqueeze(2)
@@ -160,11 +174,17 @@ class LongCatVideoPipeline:
         if output_type == "latent":
             self._check_vae_range()
             return latents
-        z = ops.latent_denorm(ops.cast(latents, torch.float32), mean, std)
-        video = self.vae.decode(z, return_dict=False)[0]
+        video = self.vae.decode(self._final_latents(latents), return_dict=False)[0]
         video = torch.stack([ops.postprocess_video(v) for v in video])[:, added_c: new_frame_size + added_c]  # PIPE:1505
         self._check_vae_range()
         return video.cpu().numpy() if output_type == "np" else video
+
+    def _final_latents(self, latents: torch.Tensor) -> torch.Tensor:
+        """PIPE:999-1000: `latents.to(self.vae.dtype)` and the de-normalisation IN THAT DTYPE (a bf16 VAE module, the LongCat entry's
+        run_longcat_worldforge_single.py:205: constants and both statements in bf16), handed to decode in the module dtype."""
+        vdt = getattr(self.vae, "dtype", torch.float32)
+        z = ops.latent_denorm(ops.cast(latents, vdt), self.vae.config.latents_mean, self.vae.config.latents_std)  # f32 holding vdt values
+        return z if vdt == torch.float32 else ops.cast(z, vdt)
 
     def _check_vae_range(self):
         """A VAE call of this job left the fp16 operand range (vae.AutoencoderKLWan.check_range): fail before handing anything back."""
@@ -288,8 +308,7 @@ class LongCatVideoPipeline:
         if output_type == "latent":
             self._check_vae_range()
             return latents
-        z = ops.latent_denorm(ops.cast(latents, torch.float32), self.vae.config.latents_mean, self.vae.config.latents_std)
-        video = self.vae.decode(z, return_dict=False)[0]
+        video = self.vae.decode(self._final_latents(latents), return_dict=False)[0]
         video = torch.stack([ops.postprocess_video(v) for v in video])  # [B,F,H,W,C] in [0,1]
         self._check_vae_range()
         return video.cpu().numpy() if output_type == "np" else video

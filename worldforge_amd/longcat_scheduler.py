@@ -248,16 +248,17 @@ class FlowMatchEulerDiscreteScheduler:
             dshape = (1, 3, (x0.shape[2] - 1) * tds + 1, x0.shape[3] * sds, x0.shape[4] * sds)
             if tuple(video_latents.shape) != dshape or mask.shape[1] != 1 or tuple(mask.shape[2:]) != dshape[2:]:
                 return pred_original_sample
-            enc = vae.decode_blend_encode(ops.latent_denorm(x0, mean, std), video_latents, mask).mode()
+            enc = vae.decode_blend_encode(self._to_vae(ops.latent_denorm(x0, mean, std), vae), video_latents, mask).mode()
         else:
-            decoded = vae.decode(ops.latent_denorm(x0, mean, std), return_dict=False)[0]
+            decoded = vae.decode(self._to_vae(ops.latent_denorm(x0, mean, std), vae), return_dict=False)[0]   # SCHED:1124 + 1127
             if tuple(video_latents.shape) != tuple(decoded.shape) or mask.shape[1] != 1 or tuple(mask.shape[2:]) != tuple(decoded.shape[2:]):
                 return pred_original_sample
-            fused = ops.blend_pixels(video_latents, mask, decoded)
-            enc = vae.encode(fused).latent_dist.mode()
+            fused = ops.blend_pixels(video_latents, mask, decoded)   # in the decoded video's dtype (SCHED:1152-1164)
+            enc = vae.encode(self._to_vae(fused, vae)).latent_dist.mode()   # SCHED:1166 + 1169
         if tuple(enc.shape) != tuple(x0.shape):
             return pred_original_sample
-        enc = ops.latent_norm(enc, mean, std, const_dtype=x0.dtype)
+        # SCHED:1183: the constants are in the prediction's dtype (fp32), which promotes a bf16 module's latents
+        enc = ops.latent_norm(ops.cast(enc, torch.float32), mean, std, const_dtype=x0.dtype)
         if use_pca_channel_selection:
             if self._channel_selector is None:
                 self._channel_selector = VideoMotionChannelSelector(self.flow_backend)
@@ -268,6 +269,12 @@ class FlowMatchEulerDiscreteScheduler:
         if hasattr(vae, "check_range"):   # fp16 range flag of this round trip (see scheduler.UniPCMultistepScheduler.fuse_latents)
             vae.check_range(wait=bool(use_pca_channel_selection))
         return ops.cast(enc, x0.dtype)
+
+    @staticmethod
+    def _to_vae(x: torch.Tensor, vae) -> torch.Tensor:
+        """`.to(dtype=vae.dtype)` (SCHED:1124, 1166): the LongCat entry loads its VAE in bf16 (run_longcat_worldforge_single.py:205)."""
+        vdt = getattr(vae, "dtype", torch.float32)
+        return x if x.dtype == vdt else ops.cast(x, vdt)
 
     def __len__(self):
         return self.config.num_train_timesteps

@@ -110,23 +110,30 @@ def latent_norm(mu: torch.Tensor, mean, std, const_dtype: torch.dtype = torch.fl
 
 
 def blend_pixels(ref: torch.Tensor, mask: torch.Tensor, dec: torch.Tensor) -> torch.Tensor:
-    """SCHED:1375-1381.  ref/dec [B,3,F,H,W] fp32, mask [B,1,F,H,W] fp32."""
+    """SCHED:1375-1381.  ref [B,3,F,H,W] fp32, mask [B,1,F,H,W] fp32; dec fp32 -> fp32, or dec bf16 (a bf16 VAE module, the LongCat
+    entry's: the statements then run in bf16, LongCat SCHED:1152-1164) -> bf16."""
     ref, mask, dec = _dev(ref), _dev(mask), _dev(dec)
-    assert ref.dtype == mask.dtype == dec.dtype == torch.float32
+    assert ref.dtype == mask.dtype == torch.float32 and dec.dtype in (torch.float32, torch.bfloat16)
     assert ref.shape == dec.shape and mask.shape[1] == 1 and mask.shape[2:] == dec.shape[2:]
     B, C = dec.shape[0], dec.shape[1]
     inner = dec.numel() // (B * C)
     out = torch.empty_like(dec)
+    if dec.dtype == torch.bfloat16:
+        call("wf_blend_pixels_bf16", ref.data_ptr(), mask.data_ptr(), dec.data_ptr(), out.data_ptr(), B, C, inner, stream())
+        return out
     call("wf_blend_pixels", ref.data_ptr(), mask.data_ptr(), dec.data_ptr(), out.data_ptr(), B, C, inner, stream())
     return out
 
 
 def postprocess_video(x: torch.Tensor) -> torch.Tensor:
-    """PIPE:744: [C,F,H,W] in [-1,1] -> [F,H,W,C] in [0,1]."""
+    """PIPE:744: [C,F,H,W] in [-1,1] -> [F,H,W,C] in [0,1] (fp32; a bf16 video is processed in bf16 and converted, as diffusers does)."""
     x = _dev(x)
-    assert x.dtype == torch.float32 and x.dim() == 4
+    assert x.dtype in (torch.float32, torch.bfloat16) and x.dim() == 4
     C, F, H, W = x.shape
     out = torch.empty((F, H, W, C), dtype=torch.float32, device=x.device)
+    if x.dtype == torch.bfloat16:
+        call("wf_postprocess_video_bf16", x.data_ptr(), out.data_ptr(), C, F, H, W, stream())
+        return out
     call("wf_postprocess_video", x.data_ptr(), out.data_ptr(), C, F, H, W, stream())
     return out
 

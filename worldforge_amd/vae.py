@@ -26,6 +26,13 @@ precision (the reference loads the VAE with torch_dtype=torch.float32, INFER:185
              figure, is the claim.  fp16 cannot hold |x| > 65504: the producers raise a device flag; it is copied to the host
              asynchronously and turned into a RuntimeError at the next check point (check_range; never a silent inf) -- such weights
              need "bf16x3".
+  "fp16"  -- round 6 (alias "tf32"): ONE fp16 term per operand (hi = fp16(x): 10 explicit mantissa bits, fp32 accumulation) on the same
+             *_f16 kernels with the same power-of-two weight scale and range flag -- the multiplicand width of a TF32 convolution, which
+             is what an fp32 `conv3d` executes under PyTorch's defaults on the reference's stack (torch.backends.cudnn.allow_tf32 = True;
+             the LongCat entry sets it explicitly, run_longcat_worldforge_single.py:144-146).  One third of "fp16x3"'s matrix work.  The
+             tensors between layers stay f32 (residual stream, norm inputs, attention scores and probabilities), as in the three-term
+             modes.  Opt-in for the Wan path (the headline keeps "fp16x3": BASELINE.md states an fp32 VAE and the parity target is the
+             CPU eager path).
   "bf16x3" -- the default of rounds 2-3.  fp32-CLASS contractions on the bf16 matrix cores, NOT IEEE fp32: every operand x is carried as hi = bf16(x),
              lo = bf16(x - hi) and every contraction as hi.hi + lo.hi + hi.lo in fp32 accumulators (wf_split_bf16x3: activations
              [hi | lo | hi], weights [hi | hi | lo] on 3x the channels, the SAME conv / GEMM kernels; the dropped lo.lo term and the
@@ -190,14 +197,28 @@ class AutoencoderKLWan:
 
     ATTN_BATCH_BYTES = 6 << 30   # split operands of the mid-block attention's batched P . V launch kept at a time (_attn_x3)
 
-    def __init__(self, device="cuda:0", comm=None, precision: str = "fp16x3"):
+    def __init__(self, device="cuda:0", comm=None, precision: str = "fp16x3", dtype: torch.dtype = torch.float32):
+        """dtype: the MODULE dtype the protocol shows (`vae.dtype`, what `from_pretrained(torch_dtype=...)` sets): torch.float32 for the
+        Wan entry (INFER:185-189), torch.bfloat16 for the LongCat entry (run_longcat_worldforge_single.py:205).  A bf16 module takes bf16
+        inputs (others are rounded to bf16 on the way in, the `.to(dtype=vae.dtype)` of LongCat's fuse_latents) and returns bf16 videos /
+        moments; in between, this implementation keeps its f32 stream with `precision` operands -- closer to the fp32 network than the
+        eager bf16 module, whose every activation is bf16 (tests/golden/g8c)."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError(f"dtype must be torch.float32 or torch.bfloat16, got {dtype}")
+        self.dtype = dtype
         if precision == "fp32":  # the fp32-CLASS mode of the round: three-term split operands, fp16 parts since round 4
             precision = "fp16x3"
-        if precision not in ("bf16", "bf16x3", "fp16x3"):
-            raise ValueError(f"precision must be 'fp16x3' (alias 'fp32'), 'bf16x3' or 'bf16', got {precision!r}")
+        if precision == "tf32":  # what the mode stands for: the multiplicand width of a TF32 convolution
+            precision = "fp16"
+        if precision not in ("bf16", "bf16x3", "fp16x3", "fp16"):
+            raise ValueError(f"precision must be 'fp16x3' (alias 'fp32'), 'bf16x3', 'fp16' (alias 'tf32') or 'bf16', got {precision!r}")
         self.precision = precision
         self.x3 = precision in ("bf16x3", "fp16x3")  # three-term split operands
-        self.f16 = precision == "fp16x3"               # ... whose parts are fp16 (v_mfma_f32_32x32x16_f16) instead of bf16
+        self.f16 = precision in ("fp16x3", "fp16")     # operand parts are fp16 (v_mfma_f32_32x32x16_f16) instead of bf16
+        # `wide`: every tensor BETWEEN two layers is f32 and the 16-bit operand is made by a producer that checks the fp16 range (the
+        # three-term modes, and the one-term fp16 mode); only "bf16" takes the 16-bit output copies of the conv / GEMM epilogues
+        self.wide = self.x3 or self.f16
+        self.terms = 3 if self.x3 else 1
         self.OP = torch.float16 if self.f16 else BF    # element type of every matrix-core operand tensor
         self._sfx = "_f16" if self.f16 else ""         # the C-ABI entry points of that element type
         self.device = torch.device(device)
@@ -221,7 +242,7 @@ class AutoencoderKLWan:
 
         def operand(w, key):  # f32 [..., Cin] (host) -> the matrix-core weight operand on the device
             w = w.to(F32)
-            if not x3:
+            if not self.wide:
                 return w.to(device=dev, dtype=BF).contiguous()
             if self.f16:
                 # hi = fp16(w), lo = fp16(w - hi): lo is an fp16 SUBNORMAL (absolute floor 2^-25) for |w| < 2^-3 -- VAE weights are ~0.02, so the
@@ -237,6 +258,8 @@ class AutoencoderKLWan:
                     w = w * (2.0 ** k)
                     W[key + ".scale"] = 2.0 ** -k
             hi = w.to(self.OP)
+            if not x3:   # "fp16": the one-term operand (the scaled weight can no longer leave the fp16 range)
+                return hi.to(dev).contiguous()
             lo = (w - hi.to(F32)).to(self.OP)
             return torch.cat([hi, hi, lo], dim=-1).to(dev).contiguous()  # weight side of wf_split_bf16x3 / wf_split_f16x3
 
@@ -335,12 +358,13 @@ class AutoencoderKLWan:
         return self.load_state_dict(diffusers_to_twin_state_dict(sd))
 
     @classmethod
-    def from_pretrained(cls, path: str, device="cuda:0", comm=None, precision: str = "fp16x3", subfolder: str = "vae"):
+    def from_pretrained(cls, path: str, device="cuda:0", comm=None, precision: str = "fp16x3", subfolder: str = "vae",
+                        torch_dtype: torch.dtype = torch.float32):
         """`AutoencoderKLWan.from_pretrained(model_id, subfolder="vae", torch_dtype=torch.float32)` (INFER:185-189) from a local
         diffusers checkpoint directory: reads `<path>/<subfolder>/*.safetensors` (sharded or not) with checkpoint.load_dir."""
         from . import checkpoint
         folder = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
-        return cls(device, comm=comm, precision=precision).load_diffusers_state_dict(checkpoint.load_dir(folder))
+        return cls(device, comm=comm, precision=precision, dtype=torch_dtype).load_diffusers_state_dict(checkpoint.load_dir(folder))
 
     def init_random(self, seed: int = 0):
         """Synthetic weights of the real shapes, generated on the host in twin layout (127 M parameters)."""
@@ -468,15 +492,15 @@ class AutoencoderKLWan:
             out = torch.empty(tuple(x.shape[:-1]) + (3 * C,), dtype=self.OP, device=x.device)
             call("wf_rms_silu_cl_x3" + self._sfx, x.data_ptr(), gamma.data_ptr(), out.data_ptr(), x.numel() // C, C, 1 if silu else 0, ops.stream())
             return out
-        out = torch.empty(x.shape, dtype=BF, device=x.device)
-        call("wf_rms_silu_cl", x.data_ptr(), gamma.data_ptr(), out.data_ptr(), None, x.numel() // C, C, 1 if silu else 0,
+        out = torch.empty(x.shape, dtype=self.OP, device=x.device)
+        call("wf_rms_silu_cl" + self._sfx, x.data_ptr(), gamma.data_ptr(), out.data_ptr(), None, x.numel() // C, C, 1 if silu else 0,
              ops.stream())
         return out
 
     def _operand(self, x, side=0, out=None):
         """f32 [..., C] -> the matrix-core operand: bf16 [..., C], or the three-term split [..., 3C] (precision="fp32"; side 0 =
         activation, 1 = weight-side layout).  `out`: a contiguous destination of the operand's shape."""
-        if not self.x3:
+        if not self.wide:
             y = ops.cast(x, BF)
             if out is not None:
                 out.copy_(y)
@@ -489,9 +513,13 @@ class AutoencoderKLWan:
             x2 = x.view(-1, C)
         else:
             x2 = x
+        n = self.terms
         if out is None:
-            out = torch.empty(tuple(x.shape[:-1]) + (3 * C,), dtype=self.OP, device=x.device)
-        assert out.is_contiguous() and out.numel() == 3 * x2.shape[0] * C and out.dtype == self.OP
+            out = torch.empty(tuple(x.shape[:-1]) + (n * C,), dtype=self.OP, device=x.device)
+        assert out.is_contiguous() and out.numel() == n * x2.shape[0] * C and out.dtype == self.OP
+        if not self.x3:   # "fp16": hi alone
+            call("wf_cast_f16", x2.data_ptr(), x2.stride(0), out.data_ptr(), C, x2.shape[0], C, ops.stream())
+            return out
         call("wf_split_f16x3" if self.f16 else "wf_split_bf16x3", x2.data_ptr(), x2.stride(0), out.data_ptr(), 3 * C, x2.shape[0], C, side, ops.stream())
         return out
 
@@ -578,14 +606,14 @@ class AutoencoderKLWan:
         hw = H * Wd
         # K / N padding for the MFMA GEMMs; padded score columns are never read by the softmax and are written as zero probabilities.  The
         # fp32-class path pads to 64 so that the batched P . V products (K = 3 hwp) qualify for the ping-pong GEMM (whole 64-wide K tiles)
-        hwp = (hw + 63) // 64 * 64 if self.x3 else (hw + 7) // 8 * 8
+        hwp = (hw + 63) // 64 * 64 if self.wide else (hw + 7) // 8 * 8
         W = self.w
         a = self._rms(x, W[p + ".norm.gamma"], silu=False)
         q0, q1 = (0, hw) if rows is None else (rows[0] * Wd, rows[1] * Wd)
         nq = q1 - q0
         if rows is not None:
             x = x[:, rows[0]:rows[1]].contiguous()
-        if self.x3:
+        if self.wide:
             return self._attn_x3(x, p, a, hw, hwp, q0, nq)
         qkv = torch.empty((T * hw + 8, 3 * C), dtype=BF, device=x.device)  # +8 rows: the padded K rows stay in-bounds
         qkv[T * hw:].zero_()
@@ -608,11 +636,13 @@ class AutoencoderKLWan:
 
     def _attn_x3(self, x, p, a, hw, hwp, q0, nq):
         """_attn with fp32-class contractions: q / k / v, the scores and the probabilities stay f32 and are split per use.  x: the rows that
-        are updated ([T, rows, W, C]: the whole frames, or the query-row slab); a: the normalised WHOLE frames."""
+        are updated ([T, rows, W, C]: the whole frames, or the query-row slab); a: the normalised WHOLE frames.  Also the one-term fp16
+        mode (n = 1 operand term instead of 3): the f32 tensors between the products are the same, each operand is hi alone."""
         T, C = x.shape[0], x.shape[-1]
         W = self.w
+        n3 = self.terms
         qkv = torch.zeros((T * hw + 64, 3 * C), dtype=F32, device=x.device)  # + 64 rows: the last frame's padded K rows stay in-bounds
-        self._gemm(a.view(-1, 3 * C), W[p + ".to_qkv.w"], W[p + ".to_qkv.b"], qkv[:T * hw], EPI_F32, wkey=p + ".to_qkv.w")
+        self._gemm(a.view(-1, n3 * C), W[p + ".to_qkv.w"], W[p + ".to_qkv.b"], qkv[:T * hw], EPI_F32, wkey=p + ".to_qkv.w")
         del a
         S = torch.empty((nq, hwp), dtype=F32, device=x.device)
         P = torch.empty((nq, hwp), dtype=F32, device=x.device)
@@ -624,10 +654,10 @@ class AutoencoderKLWan:
         # their products run as ONE batched launch; per frame the arithmetic is that of the single call (same kernel, same tiles).  The chunk
         # is bounded by a byte budget (ATTN_BATCH_BYTES: 4.9 GB at 480p = all 21 frames in one launch; 720p on one GPU = 26 GB unchunked,
         # ADVICE r4): whole frames while they fit, never fewer than one.
-        per_frame = (nq + C) * 3 * hwp * 2
+        per_frame = (nq + C) * n3 * hwp * 2
         tb = max(1, min(T, self.ATTN_BATCH_BYTES // per_frame))
-        P3 = torch.empty((tb, nq, 3 * hwp), dtype=self.OP, device=x.device)
-        V3 = torch.empty((tb, C, 3 * hwp), dtype=self.OP, device=x.device)
+        P3 = torch.empty((tb, nq, n3 * hwp), dtype=self.OP, device=x.device)
+        V3 = torch.empty((tb, C, n3 * hwp), dtype=self.OP, device=x.device)
         for t0 in range(0, T, tb):
             n = min(tb, T - t0)
             for t in range(t0, t0 + n):
@@ -638,10 +668,10 @@ class AutoencoderKLWan:
                 self._operand(P, 0, out=P3[t - t0])
                 self._operand(Vt, 1, out=V3[t - t0])
             call("wf_gemm_f16_batched" if self.f16 else "wf_gemm_bf16_batched", P3.data_ptr(), V3.data_ptr(), Of[t0 * nq:].data_ptr(), n, nq, C,
-                 3 * hwp, 3 * hwp, 3 * hwp, C, nq * 3 * hwp, C * 3 * hwp, nq * C, EPI_F32, ops.stream())
+                 n3 * hwp, n3 * hwp, n3 * hwp, C, nq * n3 * hwp, C * n3 * hwp, nq * C, EPI_F32, ops.stream())
         del P3, V3
         self._gemm(self._operand(Of), W[p + ".proj.w"], W[p + ".proj.b"], x.view(-1, C), EPI_F32_ACC, wkey=p + ".proj.w")
-        self.flops_last += 3 * (T * (4 * nq * hw * C) + 2 * T * hw * C * 3 * C + 2 * T * nq * C * C)
+        self.flops_last += n3 * (T * (4 * nq * hw * C) + 2 * T * hw * C * 3 * C + 2 * T * nq * C * C)
         return x
 
     def _down(self, x, p, C, temporal):
@@ -652,9 +682,9 @@ class AutoencoderKLWan:
         if not temporal or T == 1:
             y, _ = self._conv(xb, p + ".resample.1", T, Ho, Wo, C, (1, 3, 3), ss=2, ps=0)
             return y
-        y, yb = self._conv(xb, p + ".resample.1", T, Ho, Wo, C, (1, 3, 3), ss=2, ps=0, out_f32=True, out_bf16=not self.x3)
+        y, yb = self._conv(xb, p + ".resample.1", T, Ho, Wo, C, (1, 3, 3), ss=2, ps=0, out_f32=True, out_bf16=not self.wide)
         del xb
-        if self.x3:
+        if self.wide:
             yb = self._operand(y)
         To = (T - 1) // 2
         out = torch.empty((1 + To, Ho, Wo, C), dtype=F32, device=x.device)
@@ -842,7 +872,7 @@ class AutoencoderKLWan:
             return xb
         W = self.w
         self.flops_last += 2 * (T - 1) * H * Wd * 2 * C * 3 * Cop
-        if self.x3:
+        if self.wide:
             yf = torch.empty((1 + 2 * (T - 1), H, Wd, C), dtype=F32, device=xb.device)  # frame 0 is not written (tsplit: 1 + 2t + h)
             call("wf_conv3d_cl" + self._sfx, xb[1:].data_ptr(), W[p + ".time_conv.w"].data_ptr(), W[p + ".time_conv.b"].data_ptr(), None,
                  yf.data_ptr(), None, T - 1, H, Wd, Cop, T - 1, H, Wd, 2 * C, 3, 1, 1, 1, 1, 2, 0, 0, 0, 1, None, *self._acc_scale(p + ".time_conv.w"), ops.stream())
@@ -884,8 +914,8 @@ class AutoencoderKLWan:
         if not temporal or T == 1:
             y, _ = self._conv(xpad, p + ".resample.1", T, Ho, Wo, C, (1, 3, 3), ss=2, ps=0, ph=-1)
             return y
-        y, yb = self._conv(xpad, p + ".resample.1", T, Ho, Wo, C, (1, 3, 3), ss=2, ps=0, ph=-1, out_f32=True, out_bf16=not self.x3)
-        if self.x3:
+        y, yb = self._conv(xpad, p + ".resample.1", T, Ho, Wo, C, (1, 3, 3), ss=2, ps=0, ph=-1, out_f32=True, out_bf16=not self.wide)
+        if self.wide:
             yb = self._operand(y)
         To = (T - 1) // 2
         out = torch.empty((1 + To, Ho, Wo, C), dtype=F32, device=x.device)
@@ -1016,6 +1046,10 @@ class AutoencoderKLWan:
     def _video_in(self, video):
         """[3,F,H,W] f32 -> channels-last conv operand [F,H,W,32 (x3)]: 3 channels zero-padded to one MFMA K slice."""
         C, Fr, H, Wd = video.shape
+        if self.f16 and not self.x3:   # one-term fp16: the converting layout kernel raises the range flag itself
+            x = torch.empty((Fr, H, Wd, 32), dtype=self.OP, device=self.device)
+            call("wf_ncthw_to_cl_f16", video.data_ptr(), None, x.data_ptr(), 3, 32, Fr * H * Wd, ops.stream())
+            return x
         if self.x3:
             xf = torch.empty((Fr, H, Wd, 32), dtype=F32, device=self.device)
             call("wf_ncthw_to_cl", video.data_ptr(), xf.data_ptr(), None, 3, 32, Fr * H * Wd, ops.stream())
@@ -1026,7 +1060,7 @@ class AutoencoderKLWan:
 
     def _latent_in(self, x, T, h, w):
         """post-quant conv2 (vae.py:558) on the channels-last latent -> conv operand [T,h,w,32 (x3)] (16 channels + 16 zero channels)."""
-        if self.x3:
+        if self.wide:
             return self._operand(self._small_conv(x, "conv2", T, h, w, 32, (1, 1, 1), out_dtype=F32))
         return self._small_conv(x, "conv2", T, h, w, 32, (1, 1, 1), out_dtype=BF)
 
@@ -1087,23 +1121,35 @@ class AutoencoderKLWan:
         One GPU: exactly decode(), ops.blend_pixels(), encode().  Row-sharded (comm): the decoded video is NOT gathered -- the blend is
         element-wise per pixel, so each rank blends and re-encodes its own row slab (the encoder's first halo comes from the neighbours);
         only latent-resolution tensors are gathered.  Bit-identical to the gathered form."""
-        z = z.to(device=self.device, dtype=F32).contiguous()
+        z = self._io_in(z)
         if z.shape[0] != 1 or not self.can_shard(z.shape[3]):
             dec = self.decode(z, return_dict=False)[0]
             return self.encode(ops.blend_pixels(ref, mask, dec)).latent_dist
         self.flops_last = 0
-        slab = self._decode_one_sharded(z[0], gather=False)               # [3, F, Hs, W]
+        slab = self._io_out(self._decode_one_sharded(z[0], gather=False))  # [3, F, Hs, W] in the module dtype
         Hs = slab.shape[2]
         y0 = self.comm.rank * Hs
         fused = ops.blend_pixels(self._row_slab_of(ref, y0, Hs), self._row_slab_of(mask, y0, Hs), slab.unsqueeze(0))
-        mom = self._encode_one_sharded(None, slab=fused[0]).unsqueeze(0)
+        mom = self._io_out(self._encode_one_sharded(None, slab=self._io_in(fused)[0]).unsqueeze(0))
         self._note_range("decode_blend_encode")
         return _LatentDist(mom[:, :Z_DIM].contiguous(), mom[:, Z_DIM:])
 
+    def _io_in(self, x: torch.Tensor) -> torch.Tensor:
+        """A tensor entering the module: on the device, holding values of the module dtype (rounded to bf16 for a bf16 module: the
+        reference's `.to(dtype=vae.dtype)`), as the contiguous f32 the kernels read."""
+        x = x.to(self.device)
+        if self.dtype == torch.bfloat16 and x.dtype != torch.bfloat16:
+            x = ops.cast(x.contiguous(), torch.bfloat16)
+        return x.contiguous() if x.dtype == F32 else ops.cast(x.contiguous(), F32)
+
+    def _io_out(self, y: torch.Tensor) -> torch.Tensor:
+        """A result leaving the module: in the module dtype."""
+        return y if self.dtype == F32 else ops.cast(y.contiguous(), self.dtype)
+
     @torch.no_grad()
     def encode(self, x: torch.Tensor, return_dict: bool = True):
-        x = x.to(device=self.device, dtype=F32).contiguous()
-        moments = torch.stack([self._encode_one(v) for v in x])
+        x = self._io_in(x)
+        moments = self._io_out(torch.stack([self._encode_one(v) for v in x]))
         self._note_range("encode")
         post = _LatentDist(moments[:, :Z_DIM].contiguous(), moments[:, Z_DIM:])
         if not return_dict:
@@ -1112,8 +1158,8 @@ class AutoencoderKLWan:
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True):
-        z = z.to(device=self.device, dtype=F32).contiguous()
-        out = torch.stack([self._decode_one(v) for v in z])
+        z = self._io_in(z)
+        out = self._io_out(torch.stack([self._decode_one(v) for v in z]))
         self._note_range("decode")
         if not return_dict:
             return (out,)
