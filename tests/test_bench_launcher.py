@@ -61,7 +61,7 @@ def test_main_becomes_launcher_before_any_gpu_call(monkeypatch):
 
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     seen = {}
-    monkeypatch.setattr(bench, "launch_ranks", lambda n, argv, script=None: seen.update(n=n, argv=list(argv)) or 0)
+    monkeypatch.setattr(bench, "launch_ranks", lambda n, argv, script=None, budget_s=None: seen.update(n=n, argv=list(argv)) or 0)
 
     def boom(*a, **k):
         raise AssertionError("the launcher parent touched the GPU")
@@ -71,6 +71,110 @@ def test_main_becomes_launcher_before_any_gpu_call(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main(["--gpus", "2", "--steps", "2", "--layers", "2"])
     assert e.value.code == 0 and seen == {"n": 2, "argv": ["--gpus", "2", "--steps", "2", "--layers", "2"]}
+
+
+# ---- the supervised two-attempt launch: a failed or hung first attempt ends in ONE conservative relaunch in fresh processes
+_RANK_PROBE = """
+    import json, os, sys, time
+    sys.path.insert(0, %(root)r)
+    import torch
+    import bench
+    from worldforge_amd import parallel
+    bench.claim_stdout()
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    attempt = int(os.environ["WF_BENCH_ATTEMPT"])
+    conservative = "--conservative" in sys.argv
+    assert (attempt == 2) == conservative and (("--exchange" in sys.argv) == conservative)
+    comm = parallel.init(world, rank, 0)                       # gloo, through the supervisor's store behind the attempt's prefix
+    comm.halo_whole_job = conservative
+    groups = comm.prepare(cfg_groups=0 if conservative else 2, halo_distances=() if conservative else parallel.halo_distances(world))
+    inject = os.environ.get("WF_TEST_INJECT", "")
+    if attempt == 1 and inject == "fail" and rank == 2:
+        print("rank 2: injected RCCL refusal", file=sys.stderr, flush=True)
+        sys.exit(3)
+    if attempt == 1 and inject == "hang" and rank == 1:
+        print("rank 1: injected hang", file=sys.stderr, flush=True)
+        time.sleep(600)
+    # a halo exchange and a job all-gather through the prepared groups
+    top, bottom = torch.full((3,), float(rank)), torch.full((3,), float(rank) + 0.5)
+    up, down = comm.neighbor_rows(top, bottom, 1)
+    assert (up is None) == (rank == 0) and (down is None) == (rank == world - 1)
+    assert up is None or float(up[0]) == rank - 1 + 0.5
+    assert down is None or float(down[0]) == rank + 1
+    up2, down2 = comm.neighbor_rows(top, bottom, 2)
+    assert (up2 is None) == (rank < 2) and (up2 is None or float(up2[0]) == rank - 2 + 0.5)
+    out = torch.empty((world, 1))
+    comm.all_gather(out, torch.tensor([float(rank)]))
+    comm.barrier()
+    if rank == 0:
+        bench.emit_json({"metric": "probe", "value": float(out.sum()), "attempt": attempt, "groups": len(groups),
+                         "kinds": sorted({k for k, _ in groups}), "collectives_used": sorted(comm.used), "rccl": parallel.rccl_info()})
+    bench.shutdown_comm()
+"""
+
+
+def _run_supervised(tmp_path, monkeypatch, inject, budget_s):
+    monkeypatch.setenv("WF_SHARE_GPU", "1")
+    monkeypatch.setenv("WF_COMM_BACKEND", "gloo")
+    monkeypatch.setenv("WF_TEST_INJECT", inject)
+    script = _probe(tmp_path, _RANK_PROBE % {"root": ROOT})
+    code = ("import sys; sys.path.insert(0, %r); import bench; sys.exit(bench.launch_ranks(4, ['--gpus', '4'], script=%r, budget_s=%r))"
+            % (ROOT, script, budget_s))
+    return subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+
+
+def test_supervisor_clean_first_attempt_prints_one_line_without_fallback(tmp_path, monkeypatch):
+    r = _run_supervised(tmp_path, monkeypatch, "", 300.0)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [x for x in r.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] == 6.0 and d["attempt"] == 1 and "fallback" not in d
+    # world + 2 CFG groups + pair groups at distances 1 and 2 of 4 ranks (3 + 2), every one created in Comm.prepare
+    assert d["groups"] == 1 + 2 + 3 + 2 and d["kinds"] == ["cfg", "halo1", "halo2", "world"]
+    assert d["collectives_used"] == ["all_gather", "barrier"] and d["rccl"]["world"] == 4 and d["rccl"]["backend"] == "gloo"
+
+
+@pytest.mark.parametrize("inject,budget_s,reason", [("fail", 300.0, "rank 2 exited with code 3"), ("hang", 25.0, "wall budget of 25 s exceeded")])
+def test_supervisor_relaunches_conservatively_after_a_failure_or_a_hang(tmp_path, monkeypatch, inject, budget_s, reason):
+    """World-4 gloo ranks through the real launcher: attempt 1 loses rank 2 (non-zero exit) or hangs on rank 1 until the wall budget;
+    every rank of it is stopped, and attempt 2 runs in fresh processes with `--exchange gather --conservative` (no process group beyond
+    the job's own: the halo rows travel by the whole-job all-gather) and labels its line."""
+    r = _run_supervised(tmp_path, monkeypatch, inject, budget_s)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [x for x in r.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, r.stdout                      # attempt 1 never reaches stdout
+    d = json.loads(lines[0])
+    assert d["fallback"] is True and d["attempt"] == 2 and d["value"] == 6.0
+    assert reason in d["first_attempt"]["reason"]
+    assert any("injected" in ln for ln in d["first_attempt"]["stderr_tail"])
+    assert d["groups"] == 1 and d["kinds"] == ["world"]    # conservative: nothing but the job's own communicator
+    assert "ONE relaunch in fresh processes" in r.stderr
+
+
+def test_supervisor_under_torch_distributed_run(tmp_path, monkeypatch):
+    """The driver's N > 1 command starts the ranks with torch.distributed.run: each of its workers then supervises the real rank as a
+    child and the supervisors agree through the launcher's own store (bench.supervise_under_launcher)."""
+    monkeypatch.setenv("WF_SHARE_GPU", "1")
+    monkeypatch.setenv("WF_COMM_BACKEND", "gloo")
+    monkeypatch.setenv("WF_TEST_INJECT", "fail")
+    body = ("import os, sys\nsys.path.insert(0, %r)\nif not os.environ.get('WF_BENCH_CHILD'):\n    import bench\n"
+            "    sys.exit(bench.supervise_under_launcher(sys.argv[1:], script=os.path.abspath(__file__), budget_s=300.0))\n" % ROOT
+            + textwrap.dedent(_RANK_PROBE % {"root": ROOT}))
+    p = tmp_path / "probe_tr.py"
+    p.write_text(body)
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(p), "--gpus", "4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [x for x in r.stdout.splitlines() if x.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["fallback"] is True and d["attempt"] == 2 and d["value"] == 6.0 and "rank 2 exited with code 3" in d["first_attempt"]["reason"]
 
 
 def test_world_size_must_match_gpus(monkeypatch):

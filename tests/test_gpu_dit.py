@@ -542,6 +542,24 @@ def test_context_kv_cache_is_transparent(monkeypatch):
     ref_c = m.forward_tokens(x, 500.0, ca, clip)
     assert not torch.equal(ref_c, ref_a)
     assert torch.equal(got_c, ref_c)
+    # weights: a reload (new dict) and a DECLARED in-place edit both start a new weights version -- never id() of a dict (the
+    # address of a freed dict can be reused, and the prompt tensors the cache keeps alive would then hit K / V of the old weights)
+    monkeypatch.delenv("WF_CTX_CACHE")
+    before = m.forward_tokens(x, 500.0, cb, clip).clone()
+    assert len(m._ctx_cache) >= 1
+    v0 = m._wver
+    m.init_random(6)
+    assert m._wver == v0 + 1 and not hasattr(m, "_ctx_cache")
+    after = m.forward_tokens(x, 500.0, cb, clip).clone()
+    monkeypatch.setenv("WF_CTX_CACHE", "0")
+    assert torch.equal(after, m.forward_tokens(x, 500.0, cb, clip)) and not torch.equal(after, before)
+    monkeypatch.delenv("WF_CTX_CACHE")
+    key = next(k for k in m.w if k.endswith("cross_attn.kv.w"))     # the prompt-context K / V projection: what the cache holds
+    m.w[key].mul_(0.5)                    # e.g. a LoRA folded into the same tensor
+    m.weights_changed()
+    edited = m.forward_tokens(x, 500.0, cb, clip).clone()
+    monkeypatch.setenv("WF_CTX_CACHE", "0")
+    assert torch.equal(edited, m.forward_tokens(x, 500.0, cb, clip)) and not torch.equal(edited, after)
 
 
 def test_diffusers_layout_transformer_checkpoint_loads(tmp_path):

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
     dict(dim=1024, ffn_dim=2048, heads=8, layers=4, Fr=13, H=64, Wd=96, steps=5, guide=3),
     dict(dim=5120, ffn_dim=13824, heads=40, layers=2, Fr=9, H=64, Wd=96, steps=4, guide=3),   # the 14B width, two layers
     dict(dim=1024, ffn_dim=2048, heads=8, layers=4, Fr=13, H=64, Wd=96, steps=5, guide=3, vae_precision="bf16"),  # the opt-in fast VAE
+    dict(dim=1024, ffn_dim=2048, heads=8, layers=4, Fr=13, H=64, Wd=96, steps=5, guide=3, vae_precision="fp16"),  # one-term fp16 = TF32-class
 ])
 def test_guided_job_frames_psnr_vs_oracle(cfg):
     import __graft_entry__ as ge
@@ -28,6 +29,10 @@ def test_guided_job_frames_psnr_vs_oracle(cfg):
     # the 16 channels lie within bf16 noise of each other, so the (discrete) channel choice of product and oracle differs -- the same
     # chaos DESIGN.md section 4b documents for Wan; the Farneback gate itself is pinned in test_gpu_flow.py
     dict(hidden=4096, heads=32, depth=1, Fr=9, H=64, Wd=64, steps=4, guide=3, flow_backend="tdiff"),
+    # the VAE as the LongCat entry loads it (run_longcat_worldforge_single.py:205): a bf16 module, bf16 matrix operands -- the defaults of
+    # bench.py's LongCat windows since round 6
+    dict(hidden=256, heads=2, depth=2, Fr=9, H=32, Wd=32, steps=4, guide=3, vae_precision="bf16", vae_dtype="bf16"),
+    dict(hidden=1024, heads=8, depth=3, Fr=13, H=64, Wd=96, steps=5, guide=4, resample=3, vae_precision="bf16", vae_dtype="bf16"),
 ])
 def test_longcat_guided_job_frames_psnr_vs_oracle(cfg):
     """LongCat-Video config of SURVEY section 8f-1: Euler flow-match sampler + IRR / FLF / DSG / CFG-zero + LongCat DiT + VAE."""
@@ -37,10 +42,11 @@ def test_longcat_guided_job_frames_psnr_vs_oracle(cfg):
     assert psnr >= 40.0, (psnr, err)
 
 
-def test_longcat_refine_pass_frames_psnr_vs_oracle():
+@pytest.mark.parametrize("vae", [dict(), dict(vae_precision="bf16", vae_dtype="bf16")])
+def test_longcat_refine_pass_frames_psnr_vs_oracle(vae):
     """the 720p refine pass end to end (block-sparse DiT + VAE + up-sampling) against the CPU oracle, which makes
     its own block selection (bf16 gating): blocks at the top-k margin may differ, so the bar is the path's 40 dB, not bit parity."""
     import __graft_entry__ as ge
-    psnr, err = ge.longcat_refine_parity_run(hidden=256, heads=2, depth=2, F0=5, H0=48, W0=64, H=128, Wd=128, steps=6)
+    psnr, err = ge.longcat_refine_parity_run(hidden=256, heads=2, depth=2, F0=5, H0=48, W0=64, H=128, Wd=128, steps=6, **vae)
     print(f"LongCat refine PSNR {psnr:.1f} dB, max abs err {err:.4f}")
     assert psnr >= 40.0, (psnr, err)

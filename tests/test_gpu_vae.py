@@ -334,9 +334,11 @@ def test_f16_range_flag_is_raised_and_reported():
 
 
 def test_vae_decode_returns_while_the_gpu_is_still_busy(model_fp32):
-    """No host synchronisation inside encode / decode (round 5: the fp16 range flag is copied asynchronously and checked later): with
-    ~100 ms of GEMMs queued in front, decode() and encode() must come back to the host before the GPU has reached their work."""
+    """No host synchronisation inside a VAE call for ITS OWN work (the fp16 range flag is copied asynchronously): with ~100 ms of GEMMs
+    queued in front, decode() must come back to the host before the GPU has reached its work.  The NEXT VAE call is the deterministic
+    check point of that flag (never timing-dependent) -- it waits for the previous call, not for its own."""
     from worldforge_amd import dit
+    from worldforge_amd.vae import AutoencoderKLWan
     a = torch.randn(8192, 8192, device=DEV).to(torch.bfloat16)
     out = torch.empty(8192, 8192, dtype=torch.bfloat16, device=DEV)
     z = torch.randn(1, 16, 2, 8, 8, device=DEV)
@@ -349,11 +351,48 @@ def test_vae_decode_returns_while_the_gpu_is_still_busy(model_fp32):
         dit.gemm(a, a, None, out, dit.EPI_BF16)
     ev = torch.cuda.Event()
     model_fp32.decode(z, return_dict=False)
-    model_fp32.encode(video)
     ev.record()
-    assert not ev.query(), "encode / decode synchronised the host with the stream"
-    model_fp32.check_range()                         # the explicit check point does wait
-    assert ev.query()
+    assert not ev.query(), "decode synchronised the host with the stream"
+    ev2 = torch.cuda.Event()
+    model_fp32.encode(video)                         # starts by waiting for decode's flag ...
+    assert ev.query()                                # ... so decode has finished by the time encode's own work is queued
+    ev2.record()
+    model_fp32.check_range()                         # the explicit check point waits for the last call
+    assert ev2.query()
+    # strict_range=True: the check runs inside the call (one host synchronisation per call) -- for callers of the bare API
+    strict = AutoencoderKLWan(DEV, precision="fp32", strict_range=True)
+    strict.w = model_fp32.w
+    for _ in range(20):
+        dit.gemm(a, a, None, out, dit.EPI_BF16)
+    strict.decode(z, return_dict=False)
+    ev3 = torch.cuda.Event()
+    ev3.record()
+    assert ev3.query() and getattr(strict, "_flag_pending", None) is None
+
+
+def test_range_flag_of_a_vae_call_surfaces_at_the_next_call_deterministically(model_fp32):
+    """a call that overflowed fp16 must fail at the NEXT VAE call whatever the timing (round 5 checked only if the flag's copy
+    had already landed).  The overflow is injected through the producer the VAE itself uses."""
+    import ctypes
+    from worldforge_amd import _ffi, ops
+    flag = ctypes.c_int(0)
+    _ffi.call("wf_f16_overflow_flag", ctypes.byref(flag), 1, ops.stream())
+    z = torch.randn(1, 16, 2, 8, 8, device=DEV)
+    model_fp32.decode(z, return_dict=False)
+    model_fp32.check_range()
+    src = torch.full((4, 32), 7.0e4, device=DEV)
+    dst = torch.empty(4, 96, dtype=torch.float16, device=DEV)
+    a = torch.randn(8192, 8192, device=DEV).to(torch.bfloat16)
+    out = torch.empty(8192, 8192, dtype=torch.bfloat16, device=DEV)
+    from worldforge_amd import dit
+    for _ in range(50):                              # the copy of the flag sits behind ~50 ms of work: it has NOT landed when the next call starts
+        dit.gemm(a, a, None, out, dit.EPI_BF16)
+    _ffi.call("wf_split_f16x3", src.data_ptr(), 32, dst.data_ptr(), 96, 4, 32, 0, ops.stream())
+    model_fp32._note_range("decode")                 # what the overflowing call ends with
+    with pytest.raises(RuntimeError, match="AutoencoderKLWan.decode"):
+        model_fp32.encode(torch.rand(1, 3, 5, 64, 64, device=DEV) * 2 - 1)
+    _ffi.call("wf_f16_overflow_flag", ctypes.byref(flag), 1, ops.stream())
+    model_fp32.check_range()
 
 
 @pytest.mark.parametrize("side", [0, 1])

@@ -322,6 +322,23 @@ class WanTransformer3DModel:
     # ------------------------------------------------------------------------------------------------------------
     # weights
     # ------------------------------------------------------------------------------------------------------------
+    @property
+    def w(self) -> Dict[str, torch.Tensor]:
+        return self._w
+
+    @w.setter
+    def w(self, W: Dict[str, torch.Tensor]):
+        """Every assignment of the weight dict (load_state_dict, init_random, sharing another instance's weights) starts a new weights
+        version and drops what was derived from the old one (the prompt-context K / V cache)."""
+        self._w = W
+        self.weights_changed()
+
+    def weights_changed(self):
+        """Call after editing weight tensors IN PLACE (e.g. folding a LoRA into the same tensors): the prompt-context K / V cache is keyed by
+        a monotonically increasing weights version, never by id() of a dict that may have been freed and its address reused."""
+        self._wver = getattr(self, "_wver", 0) + 1
+        self.__dict__.pop("_ctx_cache", None)
+
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         """Twin-keyed state dict (any dtype / device) -> device tensors: matrices bf16, vectors fp32, q/k/v fused."""
         cfg, dev = self.cfg, self.device
@@ -481,13 +498,14 @@ class WanTransformer3DModel:
         K / V of the prompt context depend on the prompt only -- not on the latents, the timestep or the step -- so the 130 forwards of a
         video compute them once per prompt (the reference recomputes them in every forward, model.py:215-218; the values are the same
         kernels on the same inputs: bit-identical, tests/test_gpu_dit.py).  Keyed by the identity AND version of the embedding storages
-        and of the weight dict, so an in-place edit of the embeddings or a weight reload starts a fresh entry; at most 4 contexts are kept
+        and by the weights version (`w` setter / weights_changed()), so an in-place edit of the embeddings, a weight reload or a declared
+        in-place weight edit starts a fresh entry; at most 4 contexts are kept
         (positive / negative prompt of the last two videos; 17 MB per layer each).  On by default since round 5 (+0.8 % steps/s at the
         81-frame 480p configuration; bench.py states it in `config.ctx_cache`); WF_CTX_CACHE=0 recomputes per forward -- the reference
         arm of the bit-equality test."""
         if os.environ.get("WF_CTX_CACHE", "1") == "0":
             return None
-        key = (text.data_ptr(), text._version, tuple(text.shape), img.data_ptr(), img._version, tuple(img.shape), id(self.w), self.cfg.num_layers, id(self.comm))
+        key = (text.data_ptr(), text._version, tuple(text.shape), img.data_ptr(), img._version, tuple(img.shape), self._wver, self.cfg.num_layers, id(self.comm))
         cache = self.__dict__.setdefault("_ctx_cache", {})
         hit = cache.get(key)
         if hit is None:

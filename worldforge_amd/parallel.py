@@ -57,22 +57,66 @@ class Comm:
         self.world, self.rank, self.group = world, rank, group
         self.ranks = list(ranks) if ranks is not None else list(range(world))  # global ranks of the group's members (dist.broadcast takes a GLOBAL src)
         self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self.used = set()            # names of the collectives issued through this communicator (bench.py reports them)
+        self.halo_whole_job = False  # conservative mode: neighbor_rows by ONE all-gather over this communicator, no two-rank groups
+        self._subs = {}              # split() results, by number of groups
+
+    def prepare(self, cfg_groups: int = 0, halo_distances=()):
+        """Create EVERY process group the job will use, in one place and in a fixed order, before anything is timed -- the CFG sub-groups
+        (`cfg_groups` = 2 for the two CFG branches) and the two-rank halo groups of the row-sharded VAE for every distance in
+        `halo_distances` -- and push one 4-byte all-gather through each of them (and through this communicator), so that RCCL's communicator
+        set-up (an eager, job-collective ncclCommSplit when the process group was created with `device_id`) happens here and not inside the
+        first guided warm-up step or a timed region (VERDICT r5 #2a).  Collective over the whole job: every rank calls it with the same
+        arguments.  -> the groups created, as [(kind, ranks)]."""
+        assert self.group is None, "prepare() is for the job's own communicator"
+        made = [("world", list(self.ranks))]
+        dev = torch.device("cuda", torch.cuda.current_device()) if (torch.cuda.is_available() and dist.get_backend() != "gloo") else torch.device("cpu")
+
+        def touch(group, n):
+            out = torch.zeros(n, dtype=torch.int32, device=dev)
+            mine = torch.ones(1, dtype=torch.int32, device=dev)
+            if dist.get_backend(group) == "gloo":
+                dist.all_gather([out[i:i + 1] for i in range(n)], mine, group=group)
+            else:
+                dist.all_gather_into_tensor(out, mine, group=group)
+            assert int(out.sum()) == n
+
+        touch(None, self.world)
+        if cfg_groups and cfg_groups > 1 and self.world % cfg_groups == 0:
+            sub = self.split(cfg_groups)
+            per = self.world // cfg_groups
+            made += [("cfg", list(range(g * per, (g + 1) * per))) for g in range(cfg_groups)]
+            if sub.world > 1:   # (torch refuses collectives on a group this rank is not in: each rank touches its own)
+                touch(sub.group, sub.world)
+        for d in sorted({int(d) for d in halo_distances if 0 < int(d) < self.world}):
+            groups = self._pair_groups(d)
+            for lo, g in enumerate(groups):
+                made.append((f"halo{d}", [self.ranks[lo], self.ranks[lo + d]]))
+                if self.rank in (lo, lo + d):
+                    touch(g, 2)
+        self.used.add("all_gather")
+        return made
 
     def split(self, n_groups: int) -> "Comm":
         """n_groups contiguous sub-groups of world / n_groups ranks each -> the Comm of THIS rank's sub-group (`group_index` = which one).
         Every rank creates every group (torch.distributed.new_group is collective over the whole job).  The 2 x 4 job of SURVEY 8e:
         `world.split(2)` is the sequence-parallel group of one CFG branch, the VAE row slabs stay on `world`."""
         assert self.world % n_groups == 0 and self.group is None, "split the job's own communicator into equal contiguous groups"
+        if n_groups in self._subs:   # created once (prepare): asking again hands back the same communicator
+            return self._subs[n_groups]
         per = self.world // n_groups
         groups = [dist.new_group(list(range(g * per, (g + 1) * per))) for g in range(n_groups)]
         mine = self.rank // per
         sub = Comm(per, self.rank % per, groups[mine], ranks=range(mine * per, (mine + 1) * per))
         sub.group_index = mine
+        sub.used = self.used
+        self._subs[n_groups] = sub
         return sub
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         """out [P, *inp.shape] <- inp from every rank."""
         assert out.shape[0] == self.world and tuple(out.shape[1:]) == tuple(inp.shape) and out.is_contiguous() and inp.is_contiguous()
+        self.used.add("all_gather")
         if dist.get_backend(self.group) == "gloo":
             if inp.data_ptr() == out[self.rank].data_ptr():  # in-place form (KVExchange): gloo copies input -> output[rank], keep them apart
                 inp = inp.clone()
@@ -105,6 +149,7 @@ class Comm:
         return ev
 
     def broadcast(self, t: torch.Tensor, src: int = 0):
+        self.used.add("broadcast")
         dist.broadcast(t, src=self.ranks[src], group=self.group)
         return t
 
@@ -117,6 +162,7 @@ class Comm:
         broadcasts of all sources before the first V^T one: the first peer run waited for 13 of 16 broadcasts at 8 ranks).
         Returns the list of P events (None on CPU)."""
         assert out.shape[0] == self.world and out.is_contiguous()
+        self.used.add("broadcast")
         gloo = dist.get_backend(self.group) == "gloo"
 
         def bcast(src):
@@ -147,6 +193,7 @@ class Comm:
     def _pair_groups(self, d: int):
         """The two-rank groups (lo, lo + d) of this communicator, created once per distance (torch.distributed.new_group is collective over
         the WHOLE job: every rank of the job must reach this call, in the same order -- the row-sharded VAE does, at its first halo)."""
+        assert self.group is None, "halo pair groups belong to the job's own communicator (new_group is collective over the whole job)"
         cache = self.__dict__.setdefault("_pairs", {})
         if d not in cache:
             cache[d] = [dist.new_group([self.ranks[lo], self.ranks[lo + d]]) for lo in range(self.world - d)]
@@ -163,6 +210,14 @@ class Comm:
         up = down = None
         if d >= P:
             return up, down
+        self.used.add("all_gather")
+        if self.halo_whole_job:
+            # conservative mode (bench.py's second attempt): every rank's two rows all-gathered over the whole job, as rounds 1-4 did --
+            # 2 (P - 1) rows received to use 2, but no communicator beyond the job's own
+            mine = torch.stack([top.contiguous(), bottom.contiguous()])
+            allr = torch.empty((P,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+            self.all_gather(allr, mine)
+            return (allr[r - d, 1] if r - d >= 0 else None), (allr[r + d, 0] if r + d < P else None)
         groups = self._pair_groups(d)
         gloo = dist.get_backend(self.group) == "gloo"
         for phase in (0, 1):
@@ -213,9 +268,13 @@ class Comm:
         return done
 
     def barrier(self):
+        self.used.add("barrier")
         dist.barrier(group=self.group)
 
     def all_reduce_max(self, t: torch.Tensor):
+        """The one collective outside north_star's "broadcast / all-gather only": bench.py's timing (max over ranks) and its exchange
+        calibration use it; nothing on the data path does."""
+        self.used.add("all_reduce(max) [timing only]")
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return t
 
@@ -237,6 +296,11 @@ class LoopbackComm:
         self.world, self.rank, self.group = world, rank, None
         self.model = dict(model) if model else None
         self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self.used = set()
+        self.halo_whole_job = False
+
+    def prepare(self, cfg_groups: int = 0, halo_distances=()):
+        return [("world (simulated)", [self.rank])]
 
     def _delay(self, nbytes: float, rate_key: str):
         if self.model is None or not torch.cuda.is_available():
@@ -247,6 +311,7 @@ class LoopbackComm:
         call("wf_delay_us", us, ops.stream())
 
     def split(self, n_groups: int) -> "LoopbackComm":
+        assert self.world % n_groups == 0, "split the job's own communicator into equal contiguous groups"
         per = self.world // n_groups
         sub = LoopbackComm(per, self.rank % per, self.model)
         sub.group_index = self.rank // per
@@ -317,8 +382,34 @@ def init(world: int, rank: int, local_rank: int, backend: Optional[str] = None) 
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device(f"cuda:{local_rank}")
+        prefix = os.environ.get("WF_STORE_PREFIX")
+        if prefix:
+            # a rank started by bench.py's supervisor: rendezvous through the store the supervisors already share (the launcher's own, or
+            # the self-launching parent's), behind a per-attempt prefix -- a relaunch never meets the keys of the attempt before it
+            from datetime import timedelta
+            base = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, False, timeout=timedelta(seconds=900),
+                                 wait_for_workers=False)
+            kw["store"] = dist.PrefixStore(prefix, base)
         dist.init_process_group(backend=backend, world_size=world, rank=rank, **kw)
     return Comm(world, rank)
+
+
+def halo_distances(world: int):
+    """Every distance the row-sharded VAE can ask neighbor_rows for on `world` ranks: 1 (every rank its own slab) and world / G for the row
+    groups G of its low-resolution stages (vae._row_groups: G a divisor of the world size) -- the proper divisors of `world`."""
+    return [d for d in range(1, world) if world % d == 0]
+
+
+def rccl_info() -> dict:
+    """What the collectives of this process travel over, for the bench line."""
+    out = {"world": dist.get_world_size() if dist.is_initialized() else 1, "backend": dist.get_backend() if dist.is_initialized() else None,
+           "version": None}
+    try:
+        v = torch.cuda.nccl.version()
+        out["version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:   # CPU-only build / gloo debug runs
+        out["version"] = f"unavailable ({type(e).__name__})"
+    return out
 
 
 def gather_rows(comm: Comm, local: torch.Tensor, plan: ShardPlan) -> torch.Tensor:

@@ -197,8 +197,10 @@ class AutoencoderKLWan:
 
     ATTN_BATCH_BYTES = 6 << 30   # split operands of the mid-block attention's batched P . V launch kept at a time (_attn_x3)
 
-    def __init__(self, device="cuda:0", comm=None, precision: str = "fp16x3", dtype: torch.dtype = torch.float32):
-        """dtype: the MODULE dtype the protocol shows (`vae.dtype`, what `from_pretrained(torch_dtype=...)` sets): torch.float32 for the
+    def __init__(self, device="cuda:0", comm=None, precision: str = "fp16x3", dtype: torch.dtype = torch.float32, strict_range: bool = False):
+        """strict_range: check the fp16 range flag INSIDE the call that raised it (one host synchronisation per encode / decode) -- for
+        callers of the bare encode / decode API who consume the result without ever calling check_range() or the VAE again.
+        dtype: the MODULE dtype the protocol shows (`vae.dtype`, what `from_pretrained(torch_dtype=...)` sets): torch.float32 for the
         Wan entry (INFER:185-189), torch.bfloat16 for the LongCat entry (run_longcat_worldforge_single.py:205).  A bf16 module takes bf16
         inputs (others are rounded to bf16 on the way in, the `.to(dtype=vae.dtype)` of LongCat's fuse_latents) and returns bf16 videos /
         moments; in between, this implementation keeps its f32 stream with `precision` operands -- closer to the fp32 network than the
@@ -206,6 +208,7 @@ class AutoencoderKLWan:
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError(f"dtype must be torch.float32 or torch.bfloat16, got {dtype}")
         self.dtype = dtype
+        self.strict_range = bool(strict_range)
         if precision == "fp32":  # the fp32-CLASS mode of the round: three-term split operands, fp16 parts since round 4
             precision = "fp16x3"
         if precision == "tf32":  # what the mode stands for: the multiplicand width of a TF32 convolution
@@ -539,17 +542,23 @@ class AutoencoderKLWan:
         """fp16 operand formats: a producer that met a value beyond +-65504 (or a NaN) raised the sticky device flag.  Queue a 4-byte
         copy of it into pinned host memory behind this call's kernels (wf_f16_overflow_flag_async) and an event -- NO host
         synchronisation inside encode / decode (no hidden device syncs; round 4 synchronised the stream once per VAE call).
-        `check_range` reads it: the next VAE call does so when the event has already fired, the schedulers' `fuse_latents` and the
-        pipelines do at the points where they synchronise anyway (FLF gate read-back, final frames)."""
+        `check_range` reads it, DETERMINISTICALLY: every encode / decode / decode_blend_encode starts by waiting for the flag
+        of the call before it (by then that call's kernels have all but finished: the wait costs a launch latency, not a drain) -- on a
+        sharded VAE too, where the calls are collective and every rank is at the same program point -- and the schedulers' `fuse_latents`
+        and the pipelines check at their own synchronisation points (FLF gate read-back, final frames).  What remains for the caller: the
+        LAST call of a job.  A caller of the bare encode / decode API must call check_range() before consuming the result, or construct the
+        VAE with strict_range=True (the check then runs inside the call, one host synchronisation each)."""
         if not self.f16:
             return
-        self.check_range(wait=False)   # an earlier call's flag, if it has landed meanwhile
+        self.check_range()   # an earlier call's flag (none, when the entry point ran its own check at the start)
         if getattr(self, "_flag_host", None) is None:
             self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         call("wf_f16_overflow_flag_async", self._flag_host.data_ptr(), ops.stream())
         ev = torch.cuda.Event()
         ev.record()
         self._flag_pending = (ev, what)
+        if self.strict_range:
+            self.check_range()
 
     def check_range(self, wait: bool = True):
         """Turn a raised fp16 range flag of an earlier encode / decode into a RuntimeError -- never a silent inf.  wait=False: only if its
@@ -562,7 +571,7 @@ class AutoencoderKLWan:
         ev, what = pend
         shared = self.comm is not None and getattr(self.comm, "world", 1) > 1
         if not wait and (shared or not ev.query()):
-            return   # (a sharded VAE decides at explicit check points only: every rank must take the same branch)
+            return   # (wait=False is timing-dependent: a sharded VAE never takes it, every rank must take the same branch)
         ev.synchronize()
         self._flag_pending = None
         bad = int(self._flag_host[0])
@@ -1121,6 +1130,7 @@ class AutoencoderKLWan:
         One GPU: exactly decode(), ops.blend_pixels(), encode().  Row-sharded (comm): the decoded video is NOT gathered -- the blend is
         element-wise per pixel, so each rank blends and re-encodes its own row slab (the encoder's first halo comes from the neighbours);
         only latent-resolution tensors are gathered.  Bit-identical to the gathered form."""
+        self.check_range()   # the flag of the VAE call before this one (see _note_range)
         z = self._io_in(z)
         if z.shape[0] != 1 or not self.can_shard(z.shape[3]):
             dec = self.decode(z, return_dict=False)[0]
@@ -1148,6 +1158,9 @@ class AutoencoderKLWan:
 
     @torch.no_grad()
     def encode(self, x: torch.Tensor, return_dict: bool = True):
+        """-> the posterior (latent_dist.mode() / .sample()).  fp16 operand modes: the range flag of THIS call is checked at the next VAE
+        call or check_range() -- call check_range() before consuming the result if neither follows (or use strict_range=True)."""
+        self.check_range()   # the flag of the VAE call before this one (see _note_range)
         x = self._io_in(x)
         moments = self._io_out(torch.stack([self._encode_one(v) for v in x]))
         self._note_range("encode")
@@ -1158,6 +1171,8 @@ class AutoencoderKLWan:
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True):
+        """-> the video, clamped to [-1, 1].  fp16 operand modes: see encode() for when the range flag of this call is checked."""
+        self.check_range()   # the flag of the VAE call before this one (see _note_range)
         z = self._io_in(z)
         out = self._io_out(torch.stack([self._decode_one(v) for v in z]))
         self._note_range("decode")
