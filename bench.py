@@ -103,6 +103,7 @@ def main(argv=None):
     device = torch.device(f"cuda:{local_rank}")
 
     from worldforge_amd import dit as wdit
+    from worldforge_amd import ops as wops
     from worldforge_amd import parallel
     from worldforge_amd.pipeline import WanImageToVideoPipeline
     from worldforge_amd.scheduler import UniPCMultistepScheduler
@@ -189,6 +190,7 @@ def main(argv=None):
             marks["t0"] = time.perf_counter()
             wdit.PROFILE_ATTN = []
             wdit.PROFILE_COMM = [] if comm is not None else None
+            wops.PROFILE_BLEND = []
         if phase == "begin":
             torch.cuda.synchronize()
             marks[("b", i)] = time.perf_counter()
@@ -220,6 +222,9 @@ def main(argv=None):
     cprof = wdit.PROFILE_COMM or []
     wdit.PROFILE_COMM = None
     comm_ms = [wdit.comm_wait_ms(e) for e in cprof]
+    bprof = wops.PROFILE_BLEND or []
+    wops.PROFILE_BLEND = None
+    blend = [(s.elapsed_time(e) * 1e3, nb) for s, e, nb in bprof]
     T = (a.frames - 1) // 4 + 1
     L = T * (a.height // 16) * (a.width // 16)
     Lq = model.local_tokens(L)
@@ -261,6 +266,9 @@ def main(argv=None):
                 # the prompt-context K / V of the cross-attention are computed once per prompt, not once per forward (bit-identical; the
                 # reference recomputes them, model.py:215-218): work removed from the timed region, stated here (VERDICT r4 #4a)
                 "ctx_cache": os.environ.get("WF_CTX_CACHE", "1") != "0",
+                # the two forwards of a CFG evaluation share what does not see the prompt (patch embedding + layer 0's self-attention block,
+                # model.py:298-306): computed once per pair, bit-identical to two forwards -> 2 x 40 - 1 self-attention launches per pair
+                "cfg_pair_shared_prefix": bool(model.pair_share_layer0),
                 "flow_backend": a.flow_backend,
                 # the Farneback branch is what an installed reference executes, but its GPU statement is checked against the
                 # in-repo restatement of OpenCV only (no cv2 in the image or the reference tree); the tdiff branch is golden-pinned
@@ -332,6 +340,12 @@ def main(argv=None):
                 if tms:
                     out["roofline"]["tracked_body_avg_launch_ms"] = tms
                     out["roofline"]["tracked_body_frac"] = attn_flop / (tms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS_BF16
+        if blend:
+            # SURVEY 8d "HBM GB/s for the injection kernels": the pixel blend of every IRR injection inside the timed window (HIP events on the
+            # launch stream), algorithmic bytes = (3 + 1 + 3 + 3) x 4 B per pixel-frame (this rank's rows when the VAE is row-sharded)
+            us, nb = sum(u for u, _ in blend) / len(blend), blend[0][1]
+            out["hbm"] = {"kernel": "k_blend4 (wf_blend_pixels, SCHED:1375-1380)", "bytes": nb, "avg_us": us, "launches": len(blend),
+                          "achieved_GBps": nb / us / 1e3, "peak_GBps": 8000.0, "frac_of_8TBps": nb / us / 1e3 / 8000.0}
         if world == 1 and a.as_rank_of <= 1:
             out["flf_gate_ms"] = flf_gate_ms(sch, (1, 16, T, a.height // 8, a.width // 8), device)
         if per_rank is not None and plain_ms:

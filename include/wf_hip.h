@@ -76,6 +76,12 @@ int wf_latent_affine(const void* z, int dt_in, void* out, int dt_out, const floa
 int wf_blend_pixels(const float* ref, const float* mask, const float* dec, float* out, int B, int C, size_t inner,
                     void* stream);
 
+/* Which pixel columns of the decoded video the blend above can see: wherever mask == 1 (exactly) the result is (2 ref - 1) + dec * 0, i.e.
+ * independent of any finite dec.  mask [n_rows, W] f32 (all frames and rows of a job's mask) -> out2 (DEVICE, 2 ints) = {first column with a
+ * pixel != 1, last such column + 1}; {W, 0} when every pixel is 1.  What lets the VAE decode only the columns an IRR injection consumes
+ * (worldforge_amd/vae.py decode(columns=...)). */
+int wf_mask_column_range(const float* mask, size_t n_rows, int W, int* out2, void* stream);
+
 /* PIPE:744 (diffusers VideoProcessor.postprocess_video)  out = clamp(x/2 + 0.5, 0, 1), [C,F,H,W] -> [F,H,W,C]. */
 int wf_postprocess_video(const float* x, float* out, int C, int F, int H, int W, void* stream);
 /* The two pixel-space statements above as eager PyTorch evaluates them behind a BF16 VAE module -- the dtype the LongCat entry loads its

@@ -1,17 +1,51 @@
-"""Tolerance bars that remember what they measured (VERDICT r3 "weak" #7: tests were 6-8x looser than the errors they see).
+"""Tolerance bars that remember what they measured (VERDICT r3 "weak" #7: tests were 6-8x looser than the errors they see; VERDICT r5 "weak"
+#5: one bar shared by the parametrised cases of a test still sat at 2.2-5.8x the smaller cases' errors).
 
-`within(name, measured, bound)` asserts `measured <= bound`; with `WF_TOL_LOG=<file>` it also appends `name measured bound` so that one
-run of the suite on the GPU shows every bar next to the error it actually sees.  Policy: a bar sits at <= 2x the error measured on an
-MI355X (the value is quoted in the comment at the call site); profiles/r5_tolerances.txt is the log of the round-end run at HEAD (tools/gpurun_scripts/final.sh regenerates it).
+`within(name, measured, bound)` asserts `measured <= bound`, where `bound` is the test's own stated bar -- AND, per test CASE, at most
+2 x the error that case measured on an MI355X: tests/golden/tolerances_mi355x.json holds the recorded error of every (name, pytest case)
+pair (the kernels are deterministic: the same binary measures the same error on every box), written by `tools/tol_record.py` from a
+`WF_TOL_LOG` of the whole GPU suite.  An error recorded as exactly 0 must stay exactly 0.  With `WF_TOL_LOG=<file>` every call appends
+`key measured bound ratio` with the bar actually applied; profiles/r6_tolerances.txt is that log of the round-end run at HEAD (no ratio
+above 2.0 for a recorded case; cases not yet recorded are marked `unrecorded` and carry the stated bar only).
 """
+import json
 import os
+
+_TABLE = None
+TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tolerances_mi355x.json")
+
+
+def _case() -> str:
+    cur = os.environ.get("PYTEST_CURRENT_TEST", "")
+    return cur.rsplit(" (", 1)[0]
+
+
+def key_of(name: str) -> str:
+    return f"{name} | {_case()}"
+
+
+def _table():
+    global _TABLE
+    if _TABLE is None:
+        try:
+            with open(TABLE_PATH) as f:
+                _TABLE = json.load(f)
+        except (OSError, ValueError):
+            _TABLE = {}
+    return _TABLE
 
 
 def within(name, measured, bound):
     measured, bound = float(measured), float(bound)
+    key = key_of(name)
+    rec = _table().get(key)
+    eff, note = bound, "unrecorded"
+    if rec is not None:
+        eff, note = min(bound, 2.0 * float(rec)), "recorded"
     path = os.environ.get("WF_TOL_LOG")
     if path:
+        ratio = 1.0 if (eff == 0.0 and measured == 0.0) else eff / max(measured, 1e-30)
         with open(path, "a") as f:
-            f.write(f"{name} measured {measured:.4e} bound {bound:.4e} ratio {bound / max(measured, 1e-30):.2f}\n")
-    assert measured <= bound, f"{name}: measured {measured:.4e} > bound {bound:.4e}"
+            f.write(f"{key} measured {measured:.4e} bound {eff:.4e} ratio {ratio:.2f} {note} (stated bar {bound:.4e})\n")
+    assert measured <= eff, f"{key}: measured {measured:.4e} > bound {eff:.4e} (stated bar {bound:.4e}; MI355X record {rec})"
     return measured

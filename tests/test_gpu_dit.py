@@ -562,6 +562,34 @@ def test_context_kv_cache_is_transparent(monkeypatch):
     assert torch.equal(edited, m.forward_tokens(x, 500.0, cb, clip)) and not torch.equal(edited, after)
 
 
+def test_cfg_pair_shares_the_prompt_independent_prefix_bit_identically():
+    """forward_tokens_pair (PIPE:593-610: same latents and timestep, two prompts) computes the patch embedding and layer 0's self-attention
+    block ONCE (round 6): both velocities must equal two independent forwards bit for bit, with one self-attention launch fewer."""
+    from worldforge_amd import dit
+    cfg = dit.DiTConfig(dim=256, ffn_dim=512, num_heads=2, num_layers=3, text_dim=64)
+    x = _rand((36, 3, 8, 10), 90).to(BF).to(DEV)
+    ca, cb = _rand((30, 64), 91).to(BF).to(DEV), _rand((12, 64), 92).to(BF).to(DEV)
+    clip = _rand((257, 1280), 93).to(BF).to(DEV)
+    m = dit.WanTransformer3DModel(cfg, DEV).init_random(5)
+    ref_a = m.forward_tokens(x, 431.0, ca, clip).clone()
+    ref_b = m.forward_tokens(x, 431.0, cb, clip).clone()
+    assert not torch.equal(ref_a, ref_b)
+    for share, launches in ((True, 2 * cfg.num_layers - 1), (False, 2 * cfg.num_layers)):
+        m.pair_share_layer0 = share
+        for _ in range(2):
+            dit.PROFILE_ATTN = []
+            a, b = m.forward_tokens_pair(x, 431.0, ca, cb, clip)
+            n = len(dit.PROFILE_ATTN)
+            dit.PROFILE_ATTN = None
+            assert torch.equal(a, ref_a) and torch.equal(b, ref_b)
+            assert n == launches, (share, n)
+    # a different timestep / different latents in the next pair: nothing stale is reused
+    m.pair_share_layer0 = True
+    x2 = _rand((36, 3, 8, 10), 94).to(BF).to(DEV)
+    a2, b2 = m.forward_tokens_pair(x2, 120.0, ca, cb, clip)
+    assert torch.equal(a2, m.forward_tokens(x2, 120.0, ca, clip)) and torch.equal(b2, m.forward_tokens(x2, 120.0, cb, clip))
+
+
 def test_diffusers_layout_transformer_checkpoint_loads(tmp_path):
     """A sharded diffusers-layout `transformer/` directory (config.json + 2 safetensors shards + index; names through the inverse of
     dit.diffusers_key_map, per-block / final scale_shift_table) -> WanTransformer3DModel.from_pretrained -> the same forward as the

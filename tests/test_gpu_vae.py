@@ -353,12 +353,11 @@ def test_vae_decode_returns_while_the_gpu_is_still_busy(model_fp32):
     model_fp32.decode(z, return_dict=False)
     ev.record()
     assert not ev.query(), "decode synchronised the host with the stream"
-    ev2 = torch.cuda.Event()
     model_fp32.encode(video)                         # starts by waiting for decode's flag ...
     assert ev.query()                                # ... so decode has finished by the time encode's own work is queued
-    ev2.record()
-    model_fp32.check_range()                         # the explicit check point waits for the last call
-    assert ev2.query()
+    assert model_fp32._flag_pending is not None      # encode's own flag is pending: nothing waited for encode itself
+    model_fp32.check_range()                         # the explicit check point waits for the last call's flag
+    assert model_fp32._flag_pending is None
     # strict_range=True: the check runs inside the call (one host synchronisation per call) -- for callers of the bare API
     strict = AutoencoderKLWan(DEV, precision="fp32", strict_range=True)
     strict.w = model_fp32.w
@@ -645,3 +644,106 @@ def test_fp16_mode_row_sharded_equals_unsharded(P, H, model_fp16):
     for r, (mu, dec) in enumerate(_run_ranks(P, run)):
         assert torch.equal(mu, mu0), (r, (mu - mu0).abs().max())
         assert torch.equal(dec, dec0), (r, (dec - dec0).abs().max())
+
+
+# ---- decoding only the pixel columns an IRR injection's blend can see (round 6) ----------------------------------------------------------
+def _hole_mask(Fr, H, W, kind):
+    """Masks in [0, 1] whose value is EXACTLY 1 outside a hole: 'right' = SURVEY 8d's growing hole with a sine-softened edge."""
+    xs = torch.arange(W).view(1, 1, 1, 1, W).float()
+    fr = torch.arange(Fr).view(1, 1, Fr, 1, 1).float() / max(Fr - 1, 1)
+    if kind == "right":
+        edge = W * (1 - 0.35 * fr)
+        d = (edge - xs).clamp(min=0)
+        return (torch.sin(math.pi / 2 * (d / 15).clamp(0, 1)) * (xs < edge)).expand(1, 1, Fr, H, W).contiguous()
+    if kind == "middle":
+        m = torch.ones(1, 1, Fr, H, W)
+        m[:, :, 1:, H // 4:H // 2, W // 2 - 20:W // 2 + 9] = 0.25
+        return m
+    if kind == "none":
+        return torch.ones(1, 1, Fr, H, W)
+    return torch.rand(1, 1, Fr, H, W, generator=torch.Generator().manual_seed(3))          # holes everywhere
+
+
+def test_mask_column_range_kernel():
+    import ctypes  # noqa: F401
+    from worldforge_amd import _ffi, ops
+    for kind, W in (("right", 256), ("middle", 200), ("none", 64), ("rand", 72)):
+        m = _hole_mask(5, 24, W, kind).to(DEV)
+        out = torch.empty(2, dtype=torch.int32, device=DEV)
+        _ffi.call("wf_mask_column_range", m.data_ptr(), m.numel() // W, W, out.data_ptr(), ops.stream())
+        cols = (m != 1).flatten(0, 3).any(0).nonzero().flatten()
+        want = (int(cols.min()), int(cols.max()) + 1) if cols.numel() else (W, 0)
+        assert tuple(int(v) for v in out.cpu()) == want, (kind, out, want)
+    m = torch.ones(2, 40, device=DEV)
+    m[1, 17] = float("nan")                      # a NaN is "not 1": the column must be decoded
+    out = torch.empty(2, dtype=torch.int32, device=DEV)
+    _ffi.call("wf_mask_column_range", m.data_ptr(), 2, 40, out.data_ptr(), ops.stream())
+    assert tuple(int(v) for v in out.cpu()) == (17, 18)
+
+
+@pytest.mark.parametrize("kind", ["right", "middle", "none", "rand"])
+@pytest.mark.parametrize("prec", ["fp16x3", "bf16"])
+def test_decode_of_the_needed_columns_gives_the_same_blend_bit_for_bit(kind, prec, model, model_fp32):
+    """The decoded video's only consumer in fuse_latents is the blend (SCHED:1380): decoding just the columns with a mask value != 1 (+ the
+    receptive-field halo, whole frames through the latent-resolution stage) must give the SAME fused video and the same posterior as
+    decoding everything -- bit for bit -- and the needed columns of the decoded video itself must be identical."""
+    from worldforge_amd import ops
+    m0 = model_fp32 if prec == "fp16x3" else model
+    g = torch.Generator().manual_seed(31)
+    Fr, H, W = 9, 64, 384                                        # 48 latent columns
+    z = torch.randn(1, 16, 3, H // 8, W // 8, generator=g).to(DEV)
+    ref = torch.rand(1, 3, Fr, H, W, generator=g).to(DEV)
+    mask = _hole_mask(Fr, H, W, kind).to(DEV)
+    full = m0.decode(z, return_dict=False)[0]
+    cols = m0.needed_columns(mask)
+    crop = m0._crop_range(cols, W // 8)
+    part = m0.decode(z, return_dict=False, columns=cols)[0]
+    if kind == "right":
+        assert cols == (30, 48) and crop == (16, 48)               # hole from pixel 0.65 * 384 - 15 = 234.6 -> latent column 29.3 ...
+    elif kind == "middle":
+        assert cols == (21, 26) and crop == (8, 40)
+    elif kind == "none":
+        assert cols == (0, 0) and crop == (0, 16)                  # nothing can reach the result: the cheapest crop
+    else:
+        assert crop is None and torch.equal(part, full)            # holes everywhere: everything is decoded
+    if crop is not None:
+        c0, c1 = cols
+        assert torch.equal(part[..., 8 * c0:8 * c1], full[..., 8 * c0:8 * c1])
+        assert not torch.equal(part, full) or kind == "none"
+        assert torch.isfinite(part).all()
+    fused_full, fused_part = ops.blend_pixels(ref, mask, full), ops.blend_pixels(ref, mask, part)
+    assert torch.equal(fused_full, fused_part)
+    # the whole round trip through the entry point the schedulers use
+    m0.crop_to_mask = False
+    mu_full = m0.decode_blend_encode(z, ref, mask).mode().clone()
+    m0.crop_to_mask = True
+    try:
+        mu_part = m0.decode_blend_encode(z, ref, mask).mode().clone()
+    finally:
+        m0.crop_to_mask = True
+    m0.check_range()
+    assert torch.equal(mu_full, mu_part)
+
+
+@pytest.mark.parametrize("P,H", [(2, 64), (8, 96)])
+def test_row_sharded_round_trip_with_cropped_decode_equals_unsharded(P, H, model_fp32):
+    from tests.test_gpu_multirank import _run_ranks
+    from worldforge_amd.vae import AutoencoderKLWan
+    g = torch.Generator().manual_seed(33)
+    Fr, W = 9, 256
+    z = torch.randn(1, 16, 3, H // 8, W // 8, generator=g).to(DEV)
+    ref = torch.rand(1, 3, Fr, H, W, generator=g).to(DEV)
+    mask = _hole_mask(Fr, H, W, "right").to(DEV)
+    model_fp32.crop_to_mask = False
+    mu0 = model_fp32.decode_blend_encode(z, ref, mask).mode().clone()
+    model_fp32.crop_to_mask = True
+    assert model_fp32._crop_range(model_fp32.needed_columns(mask), W // 8) is not None
+
+    def run(comm):
+        v = AutoencoderKLWan(DEV, comm=comm, precision="fp32")
+        v.w = model_fp32.w
+        assert v.can_shard(H // 8) and v.crop_to_mask
+        return v.decode_blend_encode(z, ref, mask).mode().clone()
+
+    for r, mu in enumerate(_run_ranks(P, run)):
+        assert torch.equal(mu, mu0), (r, (mu - mu0).abs().max())

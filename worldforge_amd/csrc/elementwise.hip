@@ -268,6 +268,41 @@ extern "C" int wf_blend_pixels(const float* ref, const float* mask, const float*
   return WF_OK;
 }
 
+// Which pixel COLUMNS of the decoded video can reach the blend's result: fused = (2 ref - 1) m + dec (1 - m) is (2 ref - 1) + (+-0) wherever
+// m == 1 and dec is finite, whatever dec is there.  out[0] = first column holding a pixel with mask != 1 (NaN counts), out[1] = last such
+// column + 1, over n_rows rows of W pixels; {W, 0} when every pixel is 1.  Integer atomics only: deterministic.
+__global__ void k_mask_cols_init(int* out, int W) {
+  out[0] = W;
+  out[1] = 0;
+}
+__global__ void k_mask_cols(const float* __restrict__ mask, size_t n, int W, int* __restrict__ out) {
+  int lo = W, hi = 0;
+  EW_LOOP(i, n) {
+    if (!(mask[i] == 1.0f)) {
+      const int x = (int)(i % (size_t)W);
+      lo = min(lo, x);
+      hi = max(hi, x + 1);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = min(lo, __shfl_xor(lo, o, 64));
+    hi = max(hi, __shfl_xor(hi, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0 && hi > 0) {
+    atomicMin(&out[0], lo);
+    atomicMax(&out[1], hi);
+  }
+}
+extern "C" int wf_mask_column_range(const float* mask, size_t n_rows, int W, int* out2, void* stream) {
+  WF_CHECK_ARG(mask && out2 && W > 0, "wf_mask_column_range: null pointer / W = %d", W);
+  hipLaunchKernelGGL(k_mask_cols_init, dim3(1), dim3(1), 0, (hipStream_t)stream, out2, W);
+  const size_t n = n_rows * (size_t)W;
+  if (n) hipLaunchKernelGGL(k_mask_cols, dim3(grid_for(n, EW_BLOCK, 4096)), dim3(EW_BLOCK), 0, (hipStream_t)stream, mask, n, W, out2);
+  WF_LAUNCH_CHECK("wf_mask_column_range");
+  return WF_OK;
+}
+
 // The same blend as eager PyTorch evaluates it when the VAE is a bf16 module (LongCat: run_longcat_worldforge_single.py:205): the decoded
 // video is bf16, `video_latents.to(decoded_video.dtype)` / `mask.to(...)` round the fp32 reference and mask to bf16
 // (scheduling_flow_match_euler_discrete.py:1152-1153) and every statement of :1156-1164 rounds its result to bf16:

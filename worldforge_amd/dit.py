@@ -619,6 +619,7 @@ class WanTransformer3DModel:
     exchange_mode = "chunked"
     exchange_chunks = 2
     pair_lockstep = True      # forward_tokens_pair under sequence parallelism: two forwards one layer apart (False: one after the other)
+    pair_share_layer0 = True  # forward_tokens_pair: the prompt-independent prefix (up to layer 0's self-attention block) computed once per pair
     attn_prescale = True      # softmax_scale * log2(e) folded into Q by its producer (k_attn_w4<4>); False: in-kernel scale (k_attn_w4<0>)
     attn_track_max = False    # True: withhold the norm bounds -> the kernel's max-tracking body (A/B and the tracked-body parity tests)
 
@@ -638,12 +639,22 @@ class WanTransformer3DModel:
         forward_tokens (exchange mode "gather") in the same order on its own buffers: results are bit-identical to two sequential calls."""
         if interleave is None:
             interleave = self.comm is not None and self.pair_lockstep
+        # What the two branches compute IDENTICALLY is computed once (round 6): same latents and timestep, different prompt
+        # (PIPE:593-610) -- patch embedding, time embedding / modulation and layer 0's whole self-attention block (LN-modulate, QKV,
+        # RoPE / norm, attention, O projection: model.py:298-306) do not see the prompt; the first prompt-dependent operation is layer 0's
+        # cross-attention.  Branch A leaves its residual stream after that block in a buffer, branch B starts from it: the same kernels on
+        # the same inputs, so bit-identical to two independent forwards (tests/test_gpu_dit.py); ~0.8 % of a CFG evaluation.
+        share = {} if self.pair_share_layer0 else None
         if not interleave:
-            va = self.forward_tokens(x_in, t_value, text_a, img)
-            return va, self.forward_tokens(x_in, t_value, text_b, img)
+            oa, ob = [None], [None]
+            for _ in self._forward_steps(x_in, t_value, text_a, img, "", oa, self.exchange_mode, share, "produce"):
+                pass
+            for _ in self._forward_steps(x_in, t_value, text_b, img, "", ob, self.exchange_mode, share, "consume"):
+                pass
+            return oa[0], ob[0]
         oa, ob = [None], [None]
-        ga = self._forward_steps(x_in, t_value, text_a, img, "", oa, "gather")
-        gb = self._forward_steps(x_in, t_value, text_b, img, "#b", ob, "gather")
+        ga = self._forward_steps(x_in, t_value, text_a, img, "", oa, "gather", share, "produce")
+        gb = self._forward_steps(x_in, t_value, text_b, img, "#b", ob, "gather", share, "consume")
         live = [ga, gb]
         while live:
             for gen in list(live):
@@ -653,10 +664,12 @@ class WanTransformer3DModel:
                     live.remove(gen)
         return oa[0], ob[0]
 
-    def _forward_steps(self, x_in, t_value, text, img, tag, result, mode="gather"):
+    def _forward_steps(self, x_in, t_value, text, img, tag, result, mode="gather", share=None, role=None):
         """Generator over one forward: yields once per layer, right after that layer's K / V^T exchange has been launched (the
         point where another forward can usefully take over the compute stream).  `tag` separates the workspaces of concurrent
-        forwards; the velocity lands in result[0]."""
+        forwards; the velocity lands in result[0].  share / role: the two forwards of a CFG pair (forward_tokens_pair) -- the "produce"
+        forward copies its residual stream after layer 0's self-attention block into share["x"], the "consume" forward starts from it
+        instead of computing the patch embedding and that block again."""
         cfg, W, dev = self.cfg, self.w, self.device
         _buf = lambda name, shape, dtype, zero=False: self._buf(name + tag, shape, dtype, zero)  # noqa: E731
         bf, f32 = torch.bfloat16, torch.float32
@@ -692,7 +705,9 @@ class WanTransformer3DModel:
 
         # patch embedding (model.py:534-537) as a GEMM -> fp32 residual stream
         x = _buf("x", (L, d), f32)
-        gemm(tok, W["patch.w"], W["patch.b"], x, EPI_F32)
+        consume = share is not None and role == "consume"
+        if not consume:
+            gemm(tok, W["patch.w"], W["patch.b"], x, EPI_F32)
 
         hbuf = _buf("h", (L, d), bf)
         qkv = _buf("qkv", (L, 3 * d), bf)
@@ -767,14 +782,22 @@ class WanTransformer3DModel:
             call("wf_act", W[p + "modulation"].data_ptr(), WF_F32, e0.data_ptr(), WF_F32, emod.data_ptr(), WF_F32, 2,
                  emod.numel(), ops.stream())
             # ---- self-attention (model.py:302-306) ----
-            self._ln(x, emod[1], emod[0], hbuf, cfg.eps, plus_one=True)
-            if comm is None:
+            if i == 0 and consume:
+                # the other branch of the CFG pair has computed this block on the same latents and timestep: take its residual stream
+                if comm is not None:
+                    if share_ctx:      # this branch's prompt context, gathered behind the producer's layer-0 exchange
+                        ctx_shared, ctx_events = launch_context()
+                    yield i            # (lock-step: the producer runs one layer ahead; its copy is queued before this one resumes)
+                x.copy_(share["x"])
+            elif comm is None:
+                self._ln(x, emod[1], emod[0], hbuf, cfg.eps, plus_one=True)
                 gemm(hbuf, W[p + "qkv.w"], W[p + "qkv.b"], qkv, EPI_BF16)
                 self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L, out_scale=q_scale, bound=qm)
                 self._heads(qkv, d, W[p + "self_attn.norm_k"], cos, sin, kh, L, bound=km)
                 self._vt(qkv, 2 * d, vt, L)
                 attention(qh, kh, vt, ao, L, sa_scale, profile=True, kmax2=km, qmax2=qm)
             else:
+                self._ln(x, emod[1], emod[0], hbuf, cfg.eps, plus_one=True)
                 # K and V first: the producers write this rank's shard (and its norm bounds) straight into its slot of the exchange
                 # buffers, chunk by chunk; the exchange runs on the communication stream under the Q projection
                 gemm(hbuf, W[p + "qkv.w"][d:], W[p + "qkv.b"][d:], qkv[:, d:], EPI_BF16)
@@ -791,7 +814,11 @@ class WanTransformer3DModel:
                 gemm(hbuf, W[p + "qkv.w"][:d], W[p + "qkv.b"][:d], qkv[:, :d], EPI_BF16)
                 self._heads(qkv, 0, W[p + "self_attn.norm_q"], cos, sin, qh, L, out_scale=q_scale, bound=qm)
                 attention_exchange(qh, ex, ao, Lfull, sa_scale, qm, use_bounds=use_bounds, profile=True)
-            gemm(ao, W[p + "self_attn.o.w"], W[p + "self_attn.o.b"], x, EPI_RESID, gate=emod[2])
+            if not (i == 0 and consume):
+                gemm(ao, W[p + "self_attn.o.w"], W[p + "self_attn.o.b"], x, EPI_RESID, gate=emod[2])
+            if i == 0 and share is not None and role == "produce":
+                share["x"] = self._buf("x_pair_layer0", (L, d), f32)
+                share["x"].copy_(x)
             # ---- cross-attention (model.py:310, 202-229) ----
             self._ln(x, W[p + "norm3.w"], W[p + "norm3.b"], hbuf, cfg.eps, plus_one=False)
             gemm(hbuf, W[p + "cross_attn.q.w"], W[p + "cross_attn.q.b"], qc, EPI_BF16)

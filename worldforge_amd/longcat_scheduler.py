@@ -250,7 +250,11 @@ class FlowMatchEulerDiscreteScheduler:
                 return pred_original_sample
             enc = vae.decode_blend_encode(self._to_vae(ops.latent_denorm(x0, mean, std), vae), video_latents, mask).mode()
         else:
-            decoded = vae.decode(self._to_vae(ops.latent_denorm(x0, mean, std), vae), return_dict=False)[0]   # SCHED:1124 + 1127
+            cols = {}
+            if hasattr(vae, "needed_columns") and getattr(vae, "crop_to_mask", False) and x0.dim() == 5 and mask.dim() == 5 \
+                    and mask.shape[1] == 1 and mask.dtype == torch.float32 and mask.is_contiguous():
+                cols = {"columns": vae.needed_columns(mask)}   # only what the blend can see is decoded (vae.decode(columns=...))
+            decoded = vae.decode(self._to_vae(ops.latent_denorm(x0, mean, std), vae), return_dict=False, **cols)[0]   # SCHED:1124 + 1127
             if tuple(video_latents.shape) != tuple(decoded.shape) or mask.shape[1] != 1 or tuple(mask.shape[2:]) != tuple(decoded.shape[2:]):
                 return pred_original_sample
             fused = ops.blend_pixels(video_latents, mask, decoded)   # in the decoded video's dtype (SCHED:1152-1164)

@@ -109,6 +109,9 @@ def latent_norm(mu: torch.Tensor, mean, std, const_dtype: torch.dtype = torch.fl
     return out
 
 
+PROFILE_BLEND = None  # bench.py sets this to a list: (start, end, bytes) HIP events around every wf_blend_pixels launch (HBM GB/s)
+
+
 def blend_pixels(ref: torch.Tensor, mask: torch.Tensor, dec: torch.Tensor) -> torch.Tensor:
     """SCHED:1375-1381.  ref [B,3,F,H,W] fp32, mask [B,1,F,H,W] fp32; dec fp32 -> fp32, or dec bf16 (a bf16 VAE module, the LongCat
     entry's: the statements then run in bf16, LongCat SCHED:1152-1164) -> bf16."""
@@ -121,7 +124,15 @@ def blend_pixels(ref: torch.Tensor, mask: torch.Tensor, dec: torch.Tensor) -> to
     if dec.dtype == torch.bfloat16:
         call("wf_blend_pixels_bf16", ref.data_ptr(), mask.data_ptr(), dec.data_ptr(), out.data_ptr(), B, C, inner, stream())
         return out
+    prof = PROFILE_BLEND
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call("wf_blend_pixels", ref.data_ptr(), mask.data_ptr(), dec.data_ptr(), out.data_ptr(), B, C, inner, stream())
+    if prof is not None:
+        e1.record()
+        # algorithmic bytes: read ref (C ch) + mask (1 ch, broadcast) + dec (C ch), write fused (C ch), fp32
+        prof.append((e0, e1, 4 * B * inner * (3 * C + 1)))
     return out
 
 

@@ -255,10 +255,22 @@ class UniPCMultistepScheduler:
                 enc = vae.decode_blend_encode(ops.latent_denorm(x0, mean, std), ref, m).mode()
                 enc = ops.latent_norm(enc, mean, std, const_dtype=x0.dtype)
         else:
+            crop = hasattr(vae, "needed_columns") and getattr(vae, "crop_to_mask", False) and x0.dim() == 5
+            if crop:
+                # the blend below is the decoded video's only consumer: where the (aligned) mask is exactly 1 its value cannot reach the
+                # result, so the VAE decodes only the pixel columns that hold a mask value != 1 (+ halo; vae.decode(columns=...)) --
+                # bit-identical blend, the decode of SURVEY 8d's mask shrinks to ~half
+                tds, sds = 2 ** sum(vae.temperal_downsample), 2 ** len(vae.temperal_downsample)
+                shape = (x0.shape[0], 3, (x0.shape[2] - 1) * tds + 1, x0.shape[3] * sds, x0.shape[4] * sds)
+                ref, m = align_reference(video_latents, mask, shape, memo=self.__dict__.setdefault("_align_memo", {}))
             with tr.range("vae_decode", step=step):
-                decoded = vae.decode(ops.latent_denorm(x0, mean, std), return_dict=False)[0]
+                if crop:
+                    decoded = vae.decode(ops.latent_denorm(x0, mean, std), return_dict=False, columns=vae.needed_columns(m))[0]
+                else:
+                    decoded = vae.decode(ops.latent_denorm(x0, mean, std), return_dict=False)[0]
             with tr.range("blend", step=step):
-                ref, m = align_reference(video_latents, mask, decoded.shape, memo=self.__dict__.setdefault("_align_memo", {}))
+                if not crop:
+                    ref, m = align_reference(video_latents, mask, decoded.shape, memo=self.__dict__.setdefault("_align_memo", {}))
                 fused = ops.blend_pixels(ref, m, decoded)
             with tr.range("vae_encode", step=step):
                 enc = vae.encode(fused).latent_dist.mode()

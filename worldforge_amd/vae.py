@@ -196,6 +196,7 @@ class AutoencoderKLWan:
     dtype = torch.float32
 
     ATTN_BATCH_BYTES = 6 << 30   # split operands of the mid-block attention's batched P . V launch kept at a time (_attn_x3)
+    crop_to_mask = True          # the IRR injection decodes only the pixel columns its blend can see (needed_columns); False: everything
 
     def __init__(self, device="cuda:0", comm=None, precision: str = "fp16x3", dtype: torch.dtype = torch.float32, strict_range: bool = False):
         """strict_range: check the fp16 range flag INSIDE the call that raised it (one host synchronisation per encode / decode) -- for
@@ -941,8 +942,9 @@ class AutoencoderKLWan:
         P = self.comm.world
         return (2 * H_lat) % P == 0 and (8 * H_lat) % (4 * P) == 0
 
-    def _decode_one_sharded(self, z: torch.Tensor, gather: bool = True) -> torch.Tensor:
-        """gather=False: return this rank's row slab [3, F, 8h/P, 8w] (rows rank * 8h/P ...) instead of the gathered video."""
+    def _decode_one_sharded(self, z: torch.Tensor, gather: bool = True, crop=None) -> torch.Tensor:
+        """gather=False: return this rank's row slab [3, F, 8h/P, 8w] (rows rank * 8h/P ...) instead of the gathered video.  crop: the
+        latent columns decoded after the latent-resolution stage (decode(columns=...))."""
         comm = self.comm
         P, rank = comm.world, comm.rank
         C, T, h, w = z.shape
@@ -969,6 +971,8 @@ class AutoencoderKLWan:
                 self._reps = 1
         else:
             x = self._run(x, plan[:first_up])                  # stage 0 replicated: [T,h,w,384] fp32
+        if crop is not None:
+            x = x[:, :, crop[0]:crop[1]].contiguous()
         kind, p, cin, cout = plan[first_up]
         Hs = 2 * h // P                                        # my rows at the next resolution
         y0 = rank * Hs
@@ -993,7 +997,7 @@ class AutoencoderKLWan:
         Fo, Ho, Wo, Cy = y.shape
         out = torch.empty((3, Fo, Ho, Wo), dtype=F32, device=self.device)
         call("wf_cl_to_ncthw", y.data_ptr(), out.data_ptr(), 3, Cy, Fo * Ho * Wo, 1.0, ops.stream())
-        return out
+        return out if crop is None else self._uncrop(out, crop, w)
 
     def _encode_one_sharded(self, video: torch.Tensor, slab: torch.Tensor = None) -> torch.Tensor:
         """video [3,F,H,W] replicated on every rank -- or slab [3,F,H/P,W]: only this rank's rows (rank * H/P ...), the halo rows of the
@@ -1094,20 +1098,79 @@ class AutoencoderKLWan:
         call("wf_cl_to_ncthw", q.data_ptr(), out.data_ptr(), 2 * Z_DIM, 2 * Z_DIM, T * h * w, 0.0, ops.stream())
         return out  # [mean | logvar]
 
-    def _decode_one(self, z: torch.Tensor) -> torch.Tensor:
-        """[16,T,h,w] f32 -> [3, 4T-3, 8h, 8w] f32 clamped to [-1,1] (vae.py:544-568, autoencoder_kl_wan.py:1222)."""
+    def _decode_one(self, z: torch.Tensor, crop=None) -> torch.Tensor:
+        """[16,T,h,w] f32 -> [3, 4T-3, 8h, 8w] f32 clamped to [-1,1] (vae.py:544-568, autoencoder_kl_wan.py:1222).  crop = (a0, a1): see
+        decode(columns=...)."""
         C, T, h, w = z.shape
         self.flops_last = 0
         if self.can_shard(h):
-            return self._decode_one_sharded(z)
+            return self._decode_one_sharded(z, crop=crop)
         x = torch.empty((T, h, w, Z_DIM), dtype=F32, device=self.device)
         call("wf_ncthw_to_cl", z.data_ptr(), x.data_ptr(), None, Z_DIM, Z_DIM, T * h * w, ops.stream())
         x = self._latent_in(x, T, h, w)  # 16 channels + 16 zero channels
-        y = self._run(x, decoder_plan())
+        plan = decoder_plan()
+        if crop is None:
+            y = self._run(x, plan)
+        else:
+            first_up = next(i for i, e in enumerate(plan) if e[0] in ("up2d", "up3d"))
+            x = self._run(x, plan[:first_up])                       # the latent-resolution stage sees whole frames (mid-block attention)
+            y = self._run(x[:, :, crop[0]:crop[1]].contiguous(), plan[first_up:])
         Fo, Ho, Wo, Cy = y.shape
         out = torch.empty((3, Fo, Ho, Wo), dtype=F32, device=self.device)
         call("wf_cl_to_ncthw", y.data_ptr(), out.data_ptr(), 3, Cy, Fo * Ho * Wo, 1.0, ops.stream())
-        return out
+        return out if crop is None else self._uncrop(out, crop, w)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # decoding only what an IRR injection consumes
+    # ------------------------------------------------------------------------------------------------------------
+    # The decoded video of fuse_latents (SCHED:1285) is consumed by ONE statement, fused = ref * m + dec * (1 - m) (SCHED:1380): wherever the
+    # mask is exactly 1 the result is the reference pixel whatever (finite) value dec has there.  Real warping masks are mostly 1 (the
+    # warped view covers most of the frame; the hole grows from one side: SURVEY 8d's synthetic mask ends at 65 % valid), so only the pixel
+    # COLUMNS that hold a mask value != 1 -- plus the receptive field of the layers that follow -- need decoding.  Everything up to the first
+    # up-sampling layer (4 % of the decoder's flops, and the only place with global spatial coupling: the mid-block attention) runs on whole
+    # frames; the rest runs on the cropped columns.  Every needed pixel is computed by the same kernels on the same inputs inside its
+    # receptive field, so the BLEND RESULT is bit-identical to decoding everything (tests/test_gpu_vae.py); the other columns of the
+    # returned video are zeros.
+    CROP_HALO = 8      # latent columns decoded beyond the needed ones on either side.  Receptive field of the layers after the crop, walking
+                       # back from a needed output pixel: head conv 1 px + 3 residual blocks 6 = 7 @480 -> (+1 conv) / 2 = 4 @240 -> + 6 + 1 = 11
+                       # -> 6 @120 -> + 6 + 1 = 13 -> 7 latent columns; 8 keeps the crop on the 64-pixel tile grid of the convolutions
+    CROP_MIN_GAIN = 0.9  # crop only when it leaves at most this fraction of the columns
+
+    def needed_columns(self, mask: torch.Tensor):
+        """mask [1,1,F,H,W] f32 (aligned to the decoded size) -> (c0, c1): the LATENT columns whose pixels the blend can see (mask != 1
+        somewhere in the column), or None when that is (nearly) everything.  One 8-byte read-back per distinct mask tensor (the mask of a job
+        is the same object for all its injections)."""
+        key = (mask.data_ptr(), mask._version, tuple(mask.shape))
+        cache = self.__dict__.setdefault("_cols_cache", {})
+        if key not in cache:
+            cache.clear()
+            W = mask.shape[-1]
+            md = mask.to(device=self.device, dtype=F32).contiguous()
+            out = torch.empty(2, dtype=torch.int32, device=self.device)
+            call("wf_mask_column_range", md.data_ptr(), md.numel() // W, W, out.data_ptr(), ops.stream())
+            x0, x1 = (int(v) for v in out.cpu())
+            cache[key] = (mask, None if x1 <= x0 else (x0 // 8, (x1 + 7) // 8))   # (`mask` is held: its address cannot be recycled under the key)
+        cols = cache[key][1]
+        if cols is None:
+            return (0, 0)   # no pixel of the decoded video reaches the result
+        return cols
+
+    def _crop_range(self, columns, w: int):
+        """(c0, c1) needed latent columns -> the latent columns [a0, a1) to decode after the latent-resolution stage, or None (decode all)."""
+        if columns is None:
+            return None
+        c0, c1 = columns
+        if c1 <= c0:
+            c0, c1 = 0, 8   # nothing is needed: the cheapest legal crop
+        a0 = max(0, (c0 - self.CROP_HALO) // 8 * 8)
+        a1 = min(w, -(-(c1 + self.CROP_HALO) // 8) * 8)
+        return (a0, a1) if (a1 - a0) <= self.CROP_MIN_GAIN * w else None
+
+    def _uncrop(self, out: torch.Tensor, crop, w: int) -> torch.Tensor:
+        """[3, F, H, 8 (a1 - a0)] -> [3, F, H, 8 w] with zeros in the columns that were not decoded."""
+        full = torch.zeros(tuple(out.shape[:-1]) + (8 * w,), dtype=out.dtype, device=out.device)
+        full[..., 8 * crop[0]:8 * crop[1]].copy_(out)
+        return full
 
     def _row_slab_of(self, t: torch.Tensor, y0: int, Hs: int) -> torch.Tensor:
         """Rows [y0, y0 + Hs) of a [1,C,F,H,W] tensor as a contiguous slab, kept while the tensor is unchanged (the reference video and the
@@ -1132,11 +1195,12 @@ class AutoencoderKLWan:
         only latent-resolution tensors are gathered.  Bit-identical to the gathered form."""
         self.check_range()   # the flag of the VAE call before this one (see _note_range)
         z = self._io_in(z)
+        cols = self.needed_columns(mask) if self.crop_to_mask else None
         if z.shape[0] != 1 or not self.can_shard(z.shape[3]):
-            dec = self.decode(z, return_dict=False)[0]
+            dec = self.decode(z, return_dict=False, columns=cols)[0]
             return self.encode(ops.blend_pixels(ref, mask, dec)).latent_dist
         self.flops_last = 0
-        slab = self._io_out(self._decode_one_sharded(z[0], gather=False))  # [3, F, Hs, W] in the module dtype
+        slab = self._io_out(self._decode_one_sharded(z[0], gather=False, crop=self._crop_range(cols, z.shape[4])))  # [3, F, Hs, W] in the module dtype
         Hs = slab.shape[2]
         y0 = self.comm.rank * Hs
         fused = ops.blend_pixels(self._row_slab_of(ref, y0, Hs), self._row_slab_of(mask, y0, Hs), slab.unsqueeze(0))
@@ -1170,11 +1234,15 @@ class AutoencoderKLWan:
         return SimpleNamespace(latent_dist=post)
 
     @torch.no_grad()
-    def decode(self, z: torch.Tensor, return_dict: bool = True):
-        """-> the video, clamped to [-1, 1].  fp16 operand modes: see encode() for when the range flag of this call is checked."""
+    def decode(self, z: torch.Tensor, return_dict: bool = True, columns=None):
+        """-> the video, clamped to [-1, 1].  fp16 operand modes: see encode() for when the range flag of this call is checked.
+        columns = (c0, c1) (an extension of the diffusers protocol, used by the IRR injection only): the caller consumes the LATENT columns
+        [c0, c1) of the video alone (pixel columns 8 c0 .. 8 c1, see needed_columns); those are what a full decode returns, bit for bit,
+        the other columns are unspecified finite values (zeros, or decoded where they fall inside the halo)."""
         self.check_range()   # the flag of the VAE call before this one (see _note_range)
         z = self._io_in(z)
-        out = self._io_out(torch.stack([self._decode_one(v) for v in z]))
+        crop = self._crop_range(columns, z.shape[4])
+        out = self._io_out(torch.stack([self._decode_one(v, crop) for v in z]))
         self._note_range("decode")
         if not return_dict:
             return (out,)
