@@ -437,6 +437,12 @@ int wf_cl_to_ncthw(const float* in, float* out, int C, int ld, size_t N, float c
  * wf_f16_overflow_flag.  wf_cast_f16: src f32 [rows, C] (row stride ld_src) -> dst fp16 [rows, C] (row stride ld_dst), C and the strides
  * multiples of 4.  The others are their bf16 namesakes with an fp16 16-bit output. */
 int wf_cast_f16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, size_t rows, int C, void* stream);
+/* Any of the operand producers (fmt 0: wf_split_bf16x3, 1: wf_split_f16x3, 2: wf_cast_f16, 3: plain bf16 rounding) writing straight into a
+ * halo-padded destination -- the row slabs of the sharded VAE, [T][Hs + 2][W][..] with the slab's own rows at 1 .. Hs of every frame: source
+ * row r -> destination row lead_rows + r + (r / group_rows) * gap_rows (group_rows = Hs W, gap_rows = 2 W, lead_rows = W; group_rows = 0: no
+ * gaps).  Same values as the stand-alone producers: it replaces producer + copy (worldforge_amd/vae.py _halo_pad_of). */
+int wf_operand_rows(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, size_t rows, int C, int fmt, int side, size_t group_rows,
+                    size_t gap_rows, size_t lead_rows, void* stream);
 int wf_rms_silu_cl_f16(const float* x, const float* gamma, void* out_f16, float* out_f32, size_t npix, int C, int silu, void* stream);
 int wf_softmax_rows_f16(const float* S, int lds, void* P, int ldp, int M, int N, float scale, void* stream);
 int wf_ncthw_to_cl_f16(const float* in, float* out_f32, void* out_f16, int C, int Cpad, size_t N, void* stream);

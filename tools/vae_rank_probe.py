@@ -3,6 +3,8 @@ the per-convolution event timings of the sharded decode: where the row-slab VAE 
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+from benchlib.measure import synthetic_inputs
 from worldforge_amd import parallel, vae as wvae
 from worldforge_amd.vae import AutoencoderKLWan
 
@@ -27,6 +29,14 @@ vp = AutoencoderKLWan(dev, comm=parallel.LoopbackComm(P, P // 2))
 vp.w = v1.w
 dp, ep = timed(lambda: vp.decode(z, return_dict=False)[0]), timed(lambda: vp.encode(video).latent_dist.mode())
 print(f"single GPU: decode {d1:.1f} ms, encode {e1:.1f} ms; rank {P // 2} of {P}: decode {dp:.1f} ms (x{d1 / dp:.2f}), encode {ep:.1f} ms (x{e1 / ep:.2f})")
+# what an IRR injection runs: decode -> blend -> encode; on the sharded VAE the decoded row slab is never gathered.  With SURVEY 8d's mask
+# (hole growing to 35 % of the width) only the columns the blend can see are decoded (vae.decode(columns=...)); CROP off = everything
+_, ref, mask, _, _, _ = synthetic_inputs(81, 480, 832, dev)
+for crop in (False, True):
+    v1.crop_to_mask = vp.crop_to_mask = crop
+    r1, rp = timed(lambda: v1.decode_blend_encode(z, ref, mask)), timed(lambda: vp.decode_blend_encode(z, ref, mask))
+    print(f"injection round trip (decode -> blend -> encode), needed columns only = {crop}: single GPU {r1:.1f} ms; rank {P // 2} of {P}: {rp:.1f} ms (x{r1 / rp:.2f})", flush=True)
+v1.crop_to_mask = vp.crop_to_mask = True
 
 # per-call timing of the conv entry points in one sharded decode
 ev = []

@@ -186,6 +186,34 @@ __global__ __launch_bounds__(256) void k_cast_f16(const float* __restrict__ src,
   }
 }
 
+// The operand producers above writing straight into a HALO-PADDED destination (row slabs of the sharded VAE: [T][Hs + 2][W][..], the
+// slab's own rows at 1 .. Hs of every frame): source row r lands at destination row lead + r + (r / group) * gap.  fmt 0 / 1: three-term
+// bf16 / fp16 split (side as k_split3), fmt 2: one-term fp16, fmt 3: one-term bf16.  Same conversions as k_split3 / k_cast_f16.
+__global__ __launch_bounds__(256) void k_operand_rows(const float* __restrict__ src, long ld_src, uint16_t* __restrict__ dst, long ld_dst,
+                                                      size_t rows, int C, int fmt, int side, size_t group, size_t gap, size_t lead) {
+  const int nvec = C >> 2;
+  const size_t n = rows * (size_t)nvec;
+  const int f16 = fmt == 1 || fmt == 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / nvec;
+    const int id = (int)(i % nvec);
+    const float4 v = reinterpret_cast<const float4*>(src + r * ld_src)[id];
+    const float y[4] = {v.x, v.y, v.z, v.w};
+    note_range(f16, y);
+    const u32x2 hi = {pack16x2(f16, y[0], y[1]), pack16x2(f16, y[2], y[3])};
+    uint16_t* o = dst + (lead + r + (group ? (r / group) * gap : 0)) * ld_dst;
+    reinterpret_cast<u32x2*>(o)[id] = hi;
+    if (fmt < 2) {
+      float t[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] = y[k] - r16(f16, y[k]);
+      const u32x2 lo = {pack16x2(f16, t[0], t[1]), pack16x2(f16, t[2], t[3])};
+      reinterpret_cast<u32x2*>(o + C)[id] = side ? hi : lo;
+      reinterpret_cast<u32x2*>(o + 2 * C)[id] = side ? lo : hi;
+    }
+  }
+}
+
 // softmax over each row of S [M, N] f32 * scale -> P f32 [M, ldp] (columns N..ldp zero): the fp32-class VAE keeps P in f32 and splits it
 __global__ __launch_bounds__(256) void k_softmax_rows_f32(const float* __restrict__ S, int lds, float* __restrict__ P, int ldp, int N,
                                                           float scale) {
@@ -355,6 +383,19 @@ extern "C" int wf_cast_f16(const float* src, int64_t ld_src, void* dst, int64_t 
   hipLaunchKernelGGL(k_cast_f16, dim3(grid_for(rows * (size_t)(C / 4), 256, 16384)), dim3(256), 0, (hipStream_t)stream, src, ld_src,
                      (uint16_t*)dst, ld_dst, rows, C);
   WF_LAUNCH_CHECK("wf_cast_f16");
+  return WF_OK;
+}
+extern "C" int wf_operand_rows(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, size_t rows, int C, int fmt, int side,
+                               size_t group_rows, size_t gap_rows, size_t lead_rows, void* stream) {
+  WF_CHECK_ARG(src && dst, "wf_operand_rows: null pointer");
+  WF_CHECK_ARG(fmt >= 0 && fmt <= 3 && (side == 0 || side == 1), "wf_operand_rows: fmt %d (0 bf16x3, 1 f16x3, 2 f16, 3 bf16) / side %d", fmt, side);
+  WF_CHECK_ARG(C > 0 && C % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && ld_src >= C && ld_dst >= (fmt < 2 ? 3L : 1L) * C,
+               "wf_operand_rows: C=%d ld_src=%ld ld_dst=%ld (C, strides multiples of 4; ld_dst >= the operand's width)", C, (long)ld_src,
+               (long)ld_dst);
+  if (rows == 0) return WF_OK;
+  hipLaunchKernelGGL(k_operand_rows, dim3(grid_for(rows * (size_t)(C / 4), 256, 16384)), dim3(256), 0, (hipStream_t)stream, src, ld_src,
+                     (uint16_t*)dst, ld_dst, rows, C, fmt, side, group_rows, gap_rows, lead_rows);
+  WF_LAUNCH_CHECK("wf_operand_rows");
   return WF_OK;
 }
 // Sticky range flag of the fp16 producers: *out = 1 if any value beyond the fp16 range (or a NaN) was converted since the last reset.

@@ -195,7 +195,7 @@ class _LatentDist:
 class AutoencoderKLWan:
     dtype = torch.float32
 
-    ATTN_BATCH_BYTES = 6 << 30   # split operands of the mid-block attention's batched P . V launch kept at a time (_attn_x3)
+    ATTN_BATCH_BYTES = 12 << 30  # scores, probabilities and split operands of the mid-block attention's batched launches kept at a time (_attn_x3)
     crop_to_mask = True          # the IRR injection decodes only the pixel columns its blend can see (needed_columns); False: everything
 
     def __init__(self, device="cuda:0", comm=None, precision: str = "fp16x3", dtype: torch.dtype = torch.float32, strict_range: bool = False):
@@ -629,17 +629,23 @@ class AutoencoderKLWan:
         qkv[T * hw:].zero_()
         self._gemm(a.view(-1, C), W[p + ".to_qkv.w"], W[p + ".to_qkv.b"], qkv[:T * hw], EPI_BF16)
         del a
-        S = torch.empty((nq, hwp), dtype=F32, device=x.device)
-        P = torch.empty((nq, hwp), dtype=BF, device=x.device)
-        Vt = torch.empty((C, hwp), dtype=BF, device=x.device)
         O = torch.empty((T * nq, C), dtype=BF, device=x.device)
         scale = 1.0 / math.sqrt(C)
-        for t in range(T):
-            blk = qkv[t * hw:t * hw + hwp]
-            self._gemm(blk[q0:q1, 0:C], blk[:, C:2 * C], None, S, EPI_F32)
-            call("wf_softmax_rows", S.data_ptr(), hwp, P.data_ptr(), hwp, nq, hw, float(scale), ops.stream())
-            call("wf_transpose_bf16", blk[:, 2 * C:].data_ptr(), 3 * C, Vt.data_ptr(), hwp, hw, C, ops.stream())
-            self._gemm(P, Vt, None, O[t * nq:(t + 1) * nq], EPI_BF16)
+        # all frames of a chunk in ONE launch per product (round 6; see _attn_x3): q / k are read in place from the qkv rows (row stride 3C,
+        # frame stride hw rows), per frame the tiles and the K order of the single call
+        tb = max(1, min(T, self.ATTN_BATCH_BYTES // (nq * hwp * 6 + C * hwp * 2)))
+        S = torch.empty((tb, nq, hwp), dtype=F32, device=x.device)
+        P = torch.empty((tb, nq, hwp), dtype=BF, device=x.device)
+        Vt = torch.empty((tb, C, hwp), dtype=BF, device=x.device)
+        for t0 in range(0, T, tb):
+            n = min(tb, T - t0)
+            call("wf_gemm_bf16_batched", qkv[t0 * hw + q0:].data_ptr(), qkv[t0 * hw:, C:].data_ptr(), S.data_ptr(), n, nq, hwp, C, 3 * C, 3 * C, hwp,
+                 hw * 3 * C, hw * 3 * C, nq * hwp, EPI_F32, ops.stream())
+            call("wf_softmax_rows", S.data_ptr(), hwp, P.data_ptr(), hwp, n * nq, hw, float(scale), ops.stream())
+            for t in range(t0, t0 + n):
+                call("wf_transpose_bf16", qkv[t * hw:, 2 * C:].data_ptr(), 3 * C, Vt[t - t0].data_ptr(), hwp, hw, C, ops.stream())
+            call("wf_gemm_bf16_batched", P.data_ptr(), Vt.data_ptr(), O[t0 * nq:].data_ptr(), n, nq, C, hwp, hwp, hwp, C, nq * hwp, C * hwp, nq * C,
+                 EPI_BF16, ops.stream())
         self._gemm(O, W[p + ".proj.w"], W[p + ".proj.b"], x.view(-1, C), EPI_F32_ACC)  # x + proj(attn)  (vae.py:262)
         self.flops_last += T * (4 * nq * hw * C) + 2 * T * hw * C * 3 * C + 2 * T * nq * C * C
         return x
@@ -654,31 +660,39 @@ class AutoencoderKLWan:
         qkv = torch.zeros((T * hw + 64, 3 * C), dtype=F32, device=x.device)  # + 64 rows: the last frame's padded K rows stay in-bounds
         self._gemm(a.view(-1, n3 * C), W[p + ".to_qkv.w"], W[p + ".to_qkv.b"], qkv[:T * hw], EPI_F32, wkey=p + ".to_qkv.w")
         del a
-        S = torch.empty((nq, hwp), dtype=F32, device=x.device)
-        P = torch.empty((nq, hwp), dtype=F32, device=x.device)
-        Vt = torch.empty((C, hwp), dtype=F32, device=x.device)
         Of = torch.empty((T * nq, C), dtype=F32, device=x.device)
         scale = 1.0 / math.sqrt(C)
-        # The P . V product of a frame is nq x C x 3 hwp: ceil(nq / 128) x 3 workgroups of the 128 x 128 kernel -- 147 at 480p, 37 on a row group's
-        # query slab -- i.e. a fraction of the chip, 21 times in a row.  The three-term operands of a CHUNK of frames are therefore kept and
-        # their products run as ONE batched launch; per frame the arithmetic is that of the single call (same kernel, same tiles).  The chunk
-        # is bounded by a byte budget (ATTN_BATCH_BYTES: 4.9 GB at 480p = all 21 frames in one launch; 720p on one GPU = 26 GB unchunked,
-        # ADVICE r4): whole frames while they fit, never fewer than one.
-        per_frame = (nq + C) * n3 * hwp * 2
+        # A frame's products are a fraction of the chip (Q . K^T: nq x hwp x n3 C = 175 workgroups of the 256 x 256 kernel at 480p, 49 on a row
+        # group's query slab; P . V: 147 / 37), 21 times in a row, with a handful of small launches each.  Round 4 batched the P . V products
+        # of a chunk of frames into ONE launch; round 6 does the same for Q . K^T, the softmax and the operand splits: q and k of ALL frames
+        # are split once (two launches), the batched GEMM addresses frame t's rows in place (batch stride hw rows; the padded key rows of a
+        # frame are the next frame's first rows, never read by the softmax), one softmax launch covers the chunk's n * nq rows, one split
+        # each its probabilities and its transposed values.  Per frame the arithmetic is that of the single call (same kernels, same tiles,
+        # same K order: the GEMM's results do not depend on the tile or on the batch).  The chunk is bounded by a byte budget
+        # (ATTN_BATCH_BYTES: 11.8 GB at 480p = all 21 frames; 720p: 4 frames at a time): whole frames while they fit, never fewer than one.
+        Q3 = self._operand(qkv[:, 0:C], 0)          # [T hw + 64, n3 C]
+        K3 = self._operand(qkv[:, C:2 * C], 1)
+        ld3 = n3 * C
+        per_frame = nq * hwp * 8 + (nq + C) * n3 * hwp * 2 + C * hwp * 4
         tb = max(1, min(T, self.ATTN_BATCH_BYTES // per_frame))
+        S = torch.empty((tb, nq, hwp), dtype=F32, device=x.device)
+        P = torch.empty((tb, nq, hwp), dtype=F32, device=x.device)
+        Vt = torch.empty((tb, C, hwp), dtype=F32, device=x.device)
         P3 = torch.empty((tb, nq, n3 * hwp), dtype=self.OP, device=x.device)
         V3 = torch.empty((tb, C, n3 * hwp), dtype=self.OP, device=x.device)
+        batched = "wf_gemm_f16_batched" if self.f16 else "wf_gemm_bf16_batched"
         for t0 in range(0, T, tb):
             n = min(tb, T - t0)
+            call(batched, Q3[t0 * hw + q0:].data_ptr(), K3[t0 * hw:].data_ptr(), S.data_ptr(), n, nq, hwp, ld3, ld3, ld3, hwp, hw * ld3, hw * ld3,
+                 nq * hwp, EPI_F32, ops.stream())
+            call("wf_softmax_rows_f32", S.data_ptr(), hwp, P.data_ptr(), hwp, n * nq, hw, float(scale), ops.stream())
             for t in range(t0, t0 + n):
-                blk = qkv[t * hw:t * hw + hwp]
-                self._gemm(self._operand(blk[q0:q0 + nq, 0:C], 0), self._operand(blk[:, C:2 * C], 1), None, S, EPI_F32)
-                call("wf_softmax_rows_f32", S.data_ptr(), hwp, P.data_ptr(), hwp, nq, hw, float(scale), ops.stream())
-                call("wf_transpose_f32", blk[:, 2 * C:].data_ptr(), 3 * C, Vt.data_ptr(), hwp, hw, C, ops.stream())
-                self._operand(P, 0, out=P3[t - t0])
-                self._operand(Vt, 1, out=V3[t - t0])
-            call("wf_gemm_f16_batched" if self.f16 else "wf_gemm_bf16_batched", P3.data_ptr(), V3.data_ptr(), Of[t0 * nq:].data_ptr(), n, nq, C,
+                call("wf_transpose_f32", qkv[t * hw:, 2 * C:].data_ptr(), 3 * C, Vt[t - t0].data_ptr(), hwp, hw, C, ops.stream())
+            self._operand(P[:n].view(n * nq, hwp), 0, out=P3[:n].view(n * nq, n3 * hwp))
+            self._operand(Vt[:n].view(n * C, hwp), 1, out=V3[:n].view(n * C, n3 * hwp))
+            call(batched, P3.data_ptr(), V3.data_ptr(), Of[t0 * nq:].data_ptr(), n, nq, C,
                  n3 * hwp, n3 * hwp, n3 * hwp, C, nq * n3 * hwp, C * n3 * hwp, nq * C, EPI_F32, ops.stream())
+        del Q3, K3, S, P, Vt
         del P3, V3
         self._gemm(self._operand(Of), W[p + ".proj.w"], W[p + ".proj.b"], x.view(-1, C), EPI_F32_ACC, wkey=p + ".proj.w")
         self.flops_last += n3 * (T * (4 * nq * hw * C) + 2 * T * hw * C * 3 * C + 2 * T * nq * C * C)
@@ -765,16 +779,19 @@ class AutoencoderKLWan:
         out[:, 1:Hs + 1].copy_(a)
         return self._halo_fill(out)
 
-    def _halo_pad_of(self, x, producer):
-        """_halo_pad(producer(x)) with the two border rows produced FIRST: their operand rows travel to the neighbours on the communication
-        stream (Comm.neighbor_rows_async) while `producer` runs on the whole slab.  x f32 [T,Hs,W,C]; producer: f32 rows [T,n,W,C] -> operand
-        rows [T,n,...] with per-pixel arithmetic (the split / norm kernels): bit-identical to exchanging rows of the produced slab."""
-        T, Hs = x.shape[:2]
-        e_op = producer(torch.stack([x[:, 0], x[:, Hs - 1]], dim=1))
+    def _halo_pad_of(self, x, producer=None):
+        """The conv operand of the row slab x f32 [T,Hs,W,C], halo-padded: [T,Hs+2,W,..] with the neighbours' boundary rows (zeros at the image
+        edge).  The two border rows are produced FIRST: their operand rows travel to the neighbours on the communication stream
+        (Comm.neighbor_rows_async) while the whole slab's operand is produced -- straight into rows 1 .. Hs of the padded buffer
+        (wf_operand_rows: round 5 produced the slab's operand and copied it in, 1-2 GB per full-resolution layer).  Per pixel the same
+        arithmetic wherever the pixel sits: bit-identical to exchanging rows of the produced slab."""
+        T, Hs, Wd, C = x.shape
+        e_op = self._operand(torch.stack([x[:, 0], x[:, Hs - 1]], dim=1))
         pending = self.comm.neighbor_rows_async(e_op[:, 0], e_op[:, 1], self._reps)
-        a = producer(x)
-        out = torch.empty((T, Hs + 2) + tuple(a.shape[2:]), dtype=a.dtype, device=a.device)
-        out[:, 1:Hs + 1].copy_(a)
+        nC = self.terms * C
+        out = torch.empty((T, Hs + 2, Wd, nC), dtype=self.OP, device=x.device)
+        fmt = (1 if self.f16 else 0) if self.x3 else (2 if self.f16 else 3)
+        call("wf_operand_rows", x.data_ptr(), C, out.data_ptr(), nC, T * Hs * Wd, C, fmt, 0, Hs * Wd, 2 * Wd, Wd, ops.stream())
         up, down = pending()
         if up is not None:
             out[:, 0].copy_(up)
@@ -919,7 +936,7 @@ class AutoencoderKLWan:
     def _down_slab(self, x, p, C, temporal):
         """fp32 slab [T,Hs,W,C] -> [T',Hs/2,W/2,C]  (ZeroPad2d((0,1,0,1)) + stride-2 conv: bottom halo row only)."""
         T, Hs, Wd, _ = x.shape
-        xpad = self._halo_pad_of(x, self._operand)
+        xpad = self._halo_pad_of(x)
         Ho, Wo = Hs // 2, Wd // 2
         if not temporal or T == 1:
             y, _ = self._conv(xpad, p + ".resample.1", T, Ho, Wo, C, (1, 3, 3), ss=2, ps=0, ph=-1)
@@ -986,7 +1003,7 @@ class AutoencoderKLWan:
                 x = self._res_slab(x, p, cin, cout)
             elif kind in ("up2d", "up3d"):
                 Hcur = x.shape[1]
-                x = self._up_slab(self._halo_pad_of(x, self._operand), p, cin, kind == "up3d", row0 - 1, 2 * row0, 2 * Hcur, h_cur)
+                x = self._up_slab(self._halo_pad_of(x), p, cin, kind == "up3d", row0 - 1, 2 * row0, 2 * Hcur, h_cur)
                 row0 *= 2
                 h_cur *= 2
             elif kind == "head":
