@@ -20,8 +20,19 @@ def _case() -> str:
     return cur.rsplit(" (", 1)[0]
 
 
+_SEEN = {"case": None, "n": {}}
+
+
 def key_of(name: str) -> str:
-    return f"{name} | {_case()}"
+    """name | pytest case [| rank r] | #k -- k counts the calls with this name inside the case (a test that checks several layers / shapes
+    under one name logs them in a fixed order), r is the rank of a real rank process (tests/rank_worker.py)."""
+    case = _case()
+    if _SEEN["case"] != case:
+        _SEEN["case"], _SEEN["n"] = case, {}
+    k = _SEEN["n"].get(name, 0)
+    _SEEN["n"][name] = k + 1
+    rank = f" | rank {os.environ['RANK']}" if os.environ.get("RANK") and os.environ.get("WORLD_SIZE", "1") != "1" else ""
+    return f"{name} | {case}{rank} | #{k}"
 
 
 def _table():
