@@ -344,7 +344,7 @@ def main(argv=None):
             # SURVEY 8d "HBM GB/s for the injection kernels": the pixel blend of every IRR injection inside the timed window (HIP events on the
             # launch stream), algorithmic bytes = (3 + 1 + 3 + 3) x 4 B per pixel-frame (this rank's rows when the VAE is row-sharded)
             us, nb = sum(u for u, _ in blend) / len(blend), blend[0][1]
-            out["hbm"] = {"kernel": "k_blend4 (wf_blend_pixels, SCHED:1375-1380)", "bytes": nb, "avg_us": us, "launches": len(blend),
+            out["hbm"] = {"kernel": "k_blend4_rgb (wf_blend_pixels, SCHED:1375-1380)", "bytes": nb, "avg_us": us, "launches": len(blend),
                           "achieved_GBps": nb / us / 1e3, "peak_GBps": 8000.0, "frac_of_8TBps": nb / us / 1e3 / 8000.0}
         if world == 1 and a.as_rank_of <= 1:
             out["flf_gate_ms"] = flf_gate_ms(sch, (1, 16, T, a.height // 8, a.width // 8), device)

@@ -222,13 +222,17 @@ int wf_attn_fwd_split(const void* Q, const void* K, const void* Vt, void* O, int
  * wf_attn_fwd with softmax_scale = 0); Q / K / Vt / bounds as wf_attn_fwd.  wf_attn_merge combines the slots exactly (the flash combine
  * wf_attn_fwd_split uses) into O once every slot has been written; the result equals the one-launch sweep up to the re-association of the
  * fp32 partial sums.
- * Round 5: nparts up to 12; an optional SECOND window [t_begin2, t_end2) in inner_splits2 splits (0 = none) behind the first -- the keys on
- * the far side of a hole, i.e. of the rank's own segment, which an earlier part launch walked without waiting for the exchange: one launch
- * then covers "every peer" of an all-gathered buffer (slots part ... part + splits of window 1 + splits of window 2 - 1; a window of n
- * tiles in k splits fills ceil(n / ceil(n / k)) slots).  seg_stride_bytes / kmax_stride as wf_attn_fwd. */
+ * Round 5: nparts up to 12; an optional SECOND window [t_begin2, t_end2) (t_end2 <= t_begin2: none) behind the first -- the keys on the far
+ * side of a hole, i.e. of the rank's own segment(s), which an earlier part launch walked without waiting for the exchange: one launch then
+ * covers "every peer" of an all-gathered buffer.  seg_stride_bytes / kmax_stride as wf_attn_fwd.
+ * Round 6: the two windows are walked as ONE sequence by the same workgroups (the hole must be whole segments): `inner_splits` splits of
+ * the joined sequence fill the slots part ... (n tiles in k splits: ceil(n / ceil(n / k)) slots) -- one slot and one prologue / epilogue
+ * per peer chunk where round 5 spent two.  O_merge != NULL (the LAST launch of a sweep: part = nparts - 1, one split): the launch folds
+ * the slots 0 .. part - 1 into its own result in its epilogue and writes the normalised bf16 rows to O_merge [Lq][ldo] -- no partial, no
+ * separate wf_attn_merge pass. */
 int wf_attn_fwd_part(const void* Q, const void* K, const void* Vt, int H, int Lq, int Lkp, int kv_len, int seg_len, size_t seg_stride_bytes,
-                     int t_begin, int t_end, int inner_splits, int t_begin2, int t_end2, int inner_splits2, int part, int nparts,
-                     void* workspace, const float* kmax2, int kmax_n, int kmax_stride, const float* qmax2, int qmax_n, void* stream);
+                     int t_begin, int t_end, int t_begin2, int t_end2, int inner_splits, int part, int nparts, void* workspace, void* O_merge,
+                     int ldo, const float* kmax2, int kmax_n, int kmax_stride, const float* qmax2, int qmax_n, void* stream);
 int wf_attn_merge(void* O, int H, int Lq, int ldo, int accumulate, int nparts, const void* workspace, void* stream);
 
 /* WanLayerNorm (model.py:92-102; eps, no affine) fused with y = ln * (plus_one + mul[c]) + add[c]:

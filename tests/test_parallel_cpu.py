@@ -243,12 +243,16 @@ def test_sweep_plan_covers_every_valid_key_once_own_shard_first(mode, chunks):
                         g, (t0, t1, k1), w2 = st["chunk"], st["win"], st["win2"]
                         tps = ex.chunk_len(g) // 64
                         assert st["slot"] == slot and t0 < t1 and k1 >= 1
-                        slot += _slots(t1 - t0, k1)
+                        joined = t1 - t0
                         seen[g] += list(range(t0, t1))
                         if w2:
                             assert w2[0] >= t1 and w2[0] < w2[1] and (t1, w2[0]) == (r * tps, (r + 1) * tps)   # the hole is the own segment
-                            slot += _slots(w2[1] - w2[0], w2[2])
+                            joined += w2[1] - w2[0]      # round 6: both sides of the hole are ONE sequence for the same workgroups
                             seen[g] += list(range(w2[0], w2[1]))
+                        assert st["nslots"] == _slots(joined, k1)
+                        slot += st["nslots"]
+                        # only the last launch may merge, and only when it is a single split with at least one slot in front of it
+                        assert st["merge"] == (st is steps[-1] and len(steps) >= 2 and st["nslots"] == 1)
                         own = st["wait"] is None
                         if own:
                             assert not peers_started and t0 >= r * tps and t1 <= (r + 1) * tps and st["km"] == (r, 1)

@@ -150,12 +150,14 @@ ok("wf_attn_fwd", Q, Kx, Vx, O, H, Lq, P4 * seg, 1000, seg, slot, H * 128, 0.0, 
 bad("wf_attn_fwd", Q, Kx, Vx, O, H, Lq, P4 * seg, 1000, seg, H * seg * 256 - 16, H * 128, 0.0, 0, None, 0, 0, None, 0, None)   # a slot shorter than its K shard
 bad("wf_attn_fwd", Q, Kx, Vx, O, H, Lq, P4 * seg, 1000, seg, slot, H * 128, 0.0, 0, KMx, P4, H - 1, f32(H), 1, None)  # bound vectors overlap
 ws6 = buf(dll.wf_attn_split_workspace_bytes(H, Lq, 4))
-ok("wf_attn_fwd_part", Q, Kx, Vx, H, Lq, P4 * seg, 1000, seg, slot, 4, 8, 1, 0, 0, 0, 0, 4, ws6, KMx + slot, 1, slot // 4, f32(H), 1, None)     # own segment 1
-ok("wf_attn_fwd_part", Q, Kx, Vx, H, Lq, P4 * seg, 1000, seg, slot, 0, 4, 1, 8, 16, 2, 1, 4, ws6, KMx, P4, slot // 4, f32(H), 1, None)          # peers: before + after in 1 + 2 splits
+ok("wf_attn_fwd_part", Q, Kx, Vx, H, Lq, P4 * seg, 1000, seg, slot, 4, 8, 0, 0, 1, 0, 4, ws6, None, 0, KMx + slot, 1, slot // 4, f32(H), 1, None)     # own segment 1
+ok("wf_attn_fwd_part", Q, Kx, Vx, H, Lq, P4 * seg, 1000, seg, slot, 0, 4, 8, 16, 3, 1, 4, ws6, None, 0, KMx, P4, slot // 4, f32(H), 1, None)          # peers: before + after as one sequence in 3 splits
 ok("wf_attn_merge", O, H, Lq, H * 128, 0, 4, ws6, None)
-bad("wf_attn_fwd_part", Q, Kx, Vx, H, Lq, P4 * seg, 1000, seg, slot, 0, 4, 1, 2, 16, 2, 1, 4, ws6, None, 0, 0, None, 0, None)                  # second window overlaps the first
-bad("wf_attn_fwd_part", Q, Kx, Vx, H, Lq, P4 * seg, 1000, seg, slot, 0, 4, 1, 8, 16, 2, 2, 4, ws6, None, 0, 0, None, 0, None)                  # slots 2..4 of 4
-bad("wf_attn_fwd_part", Q, Kx, Vx, H, Lq, P4 * seg, 1000, seg, slot, 16, 20, 1, 0, 0, 0, 0, 4, ws6, None, 0, 0, None, 0, None)                 # window behind the last valid tile
+bad("wf_attn_fwd_part", Q, Kx, Vx, H, Lq, P4 * seg, 1000, seg, slot, 0, 4, 2, 16, 3, 1, 4, ws6, None, 0, None, 0, 0, None, 0, None)                  # second window overlaps the first
+bad("wf_attn_fwd_part", Q, Kx, Vx, H, Lq, P4 * seg, 1000, seg, slot, 0, 4, 8, 16, 3, 1, 4, ws6, O, H * 128, None, 0, 0, None, 0, None)             # a merging launch must be the last slot, one split
+bad("wf_attn_fwd_part", Q, Kx, Vx, H, Lq, P4 * seg, 1000, seg, slot, 0, 4, 8, 16, 3, 2, 4, ws6, None, 0, None, 0, 0, None, 0, None)                  # slots 2..4 of 4
+bad("wf_attn_fwd_part", Q, Kx, Vx, H, Lq, P4 * seg, 1000, seg, slot, 16, 20, 0, 0, 1, 0, 4, ws6, None, 0, None, 0, 0, None, 0, None)                 # window behind the last valid tile
+bad("wf_attn_fwd_part", Q, Kx, Vx, H, Lq, P4 * seg, 1000, seg, slot, 0, 3, 8, 16, 1, 1, 4, ws6, None, 0, None, 0, 0, None, 0, None)                   # the hole must be whole segments (4 tiles each)
 bad("wf_attn_merge", O, H, Lq, H * 128, 0, 13, ws6, None)                                                                                # more than 12 slots
 ok("wf_head_max_norm2", K, H, 1000, Lkp, f32(H), None)
 ok("wf_attn_cross2_fwd", Q, buf(2 * H * 832 * 128), buf(2 * H * 832 * 128), O, H, Lq, 320, 257, 512, 512, H * 128, 0.0884, None)

@@ -71,6 +71,11 @@ struct AttnArgs {
   // optional SECOND window of a part launch (the keys on the far side of a hole -- the rank's own segment, walked earlier without a wait):
   // splits s >= n_first work on tiles [t_begin2 + (s - n_first) * tiles_per_split2, ...) below t_end2.  Launches with one window: n_first = INT_MAX
   int n_first, t_begin2, t_end2, tiles_per_split2;
+  // PART launches (k_attn_w4_part) read the four fields above differently: the launch walks the JOINED sequence [t_begin0, t_end) ++
+  // [t_begin2, t_end2) in splits of tiles_per_split; n_first = tiles in front of the hole (INT_MAX: no hole), tiles_per_split2 = the joined
+  // length.  merge_n > 0 (a single-split LAST launch of a sweep): fold the partial slots 0 .. merge_n - 1 into this launch's own result
+  // and write the normalised bf16 rows to O instead of leaving a partial.
+  int merge_n = 0;
   float* o_part;   // [nsplit][Lq][H*128] f32
   float* ml_part;  // [nsplit][H][Lq][2] f32: reference max m (raw score units), row sum l
   // block-sparse attention (KIND 3): per (head, 256-row query group) a list of 128-key blocks to visit, entry = block * 4 + flags,
@@ -102,6 +107,14 @@ struct AttnArgs {
 // Per-phase cycle accounting (debug builds only: python -m worldforge_amd.build with WF_EXTRA_HIPCC_FLAGS=-DWF_ATTN_TIMING).
 __device__ unsigned long long g_attn_cycles[32];  // k_attn_w4: B*8 + (gap >> 3) for the 8-gap groups of even (B=0) / odd tiles, 16 commit, 17 drain, 18 barrier, 19 tiles
 #endif
+
+constexpr int MAX_MERGE = 11;  // earlier partial slots a merging part launch can fold in (MAX_PARTS - 1)
+__device__ __forceinline__ float ws_at(const float (&w)[MAX_MERGE], int s) {  // w[s] for a run-time (wave-uniform) s without spilling the array
+  float r = w[0];
+#pragma unroll
+  for (int i = 1; i < MAX_MERGE; ++i) r = s == i ? w[i] : r;
+  return r;
+}
 
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
@@ -141,7 +154,14 @@ __device__ __forceinline__ float add_rn(float a, float b) {
 
 // NOMAX (KIND 4 only, chosen per workgroup by the kernel below): no running-max tracking after tile 0 -- the reference max of every row
 // stays the first tile's for the whole sweep.
-template <int KIND, bool NOMAX>
+// PART (round 6): the instantiation wf_attn_fwd_part launches.  (i) Its tile window may have a HOLE -- tiles [t_begin0, t_end) and
+// [t_begin2, t_end2) are walked by the SAME workgroups as one sequence (the hole is the rank's own segment of the exchange buffer, walked
+// earlier without a wait): one partial slot and one prologue / epilogue per peer chunk where round 5 used a separate set of workgroups and
+// a separate slot per side of the hole.  (ii) The LAST part launch of a sweep merges the earlier launches' partial slots in its epilogue
+// and writes the normalised bf16 result (merge_n earlier slots; the arithmetic and its order are k_attn_merge's) instead of storing its own
+// partial for a separate merge pass.  Everything PART adds is `if constexpr`: the whole-sweep instantiations are unchanged instruction for
+// instruction.
+template <int KIND, bool NOMAX, bool PART = false>
 __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BUF_BYTES = K_TILE_BYTES + V_TILE_BYTES;
@@ -233,10 +253,23 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
   const float c = PS ? 1.0f : a.scale_log2;
   const int ntiles_all = (KIND == 5 ? a.n1 : 0) + (a.kv_len + KB - 1) / KB;
   const int split = a.part0 + blockIdx.y;                                // partial slot of this split
-  const bool win2 = (int)blockIdx.y >= a.n_first;                        // (scalar: blockIdx.y is uniform) second window of a part launch
-  const int tps_w = win2 ? a.tiles_per_split2 : a.tiles_per_split;
-  const int t_begin = win2 ? a.t_begin2 + ((int)blockIdx.y - a.n_first) * tps_w : a.t_begin0 + (int)blockIdx.y * tps_w;  // first KV tile of this split (absolute)
-  int ntiles_ = min(tps_w, min(ntiles_all, win2 ? a.t_end2 : a.t_end) - t_begin);  // tiles of this split (>= 1 by construction of the grid)
+  // PART: the launch's tiles are the JOINED sequence [t_begin0, t_end) ++ [t_begin2, t_end2) (n_first = its length up to the hole, INT_MAX
+  // without one; tiles_per_split2 = its whole length); split s takes tiles_per_split of them from relative tile s * tiles_per_split on.
+  // hole_at: relative tile (within this split) in front of which the sweep hops over the hole; hole_tiles: what it skips.
+  int t_begin, ntiles_, hole_at = INT_MAX, hole_tiles = 0;
+  if constexpr (PART) {
+    const int rel0 = (int)blockIdx.y * a.tiles_per_split;
+    const bool after = rel0 >= a.n_first;
+    t_begin = after ? a.t_begin2 + (rel0 - a.n_first) : a.t_begin0 + rel0;
+    ntiles_ = min(a.tiles_per_split, a.tiles_per_split2 - rel0);
+    if (!after && rel0 + ntiles_ > a.n_first) {
+      hole_at = a.n_first - rel0;
+      hole_tiles = a.t_begin2 - a.t_end;
+    }
+  } else {
+    t_begin = a.t_begin0 + (int)blockIdx.y * a.tiles_per_split;  // first KV tile of this split (absolute)
+    ntiles_ = min(a.tiles_per_split, min(ntiles_all, a.t_end) - t_begin);  // tiles of this split (>= 1 by construction of the grid)
+  }
   // block-sparse variant: per-workgroup list of PHYSICAL key blocks (entry = block * 2^g + flags, g = bsa_shift query blocks per
   // workgroup = 2 waves each for 128-token blocks / 1 wave each for 64-token blocks), tpe tiles per entry
   const int* bsa = nullptr;
@@ -257,7 +290,7 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
   }
   const int ntiles = ntiles_;
   const bool ragged = KIND != 3 && KIND != 5 && (a.kv_len & (KB - 1)) != 0;
-  const int rag_t = ragged ? ntiles_all - 2 - t_begin : -1;  // the tile in which the scores of the ragged last tile are produced (one scalar compare per tile)
+  const int rag_t = ragged ? ntiles_all - 2 - t_begin - hole_tiles : -1;  // the tile in which the scores of the ragged last tile are produced (one scalar compare per tile; relative to the split: minus the tiles of a hole hopped over)
   const bool rag1 = KIND == 5 && (a.kv_len1 & (KB - 1)) != 0, rag2 = KIND == 5 && (a.kv_len & (KB - 1)) != 0;  // ragged last tile of either context
 
   // Element offset / LDS slot of the tile being staged (wave-uniform), advanced one tile at a time: a handful of scalar
@@ -265,6 +298,7 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
   // tile into the next ring slots, whose tiles (ntiles-5 ... ntiles-3) are dead by then.
   const size_t tile_bytes = (size_t)(KB * D * 2);
   const size_t seg_jump = a.seg_stride - (size_t)tiles_per_seg * tile_bytes;  // to the next K/V segment of the same head (all-gathered shards)
+  const size_t hole_bytes = (size_t)(hole_tiles / tiles_per_seg) * a.seg_stride;  // PART: the whole segments a hop skips
   const int seg0 = t_begin / tiles_per_seg, in0 = t_begin - seg0 * tiles_per_seg;
   size_t st_off = (size_t)seg0 * a.seg_stride + ((size_t)head * tiles_per_seg + in0) * tile_bytes;  // byte offset of the staged tile in K and in V^T
   int st_tile = 0, st_left = tiles_per_seg - in0;  // tile number (in the split), tiles left in its segment
@@ -299,7 +333,12 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
       return;
     }
     const bool wrap = --st_left == 0;
-    st_off += live ? (wrap ? tile_bytes + seg_jump : tile_bytes) : 0;
+    if constexpr (PART) {  // the hole starts and ends on segment boundaries: the hop is a longer segment jump (scalar, branch-free like the rest)
+      const bool hop = st_tile == hole_at;
+      st_off += live ? (wrap ? tile_bytes + seg_jump + (hop ? hole_bytes : 0) : tile_bytes) : 0;
+    } else {
+      st_off += live ? (wrap ? tile_bytes + seg_jump : tile_bytes) : 0;
+    }
     st_left = wrap ? tiles_per_seg : st_left;
     st_base = st_base + BUF_BYTES >= (uint32_t)(NBUF * BUF_BYTES) ? st_base + BUF_BYTES - NBUF * BUF_BYTES : st_base + BUF_BYTES;
   };
@@ -430,7 +469,7 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          int key = (t_begin + t) * KB + 32 * kb + 16 * (r >> 3) + 8 * hi + (r & 7);
+          int key = (t_begin + t + (PART && t >= hole_at ? hole_tiles : 0)) * KB + 32 * kb + 16 * (r >> 3) + 8 * hi + (r & 7);
           if (key >= a.kv_len) sb[B][x][kb][r] = -INFINITY;
         }
   };
@@ -809,7 +848,49 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
     l += __shfl_xor(l, 32, 64);
     float inv = 1.0f / l;
     if constexpr (KIND == 3) inv = l > 0.f ? inv : 0.f;  // empty selection of this query block: zeros
-    if (a.nsplit > 1) {  // un-normalised partial result of this KV split: O (f32), reference max, row sum -> k_attn_merge
+    bool merged = false;
+    if constexpr (PART) {
+      if (a.merge_n > 0) {
+        // the flash combine of k_attn_merge with this launch's own (m, l, O) still in registers: M = max over the slots' reference maxima
+        // and the own one, every term weighted by 2^(m_s - M) (pre-scaled Q: exp2 domain), then the normalised store below
+        merged = true;
+        const size_t qr = (size_t)min(q_row[x], a.Lq - 1);
+        float ms[MAX_MERGE], ws[MAX_MERGE];
+        float M = m_run[x];
+#pragma unroll
+        for (int s = 0; s < MAX_MERGE; ++s) {
+          ms[s] = s < a.merge_n ? a.ml_part[(((size_t)s * a.H + head) * a.Lq + qr) * 2] : -INFINITY;
+          M = fmaxf(M, ms[s]);
+        }
+        const float w_own = __builtin_amdgcn_exp2f(m_run[x] - M);
+        float lt = 0.f;
+#pragma unroll
+        for (int s = 0; s < MAX_MERGE; ++s) {
+          ws[s] = s < a.merge_n ? __builtin_amdgcn_exp2f(ms[s] - M) : 0.f;
+          if (s < a.merge_n) lt += ws[s] * a.ml_part[(((size_t)s * a.H + head) * a.Lq + qr) * 2 + 1];
+        }
+        l = lt + w_own * l;
+        inv = 1.0f / l;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          f32x16 ov = o[x][db];
+          asm volatile("" : "+v"(ov));
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < a.merge_n; ++s) {
+              const f32x4 pv = *reinterpret_cast<const f32x4*>(a.o_part + ((size_t)s * a.Lq + qr) * (size_t)(a.H * D) + head * D + db * 32 + 8 * g + 4 * hi);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) acc[k] += ws_at(ws, s) * pv[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ov[4 * g + k] = acc[k] + w_own * ov[4 * g + k];
+          }
+          o[x][db] = ov;
+        }
+      }
+    }
+    if (a.nsplit > 1 && !merged) {  // un-normalised partial result of this KV split: O (f32), reference max, row sum -> k_attn_merge
       if (q_row[x] < a.Lq) {
         float* op = a.o_part + ((size_t)split * a.Lq + q_row[x]) * (size_t)(a.H * D) + head * D;
 #pragma unroll
@@ -883,22 +964,27 @@ __device__ __forceinline__ void attn_w4_body(const AttnArgs& a) {
 // exp2(s - m) or the fp32 row sums (P <= 2^100, l <= 2^117) and, the SAME m being used for P and l, the result is exact for that m: the
 // workgroup runs the body WITHOUT running-max tracking (38 VALU + the rescale test per tile).  Otherwise (no bounds given, large norms,
 // NaNs) it runs the tracked body.  The choice is made once, before anything else, and is uniform over the workgroup.
+__device__ __forceinline__ bool attn_untracked_ok(const AttnArgs& a) {
+  bool fast = false;
+  if (a.kmax2 && a.qmax2) {
+    const int b = blockIdx.x;
+    const int head = ((b >> 3) / a.n_qblk) * 8 + (b & 7);
+    if (head < a.H) {
+      float kn2 = 0.f, qn2 = 0.f;
+      for (int i = 0; i < a.kmax_n; ++i) kn2 = fmaxf(kn2, a.kmax2[(size_t)i * a.kmax_stride + head]);
+      for (int i = 0; i < a.qmax_n; ++i) qn2 = fmaxf(qn2, a.qmax2[i * a.H + head]);
+      fast = qn2 * kn2 <= 2500.0f;  // B <= 50.  Non-finite rows: k_head_max_norm2 reports +inf for a row holding a NaN or an inf, and
+                                    // inf * x is inf (or NaN for x = 0), for which `<=` is false -> the tracked body
+    }
+  }
+  if (a.dbg_body && threadIdx.x == 0) atomicAdd(a.dbg_body + (fast ? 1 : 0), 1u);
+  return fast;
+}
+
 template <int KIND>
 __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
   if constexpr (KIND == 4) {
-    bool fast = false;
-    if (a.kmax2 && a.qmax2) {
-      const int b = blockIdx.x;
-      const int head = ((b >> 3) / a.n_qblk) * 8 + (b & 7);
-      if (head < a.H) {
-        float kn2 = 0.f, qn2 = 0.f;
-        for (int i = 0; i < a.kmax_n; ++i) kn2 = fmaxf(kn2, a.kmax2[(size_t)i * a.kmax_stride + head]);
-        for (int i = 0; i < a.qmax_n; ++i) qn2 = fmaxf(qn2, a.qmax2[i * a.H + head]);
-        fast = qn2 * kn2 <= 2500.0f;  // B <= 50.  Non-finite rows: k_head_max_norm2 reports +inf for a row holding a NaN or an inf, and
-                                      // inf * x is inf (or NaN for x = 0), for which `<=` is false -> the tracked body
-      }
-    }
-    if (a.dbg_body && threadIdx.x == 0) atomicAdd(a.dbg_body + (fast ? 1 : 0), 1u);
+    const bool fast = attn_untracked_ok(a);
     if (__builtin_amdgcn_readfirstlane((int)fast))
       attn_w4_body<4, true>(a);
     else
@@ -906,6 +992,15 @@ __global__ __launch_bounds__(NT4, 1) void k_attn_w4(AttnArgs a) {
   } else {
     attn_w4_body<KIND, false>(a);
   }
+}
+
+// The part launches of an own-first sweep (wf_attn_fwd_part): KIND 4 with the joined tile windows and the merging epilogue (PART).
+__global__ __launch_bounds__(NT4, 1) void k_attn_w4_part(AttnArgs a) {
+  const bool fast = attn_untracked_ok(a);
+  if (__builtin_amdgcn_readfirstlane((int)fast))
+    attn_w4_body<4, true, true>(a);
+  else
+    attn_w4_body<4, false, true>(a);
 }
 
 // Merge of the KV splits of k_attn_w4:  O = sum_s O_s 2^(c (m_s - M)) / sum_s l_s 2^(c (m_s - M)),  M = max_s m_s  (exact flash combine).
@@ -951,8 +1046,9 @@ static unsigned int* g_dbg_body = nullptr;  // wf_attn_debug_body_counter
 
 // part_index >= 0: a PART launch (wf_attn_fwd_part) -- KV tiles [part_t0, part_t1) only, un-normalised partials into slot part_index of the
 // `nsplit`-slot workspace, no merge (wf_attn_merge follows once every slot is filled)
-struct PartWindow {  // a part launch (wf_attn_fwd_part): KV tiles [t0, t1) in `inner` splits (+ optionally [t0b, t1b) in `inner_b`)
-  int index = -1, t0 = 0, t1 = 0, inner = 1, t0b = 0, t1b = 0, inner_b = 0;
+struct PartWindow {  // a part launch (wf_attn_fwd_part): KV tiles [t0, t1) (+ optionally, behind a hole, [t0b, t1b)) walked as ONE sequence in
+  int index = -1, t0 = 0, t1 = 0, inner = 1, t0b = 0, t1b = 0;  // `inner` splits; merge: fold slots 0 .. index - 1 in and write O
+  bool merge = false;
 };
 constexpr int MAX_PARTS = 12;
 
@@ -1019,19 +1115,29 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
     WF_CHECK_ARG(softmax_scale == 0.0f, "%s: part launches are built for the pre-scaled-Q form only (softmax_scale = 0)", who);
     WF_CHECK_ARG(part_t0 >= 0 && part_t0 < part_t1 && part_t0 < ntiles, "%s: empty tile window [%d, %d) of %d tiles", who, part_t0, part_t1, ntiles);
     const int t1 = part_t1 < ntiles ? part_t1 : ntiles;
-    // inner splits of the window (blockIdx.y): whole rounds of workgroups for short query shards, as wf_attn_fwd_split does for the whole sweep
-    const int tps = ceil_div(t1 - part_t0, part_inner < 1 ? 1 : part_inner);
-    grid_y = ceil_div(t1 - part_t0, tps);  // splits that actually get tiles
-    if (pw.inner_b > 0) {  // second window: the tiles beyond a hole (the own segment of the exchange buffer, walked by an earlier launch)
-      WF_CHECK_ARG(pw.t0b >= t1 && pw.t0b < pw.t1b && pw.t0b < ntiles, "%s: second tile window [%d, %d) must lie behind the first [%d, %d) and inside the %d tiles",
-                   who, pw.t0b, pw.t1b, part_t0, t1, ntiles);
-      const int t1b = pw.t1b < ntiles ? pw.t1b : ntiles;
-      const int tps_b = ceil_div(t1b - pw.t0b, pw.inner_b);
-      a.n_first = grid_y;
+    int joined = t1 - part_t0, t1b = 0;
+    a.n_first = INT_MAX;
+    if (pw.t1b > pw.t0b) {  // second window: the tiles beyond a hole (the own segment of the exchange buffer, walked by an earlier launch)
+      const int tps_seg = seg_len / KB;
+      WF_CHECK_ARG(pw.t0b >= t1 && pw.t0b < ntiles, "%s: second tile window [%d, %d) must lie behind the first [%d, %d) and inside the %d tiles", who,
+                   pw.t0b, pw.t1b, part_t0, t1, ntiles);
+      WF_CHECK_ARG(t1 == part_t1 && t1 % tps_seg == 0 && pw.t0b % tps_seg == 0 && pw.t0b > t1,
+                   "%s: the hole [%d, %d) between the two windows must be whole segments of %d tiles", who, t1, pw.t0b, tps_seg);
+      t1b = pw.t1b < ntiles ? pw.t1b : ntiles;
+      a.n_first = t1 - part_t0;
       a.t_begin2 = pw.t0b;
       a.t_end2 = t1b;
-      a.tiles_per_split2 = tps_b;
-      grid_y += ceil_div(t1b - pw.t0b, tps_b);
+      joined += t1b - pw.t0b;
+    }
+    // inner splits of the joined sequence (blockIdx.y): whole rounds of workgroups for short query shards, as wf_attn_fwd_split does for the
+    // whole sweep
+    const int tps = ceil_div(joined, part_inner < 1 ? 1 : part_inner);
+    grid_y = ceil_div(joined, tps);  // splits that actually get tiles
+    a.tiles_per_split2 = joined;
+    if (pw.merge) {
+      WF_CHECK_ARG(grid_y == 1 && part_index >= 1 && part_index <= MAX_MERGE && part_index == nsplit - 1,
+                   "%s: a merging part launch is the LAST of its sweep and has one split (slot %d of %d, %d split(s))", who, part_index, nsplit, grid_y);
+      a.merge_n = part_index;
     }
     WF_CHECK_ARG(nsplit >= 2 && nsplit <= MAX_PARTS && part_index + grid_y <= nsplit, "%s: slots %d..%d of %d (2..%d)", who, part_index,
                  part_index + grid_y - 1, nsplit, MAX_PARTS);
@@ -1053,7 +1159,9 @@ static int attn_launch(const void* Q, const void* K, const void* Vt, void* O, in
     a.ml_part = a.o_part + (size_t)ns * Lq * H * D;
     grid_y = ns;
   }
-  if (prescaled)
+  if (part_index >= 0)
+    hipLaunchKernelGGL(k_attn_w4_part, dim3(grid, grid_y), dim3(NT4), lds_w4, (hipStream_t)stream, a);
+  else if (prescaled)
     hipLaunchKernelGGL(k_attn_w4<4>, dim3(grid, grid_y), dim3(NT4), lds_w4, (hipStream_t)stream, a);
 #ifdef WF_ATTN_LAB  // lab builds (tools/attn_lab.py) instantiate the timed kernel only: 5x shorter compile
   else
@@ -1255,11 +1363,13 @@ extern "C" int wf_attn_cross2_fwd(const void* Q, const void* K, const void* Vt, 
 // launch walks only the tiles [t_begin, t_end) that are there already (pre-scaled Q form) and leaves un-normalised partials (O f32, reference
 // max, row sum) in slot `part` of an `nparts`-slot workspace (wf_attn_split_workspace_bytes(H, Lq, nparts)); wf_attn_merge combines the
 // slots exactly (the flash combine of wf_attn_fwd_split) once every slot has been written.  The rank's own shard needs no wait at all, so a
-// forward WITHOUT a second CFG branch to hide under still overlaps the exchange with attention itself.
+// forward WITHOUT a second CFG branch to hide under still overlaps the exchange with attention itself.  Round 6: a second window behind a
+// hole is walked by the SAME workgroups (one slot per launch and split), and the last launch of a sweep can fold the earlier slots in itself
+// (O_merge) -- see attn_w4_body's PART notes.
 extern "C" int wf_attn_fwd_part(const void* Q, const void* K, const void* Vt, int H, int Lq, int Lkp, int kv_len, int seg_len,
-                                size_t seg_stride_bytes, int t_begin, int t_end, int inner_splits, int t_begin2, int t_end2,
-                                int inner_splits2, int part, int nparts, void* workspace, const float* kmax2, int kmax_n, int kmax_stride,
-                                const float* qmax2, int qmax_n, void* stream) {
+                                size_t seg_stride_bytes, int t_begin, int t_end, int t_begin2, int t_end2, int inner_splits, int part, int nparts,
+                                void* workspace, void* O_merge, int ldo, const float* kmax2, int kmax_n, int kmax_stride, const float* qmax2,
+                                int qmax_n, void* stream) {
   PartWindow pw;
   pw.index = part;
   pw.t0 = t_begin;
@@ -1267,11 +1377,11 @@ extern "C" int wf_attn_fwd_part(const void* Q, const void* K, const void* Vt, in
   pw.inner = inner_splits;
   pw.t0b = t_begin2;
   pw.t1b = t_end2;
-  pw.inner_b = inner_splits2 > 0 && t_end2 > t_begin2 ? inner_splits2 : 0;
+  pw.merge = O_merge != nullptr;
   WF_CHECK_ARG(part >= 0, "wf_attn_fwd_part: part index %d", part);
-  // O is not written by a part launch; the checks of attn_launch want a valid aligned pointer: the workspace serves
-  return attn_launch(Q, K, Vt, workspace, H, Lq, Lkp, kv_len, seg_len, H * D, 0.0f, 0, nparts, workspace, kmax2, kmax_n, qmax2, qmax_n, stream,
-                     "wf_attn_fwd_part", seg_stride_bytes, kmax_stride, pw);
+  // O is written by a merging (last) part launch only; the others hand attn_launch's pointer checks the workspace
+  return attn_launch(Q, K, Vt, O_merge ? O_merge : workspace, H, Lq, Lkp, kv_len, seg_len, O_merge ? ldo : H * D, 0.0f, 0, nparts, workspace, kmax2,
+                     kmax_n, qmax2, qmax_n, stream, "wf_attn_fwd_part", seg_stride_bytes, kmax_stride, pw);
 }
 
 extern "C" int wf_attn_merge(void* O, int H, int Lq, int ldo, int accumulate, int nparts, const void* workspace, void* stream) {

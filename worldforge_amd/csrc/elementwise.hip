@@ -250,13 +250,39 @@ __global__ void k_blend4(const float4* __restrict__ ref, const float4* __restric
     out[i] = o;
   }
 }
+// The video case (C = 3 colour planes, 16-byte aligned, inner % 4 == 0): one thread handles one float4 of pixels in ALL THREE planes -- the
+// mask is read once (the algorithmic (3 + 1 + 3 + 3) x 4 bytes per pixel), no 64-bit division per element (k_blend4 spends two on
+// its flat index), blockIdx.y = batch.  Same expression per element as k_blend4 / k_blend: same bits.
+__global__ __launch_bounds__(256) void k_blend4_rgb(const float4* __restrict__ ref, const float4* __restrict__ mask, const float4* __restrict__ dec,
+                                                    float4* __restrict__ out, size_t inner4) {
+  const size_t b = blockIdx.y;
+  const float4* mb = mask + b * inner4;
+  const size_t base = b * 3 * inner4;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < inner4; p += (size_t)gridDim.x * blockDim.x) {
+    const float4 m = mb[p];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const size_t i = base + (size_t)c * inner4 + p;
+      const float4 r = ref[i], d = dec[i];
+      float4 o;
+      o.x = (2.0f * r.x - 1.0f) * m.x + d.x * (1.0f - m.x);
+      o.y = (2.0f * r.y - 1.0f) * m.y + d.y * (1.0f - m.y);
+      o.z = (2.0f * r.z - 1.0f) * m.z + d.z * (1.0f - m.z);
+      o.w = (2.0f * r.w - 1.0f) * m.w + d.w * (1.0f - m.w);
+      out[i] = o;
+    }
+  }
+}
 extern "C" int wf_blend_pixels(const float* ref, const float* mask, const float* dec, float* out, int B, int C,
                                size_t inner, void* stream) {
   WF_CHECK_ARG(ref && mask && dec && out, "wf_blend_pixels: null pointer");
   size_t n = (size_t)B * C * inner;
   if (n == 0) return WF_OK;
   bool al = (((uintptr_t)ref | (uintptr_t)mask | (uintptr_t)dec | (uintptr_t)out) & 15) == 0 && (inner % 4 == 0);
-  if (al) {
+  if (al && C == 3 && B <= 65535) {
+    hipLaunchKernelGGL(k_blend4_rgb, dim3(grid_for(inner / 4, 256, 8192), B), dim3(256), 0, (hipStream_t)stream, (const float4*)ref,
+                       (const float4*)mask, (const float4*)dec, (float4*)out, inner / 4);
+  } else if (al) {
     size_t n4 = n / 4;
     hipLaunchKernelGGL(k_blend4, dim3(grid_for(n4, EW_BLOCK, 4096)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
                        (const float4*)ref, (const float4*)mask, (const float4*)dec, (float4*)out, C, inner / 4, n4);

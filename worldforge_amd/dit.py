@@ -169,7 +169,8 @@ def attention_exchange(q: torch.Tensor, ex, out: torch.Tensor, kv_len: int, scal
       chunked / bcast   own-first part launches (parallel.sweep_plan; wf_attn_fwd_part needs the pre-scaled Q form, scale == 0): the
                         rank's own keys without any wait, then each window after the event of its chunk / last source -- the exposed
                         part of the exchange is what the compute stream still has to wait for THEN (PROFILE_COMM records every wait)
-                        -- and one exact merge (wf_attn_merge).  Result = the one-launch sweep up to the re-association of the fp32
+                        -- and one exact merge, in the last part launch's own epilogue (or wf_attn_merge when that launch has several
+                        splits).  Result = the one-launch sweep up to the re-association of the fp32
                         partial sums (the class the 8-rank split sweep already has).
     release: the compute stream ends up behind the LAST collective (KVExchange.wait_all) before the caller goes on to write the
     exchange buffers again."""
@@ -225,9 +226,10 @@ def attention_exchange(q: torch.Tensor, ex, out: torch.Tensor, kv_len: int, scal
                 kmp, kmn, kms, qmp, qmn = ex.km[g][a].data_ptr(), n, ex.km_stride(g), qmax2.data_ptr(), qmax2.numel() // H
             (t0, t1, inner), w2 = st["win"], st["win2"] or (0, 0, 0)
             call("wf_attn_fwd_part", q.data_ptr(), ex.k[g].data_ptr(), ex.vt[g].data_ptr(), H, Lq, ex.P * sc, ex.chunk_kv_len(kv_len, g), sc,
-                 ex.seg_stride_bytes(g), t0, t1, inner, w2[0], w2[1], w2[2], st["slot"], nparts, ws.data_ptr(), kmp, kmn, kms, qmp, qmn,
-                 ops.stream())
-        call("wf_attn_merge", out.data_ptr(), H, Lq, out.stride(0), 0, nparts, ws.data_ptr(), ops.stream())
+                 ex.seg_stride_bytes(g), t0, t1, w2[0], w2[1], inner, st["slot"], nparts, ws.data_ptr(),
+                 out.data_ptr() if st["merge"] else None, out.stride(0), kmp, kmn, kms, qmp, qmn, ops.stream())
+        if not steps[-1]["merge"]:
+            call("wf_attn_merge", out.data_ptr(), H, Lq, out.stride(0), 0, nparts, ws.data_ptr(), ops.stream())
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1))

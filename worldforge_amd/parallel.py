@@ -556,9 +556,12 @@ def segment_groups(P: int, rank: int, peer_groups: int = 2):
 
 def sweep_plan(ex: KVExchange, kv_len: int, workgroups: int, peer_groups: int = 2, n_cu: int = 256):
     """The part launches of one own-first sweep over `ex` (modes chunked / bcast) for queries that attend to the first kv_len keys.
-    -> (steps, nparts); a step = dict(chunk, wait: index into ex.events or None, win: (t0, t1, inner), win2: (t0, t1, inner) or None,
-    slot, km: (first segment, count)).  Tile indices are in the chunk buffer's own segment order.  `workgroups` = ceil(Lq / 256) * H of
-    one split: a launch that would leave much of its last round of `n_cu` workgroups idle gets two splits where it has one window.
+    -> (steps, nparts); a step = dict(chunk, wait: index into ex.events or None, win: (t0, t1, inner), win2: (t0, t1, 0) or None,
+    slot, km: (first segment, count), merge: bool).  Tile indices are in the chunk buffer's own segment order.  A step's two windows (the
+    peers on either side of the rank's own segment) are walked as ONE sequence by the same workgroups (round 6; wf_attn_fwd_part), in
+    `inner` splits of the joined sequence = that many partial slots; `workgroups` = ceil(Lq / 256) * H of one split: a launch that would
+    leave much of its last round of `n_cu` workgroups idle gets two splits.  merge: the LAST step, when it has a single split, folds the
+    earlier slots into its own result and writes the output itself (no wf_attn_merge pass).
     A pure function of shapes and rank (never of timing): every rank of a job derives its own plan, the collectives are the same."""
     P, r = ex.P, ex.rank
     fill = (workgroups / n_cu) / -(-workgroups // n_cu)
@@ -567,8 +570,8 @@ def sweep_plan(ex: KVExchange, kv_len: int, workgroups: int, peer_groups: int = 
 
     def add(chunk, wait, win, win2, km):
         nonlocal slot
-        n = _slots(win[1] - win[0], win[2]) + (_slots(win2[1] - win2[0], win2[2]) if win2 else 0)
-        steps.append(dict(chunk=chunk, wait=wait, win=win, win2=win2, slot=slot, km=km))
+        n = _slots(win[1] - win[0] + (win2[1] - win2[0] if win2 else 0), win[2])
+        steps.append(dict(chunk=chunk, wait=wait, win=win, win2=win2, slot=slot, km=km, merge=False, nslots=n))
         slot += n
 
     if ex.mode == "bcast":
@@ -596,9 +599,12 @@ def sweep_plan(ex: KVExchange, kv_len: int, workgroups: int, peer_groups: int = 
             wins = [w for w in (before, after) if w[0] < w[1]]
             if not wins:
                 continue
+            n = sum(w[1] - w[0] for w in wins)
+            inner = max(1, min(n_tot, n // 8))
             if len(wins) == 2:
-                add(g, g, wins[0] + (1,), wins[1] + (1,), (0, P))
+                add(g, g, wins[0] + (inner,), wins[1] + (0,), (0, P))
             else:
-                n = wins[0][1] - wins[0][0]
-                add(g, g, wins[0] + (max(1, min(n_tot, n // 8)),), None, (0, P))
+                add(g, g, wins[0] + (inner,), None, (0, P))
+    if len(steps) >= 2 and steps[-1]["nslots"] == 1 and slot - 1 <= MAX_ATTN_PARTS - 1:
+        steps[-1]["merge"] = True
     return steps, slot
