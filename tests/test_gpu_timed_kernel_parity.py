@@ -111,7 +111,7 @@ def test_timed_self_attention_production_chain_vs_oracle(grid):
     with _BodyCounter() as n:
         dit.attention(c["qh"], c["kh"], c["vt"], out_u, L, 0.0, nsplit=1, kmax2=c["km"], qmax2=c["qm"])
     assert (n.tracked, n.untracked) == (0, _wgs(L)), (n.tracked, n.untracked)       # the body bench.py times
-    # bars at <= 2x the error measured on an MI355X (profiles/r5_tolerances.txt, regenerated at HEAD every round-end run): max abs 2.5e-4 / 1.3e-4, rel L2 4.9e-3 / 5.2e-3 at C2 / C3
+    # bars at <= 2x the error measured on an MI355X (profiles/r6_tolerances.txt, regenerated at HEAD every round-end run): max abs 2.5e-4 / 1.3e-4, rel L2 4.9e-3 / 5.2e-3 at C2 / C3
     tol_abs = 5e-4 if grid == GRID_C2 else 2.6e-4
     eu = _compare(out_u, want, ROWS[grid], heads, tol_abs, 1e-2, f"timed_attn.untracked.L{L}")
     out_t = torch.empty_like(out_u)

@@ -410,7 +410,7 @@ def test_split_bf16x3_reconstructs_fp32(side):
 
 
 # bars per fp32-class mode: (rel L2 of mu / dec, max abs on pixels in [-1, 1]) against the fp32 goldens
-# (measured on MI355X, profiles/r5_tolerances.txt: fp16x3 2.6e-6 / 3.4e-6 / 8.8e-6 with the weight operands stored power-of-two scaled --
+# (measured on MI355X, profiles/r6_tolerances.txt: fp16x3 2.6e-6 / 3.4e-6 / 8.8e-6 with the weight operands stored power-of-two scaled --
 # round 4, unscaled: 4.2e-6 / 6.0e-6 / 1.6e-5 -- the level at which two fp32 implementations of the same network differ by accumulation
 # order; bf16x3 1.9e-5 / 2.2e-5 / 5.2e-5; the bars sit at <= 2x)
 FP32_CLASS_BARS = {"bf16x3": (4.4e-5, 1.04e-4), "fp16x3": (6.8e-6, 1.76e-5)}
