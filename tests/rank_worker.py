@@ -18,6 +18,9 @@ def main():
     from worldforge_amd import dit, parallel
     from worldforge_amd.vae import AutoencoderKLWan
     comm = parallel.init(world, rank, local)
+    # what bench.py does right after init: every process group of the job created and exercised at start-up (Comm.prepare)
+    groups = comm.prepare(cfg_groups=2 if world % 2 == 0 else 0, halo_distances=parallel.halo_distances(world))
+    assert ("world", list(range(world))) in groups
     BF = torch.bfloat16
 
     def rnd(shape, seed, scale=1.0):
@@ -69,6 +72,21 @@ def main():
     assert v1.can_shard(8) == (world > 1)
     assert torch.equal(v1.encode(video).latent_dist.mode(), v0.encode(video).latent_dist.mode()), "sharded VAE encode differs"
     assert torch.equal(v1.decode(z, return_dict=False)[0], v0.decode(z, return_dict=False)[0]), "sharded VAE decode differs"
+    # the injection round trip with the needed-columns decode (a hole on the right third), and the CONSERVATIVE halo path of bench.py's second
+    # attempt (halo rows by one all-gather over the job instead of the two-rank groups): same bits
+    ref_v = torch.rand(1, 3, 5, 64, 96, generator=torch.Generator().manual_seed(9)).to(dev)
+    mask = torch.ones(1, 1, 5, 64, 96, device=dev)
+    mask[..., 70:] = 0.0
+    v0.crop_to_mask = False
+    want = v0.decode_blend_encode(z, ref_v, mask).mode().clone()
+    got = v1.decode_blend_encode(z, ref_v, mask).mode()
+    assert torch.equal(got, want), "sharded round trip (needed columns) differs"
+    comm.halo_whole_job = True
+    got2 = v1.decode_blend_encode(z, ref_v, mask).mode()
+    comm.halo_whole_job = False
+    assert torch.equal(got2, want), "conservative halo path differs"
+    v1.check_range()
+    v0.check_range()
     comm.barrier()
     torch.cuda.synchronize()
     print(f"rank {rank}/{world} ok ({torch.distributed.get_backend()})", flush=True)
