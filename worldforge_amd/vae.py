@@ -862,6 +862,30 @@ class AutoencoderKLWan:
             allr = allr[::self._reps]
         return allr.permute(1, 0, 2, 3, 4).reshape(slab.shape[0], allr.shape[0] * slab.shape[1], slab.shape[2], slab.shape[3]).contiguous()
 
+    def _attn_group(self, x, p, g: int, Hg: int):
+        """The mid-block attention of row group g (x: the group's slab [T, Hg, W, C], the same on the group's `reps` ranks): keys / values are
+        the whole frame (gathered), and the group's QUERY rows are divided among its replicas (round 6: each of the `reps` ranks computed all
+        Hg rows before -- at 8 ranks, 4 groups x 2, every rank did a quarter of the queries instead of an eighth); the replicas' rows come back
+        by one all-gather.  Per output row the arithmetic of the whole-frame call: bit-identical."""
+        comm, reps = self.comm, self._reps
+        full = self._gather_rows(x)
+        if reps == 1:
+            return self._attn(full, p, rows=(g * Hg, (g + 1) * Hg))
+        T, _, Wd, C = x.shape
+        j, per = comm.rank % reps, -(-Hg // reps)
+        r0, r1 = min(j * per, Hg), min((j + 1) * per, Hg)
+        mine = torch.zeros((T, per, Wd, C), dtype=F32, device=x.device)
+        if r1 > r0:
+            mine[:, :r1 - r0].copy_(self._attn(full, p, rows=(g * Hg + r0, g * Hg + r1)))
+        allr = torch.empty((comm.world,) + tuple(mine.shape), dtype=F32, device=x.device)
+        comm.all_gather(allr, mine)
+        parts = []
+        for jj in range(reps):
+            n = min((jj + 1) * per, Hg) - min(jj * per, Hg)
+            if n > 0:
+                parts.append(allr[g * reps + jj, :, :n])
+        return torch.cat(parts, dim=1).contiguous()
+
     def _row_groups(self, h: int, even: bool = False) -> int:
         """Row groups for a stage of h rows: the largest divisor G of the world size with h % G == 0 (and an even number of rows per group
         if a stride-2 conv follows); world / G consecutive ranks then compute the same slab (the low-resolution stage: 60 rows on 8 ranks =
@@ -982,7 +1006,7 @@ class AutoencoderKLWan:
                     if kind == "res":
                         x = self._res_slab(x, p, cin, cout)
                     else:  # attention: the keys / values are the whole frame, the queries this group's rows
-                        x = self._attn(self._gather_rows(x), p, rows=(g * Hg, (g + 1) * Hg))
+                        x = self._attn_group(x, p, g, Hg)
                 x = self._gather_rows(x)                       # whole frames on every rank again: [T,h,w,384] fp32
             finally:
                 self._reps = 1
@@ -994,7 +1018,7 @@ class AutoencoderKLWan:
         Hs = 2 * h // P                                        # my rows at the next resolution
         y0 = rank * Hs
         s0, s1 = (y0 - 1) >> 1, ((y0 + Hs) >> 1) + 1               # source rows incl. halo (s0 = -1 -> zero row)
-        src = self._rows_from_full(self._operand(x), s0, s1)
+        src = self._operand(self._rows_from_full(x, s0, s1))       # (rows first: the operand of this rank's rows only; zero rows stay zero)
         x = self._up_slab(src, p, cin, kind == "up3d", s0, y0, Hs, h)
         h_cur = 2 * h                                          # full image height at the current resolution
         row0 = y0                                              # global first row of my slab at the current resolution
@@ -1010,10 +1034,16 @@ class AutoencoderKLWan:
                 Tn, Hn, Wn, _ = x.shape
                 a = self._halo_operand(x, self.w[p + ".0.gamma"])
                 x, _ = self._conv(a, p + ".2", Tn, Hn, Wn, (cout + 31) // 32 * 32, (3, 3, 3), pt=2, ps=1, ph=0)
-        y = self._gather_rows(x) if gather else x.contiguous()
-        Fo, Ho, Wo, Cy = y.shape
-        out = torch.empty((3, Fo, Ho, Wo), dtype=F32, device=self.device)
-        call("wf_cl_to_ncthw", y.data_ptr(), out.data_ptr(), 3, Cy, Fo * Ho * Wo, 1.0, ops.stream())
+        # channels-last (32 padded channels) -> [3, F, rows, W] on the SLAB, then -- for the gathered form -- one all-gather of the 3-channel
+        # slabs (round 5 gathered the padded 32-channel slabs, 4.1 GB at C2, and converted the whole video on every rank)
+        x = x.contiguous()
+        Fo, Hs_, Wo, Cy = x.shape
+        out = torch.empty((3, Fo, Hs_, Wo), dtype=F32, device=self.device)
+        call("wf_cl_to_ncthw", x.data_ptr(), out.data_ptr(), 3, Cy, Fo * Hs_ * Wo, 1.0, ops.stream())
+        if gather:
+            allr = torch.empty((P, 3, Fo, Hs_, Wo), dtype=F32, device=self.device)
+            comm.all_gather(allr, out)
+            out = allr.permute(1, 2, 0, 3, 4).reshape(3, Fo, P * Hs_, Wo).contiguous()
         return out if crop is None else self._uncrop(out, crop, w)
 
     def _encode_one_sharded(self, video: torch.Tensor, slab: torch.Tensor = None) -> torch.Tensor:
@@ -1028,11 +1058,11 @@ class AutoencoderKLWan:
             xpad = self._halo_pad(self._video_in(slab))
         else:
             C, Fr, H, Wd = video.shape
-            xfull = self._video_in(video)
             Hs = H // P
             y0 = rank * Hs
-            xpad = self._rows_from_full(xfull, y0 - 1, y0 + Hs + 1)
-            del xfull
+            lo, hi = max(y0 - 1, 0), min(y0 + Hs + 1, H)      # this rank's rows + halo: only those are converted (round 5: the whole video)
+            xs = self._video_in(video[:, :, lo:hi].contiguous())
+            xpad = self._rows_from_full(xs, y0 - 1 - lo, y0 + Hs + 1 - lo)
         kind, p, cin, cout = plan[0]
         x, _ = self._conv(xpad, p, Fr, Hs, Wd, cout, (3, 3, 3), pt=2, ps=1, ph=0)
         downs = [i for i, e in enumerate(plan) if e[0] in ("down2d", "down3d")]
@@ -1057,7 +1087,7 @@ class AutoencoderKLWan:
                         x = self._down_slab(x, p, cin, kind == "down3d")
                     elif kind == "attn":
                         Hc = x.shape[1]
-                        x = self._attn(self._gather_rows(x), p, rows=(g * Hc, (g + 1) * Hc))
+                        x = self._attn_group(x, p, g, x.shape[1])
                     else:  # head
                         Tn, Hn, Wn, _ = x.shape
                         a = self._halo_operand(x, self.w[p + ".0.gamma"])
