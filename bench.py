@@ -15,8 +15,6 @@ inside the timed region; inputs are resident in HBM before it starts.
 from __future__ import annotations
 
 import argparse
-import json
-import math
 import os
 import sys
 import time

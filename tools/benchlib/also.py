@@ -1,10 +1,7 @@
 """Short driver-timed windows of BASELINE configs 3 and 4 (and of config 2 with the TF32-class VAE) after the headline window."""
 from __future__ import annotations
 
-import json
-import math
 import os
-import sys
 import time
 
 import torch

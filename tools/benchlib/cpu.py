@@ -1,10 +1,7 @@
 """bench.py's `cpu_baseline` leg: the ONLY place of the bench that imports oracle/ (as the thing timed beside the GPU number, never as the product)."""
 from __future__ import annotations
 
-import json
-import math
 import os
-import sys
 import time
 
 import torch

@@ -1,8 +1,6 @@
 """N > 1: which K / V^T exchange does THIS node hide best?  Timed on a few real-width layers before the timed window (VERDICT r4 #1d)."""
 from __future__ import annotations
 
-import json
-import math
 import os
 import sys
 import time

@@ -2,12 +2,10 @@
 from __future__ import annotations
 
 import json
-import math
 import os
 import sys
 import time
 
-import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 

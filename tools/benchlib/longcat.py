@@ -1,10 +1,7 @@
 """`bench.py --workload longcat`: the same contract on LongCat-Video 13.6B guided i2v (BASELINE config 4's model)."""
 from __future__ import annotations
 
-import json
-import math
 import os
-import sys
 import time
 
 import torch

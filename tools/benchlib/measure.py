@@ -4,7 +4,6 @@ from __future__ import annotations
 import json
 import math
 import os
-import sys
 import time
 
 import torch
@@ -16,7 +15,6 @@ MFMA_PEAK_TFLOPS_BF16 = 2500.0  # dense, MI355X_MICROARCH.md
 # --pmc passes over tools/attn_once.py (the guide forbids mixing counters with the timed run); their summary is the tracked file below,
 # written by tools/pmc_summary.py --json.  They are emitted only when this run launches the very kernel / shape the file describes.
 ATTN_PMC_FILE = os.path.join(ROOT, "profiles", "attn_pmc_latest.json")
-
 
 
 BOX_CALIB_REFERENCE_TFLOPS = 1800.0  # the bare-MFMA rate `value_normalised` is quoted at (round 3's lab box: 1818 on N(0,1) operands)

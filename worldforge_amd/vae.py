@@ -779,7 +779,7 @@ class AutoencoderKLWan:
         out[:, 1:Hs + 1].copy_(a)
         return self._halo_fill(out)
 
-    def _halo_pad_of(self, x, producer=None):
+    def _halo_pad_of(self, x):
         """The conv operand of the row slab x f32 [T,Hs,W,C], halo-padded: [T,Hs+2,W,..] with the neighbours' boundary rows (zeros at the image
         edge).  The two border rows are produced FIRST: their operand rows travel to the neighbours on the communication stream
         (Comm.neighbor_rows_async) while the whole slab's operand is produced -- straight into rows 1 .. Hs of the padded buffer
@@ -1086,7 +1086,6 @@ class AutoencoderKLWan:
                     elif kind in ("down2d", "down3d"):
                         x = self._down_slab(x, p, cin, kind == "down3d")
                     elif kind == "attn":
-                        Hc = x.shape[1]
                         x = self._attn_group(x, p, g, x.shape[1])
                     else:  # head
                         Tn, Hn, Wn, _ = x.shape
