@@ -237,6 +237,7 @@ def main(argv=None):
         comm.all_gather(allr, mine)
         per_rank = [{"rank": r, "attn_avg_ms": v[0], "attn_tflops": (v[1] / (v[0] * 1e-3) / 1e12) if v[0] > 0 else None,
                      "comm_exposed_ms_per_layer": v[2], "layers_timed": int(v[3])} for r, v in enumerate(allr.cpu().tolist())]
+    crop_cols = vae._crop_range(vae.needed_columns(mask), a.width // 8) if vae.crop_to_mask else None   # (cached: no new read-back)
     guided_ms = [1e3 * (marks[("e", i)] - marks[("b", i)]) for i in range(start + Wm, start + Wm + K) if i < guide]
     plain_ms = [1e3 * (marks[("e", i)] - marks[("b", i)]) for i in range(start + Wm, start + Wm + K) if i >= guide]
 
@@ -267,6 +268,10 @@ def main(argv=None):
                 # the two forwards of a CFG evaluation share what does not see the prompt (patch embedding + layer 0's self-attention block,
                 # model.py:298-306): computed once per pair, bit-identical to two forwards -> 2 x 40 - 1 self-attention launches per pair
                 "cfg_pair_shared_prefix": bool(model.pair_share_layer0),
+                # the IRR injection decodes only the pixel columns its blend can see (mask != 1, + receptive-field halo; whole frames through
+                # the latent-resolution stage): bit-identical blend (tests/test_gpu_vae.py, test_gpu_e2e.py); on THIS workload's mask:
+                "vae_decode_needed_columns": {"enabled": bool(vae.crop_to_mask), "latent_columns_total": a.width // 8,
+                                              "latent_columns_decoded": (list(crop_cols) if crop_cols else None)},
                 "flow_backend": a.flow_backend,
                 # the Farneback branch is what an installed reference executes, but its GPU statement is checked against the
                 # in-repo restatement of OpenCV only (no cv2 in the image or the reference tree); the tdiff branch is golden-pinned
