@@ -152,6 +152,37 @@ def test_supervisor_relaunches_conservatively_after_a_failure_or_a_hang(tmp_path
     assert "ONE relaunch in fresh processes" in r.stderr
 
 
+def test_supervisor_killed_by_its_launcher_takes_its_ranks_with_it(tmp_path, monkeypatch):
+    """A launcher that gives up sends SIGTERM: the supervisor must not leave rank processes behind (on a real node they would hold the
+    GPUs and wedge the next run)."""
+    import signal
+    import time
+    monkeypatch.setenv("WF_SHARE_GPU", "1")
+    pidfile = tmp_path / "pids"
+    script = _probe(tmp_path, f"""
+        import os, time
+        open({str(pidfile)!r}, "a").write(str(os.getpid()) + "\\n")
+        time.sleep(600)
+    """)
+    code = ("import sys; sys.path.insert(0, %r); import bench; sys.exit(bench.launch_ranks(2, [], script=%r, budget_s=500.0))" % (ROOT, script))
+    sup = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    t0 = time.time()
+    while time.time() - t0 < 120 and (not pidfile.exists() or len(pidfile.read_text().split()) < 2):
+        time.sleep(0.2)
+    pids = [int(x) for x in pidfile.read_text().split()]
+    assert len(pids) == 2
+    sup.send_signal(signal.SIGTERM)
+    sup.wait(timeout=60)
+    time.sleep(1.0)
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = open(f"/proc/{pid}/status").read().split("State:")[1].split()[0] != "Z"
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive, f"rank process {pid} survived its supervisor"
+
+
 def test_supervisor_under_torch_distributed_run(tmp_path, monkeypatch):
     """The driver's N > 1 command starts the ranks with torch.distributed.run: each of its workers then supervises the real rank as a
     child and the supervisors agree through the launcher's own store (bench.supervise_under_launcher)."""

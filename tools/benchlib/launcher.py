@@ -75,11 +75,36 @@ def supervise(my_ranks, world: int, argv, script: str, coord: _Coord, host: str,
     conservative configuration (`fallback_args`), whose JSON line carries `"fallback": true` and the first attempt's last stderr lines.
     The supervisor never touches the GPU and never re-execs; rank 0's stdout (the one JSON line) is held back until its attempt is known
     to have succeeded everywhere.  -> exit code."""
+    import signal
+
+    my_ranks = list(my_ranks)
+    live = []   # child processes that may still run: never left behind, whatever ends this supervisor (the finally below; SIGTERM from a
+                # launcher that gives up becomes SystemExit so that it runs)
+
+    def _on_term(signum, frame):
+        raise SystemExit(128 + signum)
+
+    old_handlers = {}
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        try:
+            old_handlers[sig] = signal.signal(sig, _on_term)
+        except (ValueError, OSError):   # not the main thread (tests): leave the handlers alone
+            pass
+    try:
+        return _supervise_attempts(my_ranks, world, argv, script, coord, host, port, budget_s, fallback_args, local_world, live)
+    finally:
+        for p in live:
+            if p.poll() is None:
+                p.kill()
+        for sig, h in old_handlers.items():
+            signal.signal(sig, h)
+
+
+def _supervise_attempts(my_ranks, world, argv, script, coord, host, port, budget_s, fallback_args, local_world, live) -> int:
     import subprocess
     import tempfile
     import threading
 
-    my_ranks = list(my_ranks)
     info_path = None
     for attempt in (1, 2):
         args = list(argv) + (list(fallback_args) if attempt == 2 else [])
@@ -93,6 +118,7 @@ def supervise(my_ranks, world: int, argv, script: str, coord: _Coord, host: str,
             if info_path:
                 env["WF_BENCH_FALLBACK_INFO"] = info_path
             p = subprocess.Popen([sys.executable, script] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            live.append(p)
             tails[r], outs[r] = [], []
             for pipe, fn, a in ((p.stderr, _tee, (p.stderr, sys.stderr.buffer, tails[r])),
                                 (p.stdout, lambda q, acc: acc.append(q.read()), (p.stdout, outs[r]))):
@@ -102,7 +128,7 @@ def supervise(my_ranks, world: int, argv, script: str, coord: _Coord, host: str,
             procs.append((r, p))
         t0 = time.time()
         pending = dict(procs)
-        stopped = False
+        stopped, t_kill = False, float("inf")
         while pending:
             for r, p in list(pending.items()):
                 rc = p.poll()
