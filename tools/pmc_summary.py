@@ -2,7 +2,7 @@
 
     python tools/pmc_summary.py <dir> [<dir> ...] [--kernel SUBSTR]
     python tools/pmc_summary.py <dir> ... --kernel "k_attn_w4<4>" --attn-json profiles/attn_pmc_latest.json --tokens 32760 --heads 40 \
-           --source "profiles/r3_attn_pmc_summary.txt"       # the roofline side fields bench.py reads (warm = last dispatch of each pass)
+           --source "profiles/r6_attn_pmc_summary.txt"       # the roofline side fields bench.py reads (warm = last dispatch of each pass)
 """
 import csv
 import glob
